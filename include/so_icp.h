@@ -1,0 +1,213 @@
+/*
+ * so_icp.h -- C ABI of libsoicp: the MI355X-native (gfx950 / HIP) scan-to-map ICP hot path that
+ * replaces, behind the reference's own member-function seams, the CPU path
+ *
+ *     LidarSLAM::Localization -> performLocalizationAndMapping      (Seam A)
+ *     LocalMap::nearestKSearchSurf                                  (Seam B)
+ *
+ * of superxslam/SuperOdom.  The reference has no plugin/FFI interface, so every
+ * entry point below names the reference member function it stands in for.  Citations are relative
+ * to /root/reference/super_odometry/ with the short names
+ *     LS.cpp = src/LidarProcess/LidarSlam.cpp          LS.h = include/super_odometry/LidarProcess/LidarSlam.h
+ *     LM.h   = include/super_odometry/LidarProcess/LocalMap.h
+ *     lmap.cpp = src/LaserMapping/laserMapping.cpp
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; `int` status (0 ok, >0 soft
+ * condition, <0 error; text via so_icp_last_error); nothing throws across the boundary; the caller
+ * owns every buffer; a context is single-caller (the reference's LidarSLAM is non-re-entrant,
+ * LS.cpp:7-9) and owns its HIP stream, device buffers and (optionally) its RCCL communicator.
+ * Pose layout = the reference's pose_parameters[7] (LS.cpp:7-9): {tx,ty,tz, qx,qy,qz,qw}.
+ * INTEGRATION.md shows the LidarSLAM-side adapter a maintainer would add.
+ */
+#ifndef SO_ICP_H
+#define SO_ICP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SO_ICP_ABI_VERSION 1
+
+/* LocalMap geometry, LM.h:131-138 */
+#define SO_ICP_MAP_W 21
+#define SO_ICP_MAP_H 21
+#define SO_ICP_MAP_D 11
+#define SO_ICP_MAP_NUM 4851
+#define SO_ICP_MAX_OUTER 16
+
+/* status codes */
+#define SO_ICP_OK 0
+#define SO_ICP_NOT_ENOUGH_MAP_FEATURES 1 /* LS.cpp:113-116: surf_from_map_num <= 50, pose = guess */
+#define SO_ICP_MAP_SEEDED 2              /* Localization(initialization=false): LS.cpp:45-46, 83-94 */
+#define SO_ICP_E_INVALID (-1)
+#define SO_ICP_E_HIP (-2)
+#define SO_ICP_E_NOMEM (-3)
+#define SO_ICP_E_RCCL (-4)
+#define SO_ICP_E_UNSUPPORTED (-5)
+
+/* MatchingResult, LS.h:85-94 (index into so_icp_iter_stats.reject_hist) */
+enum {
+  SO_ICP_MATCH_SUCCESS = 0,
+  SO_ICP_MATCH_NOT_ENOUGH_NEIGHBORS = 1,
+  SO_ICP_MATCH_NEIGHBORS_TOO_FAR = 2,
+  SO_ICP_MATCH_BAD_PCA_STRUCTURE = 3,
+  SO_ICP_MATCH_INVALID_NUMERICAL = 4,
+  SO_ICP_MATCH_MSE_TOO_LARGE = 5,
+  SO_ICP_MATCH_UNKNOWN = 6,
+  SO_ICP_N_REJECT = 7
+};
+#define SO_ICP_N_OBS 9 /* Feature_observability, LS.h:96-107 */
+
+typedef struct so_icp_ctx so_icp_ctx;
+
+/* Knobs the node pushes into LidarSLAM before each call (lmap.cpp:103-120, 648-649, 703-711) plus
+ * device placement.  Fill with so_icp_default_config() first. */
+typedef struct {
+  int32_t abi_version;          /* SO_ICP_ABI_VERSION */
+  int32_t device_id;            /* HIP device ordinal (one process per GPU); < 0: host-only context -- LocalMap
+                                   bookkeeping works, every compute entry point returns SO_ICP_E_HIP (no CPU fallback) */
+  int32_t rank, world_size;     /* map shard owned by this context (brick-hash of the voxel grid) */
+  int32_t max_iterations;       /* LocalizationICPMaxIter (LS.h:273; YAML max_iterations: 5) */
+  int32_t lm_max_iterations;    /* ceres max_num_iterations = 4 (LS.cpp:232) */
+  int32_t max_surface_features; /* OptSet.max_surface_features (LS.cpp:346-351); <=0: use all points */
+  int32_t k;                    /* LocalizationPlaneDistanceNbrNeighbors = 5 (LS.h:277); only 5 supported */
+  int32_t tukey_variant;        /* 0 = Ceres 2.0.0 TukeyLoss (rho' = 0.5 (1-s/a^2)^2); 1 = Ceres >= 2.1 */
+  int32_t time_kernels;         /* 1: bracket the k-NN and evaluation kernels with HIP events (so_icp_get_timing) */
+  float line_res, plane_res;    /* localMap.lineRes_/planeRes_ (LM.h:760-761; pushed every frame, lmap.cpp:648-649) */
+  double yaw_ratio;             /* OptSet.yaw_ratio (LS.cpp:906) */
+  double velocity_failure_threshold; /* OptSet.velocity_failure_threshold (LS.cpp:179) */
+} so_icp_config;
+
+/* super_odometry_msgs/msg/IterationStats.msg + what LS.cpp:242-251 fills + solver summary */
+typedef struct {
+  double translation_norm, rotation_norm;
+  int32_t num_surf_from_scan;   /* accepted correspondences A (planner_num) */
+  int32_t num_corner_from_scan; /* always 0: the edge path is dead */
+  int32_t lm_iterations;        /* minimizer iterations executed (iteration 0 not counted) */
+  int32_t num_successful_steps; /* ceres::Solver::Summary::num_successful_steps (LS.cpp:141) */
+  int32_t termination;          /* 0 max-iter, 1 function tol, 2 parameter tol, 3 gradient tol, 4 no residuals, 5 failure */
+  int32_t reserved;
+  double initial_cost, final_cost;
+  int32_t reject_hist[SO_ICP_N_REJECT]; /* MatchRejectionHistogramPlane, LS.cpp:341 */
+  int32_t obs_hist[SO_ICP_N_OBS];       /* PlaneFeatureHistogramObs, LS.cpp:336-339 */
+  double pose_after[7];
+} so_icp_iter_stats;
+
+/* super_odometry_msgs/msg/OptimizationStats.msg: every field the reference fills (LS.cpp:198-210,
+ * 242-251, 371-377, 969-974) + the final normal equations (enables EstimateRegistrationError,
+ * LS.cpp:854-889, on the caller side without the A x 6 SVD). */
+typedef struct {
+  int32_t laser_cloud_surf_from_map_num;
+  int32_t laser_cloud_corner_from_map_num; /* 0 */
+  int32_t laser_cloud_surf_stack_num;
+  int32_t laser_cloud_corner_stack_num;    /* 0 */
+  int32_t n_iterations;                    /* outer ICP iterations executed */
+  int32_t startup_count;                   /* LidarSLAM::startupCount side effect (LS.cpp:181) */
+  int32_t pos_in_localmap[3];              /* LS.cpp:363 */
+  int32_t prediction_source;               /* LS.cpp:278: reset to 0 */
+  double total_translation, total_rotation;
+  double translation_from_last, rotation_from_last;
+  double time_elapsed_ms;                  /* TicToc over the ICP loop, LS.cpp:118,199-200 */
+  double uncertainty[6];                   /* x y z roll pitch yaw, LS.cpp:915-974 (histogram of the previous scan) */
+  double JtJ[36], Jtr[6];                  /* loss-corrected normal equations at the returned pose */
+  so_icp_iter_stats iterations[SO_ICP_MAX_OUTER];
+} so_icp_stats;
+
+/* average kernel durations since the last so_icp_reset_timing (HIP events on the context's stream) */
+typedef struct {
+  double knn_ms_total;   int64_t knn_launches;   int64_t knn_queries;   int64_t knn_map_points;
+  double eval_ms_total;  int64_t eval_launches;  int64_t eval_points;
+  double prep_ms_total;  int64_t prep_launches;
+  double host_ms_total;  int64_t registrations;
+} so_icp_timing;
+
+/* -------- lifecycle ------------------------------------------------------------------------ */
+void so_icp_default_config(so_icp_config *cfg);
+so_icp_ctx *so_icp_create(const so_icp_config *cfg); /* NULL on failure: see so_icp_last_error(NULL) */
+void so_icp_destroy(so_icp_ctx *ctx);
+const char *so_icp_last_error(const so_icp_ctx *ctx); /* ctx may be NULL for creation errors */
+int so_icp_abi_version(void);
+/* 1 when a HIP device is usable by this library; the product has NO CPU fallback */
+int so_icp_device_available(void);
+
+/* -------- per-frame knobs (public fields the node writes, lmap.cpp:648-649, 703-711) ---------- */
+int so_icp_set_resolution(so_icp_ctx *ctx, float line_res, float plane_res);
+int so_icp_set_max_surface_features(so_icp_ctx *ctx, int max_surface_features);
+int so_icp_set_max_iterations(so_icp_ctx *ctx, int max_iterations);
+
+/* -------- LocalMap (LM.h) ------------------------------------------------------------------ */
+int so_icp_map_set_origin(so_icp_ctx *ctx, const double t_w_cur[3], int origin_out[3]); /* LocalMap::setOrigin, LM.h:146-164 */
+int so_icp_map_shift(so_icp_ctx *ctx, const double t_w_cur[3], int pos_in_map[3]);      /* LocalMap::shiftMap,  LM.h:169-287 */
+/* LocalMap::addSurfPointCloud, LM.h:591-645: world-frame points (stride in bytes, 12 for packed xyz,
+ * 32 for pcl::PointXYZI); bins into 50 m cubes, VoxelGrid(planeRes) per touched cube, rebuilds the
+ * device index.  Returns the number of points that fell inside the 21x21x11 window, or <0. */
+int so_icp_map_add_surf(so_icp_ctx *ctx, const float *xyz, size_t n, size_t stride_bytes);
+int so_icp_map_count_5x5(so_icp_ctx *ctx, const int pos[3], int *n_edge, int *n_surf);  /* get5x5LocalMapFeatureSize, LM.h:292-318 */
+/* getAllLocalMap / get5x5LocalMap (LM.h:646-688): points in the canonical (device) order */
+int so_icp_map_export(so_icp_ctx *ctx, float *xyz, size_t cap_points, size_t *n_out, int only_5x5, const int pos[3]);
+int so_icp_map_size(so_icp_ctx *ctx, size_t *n_points, size_t *n_points_this_rank);
+int so_icp_map_clear(so_icp_ctx *ctx);
+int so_icp_map_get_origin(so_icp_ctx *ctx, int origin_out[3]);
+
+/* -------- Seam B: LocalMap::nearestKSearchSurf (LM.h:481-525), batched ------------------------ */
+/* Host buffers. found[i]=0 reproduces the `return false` paths (cube outside the window, LM.h:499-502,
+ * or no tree, LM.h:506).  Unfilled slots reproduce nanoflann.h:87-100 (idx 0 -> first point of the cube,
+ * d2 = 0 except d2[k-1] = FLT_MAX). Exact cube-restricted k-NN; ties by ascending canonical index. */
+int so_icp_knn_surf(so_icp_ctx *ctx, const float *q_xyz, size_t nq, int k,
+                    float *nbr_xyz /* nq*k*3 */, float *d2 /* nq*k */, int32_t *nbr_index /* nq*k, nullable */,
+                    uint8_t *found /* nq */);
+
+/* -------- Seam A: LidarSLAM::performLocalizationAndMapping (LS.cpp:107-152 + 155-210) --------- */
+/* scan: sensor frame, already voxel-filtered by the node (lmap.cpp:643-645).  Does shiftMap,
+ * the <=50-feature check, the outer ICP loop and the post-processing statistics; does NOT insert
+ * the scan into the map (so_icp_localization does).  prev uncertainty comes from the previous call. */
+int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes,
+                    const double pose_in[7], double pose_out[7], so_icp_stats *stats);
+/* same, scan already resident in HBM as packed float xyz (n*3 floats, device pointer) */
+int so_icp_register_dev(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n,
+                        const double pose_in[7], double pose_out[7], so_icp_stats *stats);
+/* upload a scan once and keep it resident (returns a device pointer owned by the context) */
+int so_icp_upload_scan(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes, void **d_scan_out);
+
+/* LidarSLAM::Localization (LS.cpp:30-51): initialization==0 seeds the map (LS.cpp:83-94) and returns
+ * SO_ICP_MAP_SEEDED; otherwise registers, applies the post-processing and inserts the scan
+ * (transformAndAddToMap, LS.cpp:60-80, 163-167). */
+int so_icp_localization(so_icp_ctx *ctx, int initialization, const double T_w_lidar[7],
+                        const float *planar_xyz, size_t n, size_t stride_bytes, double time_laser_odometry,
+                        double pose_out[7], so_icp_stats *stats);
+
+/* -------- multi-GPU: one process per GPU, one collective (sum of 45 fp64) per evaluation ------- */
+#define SO_ICP_UNIQUE_ID_BYTES 128
+int so_icp_comm_unique_id(uint8_t id[SO_ICP_UNIQUE_ID_BYTES]);                 /* rank 0: ncclGetUniqueId */
+int so_icp_comm_init(so_icp_ctx *ctx, const uint8_t id[SO_ICP_UNIQUE_ID_BYTES]); /* all ranks: ncclCommInitRank on ctx->rank/world_size */
+/* brick-hash ownership of the shard (host logic, testable without a GPU) */
+int so_icp_shard_owner_of_point(const float p[3], const int origin[3], float plane_res, int world_size);
+int so_icp_cells_per_cube(float plane_res, double *cell_size);
+
+/* -------- host-side Levenberg-Marquardt state machine (the Ceres restatement the device path is
+ * driven by; exposed so it can be tested without a GPU) ------------------------------------------ */
+typedef struct {
+  double cost;      /* 0.5 * sum c_i rho(s_i) */
+  double count;     /* accepted correspondences */
+  double Jtr[6];
+  double JtJ[21];   /* upper triangle, row-major: (0,0..5),(1,1..5),... */
+  double hist[16];  /* reject_hist[7] then obs_hist[9] (carried through the same all-reduce) */
+} so_icp_sums;      /* 45 doubles */
+typedef struct { double opaque[96]; } so_icp_lm_state;
+/* begin: sums evaluated at x0. returns 1 and writes next_pose when another evaluation is needed, 0 when done */
+int so_icp_lm_begin(so_icp_lm_state *s, const double x0[7], const so_icp_sums *sums_at_x0, int max_iterations, double next_pose[7]);
+int so_icp_lm_feed(so_icp_lm_state *s, const so_icp_sums *sums_at_next, double next_pose[7]);
+int so_icp_lm_result(const so_icp_lm_state *s, double pose[7], so_icp_iter_stats *stats /* solver fields only */);
+
+/* -------- measurement ------------------------------------------------------------------------ */
+int so_icp_get_timing(so_icp_ctx *ctx, so_icp_timing *t);
+int so_icp_reset_timing(so_icp_ctx *ctx);
+int so_icp_synchronize(so_icp_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SO_ICP_H */

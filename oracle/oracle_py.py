@@ -1,0 +1,254 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) and of the compiled reference octree
+(oracle/_ref/libref_octree.so).  TEST INFRASTRUCTURE: imported only by tests/, by
+__graft_entry__.smoke() and by bench.py's cpu_baseline leg -- never by superodom_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+N_REJECT, N_OBS, MAX_OUTER = 7, 9, 16
+
+
+class Config(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("lm_max_iterations", C.c_int), ("max_surface_features", C.c_int),
+                ("k", C.c_int), ("tukey_variant", C.c_int), ("use_grid_knn", C.c_int),
+                ("yaw_ratio", C.c_double), ("velocity_failure_threshold", C.c_double)]
+
+
+class Corr(C.Structure):
+    _fields_ = [("p", C.c_double * 3), ("n", C.c_double * 3), ("d", C.c_double), ("coeff", C.c_double),
+                ("status", C.c_int32), ("obs", C.c_int32 * 4), ("nbr", C.c_float * 15), ("d2", C.c_float * 5),
+                ("eig", C.c_double * 3)]
+
+
+class IterStats(C.Structure):
+    _fields_ = [("translation_norm", C.c_double), ("rotation_norm", C.c_double), ("num_surf", C.c_int32),
+                ("lm_iterations", C.c_int32), ("num_successful_steps", C.c_int32), ("termination", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("reject_hist", C.c_int32 * N_REJECT), ("obs_hist", C.c_int32 * N_OBS), ("pose_after", C.c_double * 7)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("surf_from_map_num", C.c_int32), ("surf_stack_num", C.c_int32), ("n_iterations", C.c_int32),
+                ("startup_count", C.c_int32), ("pos_in_map", C.c_int32 * 3),
+                ("total_translation", C.c_double), ("total_rotation", C.c_double),
+                ("translation_from_last", C.c_double), ("rotation_from_last", C.c_double),
+                ("uncertainty", C.c_double * 6), ("JtJ", C.c_double * 36), ("Jtr", C.c_double * 6),
+                ("iters", IterStats * MAX_OUTER)]
+
+
+CORR_DTYPE = np.dtype([("p", "f8", 3), ("n", "f8", 3), ("d", "f8"), ("coeff", "f8"), ("status", "i4"),
+                       ("obs", "i4", 4), ("nbr", "f4", 15), ("d2", "f4", 5), ("eig", "f8", 3)], align=True)
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    vp, f32p, f64p, i32p, i64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    L.orc_map_create.restype = vp
+    L.orc_map_destroy.argtypes = [vp]
+    L.orc_map_set_resolution.argtypes = [vp, C.c_float, C.c_float]
+    L.orc_map_set_origin.argtypes = [vp, f64p, i32p]
+    L.orc_map_shift.argtypes = [vp, f64p, i32p]
+    L.orc_map_get_origin.argtypes = [vp, i32p]
+    L.orc_map_add_surf.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
+    L.orc_map_add_surf_raw.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
+    L.orc_map_count_5x5.argtypes = [vp, i32p]
+    L.orc_map_size.argtypes = [vp]; L.orc_map_size.restype = C.c_size_t
+    L.orc_map_export.argtypes = [vp, f32p, C.c_size_t]; L.orc_map_export.restype = C.c_size_t
+    L.orc_map_cube_size.argtypes = [vp, C.c_int]; L.orc_map_cube_size.restype = C.c_size_t
+    L.orc_knn_surf.argtypes = [vp, f32p, C.c_int, C.c_int, f32p, f32p, i64p, C.POINTER(C.c_int)]
+    L.orc_voxel_grid.argtypes = [f32p, C.c_size_t, C.c_float, f32p]; L.orc_voxel_grid.restype = C.c_size_t
+    L.orc_plane_match.argtypes = [vp, f64p, f32p, C.POINTER(Config), C.POINTER(Corr)]
+    L.orc_eig3_sym.argtypes = [f64p, f64p, f64p]
+    L.orc_plane_ls5.argtypes = [f64p, f64p]
+    L.orc_residual_jacobian.argtypes = [f64p, f64p, f64p, C.c_double, f64p, f64p]
+    L.orc_pose_plus.argtypes = [f64p, f64p, f64p]
+    L.orc_tukey_scaled.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, f64p]
+    L.orc_evaluate.argtypes = [vp, C.c_size_t, f64p, C.c_float, C.c_int, f64p, f64p, f64p, C.POINTER(C.c_int)]
+    L.orc_lm_solve.argtypes = [vp, C.c_size_t, f64p, C.c_float, C.POINTER(Config), C.POINTER(IterStats)]
+    L.orc_uncertainty_from_hist.argtypes = [i32p, f64p]
+    L.orc_should_process.argtypes = [C.c_size_t, C.c_size_t, C.c_int]
+    L.orc_yaw_correction.argtypes = [f64p, f64p, C.c_double]
+    L.orc_register.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, C.POINTER(Config), i32p, f64p, C.POINTER(Stats), vp]
+    L.orc_transform_and_add.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p]
+    _lib = L
+    return L
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def default_config(**kw):
+    c = Config(max_iterations=5, lm_max_iterations=4, max_surface_features=-1, k=5, tukey_variant=0,
+               use_grid_knn=1, yaw_ratio=0.0, velocity_failure_threshold=30.0)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+class OracleMap:
+    """LocalMap (LocalMap.h) restated on the CPU."""
+
+    def __init__(self, plane_res=0.2, line_res=0.1):
+        self.L = lib()
+        self.h = self.L.orc_map_create()
+        self.L.orc_map_set_resolution(self.h, line_res, plane_res)
+        self.plane_res = np.float32(plane_res)
+
+    def __del__(self):
+        try:
+            self.L.orc_map_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_resolution(self, line_res, plane_res):
+        self.L.orc_map_set_resolution(self.h, line_res, plane_res)
+        self.plane_res = np.float32(plane_res)
+
+    def set_origin(self, t):
+        t = np.ascontiguousarray(t, dtype=np.float64); o = np.zeros(3, np.int32)
+        self.L.orc_map_set_origin(self.h, _p(t, C.c_double), _p(o, C.c_int32))
+        return o
+
+    def shift(self, t):
+        t = np.ascontiguousarray(t, dtype=np.float64); o = np.zeros(3, np.int32)
+        self.L.orc_map_shift(self.h, _p(t, C.c_double), _p(o, C.c_int32))
+        return o
+
+    def origin(self):
+        o = np.zeros(3, np.int32); self.L.orc_map_get_origin(self.h, _p(o, C.c_int32)); return o
+
+    def add_surf(self, xyz, raw=False):
+        xyz = _f32(xyz).reshape(-1, 3)
+        f = self.L.orc_map_add_surf_raw if raw else self.L.orc_map_add_surf
+        return f(self.h, _p(xyz, C.c_float), len(xyz), 3)
+
+    def count_5x5(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        return self.L.orc_map_count_5x5(self.h, _p(pos, C.c_int32))
+
+    def size(self):
+        return self.L.orc_map_size(self.h)
+
+    def export(self):
+        n = self.size(); out = np.zeros((n, 3), np.float32)
+        m = self.L.orc_map_export(self.h, _p(out, C.c_float), n)
+        return out[:m]
+
+    def knn(self, q, k=5, use_grid=1):
+        q = _f32(q).reshape(-1, 3); nq = len(q)
+        nbr = np.zeros((nq, k, 3), np.float32); d2 = np.zeros((nq, k), np.float32)
+        idx = np.zeros((nq, k), np.int64); found = np.zeros(nq, np.uint8); cube = np.zeros(nq, np.int32)
+        if use_grid:
+            self.ensure_grids()
+        ci = C.c_int()
+        for i in range(nq):
+            found[i] = self.L.orc_knn_surf(self.h, _p(q[i], C.c_float), k, use_grid, _p(nbr[i], C.c_float),
+                                           _p(d2[i], C.c_float), _p(idx[i], C.c_int64), C.byref(ci))
+            cube[i] = ci.value
+        return found, nbr, d2, idx, cube
+
+    def ensure_grids(self):
+        # orc_register builds the grids lazily; for direct knn calls run a dummy zero-point registration
+        cfg = default_config(); st = Stats(); pose = np.array([0, 0, 0, 0, 0, 0, 1.0]); out = np.zeros(7)
+        scan = np.zeros((1, 3), np.float32)
+        # shifting with the current origin-centre keeps the window in place
+        o = self.origin()
+        centre = np.array([(10 - o[0]) * 50.0, (10 - o[1]) * 50.0, (5 - o[2]) * 50.0])
+        pose[:3] = centre
+        self.L.orc_register(self.h, _p(scan, C.c_float), 0, 3, _p(pose, C.c_double), C.byref(cfg), None,
+                            _p(out, C.c_double), C.byref(st), None)
+
+    def plane_match(self, pose, pts, cfg=None):
+        cfg = cfg or default_config()
+        pose = np.ascontiguousarray(pose, dtype=np.float64); pts = _f32(pts).reshape(-1, 3)
+        out = np.zeros(len(pts), CORR_DTYPE)
+        if cfg.use_grid_knn:
+            self.ensure_grids()
+        for i in range(len(pts)):
+            self.L.orc_plane_match(self.h, _p(pose, C.c_double), _p(pts[i], C.c_float), C.byref(cfg),
+                                   C.cast(out[i:i + 1].ctypes.data, C.POINTER(Corr)))
+        return out
+
+    def register(self, scan, pose_in, cfg=None, prev_obs_hist=None, want_corrs=False):
+        cfg = cfg or default_config()
+        scan = _f32(scan).reshape(-1, 3); pose_in = np.ascontiguousarray(pose_in, dtype=np.float64)
+        out = np.zeros(7); st = Stats()
+        corrs = np.zeros(len(scan), CORR_DTYPE) if want_corrs else None
+        hist = None if prev_obs_hist is None else np.ascontiguousarray(prev_obs_hist, dtype=np.int32)
+        rc = self.L.orc_register(self.h, _p(scan, C.c_float), len(scan), 3, _p(pose_in, C.c_double), C.byref(cfg),
+                                 None if hist is None else _p(hist, C.c_int32), _p(out, C.c_double), C.byref(st),
+                                 None if corrs is None else corrs.ctypes.data)
+        return rc, out, st, corrs
+
+    def transform_and_add(self, scan, pose):
+        scan = _f32(scan).reshape(-1, 3); pose = np.ascontiguousarray(pose, dtype=np.float64)
+        return self.L.orc_transform_and_add(self.h, _p(scan, C.c_float), len(scan), 3, _p(pose, C.c_double))
+
+
+def evaluate(corrs, pose, plane_res, tukey_variant=0):
+    L = lib(); pose = np.ascontiguousarray(pose, dtype=np.float64)
+    corrs = np.ascontiguousarray(corrs)
+    cost = C.c_double(); JtJ = np.zeros(36); Jtr = np.zeros(6); cnt = C.c_int()
+    L.orc_evaluate(corrs.ctypes.data, len(corrs), _p(pose, C.c_double), float(plane_res), tukey_variant,
+                   C.byref(cost), _p(JtJ, C.c_double), _p(Jtr, C.c_double), C.byref(cnt))
+    return cost.value, JtJ.reshape(6, 6), Jtr, cnt.value
+
+
+def lm_solve(corrs, pose, plane_res, cfg=None):
+    L = lib(); cfg = cfg or default_config()
+    pose = np.array(pose, dtype=np.float64); st = IterStats(); corrs = np.ascontiguousarray(corrs)
+    L.orc_lm_solve(corrs.ctypes.data, len(corrs), _p(pose, C.c_double), float(plane_res), C.byref(cfg), C.byref(st))
+    return pose, st
+
+
+def voxel_grid(xyz, leaf):
+    L = lib(); xyz = _f32(xyz).reshape(-1, 3); out = np.zeros_like(xyz)
+    n = L.orc_voxel_grid(_p(xyz, C.c_float), len(xyz), float(leaf), _p(out, C.c_float))
+    return out[:n].copy()
+
+
+class RefOctree:
+    """The reference's own nanoflann::Octree (octree.h), compiled verbatim into oracle/_ref/."""
+
+    def __init__(self, xyz):
+        path = os.path.join(HERE, "_ref", "libref_octree.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.R = C.CDLL(path)
+        self.R.ref_octree_build.restype = C.c_void_p
+        self.R.ref_octree_build.argtypes = [C.POINTER(C.c_float), C.c_size_t]
+        self.R.ref_octree_free.argtypes = [C.c_void_p]
+        self.R.ref_octree_knn.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)]
+        self.xyz = _f32(xyz).reshape(-1, 3)
+        self.h = self.R.ref_octree_build(_p(self.xyz, C.c_float), len(self.xyz))
+
+    def __del__(self):
+        try:
+            self.R.ref_octree_free(self.h)
+        except Exception:
+            pass
+
+    def knn(self, q, k=5):
+        q = _f32(q).reshape(-1, 3); idx = np.zeros((len(q), k), np.int64); d2 = np.zeros((len(q), k), np.float32)
+        self.R.ref_octree_knn(self.h, _p(q, C.c_float), len(q), k, _p(idx, C.c_int64), _p(d2, C.c_float))
+        return idx, d2

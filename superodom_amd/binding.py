@@ -1,0 +1,311 @@
+"""ctypes binding of libsoicp.so (include/so_icp.h).
+
+This is the thin host-side mirror used by tests and bench.py.  The reference's host is C++
+(LidarSLAM, src/LidarProcess/LidarSlam.cpp); its C++ adapter is shown in INTEGRATION.md.  Loading
+fails loudly when the library is missing or when no HIP device is usable -- there is no CPU path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsoicp.so")
+N_REJECT, N_OBS, MAX_OUTER, UID_BYTES = 7, 9, 16, 128
+
+OK, NOT_ENOUGH_MAP_FEATURES, MAP_SEEDED = 0, 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device_id", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
+                ("max_iterations", C.c_int32), ("lm_max_iterations", C.c_int32), ("max_surface_features", C.c_int32),
+                ("k", C.c_int32), ("tukey_variant", C.c_int32), ("time_kernels", C.c_int32),
+                ("line_res", C.c_float), ("plane_res", C.c_float), ("yaw_ratio", C.c_double),
+                ("velocity_failure_threshold", C.c_double)]
+
+
+class IterStats(C.Structure):
+    _fields_ = [("translation_norm", C.c_double), ("rotation_norm", C.c_double), ("num_surf_from_scan", C.c_int32),
+                ("num_corner_from_scan", C.c_int32), ("lm_iterations", C.c_int32), ("num_successful_steps", C.c_int32),
+                ("termination", C.c_int32), ("reserved", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("reject_hist", C.c_int32 * N_REJECT), ("obs_hist", C.c_int32 * N_OBS), ("pose_after", C.c_double * 7)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("laser_cloud_surf_from_map_num", C.c_int32), ("laser_cloud_corner_from_map_num", C.c_int32),
+                ("laser_cloud_surf_stack_num", C.c_int32), ("laser_cloud_corner_stack_num", C.c_int32),
+                ("n_iterations", C.c_int32), ("startup_count", C.c_int32), ("pos_in_localmap", C.c_int32 * 3),
+                ("prediction_source", C.c_int32), ("total_translation", C.c_double), ("total_rotation", C.c_double),
+                ("translation_from_last", C.c_double), ("rotation_from_last", C.c_double), ("time_elapsed_ms", C.c_double),
+                ("uncertainty", C.c_double * 6), ("JtJ", C.c_double * 36), ("Jtr", C.c_double * 6),
+                ("iterations", IterStats * MAX_OUTER)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("knn_ms_total", C.c_double), ("knn_launches", C.c_int64), ("knn_queries", C.c_int64), ("knn_map_points", C.c_int64),
+                ("eval_ms_total", C.c_double), ("eval_launches", C.c_int64), ("eval_points", C.c_int64),
+                ("prep_ms_total", C.c_double), ("prep_launches", C.c_int64),
+                ("host_ms_total", C.c_double), ("registrations", C.c_int64)]
+
+
+class Sums(C.Structure):
+    _fields_ = [("cost", C.c_double), ("count", C.c_double), ("Jtr", C.c_double * 6), ("JtJ", C.c_double * 21), ("hist", C.c_double * 16)]
+
+
+class LmState(C.Structure):
+    _fields_ = [("opaque", C.c_double * 96)]
+
+
+EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_last_error", "so_icp_abi_version",
+            "so_icp_device_available", "so_icp_set_resolution", "so_icp_set_max_surface_features", "so_icp_set_max_iterations",
+            "so_icp_map_set_origin", "so_icp_map_shift", "so_icp_map_add_surf", "so_icp_map_count_5x5", "so_icp_map_export",
+            "so_icp_map_size", "so_icp_map_clear", "so_icp_map_get_origin", "so_icp_knn_surf", "so_icp_register",
+            "so_icp_register_dev", "so_icp_upload_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
+            "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
+            "so_icp_get_timing", "so_icp_reset_timing", "so_icp_synchronize"]
+
+_lib = None
+
+
+def load():
+    """Load libsoicp.so; raise if it is absent (run `python -m superodom_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not built: run `python -m superodom_amd.build` (hipcc, gfx950). "
+                           "superodom_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, f32p, f64p, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    u8p = C.POINTER(C.c_uint8)
+    L.so_icp_default_config.argtypes = [C.POINTER(Config)]; L.so_icp_default_config.restype = None
+    L.so_icp_create.argtypes = [C.POINTER(Config)]; L.so_icp_create.restype = vp
+    L.so_icp_destroy.argtypes = [vp]; L.so_icp_destroy.restype = None
+    L.so_icp_last_error.argtypes = [vp]; L.so_icp_last_error.restype = C.c_char_p
+    L.so_icp_set_resolution.argtypes = [vp, C.c_float, C.c_float]
+    L.so_icp_set_max_surface_features.argtypes = [vp, C.c_int]
+    L.so_icp_set_max_iterations.argtypes = [vp, C.c_int]
+    L.so_icp_map_set_origin.argtypes = [vp, f64p, i32p]
+    L.so_icp_map_shift.argtypes = [vp, f64p, i32p]
+    L.so_icp_map_add_surf.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
+    L.so_icp_map_count_5x5.argtypes = [vp, i32p, i32p, i32p]
+    L.so_icp_map_export.argtypes = [vp, f32p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, i32p]
+    L.so_icp_map_size.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.so_icp_map_clear.argtypes = [vp]
+    L.so_icp_map_get_origin.argtypes = [vp, i32p]
+    L.so_icp_knn_surf.argtypes = [vp, f32p, C.c_size_t, C.c_int, f32p, f32p, i32p, u8p]
+    L.so_icp_register.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, f64p, C.POINTER(Stats)]
+    L.so_icp_register_dev.argtypes = [vp, vp, C.c_size_t, f64p, f64p, C.POINTER(Stats)]
+    L.so_icp_upload_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.so_icp_localization.argtypes = [vp, C.c_int, f64p, f32p, C.c_size_t, C.c_size_t, C.c_double, f64p, C.POINTER(Stats)]
+    L.so_icp_comm_unique_id.argtypes = [u8p]
+    L.so_icp_comm_init.argtypes = [vp, u8p]
+    L.so_icp_shard_owner_of_point.argtypes = [f32p, i32p, C.c_float, C.c_int]
+    L.so_icp_cells_per_cube.argtypes = [C.c_float, f64p]
+    L.so_icp_lm_begin.argtypes = [C.POINTER(LmState), f64p, C.POINTER(Sums), C.c_int, f64p]
+    L.so_icp_lm_feed.argtypes = [C.POINTER(LmState), C.POINTER(Sums), f64p]
+    L.so_icp_lm_result.argtypes = [C.POINTER(LmState), f64p, C.POINTER(IterStats)]
+    L.so_icp_get_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.so_icp_reset_timing.argtypes = [vp]
+    L.so_icp_synchronize.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def default_config(**kw):
+    cfg = Config()
+    load().so_icp_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class SoIcpError(RuntimeError):
+    pass
+
+
+class LidarSlamGpu:
+    """Host-side mirror of the reference's LidarSLAM object for this path: owns one so_icp_ctx
+    (= LidarSLAM::localMap + the ICP state), methods named after the reference members they replace."""
+
+    def __init__(self, **cfg_kw):
+        self.L = load()
+        self.cfg = default_config(**cfg_kw)
+        self.h = self.L.so_icp_create(C.byref(self.cfg))
+        if not self.h:
+            raise SoIcpError(self.L.so_icp_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.so_icp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise SoIcpError(f"so_icp error {rc}: {self.L.so_icp_last_error(self.h).decode()}")
+        return rc
+
+    # ---- LocalMap ----
+    def set_resolution(self, line_res, plane_res):
+        self._check(self.L.so_icp_set_resolution(self.h, line_res, plane_res))
+
+    def set_max_surface_features(self, n):
+        self._check(self.L.so_icp_set_max_surface_features(self.h, int(n)))
+
+    def set_max_iterations(self, n):
+        self._check(self.L.so_icp_set_max_iterations(self.h, int(n)))
+
+    def set_origin(self, t):
+        t = np.ascontiguousarray(t, dtype=np.float64); o = np.zeros(3, np.int32)
+        self._check(self.L.so_icp_map_set_origin(self.h, _p(t, C.c_double), _p(o, C.c_int32)))
+        return o
+
+    def origin(self):
+        o = np.zeros(3, np.int32); self._check(self.L.so_icp_map_get_origin(self.h, _p(o, C.c_int32))); return o
+
+    def shift_map(self, t):
+        t = np.ascontiguousarray(t, dtype=np.float64); o = np.zeros(3, np.int32)
+        self._check(self.L.so_icp_map_shift(self.h, _p(t, C.c_double), _p(o, C.c_int32)))
+        return o
+
+    def add_surf_point_cloud(self, xyz):
+        xyz = _f32(xyz).reshape(-1, 3)
+        return self._check(self.L.so_icp_map_add_surf(self.h, _p(xyz, C.c_float), len(xyz), 12))
+
+    def count_5x5(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.int32); ne = C.c_int32(); ns = C.c_int32()
+        self._check(self.L.so_icp_map_count_5x5(self.h, _p(pos, C.c_int32), C.byref(ne), C.byref(ns)))
+        return ns.value
+
+    def map_size(self, this_rank=False):
+        n = C.c_size_t(); nr = C.c_size_t()
+        self._check(self.L.so_icp_map_size(self.h, C.byref(n), C.byref(nr) if this_rank else None))
+        return (n.value, nr.value) if this_rank else n.value
+
+    def export_map(self, only_5x5=False, pos=None):
+        n = self.map_size(); out = np.zeros((max(n, 1), 3), np.float32); m = C.c_size_t()
+        posa = None if pos is None else np.ascontiguousarray(pos, dtype=np.int32)
+        self._check(self.L.so_icp_map_export(self.h, _p(out, C.c_float), n, C.byref(m), int(only_5x5),
+                                             None if posa is None else _p(posa, C.c_int32)))
+        return out[:m.value].copy()
+
+    def clear_map(self):
+        self._check(self.L.so_icp_map_clear(self.h))
+
+    # ---- Seam B ----
+    def nearest_k_search_surf(self, q, k=5, want_index=True):
+        q = _f32(q).reshape(-1, 3); nq = len(q)
+        nbr = np.zeros((nq, k, 3), np.float32); d2 = np.zeros((nq, k), np.float32)
+        idx = np.zeros((nq, k), np.int32); found = np.zeros(nq, np.uint8)
+        self._check(self.L.so_icp_knn_surf(self.h, _p(q, C.c_float), nq, k, _p(nbr, C.c_float), _p(d2, C.c_float),
+                                           _p(idx, C.c_int32) if want_index else None, _p(found, C.c_uint8)))
+        return found, nbr, d2, idx
+
+    # ---- Seam A ----
+    def register(self, scan, pose_in):
+        scan = _f32(scan).reshape(-1, 3); pose_in = np.ascontiguousarray(pose_in, dtype=np.float64)
+        out = np.zeros(7); st = Stats()
+        rc = self._check(self.L.so_icp_register(self.h, _p(scan, C.c_float), len(scan), 12, _p(pose_in, C.c_double),
+                                                _p(out, C.c_double), C.byref(st)))
+        return rc, out, st
+
+    def upload_scan(self, scan):
+        scan = _f32(scan).reshape(-1, 3); d = C.c_void_p()
+        self._check(self.L.so_icp_upload_scan(self.h, _p(scan, C.c_float), len(scan), 12, C.byref(d)))
+        return d.value, len(scan)
+
+    def register_dev(self, d_scan, n, pose_in, stats=None):
+        pose_in = np.ascontiguousarray(pose_in, dtype=np.float64); out = np.zeros(7)
+        st = stats if stats is not None else Stats()
+        rc = self._check(self.L.so_icp_register_dev(self.h, d_scan, n, _p(pose_in, C.c_double), _p(out, C.c_double), C.byref(st)))
+        return rc, out, st
+
+    def localization(self, initialization, T_w_lidar, planar_points, time_laser_odometry):
+        scan = _f32(planar_points).reshape(-1, 3); T = np.ascontiguousarray(T_w_lidar, dtype=np.float64)
+        out = np.zeros(7); st = Stats()
+        rc = self._check(self.L.so_icp_localization(self.h, int(bool(initialization)), _p(T, C.c_double), _p(scan, C.c_float),
+                                                    len(scan), 12, float(time_laser_odometry), _p(out, C.c_double), C.byref(st)))
+        return rc, out, st
+
+    # ---- multi-GPU ----
+    def comm_init(self, uid_bytes):
+        uid = np.frombuffer(bytes(uid_bytes), dtype=np.uint8).copy()
+        self._check(self.L.so_icp_comm_init(self.h, _p(uid, C.c_uint8)))
+
+    # ---- measurement ----
+    def timing(self):
+        t = Timing(); self._check(self.L.so_icp_get_timing(self.h, C.byref(t))); return t
+
+    def reset_timing(self):
+        self._check(self.L.so_icp_reset_timing(self.h))
+
+    def synchronize(self):
+        self._check(self.L.so_icp_synchronize(self.h))
+
+
+def comm_unique_id():
+    uid = np.zeros(UID_BYTES, np.uint8)
+    rc = load().so_icp_comm_unique_id(_p(uid, C.c_uint8))
+    if rc:
+        raise SoIcpError(f"so_icp_comm_unique_id: {load().so_icp_last_error(None).decode()}")
+    return uid.tobytes()
+
+
+def cells_per_cube(plane_res):
+    cell = C.c_double()
+    nc = load().so_icp_cells_per_cube(float(plane_res), C.byref(cell))
+    return nc, cell.value
+
+
+def shard_owner_of_point(p, origin, plane_res, world_size):
+    p = _f32(p); o = np.ascontiguousarray(origin, dtype=np.int32)
+    return load().so_icp_shard_owner_of_point(_p(p, C.c_float), _p(o, C.c_int32), float(plane_res), int(world_size))
+
+
+class LmDriver:
+    """so_icp_lm_* state machine (Ceres restatement) driven from Python -- used by CPU tests."""
+
+    def __init__(self):
+        self.L = load(); self.s = LmState()
+
+    @staticmethod
+    def sums(cost, count, Jtr, JtJ_full, hist=None):
+        s = Sums(); s.cost = cost; s.count = count
+        for i in range(6):
+            s.Jtr[i] = Jtr[i]
+        k = 0
+        for i in range(6):
+            for j in range(i, 6):
+                s.JtJ[k] = JtJ_full[i][j]; k += 1
+        if hist is not None:
+            for i in range(16):
+                s.hist[i] = hist[i]
+        return s
+
+    def begin(self, x0, sums, max_iterations=4):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64); nxt = np.zeros(7)
+        more = self.L.so_icp_lm_begin(C.byref(self.s), _p(x0, C.c_double), C.byref(sums), max_iterations, _p(nxt, C.c_double))
+        return more, nxt
+
+    def feed(self, sums):
+        nxt = np.zeros(7)
+        more = self.L.so_icp_lm_feed(C.byref(self.s), C.byref(sums), _p(nxt, C.c_double))
+        return more, nxt
+
+    def result(self):
+        pose = np.zeros(7); st = IterStats()
+        self.L.so_icp_lm_result(C.byref(self.s), _p(pose, C.c_double), C.byref(st))
+        return pose, st

@@ -1,0 +1,193 @@
+// lm_solver.h -- the trust-region Levenberg-Marquardt controller that drives the HIP evaluation
+// kernel.  It restates what the reference obtains from Ceres through
+//   LidarSLAM::solveOptimizationProblem   src/LidarProcess/LidarSlam.cpp:230-240
+//     (TRUST_REGION / LEVENBERG_MARQUARDT, max_num_iterations = 4, DENSE_QR, every other option default)
+// [UPSTREAM: ceres-solver 2.0.0 trust_region_minimizer.cc, levenberg_marquardt_strategy.cc,
+//  dense_qr_solver.cc, trust_region_step_evaluator.cc -- not under /root/reference].
+//
+// Design: the kernel returns, per evaluation point, the loss-corrected normal equations
+//   H = sum w_i J_i J_i^T,  g = sum w_i J_i r_i,  cost = 1/2 sum c_i rho(s_i)      (w_i = c_i rho'(s_i))
+// in one fused pass (Ceres evaluates "cost only" at the candidate and re-evaluates with Jacobians after
+// acceptance; both collapse into ONE fused evaluation here, so a solve costs 1 + (#iterations) passes).
+// Ceres factors the A x 6 Jacobian by QR; with fp64 sums the 6x6 Cholesky route agrees to ~1e-12.
+// The controller is a resumable state machine (begin -> [evaluate at next_pose -> feed]*), written
+// SO_HD so that the same source runs on the host today and inside a single-wave kernel later.
+#pragma once
+#include "so_math.h"
+
+namespace soicp {
+
+struct LmSums {      // == so_icp_sums (include/so_icp.h), 45 doubles
+  double cost, count;
+  double Jtr[6];
+  double JtJ[21];    // upper triangle, row-major
+  double hist[16];
+};
+
+struct LmState {
+  double x[7], cand[7];
+  double H[36], g[6];
+  double scale[6], diag[6];
+  double x_cost, x_norm, radius, decrease_factor, model_cost_change, initial_cost, count;
+  int32_t iter, max_iter, reuse_diagonal, invalid_steps, num_successful, termination, done, lm_iterations;
+};
+
+// Ceres defaults in effect (solver.h, ceres 2.0.0)
+struct LmConst {
+  static constexpr double kInitialRadius = 1e4, kMaxRadius = 1e16, kMinRadius = 1e-32;
+  static constexpr double kMinRelativeDecrease = 1e-3, kMinLmDiagonal = 1e-6, kMaxLmDiagonal = 1e32;
+  static constexpr double kFunctionTolerance = 1e-6, kGradientTolerance = 1e-10, kParameterTolerance = 1e-8;
+  static constexpr int kMaxConsecutiveInvalidSteps = 5;
+};
+
+SO_HD void lm_unpack(const LmSums& s, double H[36], double g[6]) {
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) { H[6 * i + j] = s.JtJ[k]; H[6 * j + i] = s.JtJ[k]; ++k; }
+  for (int i = 0; i < 6; ++i) g[i] = s.Jtr[i];
+}
+
+// | x - Plus(x, -g) |_inf : TrustRegionMinimizer::EvaluateGradientAndJacobian
+SO_HD double lm_gradient_max_norm(const double x[7], const double g[6]) {
+  double ng[6], xp[7], m = 0;
+  for (int i = 0; i < 6; ++i) ng[i] = -g[i];
+  pose_plus(x, ng, xp);
+  for (int i = 0; i < 7; ++i) { double v = fabs(x[i] - xp[i]); if (v > m) m = v; }
+  return m;
+}
+
+// Cholesky solve of a 6x6 SPD system; returns false when a pivot is not positive / result not finite.
+SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
+  for (int j = 0; j < 6; ++j) {
+    double d = A[6 * j + j];
+    for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
+    if (!(d > 0.0)) return false;
+    d = sqrt(d);
+    A[6 * j + j] = d;
+    for (int i = j + 1; i < 6; ++i) {
+      double s = A[6 * i + j];
+      for (int k = 0; k < j; ++k) s -= A[6 * i + k] * A[6 * j + k];
+      A[6 * i + j] = s / d;
+    }
+  }
+  double z[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= A[6 * i + k] * z[k];
+    z[i] = s / A[6 * i + i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < 6; ++k) s -= A[6 * k + i] * y[k];
+    y[i] = s / A[6 * i + i];
+  }
+  for (int i = 0; i < 6; ++i) if (!isfinite(y[i])) return false;
+  return true;
+}
+
+// One pass of the while(FinalizeIterationAndCheckIfMinimizerCanContinue()) loop up to the point
+// where the candidate must be evaluated.  Returns 1 (evaluate S.cand) or 0 (solver finished).
+SO_HD int lm_propose(LmState& S, double next_pose[7]) {
+  for (;;) {
+    if (S.iter >= S.max_iter) { S.termination = 0; S.done = 1; return 0; }           // MaxSolverIterationsReached
+    if (S.radius <= LmConst::kMinRadius) { S.termination = 5; S.done = 1; return 0; } // MinTrustRegionRadiusReached
+    S.iter++;
+    S.lm_iterations = S.iter;
+    // jacobian_ is column-scaled: Hs = S H S, gs = S g
+    if (!S.reuse_diagonal) {
+      for (int j = 0; j < 6; ++j) {
+        double v = S.H[7 * j] * S.scale[j] * S.scale[j];
+        v = v < LmConst::kMinLmDiagonal ? LmConst::kMinLmDiagonal : v;
+        S.diag[j] = v > LmConst::kMaxLmDiagonal ? LmConst::kMaxLmDiagonal : v;
+      }
+    }
+    double A[36], Hs[36], gs[6], y[6], step[6];
+    for (int i = 0; i < 6; ++i) {
+      gs[i] = S.g[i] * S.scale[i];
+      for (int j = 0; j < 6; ++j) { Hs[6 * i + j] = S.H[6 * i + j] * S.scale[i] * S.scale[j]; A[6 * i + j] = Hs[6 * i + j]; }
+      A[7 * i] += S.diag[i] / S.radius;  // lm_diagonal^2
+    }
+    const bool ok = lm_chol6(A, gs, y);  // (Hs + D^2) y = gs ; step = -y
+    S.reuse_diagonal = 1;
+    double mcc = 0;
+    if (ok) {
+      double sHs = 0, sg = 0;
+      for (int i = 0; i < 6; ++i) {
+        step[i] = -y[i];
+        sg += step[i] * gs[i];
+      }
+      for (int i = 0; i < 6; ++i) {
+        double r = 0;
+        for (int j = 0; j < 6; ++j) r += Hs[6 * i + j] * step[j];
+        sHs += step[i] * r;
+      }
+      mcc = -sg - 0.5 * sHs;  // -(J s)^T (r + J s / 2)
+    }
+    if (!ok || !(mcc > 0.0)) {  // HandleInvalidStep
+      if (++S.invalid_steps >= LmConst::kMaxConsecutiveInvalidSteps) { S.termination = 5; S.done = 1; return 0; }
+      S.radius *= 0.5;
+      continue;
+    }
+    S.invalid_steps = 0;
+    S.model_cost_change = mcc;
+    double delta[6];
+    for (int i = 0; i < 6; ++i) delta[i] = step[i] * S.scale[i];
+    pose_plus(S.x, delta, S.cand);
+    for (int i = 0; i < 7; ++i) next_pose[i] = S.cand[i];
+    return 1;
+  }
+}
+
+SO_HD int lm_begin(LmState& S, const double x0[7], const LmSums& sums, int max_iterations, double next_pose[7]) {
+  for (int i = 0; i < 7; ++i) { S.x[i] = x0[i]; S.cand[i] = x0[i]; }
+  S.iter = 0; S.max_iter = max_iterations; S.reuse_diagonal = 0; S.invalid_steps = 0; S.num_successful = 0;
+  S.termination = 0; S.done = 0; S.lm_iterations = 0;
+  S.radius = LmConst::kInitialRadius; S.decrease_factor = 2.0; S.model_cost_change = 0;
+  S.count = sums.count; S.x_cost = sums.cost; S.initial_cost = sums.cost;
+  lm_unpack(sums, S.H, S.g);
+  for (int j = 0; j < 6; ++j) { S.scale[j] = 1.0; S.diag[j] = 0; }
+  if (!(sums.count > 0)) { S.termination = 4; S.done = 1; return 0; }  // no residual blocks: nothing to minimise
+  for (int j = 0; j < 6; ++j) S.scale[j] = 1.0 / (1.0 + sqrt(S.H[7 * j]));  // jacobi_scaling, fixed at iteration 0
+  double n2 = 0;
+  for (int i = 0; i < 7; ++i) n2 += S.x[i] * S.x[i];
+  S.x_norm = sqrt(n2);
+  if (lm_gradient_max_norm(S.x, S.g) <= LmConst::kGradientTolerance) { S.termination = 3; S.done = 1; return 0; }
+  return lm_propose(S, next_pose);
+}
+
+SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7]) {
+  if (S.done) return 0;
+  const double cand_cost = sums.cost;
+  // ParameterToleranceReached
+  double sn = 0;
+  for (int i = 0; i < 7; ++i) sn += (S.x[i] - S.cand[i]) * (S.x[i] - S.cand[i]);
+  sn = sqrt(sn);
+  if (sn <= LmConst::kParameterTolerance * (S.x_norm + LmConst::kParameterTolerance)) { S.termination = 2; S.done = 1; return 0; }
+  // FunctionToleranceReached
+  const double cost_change = S.x_cost - cand_cost;
+  if (fabs(cost_change) <= LmConst::kFunctionTolerance * S.x_cost) { S.termination = 1; S.done = 1; return 0; }
+  const double rel = cost_change / S.model_cost_change;  // TrustRegionStepEvaluator::StepQuality, monotonic
+  if (rel > LmConst::kMinRelativeDecrease) {             // HandleSuccessfulStep
+    for (int i = 0; i < 7; ++i) S.x[i] = S.cand[i];
+    double n2 = 0;
+    for (int i = 0; i < 7; ++i) n2 += S.x[i] * S.x[i];
+    S.x_norm = sqrt(n2);
+    S.x_cost = cand_cost;
+    lm_unpack(sums, S.H, S.g);
+    S.num_successful++;
+    double f = 1.0 - pow(2.0 * rel - 1.0, 3);  // LevenbergMarquardtStrategy::StepAccepted
+    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+    S.radius = S.radius / f;
+    if (S.radius > LmConst::kMaxRadius) S.radius = LmConst::kMaxRadius;
+    S.decrease_factor = 2.0;
+    S.reuse_diagonal = 0;
+    if (lm_gradient_max_norm(S.x, S.g) <= LmConst::kGradientTolerance) { S.termination = 3; S.done = 1; return 0; }
+  } else {  // HandleUnsuccessfulStep / StepRejected
+    S.radius = S.radius / S.decrease_factor;
+    S.decrease_factor *= 2.0;
+    S.reuse_diagonal = 1;
+  }
+  return lm_propose(S, next_pose);
+}
+
+}  // namespace soicp

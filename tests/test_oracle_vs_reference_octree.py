@@ -1,0 +1,109 @@
+"""PIN of the oracle's k-NN stage against the REFERENCE's own engine: nanoflann::Octree from
+/root/reference/super_odometry/include/super_odometry/flann/octree.h, compiled verbatim into
+oracle/_ref/libref_octree.so (oracle/Makefile).  Skipped only if that .so is absent (it is built
+whenever /root/reference exists and travels with the gpurun snapshot).
+
+What is pinned:
+  * L2Distance arithmetic (octree.h:93-102): d2 returned by the reference == oracle d2, bit for bit;
+  * result ordering / KNNResult semantics (nanoflann.h:117-147);
+  * equality of the complete neighbour lists on a scene where the stock octree's two pruning bugs
+    (octree.h:384-385 bounding box, octree.h:988-990 `inside`) are inert;
+  * on the SURVEY probe scene the stock octree is NOT exact (the documented 15-36 % mismatch) while
+    never beating the exact oracle -- i.e. the oracle is the DONT_USE_SELF_OCTREE semantics."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import noisy_planes_cloud
+
+REF_SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_octree.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libref_octree.so not built (needs /root/reference)")
+
+
+def _oracle_knn_single_cube(oracle, pts, q, use_grid):
+    """All points inside one cube: put the map origin so that the cloud's cube is the centre block."""
+    m = oracle.OracleMap(plane_res=0.2)
+    m.set_origin(pts.mean(0).astype(np.float64))
+    n = m.add_surf(pts, raw=True)
+    assert n == len(pts)
+    found, nbr, d2, idx, cube = m.knn(q, 5, use_grid=use_grid)
+    return found, nbr, d2, idx, cube
+
+
+def test_bug_neutral_scene_identical_lists(oracle):
+    # x-range dominates (root cube covers the cloud despite the bbox bug) and |q.x - centre.y|, |q.x - centre.z|
+    # are huge (the buggy `inside` never returns true) -> the stock octree degenerates to an exact search.
+    rng = np.random.default_rng(7)
+    n = 20000
+    pts = np.c_[1000.0 + rng.random(n) * 20.0, rng.random(n) * 6.0 - 3.0, rng.random(n) * 6.0 - 3.0].astype(np.float32)
+    q = (pts[rng.integers(0, n, 3000)] + rng.normal(0, 0.05, (3000, 3))).astype(np.float32)
+    ref = oracle.RefOctree(pts)
+    ridx, rd2 = ref.knn(q, 5)
+    found, nbr, d2, idx, cube = _oracle_knn_single_cube(oracle, pts, q, use_grid=0)
+    assert found.all() and len(set(cube.tolist())) == 1
+    assert np.array_equal(rd2.view(np.uint32), d2.view(np.uint32)), "d2 must be bit-identical to octree.h L2Distance"
+    same = (ridx == idx).all(1)
+    # rows may differ only by the order of exactly tied distances
+    for r in np.nonzero(~same)[0]:
+        assert sorted(ridx[r].tolist()) == sorted(idx[r].tolist()) or np.unique(d2[r]).size < 5
+    assert same.mean() > 0.999
+    assert np.array_equal(nbr, pts[idx])
+
+
+def test_distance_arithmetic_on_reference_results(oracle):
+    # general scene: whatever neighbours the (buggy) reference returns, its d2 for them must equal the
+    # oracle's distance function bit for bit, and the lists must be ascending.
+    rng = np.random.default_rng(3)
+    pts = noisy_planes_cloud(50000, rng)
+    q = (pts[rng.integers(0, len(pts), 5000)] + np.array([0.05, 0.05, 0.03])).astype(np.float32)
+    ref = oracle.RefOctree(pts)
+    ridx, rd2 = ref.knn(q, 5)
+    diff = q[:, None, :] - pts[ridx]  # float32 differences
+    want = (diff.astype(np.float64) ** 2).sum(-1).astype(np.float32)
+    # sum order in octree.h: (dx^2 + dy^2) + dz^2 in double
+    d = diff.astype(np.float64)
+    want = ((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(np.float32)
+    assert np.array_equal(want.view(np.uint32), rd2.view(np.uint32))
+    assert (np.diff(rd2, axis=1) >= 0).all()
+
+
+@pytest.mark.parametrize("offset,lo,hi", [((0.0, 0.0, 0.0), 0.05, 0.30), ((100.0, 30.0, 0.0), 0.001, 0.60)])
+def test_stock_octree_is_inexact_oracle_is_optimal(oracle, offset, lo, hi):
+    rng = np.random.default_rng(11)
+    pts = noisy_planes_cloud(50000, rng, offset=offset)
+    q = (pts[rng.integers(0, len(pts), 20000)] + np.array([0.05, 0.05, 0.03])).astype(np.float32)
+    ref = oracle.RefOctree(pts)
+    ridx, rd2 = ref.knn(q, 5)
+    m = oracle.OracleMap(plane_res=0.2)
+    m.set_origin(np.array(offset, float))
+    m.add_surf(pts, raw=True)
+    # the offset scene straddles several cubes: compare per-query only where the whole 5-NN stays inside one cube
+    found, nbr, d2, idx, cube = m.knn(q, 5, use_grid=1)
+    if offset == (0.0, 0.0, 0.0):
+        assert found.all() and len(set(cube.tolist())) == 1
+        # exact oracle is never worse than the stock octree, element-wise
+        assert (d2 <= rd2 + 0).all()
+        mismatch = (np.abs(d2 - rd2) > 1e-7).any(1).mean()
+        assert lo < mismatch < hi, f"stock octree mismatch rate {mismatch:.3f} outside the documented band"
+    else:
+        # brute force over ALL points is what the reference octree approximates here (single tree, no cubes)
+        sample = rng.integers(0, len(q), 1500)
+        mism = 0
+        for i in sample:
+            diff = (q[i] - pts).astype(np.float32).astype(np.float64)
+            dd = ((diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]).astype(np.float32)
+            best = np.sort(dd)[:5]
+            assert (best <= rd2[i]).all()
+            mism += bool((np.abs(best - rd2[i]) > 1e-7).any())
+        rate = mism / len(sample)
+        assert lo < rate < hi, f"stock octree mismatch rate {rate:.3f} outside the documented band"
+
+
+def test_grid_search_equals_brute_force_against_reference_scene(oracle):
+    rng = np.random.default_rng(5)
+    pts = noisy_planes_cloud(30000, rng)
+    q = (pts[rng.integers(0, len(pts), 2000)] + rng.normal(0, 0.2, (2000, 3))).astype(np.float32)
+    a = _oracle_knn_single_cube(oracle, pts, q, use_grid=0)
+    b = _oracle_knn_single_cube(oracle, pts, q, use_grid=1)
+    assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)) and np.array_equal(a[3], b[3])
