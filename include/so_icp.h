@@ -169,8 +169,10 @@ int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t str
 /* same, scan already resident in HBM as packed float xyz (n*3 floats, device pointer) */
 int so_icp_register_dev(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n,
                         const double pose_in[7], double pose_out[7], so_icp_stats *stats);
-/* upload a scan once and keep it resident (returns a device pointer owned by the context) */
+/* upload a scan once and keep it resident in HBM (device pointer owned by the context until
+ * so_icp_free_scan / so_icp_destroy) */
 int so_icp_upload_scan(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes, void **d_scan_out);
+int so_icp_free_scan(so_icp_ctx *ctx, void *d_scan);
 
 /* LidarSLAM::Localization (LS.cpp:30-51): initialization==0 seeds the map (LS.cpp:83-94) and returns
  * SO_ICP_MAP_SEEDED; otherwise registers, applies the post-processing and inserts the scan

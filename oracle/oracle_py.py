@@ -85,8 +85,17 @@ def lib():
     L.orc_yaw_correction.argtypes = [f64p, f64p, C.c_double]
     L.orc_register.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, C.POINTER(Config), i32p, f64p, C.POINTER(Stats), vp]
     L.orc_transform_and_add.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p]
+    L.orc_set_num_threads.argtypes = [C.c_int]
     _lib = L
     return L
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def num_threads():
+    return lib().orc_num_threads()
 
 
 def _f32(a):

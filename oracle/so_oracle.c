@@ -977,6 +977,14 @@ int orc_transform_and_add(orc_map *m, const float *scan, size_t n, size_t stride
   return r;
 }
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -162,6 +162,7 @@ int orc_register(orc_map *m, const float *scan_xyz, size_t n, size_t stride_floa
 int orc_transform_and_add(orc_map *m, const float *scan_xyz, size_t n, size_t stride_floats, const double pose[7]);
 
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -59,7 +59,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_device_available", "so_icp_set_resolution", "so_icp_set_max_surface_features", "so_icp_set_max_iterations",
             "so_icp_map_set_origin", "so_icp_map_shift", "so_icp_map_add_surf", "so_icp_map_count_5x5", "so_icp_map_export",
             "so_icp_map_size", "so_icp_map_clear", "so_icp_map_get_origin", "so_icp_knn_surf", "so_icp_register",
-            "so_icp_register_dev", "so_icp_upload_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
+            "so_icp_register_dev", "so_icp_upload_scan", "so_icp_free_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_synchronize"]
 
@@ -96,6 +96,7 @@ def load():
     L.so_icp_register.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, f64p, C.POINTER(Stats)]
     L.so_icp_register_dev.argtypes = [vp, vp, C.c_size_t, f64p, f64p, C.POINTER(Stats)]
     L.so_icp_upload_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.so_icp_free_scan.argtypes = [vp, vp]
     L.so_icp_localization.argtypes = [vp, C.c_int, f64p, f32p, C.c_size_t, C.c_size_t, C.c_double, f64p, C.POINTER(Stats)]
     L.so_icp_comm_unique_id.argtypes = [u8p]
     L.so_icp_comm_init.argtypes = [vp, u8p]
@@ -226,6 +227,9 @@ class LidarSlamGpu:
         scan = _f32(scan).reshape(-1, 3); d = C.c_void_p()
         self._check(self.L.so_icp_upload_scan(self.h, _p(scan, C.c_float), len(scan), 12, C.byref(d)))
         return d.value, len(scan)
+
+    def free_scan(self, d_scan):
+        self._check(self.L.so_icp_free_scan(self.h, d_scan))
 
     def register_dev(self, d_scan, n, pose_in, stats=None):
         pose_in = np.ascontiguousarray(pose_in, dtype=np.float64); out = np.zeros(7)

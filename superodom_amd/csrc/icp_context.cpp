@@ -95,6 +95,7 @@ struct so_icp_ctx {
   int32_t* d_hist = nullptr; uint32_t* d_ticket = nullptr; uint32_t* d_nkept = nullptr; uint32_t* d_fbcount = nullptr;
   LmSums* d_sums = nullptr; double* d_partials = nullptr;
   LmSums* h_sums = nullptr; uint32_t* h_u32 = nullptr;  // pinned
+  std::vector<DevBuf> resident_scans;  // so_icp_upload_scan
   // Seam B scratch
   DevBuf d_q, d_nbr, d_d2, d_idx, d_found, d_fblist;
   // persistent LidarSLAM state
@@ -393,6 +394,7 @@ so_icp_ctx::~so_icp_ctx() {
                     &d_sort_tmp, &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist})
     b->release();
+  for (DevBuf& b : resident_scans) b.release();
   if (h_sums) (void)hipHostFree(h_sums);
   if (h_u32) (void)hipHostFree(h_u32);
   for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -565,10 +567,25 @@ int so_icp_upload_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_
   if (!c || (!xyz && n) || !d_out) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);
   HIP_TRY(c, hipSetDevice(c->cfg.device_id));
-  const int rc = upload_scan_impl(c, xyz, n, stride_bytes, c->d_scan_own);
-  if (rc) return rc;
-  *d_out = c->d_scan_own.p;
+  DevBuf b;
+  const int rc = upload_scan_impl(c, xyz, n, stride_bytes, b);
+  if (rc) { b.release(); return rc; }
+  c->resident_scans.push_back(b);
+  *d_out = b.p;
   return SO_ICP_OK;
+}
+
+int so_icp_free_scan(so_icp_ctx* c, void* d_scan) {
+  if (!c) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  for (size_t i = 0; i < c->resident_scans.size(); ++i)
+    if (c->resident_scans[i].p == d_scan) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      c->resident_scans[i].release();
+      c->resident_scans.erase(c->resident_scans.begin() + i);
+      return SO_ICP_OK;
+    }
+  return fail(c, SO_ICP_E_INVALID, "so_icp_free_scan: unknown scan pointer");
 }
 
 int so_icp_register_dev(so_icp_ctx* c, const void* d_scan, size_t n, const double pose_in[7], double pose_out[7], so_icp_stats* st) {

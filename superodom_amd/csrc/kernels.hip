@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
       key = (rank == 0) ? kKeyNoCube : kKeyDropped;  // counted once (NOT_ENOUGH_NEIGHBORS) by rank 0
     } else {
       int owner = 0;
-      if (world > 1) owner = (int)(brick_hash(w[0], w[1], w[2], c.cx / 8, c.cy / 8, c.cz / 8) % (uint32_t)world);
+      if (world > 1) owner = (int)(brick_hash(w[0], w[1], w[2], c.cx / kBrickCells, c.cy / kBrickCells, c.cz / kBrickCells) % (uint32_t)world);
       if (owner == rank) key = ((uint32_t)c.slot << 18) | morton3((uint32_t)c.cx, (uint32_t)c.cy, (uint32_t)c.cz);
     }
   }

@@ -25,7 +25,7 @@ int cells_per_cube(float plane_res, double* cell_size) {
 
 int shard_owner_of_cell(int wx, int wy, int wz, int cx, int cy, int cz, int world_size) {
   if (world_size <= 1) return 0;
-  return (int)(brick_hash(wx, wy, wz, cx / kBrick, cy / kBrick, cz / kBrick) % (uint32_t)world_size);
+  return (int)(brick_hash(wx, wy, wz, cx / kBrickCells, cy / kBrickCells, cz / kBrickCells) % (uint32_t)world_size);
 }
 
 LocalMap::LocalMap() {
@@ -220,11 +220,11 @@ void LocalMap::build_canonical(int rank, int world, CanonicalMap& out) const {
         // needed by `rank` iff some cell of the 3x3x3 neighbourhood lies in a brick owned by it
         bool need = false;
         int lo[3], hi[3];
-        for (int a = 0; a < 3; ++a) { lo[a] = std::max(g[a] - 1, 0) / kBrick; hi[a] = std::min(g[a] + 1, nc - 1) / kBrick; }
+        for (int a = 0; a < 3; ++a) { lo[a] = std::max(g[a] - 1, 0) / kBrickCells; hi[a] = std::min(g[a] + 1, nc - 1) / kBrickCells; }
         for (int bz = lo[2]; bz <= hi[2] && !need; ++bz)
           for (int by = lo[1]; by <= hi[1] && !need; ++by)
             for (int bx = lo[0]; bx <= hi[0] && !need; ++bx)
-              need = shard_owner_of_cell(w[0], w[1], w[2], bx * kBrick, by * kBrick, bz * kBrick, world) == rank;
+              need = shard_owner_of_cell(w[0], w[1], w[2], bx * kBrickCells, by * kBrickCells, bz * kBrickCells, world) == rank;
         keep[i] = need;
       }
       if (keep[i]) counts[cellid[i] + 1]++;

@@ -21,7 +21,6 @@ namespace soicp {
 
 constexpr int kMapW = 21, kMapH = 21, kMapD = 11, kMapNum = kMapW * kMapH * kMapD;  // LocalMap.h:131-135
 constexpr double kCube = 50.0, kHalfCube = 25.0;                                     // LocalMap.h:137-138
-constexpr int kBrick = 8;  // cells per brick edge (shard ownership granule)
 
 struct CanonicalMap {
   int nc = 1;             // cells per cube edge

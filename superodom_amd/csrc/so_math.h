@@ -90,7 +90,12 @@ SO_HD uint32_t part1by2(uint32_t x) {
 }
 SO_HD uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) { return part1by2(x) | (part1by2(y) << 1) | (part1by2(z) << 2); }
 
-// brick (8x8x8 cells) ownership hash over WORLD cube ids, stable under LocalMap::shiftMap.
+// Shard ownership granule: a brick of kBrickCells^3 cells.  Hash over WORLD cube ids + brick coordinates,
+// stable under LocalMap::shiftMap.
+#ifndef SO_BRICK_CELLS
+#define SO_BRICK_CELLS 4
+#endif
+constexpr int kBrickCells = SO_BRICK_CELLS;
 SO_HD uint32_t brick_hash(int wx, int wy, int wz, int bx, int by, int bz) {
   uint32_t h = 2166136261u;
   const uint32_t v[6] = {(uint32_t)wx, (uint32_t)wy, (uint32_t)wz, (uint32_t)bx, (uint32_t)by, (uint32_t)bz};

@@ -25,6 +25,7 @@ def _oracle_knn_single_cube(oracle, pts, q, use_grid):
     """All points inside one cube: put the map origin so that the cloud's cube is the centre block."""
     m = oracle.OracleMap(plane_res=0.2)
     m.set_origin(pts.mean(0).astype(np.float64))
+    m.shift(pts.mean(0).astype(np.float64))  # sensor block to index >= 3 so that the neighbouring blocks exist
     n = m.add_surf(pts, raw=True)
     assert n == len(pts)
     found, nbr, d2, idx, cube = m.knn(q, 5, use_grid=use_grid)
@@ -76,7 +77,6 @@ def test_stock_octree_is_inexact_oracle_is_optimal(oracle, offset, lo, hi):
     ref = oracle.RefOctree(pts)
     ridx, rd2 = ref.knn(q, 5)
     m = oracle.OracleMap(plane_res=0.2)
-    m.set_origin(np.array(offset, float))
     m.add_surf(pts, raw=True)
     # the offset scene straddles several cubes: compare per-query only where the whole 5-NN stays inside one cube
     found, nbr, d2, idx, cube = m.knn(q, 5, use_grid=1)
