@@ -153,7 +153,10 @@ def main():
         "kernels": {"knn_plane_ms_per_step": tm.knn_ms_total / args.steps, "eval_ms_per_step": tm.eval_ms_total / args.steps,
                     "prep_sort_ms_per_step": tm.prep_ms_total / args.steps,
                     "eval_avg_launch_ms": eval_ms, "eval_launches_per_step": tm.eval_launches / args.steps,
-                    "eval_achieved_GBs": (b_eval / (eval_ms * 1e-3) / 1e9) if eval_ms > 0 else 0.0},
+                    "eval_achieved_GBs": (b_eval / (eval_ms * 1e-3) / 1e9) if eval_ms > 0 else 0.0,
+                    "knn_group_passes_per_wave": tm.knn_group_passes / max(tm.knn_queries / 64.0, 1.0),
+                    "knn_fallback_lane_frac": tm.knn_fallback_lanes / max(tm.knn_queries, 1),
+                    "knn_candidates_per_group_pass": tm.knn_candidates_scanned / max(tm.knn_group_passes, 1)},
     }
 
     # ---- CPU baseline: the oracle (restatement of the reference CPU path), same scans, bounded sample

@@ -122,6 +122,9 @@ typedef struct {
   double eval_ms_total;  int64_t eval_launches;  int64_t eval_points;
   double prep_ms_total;  int64_t prep_launches;
   double host_ms_total;  int64_t registrations;
+  /* k-NN kernel statistics (time_kernels only): wave group passes, lanes sent to the exact per-lane scan,
+   * wave-uniform candidates streamed */
+  int64_t knn_group_passes, knn_fallback_lanes, knn_candidates_scanned;
 } so_icp_timing;
 
 /* -------- lifecycle ------------------------------------------------------------------------ */

@@ -44,7 +44,8 @@ class Timing(C.Structure):
     _fields_ = [("knn_ms_total", C.c_double), ("knn_launches", C.c_int64), ("knn_queries", C.c_int64), ("knn_map_points", C.c_int64),
                 ("eval_ms_total", C.c_double), ("eval_launches", C.c_int64), ("eval_points", C.c_int64),
                 ("prep_ms_total", C.c_double), ("prep_launches", C.c_int64),
-                ("host_ms_total", C.c_double), ("registrations", C.c_int64)]
+                ("host_ms_total", C.c_double), ("registrations", C.c_int64),
+                ("knn_group_passes", C.c_int64), ("knn_fallback_lanes", C.c_int64), ("knn_candidates_scanned", C.c_int64)]
 
 
 class Sums(C.Structure):

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -87,10 +88,10 @@ struct so_icp_ctx {
   uint64_t uploaded_version = 0;
   hipStream_t stream = nullptr;
   // map shard in HBM
-  DevBuf d_mx, d_my, d_mz, d_cell_start, d_cube_slot;
+  DevBuf d_mpts, d_cell_start, d_cube_slot;
   DevMapView view{};
   // scan / correspondence buffers
-  DevBuf d_scan_own, d_keys0, d_keys1, d_vals0, d_vals1, d_sort_tmp, d_spx, d_spy, d_spz, d_nd, d_coeff, d_status;
+  DevBuf d_scan_own, d_keys0, d_keys1, d_vals0, d_vals1, d_chunks, d_sort_tmp, d_spx, d_spy, d_spz, d_nd, d_coeff, d_status;
   DevBuf d_small;  // hist[16] int32 | ticket | n_kept | fb_count | LmSums | partials
   int32_t* d_hist = nullptr; uint32_t* d_ticket = nullptr; uint32_t* d_nkept = nullptr; uint32_t* d_fbcount = nullptr;
   LmSums* d_sums = nullptr; double* d_partials = nullptr;
@@ -166,21 +167,19 @@ int upload_map(so_icp_ctx* c) {
   if (c->uploaded_version == c->map.version()) return SO_ICP_OK;
   c->map.build_canonical(c->cfg.rank, c->cfg.world_size, c->cm);
   const CanonicalMap& m = c->cm;
-  const size_t n = m.x.size();
-  HIP_TRY(c, c->d_mx.reserve((n + 64) * 4)); HIP_TRY(c, c->d_my.reserve((n + 64) * 4)); HIP_TRY(c, c->d_mz.reserve((n + 64) * 4));
+  const size_t n = m.n_points();
+  HIP_TRY(c, c->d_mpts.reserve((n + 16) * 16));
   HIP_TRY(c, c->d_cell_start.reserve((m.cell_start.size() + 1) * 4));
   HIP_TRY(c, c->d_cube_slot.reserve(kMapNum * 4));
   if (n) {
-    HIP_TRY(c, hipMemcpyAsync(c->d_mx.p, m.x.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_my.p, m.y.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_mz.p, m.z.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_mpts.p, m.xyzw.data(), n * 16, hipMemcpyHostToDevice, c->stream));
   }
   if (!m.cell_start.empty())
     HIP_TRY(c, hipMemcpyAsync(c->d_cell_start.p, m.cell_start.data(), m.cell_start.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_cube_slot.p, m.cube_slot.data(), kMapNum * 4, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be rebuilt right after
   DevMapView& v = c->view;
-  v.x = c->d_mx.as<float>(); v.y = c->d_my.as<float>(); v.z = c->d_mz.as<float>();
+  v.pts = c->d_mpts.as<float4>();
   v.cell_start = c->d_cell_start.as<uint32_t>(); v.cube_slot = c->d_cube_slot.as<int32_t>();
   v.nc = m.nc; v.ncell1 = (uint32_t)((size_t)m.nc * m.nc * m.nc + 1); v.inv_cell = 1.0 / m.cell;
   v.origin[0] = c->map.origin()[0]; v.origin[1] = c->map.origin()[1]; v.origin[2] = c->map.origin()[2];
@@ -192,7 +191,7 @@ int upload_map(so_icp_ctx* c) {
 int reserve_scan_buffers(so_icp_ctx* c, size_t n) {
   const size_t m = n + 256;
   HIP_TRY(c, c->d_keys0.reserve(m * 4)); HIP_TRY(c, c->d_keys1.reserve(m * 4));
-  HIP_TRY(c, c->d_vals0.reserve(m * 4)); HIP_TRY(c, c->d_vals1.reserve(m * 4));
+  HIP_TRY(c, c->d_vals0.reserve(m * 4)); HIP_TRY(c, c->d_vals1.reserve(m * 4)); HIP_TRY(c, c->d_chunks.reserve(m * 4));
   HIP_TRY(c, c->d_sort_tmp.reserve(sort_temp_bytes(m) + 256));
   HIP_TRY(c, c->d_spx.reserve(m * 4)); HIP_TRY(c, c->d_spy.reserve(m * 4)); HIP_TRY(c, c->d_spz.reserve(m * 4));
   HIP_TRY(c, c->d_nd.reserve(m * 32)); HIP_TRY(c, c->d_coeff.reserve(m * 8)); HIP_TRY(c, c->d_status.reserve(m));
@@ -204,6 +203,8 @@ MatchParams match_params(float plane_res) {
   mp.plane_res = plane_res;
   mp.sq_max_dist_f = 3 * plane_res;           // float product (LidarSlam.cpp:526)
   mp.max_point_dist = (double)plane_res / 2.0; // LidarSlam.cpp:820
+  static const int ablate = std::getenv("SOICP_ABLATE") ? std::atoi(std::getenv("SOICP_ABLATE")) : 0;
+  mp.ablate = ablate;
   return mp;
 }
 EvalParams eval_params(float plane_res, int variant) {
@@ -294,10 +295,11 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   const auto t_icp = std::chrono::steady_clock::now();  // TicToc t_opt, LidarSlam.cpp:118
 
   // ---- once per registration: sampling, spatial sort (locality survives the small pose updates) ----
-  uint32_t n_kept = 0;
+  uint32_t n_kept = 0, n_chunks = 0;
+  if (c->cfg.time_kernels) HIP_TRY(c, hipMemsetAsync(c->d_hist + 16, 0, 4 * sizeof(int32_t), c->stream));
   if (n) {
     span_begin(c, 2, (uint32_t)n);
-    HIP_TRY(c, hipMemsetAsync(c->d_nkept, 0, 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_nkept, 0, 8, c->stream));  // n_kept, n_chunks
     launch_scan_keys(d_scan, (uint32_t)n, pose_from_array(T), c->view, c->cfg.max_surface_features, c->cfg.rank,
                      c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_nkept, c->stream);
     launch_sort_pairs(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->d_keys0.as<uint32_t>(), c->d_keys1.as<uint32_t>(),
@@ -305,7 +307,11 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     HIP_TRY(c, hipMemcpyAsync(c->h_u32, c->d_nkept, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     n_kept = c->h_u32[0];
+    launch_chunk_heads(c->d_keys1.as<uint32_t>(), n_kept, c->d_chunks.as<uint32_t>(), c->d_nkept + 1, c->stream);
+    HIP_TRY(c, hipMemcpyAsync(c->h_u32 + 1, c->d_nkept + 1, 4, hipMemcpyDeviceToHost, c->stream));
     launch_gather_scan(d_scan, c->d_vals1.as<uint32_t>(), n_kept, c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->stream);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    n_chunks = c->h_u32[1];
     span_end(c);
   }
 
@@ -322,7 +328,8 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     // processPlannerFeatures: every (kept) query in parallel (LidarSlam.cpp:323-344)
     HIP_TRY(c, hipMemsetAsync(c->d_hist, 0, 16 * sizeof(int32_t), c->stream));  // ResetDistanceParameters, :847-852
     span_begin(c, 0, n_kept);
-    launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), n_kept, pose_from_array(T), c->view, mp, corr, c->d_hist, c->stream);
+    launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), n_kept, c->d_keys1.as<uint32_t>(), c->d_chunks.as<uint32_t>(),
+                     n_chunks, pose_from_array(T), c->view, mp, corr, c->d_hist, c->stream);
     span_end(c);
     // setupOptimizationProblem + solveOptimizationProblem (LidarSlam.cpp:213-240)
     double prev[7];
@@ -362,7 +369,13 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   relative_motion(T_last, T, st->translation_from_last, st->rotation_from_last);
   st->prediction_source = 0;
   std::memcpy(pose_out, T, sizeof(T));
-  if (c->cfg.time_kernels) spans_collect(c);
+  if (c->cfg.time_kernels) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_u32 + 4, c->d_hist + 16, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->timing.knn_group_passes += c->h_u32[4]; c->timing.knn_fallback_lanes += c->h_u32[5];
+    c->timing.knn_candidates_scanned += (int64_t)c->h_u32[6] * 16;
+    spans_collect(c);
+  }
   c->timing.registrations++;
   c->timing.host_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return SO_ICP_OK;
@@ -390,7 +403,7 @@ int upload_scan_impl(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_by
 
 so_icp_ctx::~so_icp_ctx() {
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
-  for (DevBuf* b : {&d_mx, &d_my, &d_mz, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1,
+  for (DevBuf* b : {&d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1, &d_chunks,
                     &d_sort_tmp, &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist})
     b->release();
@@ -457,16 +470,16 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   c->map.set_resolution(cfg->line_res, cfg->plane_res);
   auto bail = [&](const std::string& m) { g_create_error = m; delete c; return (so_icp_ctx*)nullptr; };
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(std::string("hipStreamCreate: ") + hipGetErrorString(e));
-  const size_t small_bytes = 256 + sizeof(LmSums) + 256 + (size_t)kEvalBlocks * kSumsStride * sizeof(double);
+  const size_t small_bytes = 512 + sizeof(LmSums) + 256 + (size_t)kEvalBlocks * kSumsStride * sizeof(double);
   if ((e = c->d_small.reserve(small_bytes)) != hipSuccess) return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
   if ((e = hipMemset(c->d_small.p, 0, c->d_small.cap)) != hipSuccess) return bail(std::string("hipMemset: ") + hipGetErrorString(e));
   char* base = c->d_small.as<char>();
-  c->d_hist = reinterpret_cast<int32_t*>(base);            // 64 B
-  c->d_ticket = reinterpret_cast<uint32_t*>(base + 64);
-  c->d_nkept = reinterpret_cast<uint32_t*>(base + 128);
-  c->d_fbcount = reinterpret_cast<uint32_t*>(base + 192);
-  c->d_sums = reinterpret_cast<LmSums*>(base + 256);
-  c->d_partials = reinterpret_cast<double*>(base + 256 + ((sizeof(LmSums) + 255) / 256) * 256);
+  c->d_hist = reinterpret_cast<int32_t*>(base);            // 16 histogram bins + 4 kernel statistics (128 B reserved)
+  c->d_ticket = reinterpret_cast<uint32_t*>(base + 128);
+  c->d_nkept = reinterpret_cast<uint32_t*>(base + 192);
+  c->d_fbcount = reinterpret_cast<uint32_t*>(base + 256);
+  c->d_sums = reinterpret_cast<LmSums*>(base + 512);
+  c->d_partials = reinterpret_cast<double*>(base + 512 + ((sizeof(LmSums) + 255) / 256) * 256);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), sizeof(LmSums))) != hipSuccess) return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_u32), 64)) != hipSuccess) return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   return c;

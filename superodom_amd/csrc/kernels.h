@@ -12,9 +12,7 @@ namespace soicp {
 
 // read-only view of the HBM-resident map shard (layout: local_map.h)
 struct DevMapView {
-  const float* x;
-  const float* y;
-  const float* z;
+  const float4* pts;           // {x, y, z, 0} per map point, canonical order (+ 64 B of readable padding)
   const uint32_t* cell_start;  // n_slots * (nc^3+1)
   const int32_t* cube_slot;    // 4851
   int32_t nc;
@@ -28,6 +26,7 @@ struct MatchParams {
   float plane_res;        // localMap.planeRes_ (float member, LocalMap.h:761)
   float sq_max_dist_f;    // 3 * planeRes evaluated in float (LidarSlam.cpp:526)
   double max_point_dist;  // planeRes / 2.0 (LidarSlam.cpp:820)
+  int32_t ablate;         // profiling only (env SOICP_ABLATE): bit0 skip plane fit, bit1 skip scan, bit2 skip re-rank
 };
 
 struct EvalParams {
@@ -56,9 +55,11 @@ void launch_sort_pairs(void* d_temp, size_t temp_bytes, const uint32_t* keys_in,
                        const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, hipStream_t s);
 void launch_gather_scan(const float* d_scan_xyz, const uint32_t* d_perm, uint32_t n_kept, float* spx, float* spy,
                         float* spz, hipStream_t s);
-void launch_knn_plane(const float* spx, const float* spy, const float* spz, uint32_t n_kept, const Pose& pose,
-                      const DevMapView& map, const MatchParams& mp, CorrBuffers corr, int32_t* d_hist /*16*/,
-                      hipStream_t s);
+void launch_chunk_heads(const uint32_t* d_keys_sorted, uint32_t n_kept, uint32_t* d_chunk_start, uint32_t* d_n_chunks,
+                        hipStream_t s);
+void launch_knn_plane(const float* spx, const float* spy, const float* spz, uint32_t n_kept, const uint32_t* d_keys_sorted,
+                      const uint32_t* d_chunk_start, uint32_t n_chunks, const Pose& pose, const DevMapView& map,
+                      const MatchParams& mp, CorrBuffers corr, int32_t* d_hist /*20*/, hipStream_t s);
 void launch_eval(const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, uint32_t n_kept,
                  const Pose& pose, const EvalParams& ep, double* d_partials, uint32_t* d_ticket,
                  const int32_t* d_hist, LmSums* d_sums, hipStream_t s);

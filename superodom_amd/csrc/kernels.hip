@@ -106,6 +106,17 @@ __global__ __launch_bounds__(256) void gather_scan_kernel(const float* __restric
   spx[j] = scan[3 * i]; spy[j] = scan[3 * i + 1]; spz[j] = scan[3 * i + 2];
 }
 
+// Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries that share one sort key (one map
+// cell under the pose the scan was sorted with) and one 64-aligned block.  One wavefront per chunk keeps the
+// cost of a wave ~ one candidate set, whatever the query density (no straggler waves in sparse regions).
+__global__ __launch_bounds__(256) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n_kept,
+                                                          uint32_t* __restrict__ chunk_start, uint32_t* __restrict__ n_chunks) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_kept) return;
+  const bool head = (i == 0) || ((i & 63u) == 0) || (keys[i] != keys[i - 1]);
+  if (head) chunk_start[atomicAdd(n_chunks, 1u)] = i;
+}
+
 // ------------------------------------------------------------------------------------------------
 // exact 5-NN inside the query's cube: candidates = the (clamped) 3x3x3 cell neighbourhood.
 // Exactness: one cell >= sqrt(3*planeRes) (local_map.cpp: cells_per_cube), so every map point within
@@ -149,7 +160,8 @@ __device__ __forceinline__ uint32_t knn27(const DevMapView& m, const CellRef& c,
       const uint32_t beg = row[x0], end = row[x1 + 1];
       seen += end - beg;
       for (uint32_t i = beg; i < end; ++i) {
-        const float d2 = l2_d2(qx, qy, qz, m.x[i], m.y[i], m.z[i]);
+        const float4 p = m.pts[i];
+        const float d2 = l2_d2(qx, qy, qz, p.x, p.y, p.z);
         top.insert(((unsigned long long)__float_as_uint(d2) << 32) | i);
       }
     }
@@ -345,37 +357,240 @@ __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const d
   return SO_MATCH_SUCCESS;
 }
 
+// ------------------------------------------------------------------------------------------------
+// knn_plane_kernel -- wave-cooperative, cell-grouped 5-NN + plane fit.
+//
+// A wavefront owns 64 consecutive queries of the spatially sorted scan.  Queries that fall into the
+// same map cell share the same 27-cell candidate set, so the wave walks its lanes cell-group by
+// cell-group (ballot / readlane) and, for one group at a time, streams the group's candidates as
+// WAVE-UNIFORM operands: the candidate index is uniform, hence every candidate is fetched once per wave
+// through the scalar cache (s_load_dwordx4) and broadcast to the 64 lanes for free; the VALU only
+// touches per-lane query data.  Selection is branch-free: a 32-bit key = (approximate fp32 d2 with its
+// low 10 mantissa bits replaced by the candidate's position in the group) runs through a sorted
+// 8-register network built from v_min_u32 / v_med3_u32 (no divergence, no 64-bit compares).
+// After all groups are done each lane re-ranks its 8 survivors with the reference's exact arithmetic
+// (octree.h:93-102, fp64 squares narrowed to float; ties by canonical index) and CERTIFIES the result:
+// every candidate outside the 8 has approximate d2 >= L (the 8th key with its index bits cleared), so if
+// the exact 5th distance is below L*(1-1e-6) no outsider can belong to the exact 5-NN.  A lane that
+// cannot be certified (8 near-equidistant candidates, or a group with more than 1024 candidates) falls
+// back to the per-lane exact scan knn27().  Result: bit-identical neighbour lists to the oracle.
+// ------------------------------------------------------------------------------------------------
+constexpr int kKeyIdxBits = 9;
+constexpr uint32_t kKeyIdxMask = (1u << kKeyIdxBits) - 1u;
+constexpr uint32_t kGroupMaxCand = 1u << kKeyIdxBits;
+
+// v_med3_u32 has no clang builtin; it is a pure VALU op (no memory, no wait states needed).
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+struct Net8 {  // ascending: a0 <= a1 <= ... <= a7
+  uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
+  __device__ __forceinline__ void init() { a0 = a1 = a2 = a3 = a4 = a5 = a6 = a7 = 0xFFFFFFFFu; }
+  __device__ __forceinline__ void push(uint32_t k) {  // new a_s = med3(a_{s-1}, a_s, k); a0 = min(a0, k)
+    a7 = umed3(a6, a7, k);
+    a6 = umed3(a5, a6, k);
+    a5 = umed3(a4, a5, k);
+    a4 = umed3(a3, a4, k);
+    a3 = umed3(a2, a3, k);
+    a2 = umed3(a1, a2, k);
+    a1 = umed3(a0, a1, k);
+    a0 = a0 < k ? a0 : k;
+  }
+};
+
+__device__ __forceinline__ uint32_t approx_key(float qx, float qy, float qz, const float4 c, uint32_t jloc) {
+  const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+  const float d2a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  return (__float_as_uint(d2a) & ~kKeyIdxMask) | jloc;
+}
+
 __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
-                                                        const float* __restrict__ spz, uint32_t n_kept, Pose pose,
-                                                        DevMapView map, MatchParams mp, CorrBuffers corr,
-                                                        int32_t* __restrict__ hist) {
-  __shared__ int32_t lh[16];
-  if (threadIdx.x < 16) lh[threadIdx.x] = 0;
+                                                        const float* __restrict__ spz, uint32_t n_kept,
+                                                        const uint32_t* __restrict__ skeys,
+                                                        const uint32_t* __restrict__ chunk_start, uint32_t n_chunks, Pose pose,
+                                                        const float4* __restrict__ mpts,
+                                                        const uint32_t* __restrict__ mcell_start, DevMapView map,
+                                                        MatchParams mp, CorrBuffers corr, int32_t* __restrict__ hist) {
+  __shared__ int32_t lh[20];
+  __shared__ __attribute__((aligned(16))) float tiles[4][4][kGroupMaxCand];  // per wavefront: x[], y[], z[], index[] (16 KB)
+  if (threadIdx.x < 20) lh[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n_kept) {
-    double pw[3];
+  const int lane = threadIdx.x & 63;
+  float* tx = tiles[threadIdx.x >> 6][0];
+  float* ty = tiles[threadIdx.x >> 6][1];
+  float* tz = tiles[threadIdx.x >> 6][2];
+  uint32_t* ti = reinterpret_cast<uint32_t*>(tiles[threadIdx.x >> 6][3]);
+  // one wavefront per chunk of the work list
+  const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  uint32_t j = 0;
+  bool valid_q = false;
+  if (chunk < n_chunks) {
+    const uint32_t start = __builtin_amdgcn_readfirstlane(chunk_start[chunk]);
+    j = start + lane;
+    valid_q = (j < n_kept) && ((j >> 6) == (start >> 6)) && (skeys[j] == skeys[start]);
+  }
+  double pw[3] = {0, 0, 0};
+  float qx = 0, qy = 0, qz = 0;
+  float ux = 0, uy = 0, uz = 0;  // cube-local coordinates of the query (for the coverage test)
+  CellRef c;
+  c.slot = -1; c.cx = c.cy = c.cz = 0;
+  if (valid_q) {
     quat_rotate<double>(pose.q, (double)spx[j], (double)spy[j], (double)spz[j], pw[0], pw[1], pw[2]);  // LidarSlam.cpp:397-398
     pw[0] += pose.t[0]; pw[1] += pose.t[1]; pw[2] += pose.t[2];
-    const float qx = (float)pw[0], qy = (float)pw[1], qz = (float)pw[2];  // LidarSlam.cpp:728-731
+    qx = (float)pw[0]; qy = (float)pw[1]; qz = (float)pw[2];                                            // LidarSlam.cpp:728-731
+    int w[3];
+    c = locate(map, qx, qy, qz, w);
+    if (c.slot >= 0) {
+      ux = (float)((double)qx - (w[0] * 50.0 - 25.0)); uy = (float)((double)qy - (w[1] * 50.0 - 25.0)); uz = (float)((double)qz - (w[2] * 50.0 - 25.0));
+    }
+  }
+  const uint32_t ckey = (valid_q && c.slot >= 0) ? (((uint32_t)c.slot << 18) | ((uint32_t)c.cz << 12) | ((uint32_t)c.cy << 6) | (uint32_t)c.cx)
+                                                 : 0xFFFFFFFFu;
+  uint32_t g0 = 0xFFFFFFFFu, g1 = g0, g2 = g0, g3 = g0, g4 = g0, g5 = g0, g6 = g0, g7 = g0;  // canonical indices of the 8 survivors
+  uint32_t k8 = 0xFFFFFFFFu;   // 8th key of the lane's group pass
+  float cov2 = 0.f;            // squared distance from the query to the boundary of the scanned block
+  bool need_exact = false;
+  const int nc = map.nc;
+  const float cell = (float)(1.0 / map.inv_cell);
+  const float join_cov = 0.58f * cell;  // join a neighbouring group only if its block still covers this much
+  bool pending = (ckey != 0xFFFFFFFFu);
+  unsigned long long todo = __ballot(pending);
+  if (mp.ablate & 2) todo = 0;
+  int n_groups = 0;
+  uint32_t n_scanned = 0;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t k = __builtin_amdgcn_readlane(ckey, leader);  // wave-uniform (SGPR) cell key of this group
+    const int gslot = (int)(k >> 18), gz = (int)((k >> 12) & 63u), gy = (int)((k >> 6) & 63u), gx = (int)(k & 63u);
+    const int x0 = gx > 0 ? gx - 1 : 0, x1 = gx < nc - 1 ? gx + 1 : nc - 1;
+    const int y0 = gy > 0 ? gy - 1 : 0, y1 = gy < nc - 1 ? gy + 1 : nc - 1;
+    const int z0 = gz > 0 ? gz - 1 : 0, z1 = gz < nc - 1 ? gz + 1 : nc - 1;
+    // coverage of the block [x0..x1]x[y0..y1]x[z0..z1] around this lane's query: nothing of the query's cube lies
+    // outside the block closer than `cov` (block faces that coincide with a cube face do not limit it)
+    const float big = 1e30f;
+    float cov = big;
+    cov = fminf(cov, x0 > 0 ? ux - (float)x0 * cell : big);
+    cov = fminf(cov, x1 < nc - 1 ? (float)(x1 + 1) * cell - ux : big);
+    cov = fminf(cov, y0 > 0 ? uy - (float)y0 * cell : big);
+    cov = fminf(cov, y1 < nc - 1 ? (float)(y1 + 1) * cell - uy : big);
+    cov = fminf(cov, z0 > 0 ? uz - (float)z0 * cell : big);
+    cov = fminf(cov, z1 < nc - 1 ? (float)(z1 + 1) * cell - uz : big);
+    const bool mine = pending && ((ckey == k) || ((int)(ckey >> 18) == gslot && cov >= join_cov));
+    pending = pending && !mine;
+    todo = __ballot(pending);
+    ++n_groups;
+    // row table: lane r (0..8) fetches the bounds of x-run r; prefix sums by readlane
+    uint32_t vb = 0, vl = 0;
+    if (lane < 9) {
+      const int z = gz + (lane / 3 - 1), y = gy + (lane % 3 - 1);
+      if (z >= 0 && z < nc && y >= 0 && y < nc) {
+        const uint32_t* row = mcell_start + (size_t)gslot * map.ncell1 + ((size_t)z * nc + y) * nc;
+        vb = row[x0]; vl = row[x1 + 1] - vb;
+      }
+    }
+    uint32_t rbeg[9], roff[9];
+    uint32_t total = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      rbeg[r] = __builtin_amdgcn_readlane(vb, r); roff[r] = total;
+      total += __builtin_amdgcn_readlane(vl, r);
+    }
+    if (total > kGroupMaxCand) {  // uniform: too many candidates for the 10-bit position field
+      need_exact = need_exact || mine;
+      continue;
+    }
+    n_scanned += total;
+    // stage the group's candidates into this wave's LDS tile with coalesced 16-byte loads; .w carries the canonical index
+    __builtin_amdgcn_wave_barrier();
+    if (!(mp.ablate & 16))
+    for (uint32_t t = lane; t < total; t += 64) {
+      uint32_t idx = rbeg[0] + t;
+#pragma unroll
+      for (int r = 1; r < 9; ++r) idx = (t >= roff[r]) ? (rbeg[r] - roff[r] + t) : idx;
+      const float4 p = mpts[idx];
+      tx[t] = p.x; ty[t] = p.y; tz[t] = p.z; ti[t] = idx;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    Net8 net;
+    net.init();
+    if (!(mp.ablate & 8)) {
+      uint32_t jl = 0;
+      for (; jl + 4 <= total; jl += 4) {  // uniform addresses: three broadcast ds_read_b128 feed four candidates
+        const float4 X = *reinterpret_cast<const float4*>(tx + jl);
+        const float4 Y = *reinterpret_cast<const float4*>(ty + jl);
+        const float4 Z = *reinterpret_cast<const float4*>(tz + jl);
+        net.push(approx_key(qx, qy, qz, make_float4(X.x, Y.x, Z.x, 0.f), jl));
+        net.push(approx_key(qx, qy, qz, make_float4(X.y, Y.y, Z.y, 0.f), jl + 1));
+        net.push(approx_key(qx, qy, qz, make_float4(X.z, Y.z, Z.z, 0.f), jl + 2));
+        net.push(approx_key(qx, qy, qz, make_float4(X.w, Y.w, Z.w, 0.f), jl + 3));
+      }
+      for (; jl < total; ++jl) net.push(approx_key(qx, qy, qz, make_float4(tx[jl], ty[jl], tz[jl], 0.f), jl));
+    }
+    // survivors' canonical indices come straight out of the tile
+    const uint32_t ks[8] = {net.a0, net.a1, net.a2, net.a3, net.a4, net.a5, net.a6, net.a7};
+    uint32_t gi[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      gi[t] = (ks[t] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ti[ks[t] & kKeyIdxMask];
+    if (mine) {
+      g0 = gi[0]; g1 = gi[1]; g2 = gi[2]; g3 = gi[3]; g4 = gi[4]; g5 = gi[5]; g6 = gi[6]; g7 = gi[7];
+      k8 = net.a7;
+      cov2 = cov >= 1e15f ? big : cov * cov;
+    }
+  }
+  if (lane == 0 && chunk < n_chunks) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
+
+  if (valid_q) {
     int status;
     double nd[4] = {0, 0, 0, 0}, coeff = 0;
     int obs[3] = {0, 0, 0};
-    const CellRef c = locate(map, qx, qy, qz);
     if (c.slot < 0) {
       status = SO_MATCH_NOT_ENOUGH;  // LidarSlam.cpp:736-739
     } else {
       Top5 top;
       top.init();
-      knn27(map, c, qx, qy, qz, top);
+      bool too_far_certain = false;
+      if (!need_exact && !(mp.ablate & 4)) {
+        const uint32_t gs[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (gs[t] != 0xFFFFFFFFu) {
+            const float4 p = mpts[gs[t]];
+            top.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, p.x, p.y, p.z)) << 32) | gs[t]);
+          }
+        }
+        // Every candidate that was NOT re-ranked has exact d2 >= R2:
+        //   in-block outsiders: approximate d2 >= L (8th key, index bits cleared), exact >= L (1 - 4e-7);
+        //   points of the cube outside the block: farther than the block boundary (cov2).
+        double R2 = (double)cov2 * (1.0 - 1e-6);
+        if (k8 != 0xFFFFFFFFu) R2 = fmin(R2, (double)__uint_as_float(k8 & ~kKeyIdxMask) * (1.0 - 1e-6));
+        const bool have5 = top.b4 != ~0ull;
+        const double d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
+        if (have5 && d5 < R2) {
+          // exact 5-NN
+        } else if (R2 > (double)mp.sq_max_dist_f) {
+          too_far_certain = true;  // the true 5th neighbour is >= R2 > gate (LidarSlam.cpp:741)
+        } else {
+          need_exact = true;
+        }
+      }
+      if (need_exact) {  // rare: exact per-lane scan of the 27 cells
+        atomicAdd(&lh[17], 1);
+        top.init();
+        knn27(map, c, qx, qy, qz, top);
+      }
       const float d2_4 = __uint_as_float((uint32_t)(top.b4 >> 32));
-      if (top.b4 == ~0ull || (double)d2_4 > (double)mp.sq_max_dist_f) {
+      if ((mp.ablate & 1) || too_far_certain || top.b4 == ~0ull || (double)d2_4 > (double)mp.sq_max_dist_f) {
         status = SO_MATCH_TOO_FAR;   // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
       } else {
         float nb[15];
         const uint32_t id[5] = {(uint32_t)top.b0, (uint32_t)top.b1, (uint32_t)top.b2, (uint32_t)top.b3, (uint32_t)top.b4};
 #pragma unroll
-        for (int t = 0; t < 5; ++t) { nb[3 * t] = map.x[id[t]]; nb[3 * t + 1] = map.y[id[t]]; nb[3 * t + 2] = map.z[id[t]]; }
+        for (int t = 0; t < 5; ++t) { const float4 p = mpts[id[t]]; nb[3 * t] = p.x; nb[3 * t + 1] = p.y; nb[3 * t + 2] = p.z; }
         status = plane_from_neighbours(nb, pw, pose, mp, nd, coeff, obs);
       }
     }
@@ -387,7 +602,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
     if (status == SO_MATCH_SUCCESS) { atomicAdd(&lh[7 + obs[0]], 1); atomicAdd(&lh[7 + obs[1]], 1); atomicAdd(&lh[7 + obs[2]], 1); }
   }
   __syncthreads();
-  if (threadIdx.x < 16 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+  if (threadIdx.x < 20 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -532,7 +747,7 @@ __global__ __launch_bounds__(256) void knn_only_kernel(const float* __restrict__
     const uint32_t id = (uint32_t)b[t];
     d2o[(size_t)i * k + t] = __uint_as_float((uint32_t)(b[t] >> 32));
     if (idxo) idxo[(size_t)i * k + t] = (int32_t)id;
-    nbr[((size_t)i * k + t) * 3] = map.x[id]; nbr[((size_t)i * k + t) * 3 + 1] = map.y[id]; nbr[((size_t)i * k + t) * 3 + 2] = map.z[id];
+    { const float4 p = map.pts[id]; nbr[((size_t)i * k + t) * 3] = p.x; nbr[((size_t)i * k + t) * 3 + 1] = p.y; nbr[((size_t)i * k + t) * 3 + 2] = p.z; }
   }
 }
 
@@ -561,7 +776,8 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(const float* __restri
   Top5 top;
   top.init();
   for (uint32_t p = beg + lane; p < end; p += 64) {
-    const float d2 = l2_d2(qx, qy, qz, map.x[p], map.y[p], map.z[p]);
+    const float4 mp = map.pts[p];
+    const float d2 = l2_d2(qx, qy, qz, mp.x, mp.y, mp.z);
     top.insert(((unsigned long long)__float_as_uint(d2) << 32) | p);
   }
   for (int t = 0; t < k; ++t) {
@@ -572,11 +788,11 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(const float* __restri
         const uint32_t id = (uint32_t)m;
         d2o[(size_t)i * k + t] = __uint_as_float((uint32_t)(m >> 32));
         if (idxo) idxo[(size_t)i * k + t] = (int32_t)id;
-        nbr[((size_t)i * k + t) * 3] = map.x[id]; nbr[((size_t)i * k + t) * 3 + 1] = map.y[id]; nbr[((size_t)i * k + t) * 3 + 2] = map.z[id];
+        { const float4 p = map.pts[id]; nbr[((size_t)i * k + t) * 3] = p.x; nbr[((size_t)i * k + t) * 3 + 1] = p.y; nbr[((size_t)i * k + t) * 3 + 2] = p.z; }
       } else {  // fewer than k points in the cube: nanoflann.h:87-100 buffer state
         d2o[(size_t)i * k + t] = (t == k - 1) ? 3.402823466e+38f : 0.f;
         if (idxo) idxo[(size_t)i * k + t] = (int32_t)beg;
-        nbr[((size_t)i * k + t) * 3] = map.x[beg]; nbr[((size_t)i * k + t) * 3 + 1] = map.y[beg]; nbr[((size_t)i * k + t) * 3 + 2] = map.z[beg];
+        { const float4 p = map.pts[beg]; nbr[((size_t)i * k + t) * 3] = p.x; nbr[((size_t)i * k + t) * 3 + 1] = p.y; nbr[((size_t)i * k + t) * 3 + 2] = p.z; }
       }
     }
   }
@@ -608,10 +824,16 @@ void launch_gather_scan(const float* d_scan, const uint32_t* perm, uint32_t n_ke
   if (!n_kept) return;
   hipLaunchKernelGGL(gather_scan_kernel, grid_for(n_kept, 256), dim3(256), 0, s, d_scan, perm, n_kept, spx, spy, spz);
 }
-void launch_knn_plane(const float* spx, const float* spy, const float* spz, uint32_t n_kept, const Pose& pose,
-                      const DevMapView& map, const MatchParams& mp, CorrBuffers corr, int32_t* hist, hipStream_t s) {
+void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n_kept, uint32_t* chunk_start, uint32_t* n_chunks, hipStream_t s) {
   if (!n_kept) return;
-  hipLaunchKernelGGL(knn_plane_kernel, grid_for(n_kept, 256), dim3(256), 0, s, spx, spy, spz, n_kept, pose, map, mp, corr, hist);
+  hipLaunchKernelGGL(chunk_heads_kernel, grid_for(n_kept, 256), dim3(256), 0, s, keys_sorted, n_kept, chunk_start, n_chunks);
+}
+void launch_knn_plane(const float* spx, const float* spy, const float* spz, uint32_t n_kept, const uint32_t* keys_sorted,
+                      const uint32_t* chunk_start, uint32_t n_chunks, const Pose& pose, const DevMapView& map,
+                      const MatchParams& mp, CorrBuffers corr, int32_t* hist, hipStream_t s) {
+  if (!n_kept || !n_chunks) return;
+  hipLaunchKernelGGL(knn_plane_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, s, spx, spy, spz, n_kept, keys_sorted, chunk_start,
+                     n_chunks, pose, map.pts, map.cell_start, map, mp, corr, hist);
 }
 void launch_eval(const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, uint32_t n_kept,
                  const Pose& pose, const EvalParams& ep, double* partials, uint32_t* ticket, const int32_t* hist,

@@ -198,7 +198,7 @@ void LocalMap::build_canonical(int rank, int world, CanonicalMap& out) const {
   const size_t ncell = (size_t)nc * nc * nc;
   out.cube_slot.assign(kMapNum, -1);
   out.slot_cube.clear();
-  out.x.clear(); out.y.clear(); out.z.clear(); out.cell_start.clear();
+  out.xyzw.clear(); out.cell_start.clear();
   out.total_points = size();
   out.n_slots = 0;
   std::vector<uint32_t> cellid, counts, fill;
@@ -230,15 +230,15 @@ void LocalMap::build_canonical(int rank, int world, CanonicalMap& out) const {
       if (keep[i]) counts[cellid[i] + 1]++;
     }
     // NOTE: a cube keeps its slot (tree exists, LocalMap.h:506) even if this rank holds none of its points
-    const uint32_t base = (uint32_t)out.x.size();
+    const uint32_t base = (uint32_t)out.n_points();
     for (size_t k = 0; k < ncell; ++k) counts[k + 1] += counts[k];
     const size_t kept = counts[ncell];
-    out.x.resize(base + kept); out.y.resize(base + kept); out.z.resize(base + kept);
+    out.xyzw.resize(4 * (size_t)(base + kept), 0.0f);
     fill.assign(counts.begin(), counts.end() - 1);
     for (size_t i = 0; i < n; ++i) {
       if (!keep[i]) continue;
       const uint32_t dst = base + fill[cellid[i]]++;
-      out.x[dst] = c->xyz[3 * i]; out.y[dst] = c->xyz[3 * i + 1]; out.z[dst] = c->xyz[3 * i + 2];
+      out.xyzw[4 * (size_t)dst] = c->xyz[3 * i]; out.xyzw[4 * (size_t)dst + 1] = c->xyz[3 * i + 1]; out.xyzw[4 * (size_t)dst + 2] = c->xyz[3 * i + 2];
     }
     const size_t off = out.cell_start.size();
     out.cell_start.resize(off + ncell + 1);
@@ -262,7 +262,7 @@ size_t LocalMap::export_points(float* xyz, size_t cap, bool only_5x5, const int 
     const size_t ncell = (size_t)cm.nc * cm.nc * cm.nc;
     const uint32_t b = cm.cell_start[s * (ncell + 1)], e = cm.cell_start[s * (ncell + 1) + ncell];
     for (uint32_t i = b; i < e; ++i) {
-      if (n < cap && xyz) { xyz[3 * n] = cm.x[i]; xyz[3 * n + 1] = cm.y[i]; xyz[3 * n + 2] = cm.z[i]; }
+      if (n < cap && xyz) { xyz[3 * n] = cm.xyzw[4 * (size_t)i]; xyz[3 * n + 1] = cm.xyzw[4 * (size_t)i + 1]; xyz[3 * n + 2] = cm.xyzw[4 * (size_t)i + 2]; }
       ++n;
     }
   }

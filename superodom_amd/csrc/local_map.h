@@ -3,7 +3,8 @@
 //
 // Reference layout: 21x21x11 MapBlocks of 50 m (LocalMap.h:131-138), each a 32-byte-AoS
 // pcl::PointXYZI cloud plus a pointer-linked octree.  MI355X layout built here:
-//   * one SoA (x[], y[], z[]) over ALL points of this rank's shard, in CANONICAL ORDER =
+//   * one 16-byte-per-point array {x,y,z,0} over ALL points of this rank's shard (one dwordx4 fetches a
+//     candidate; a wave reads it through the scalar cache as a broadcast operand), in CANONICAL ORDER =
 //     ascending (cube index, cell z, cell y, cell x), stable in the cube-local order;
 //   * per occupied cube a dense table of nc^3+1 prefix offsets into that SoA (cells of 50/nc m,
 //     nc = cells_per_cube(planeRes) chosen so that one cell >= sqrt(3*planeRes), the reference's
@@ -26,7 +27,8 @@ struct CanonicalMap {
   int nc = 1;             // cells per cube edge
   double cell = 50.0;     // cell edge (m)
   int n_slots = 0;
-  std::vector<float> x, y, z;
+  std::vector<float> xyzw;           // 4 floats per point: x, y, z, 0
+  size_t n_points() const { return xyzw.size() / 4; }
   std::vector<uint32_t> cell_start;  // n_slots * (nc^3 + 1), global offsets
   std::vector<int32_t> cube_slot;    // kMapNum
   std::vector<int32_t> slot_cube;    // n_slots -> cube index
