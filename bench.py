@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--workload", default="os1_128_2m")
     ap.add_argument("--scans", type=int, default=4, help="distinct synthetic scans cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every kernel (adds bubbles)")
     ap.add_argument("--cpu-sample", type=int, default=1, help="registrations timed for the CPU baseline")
     args = ap.parse_args()
 
@@ -61,7 +62,7 @@ def main():
     max_outer, lm_iters = 5, 4
     slam = binding.LidarSlamGpu(device_id=local_rank, rank=rank, world_size=world, plane_res=sc.plane_res,
                                 line_res=sc.plane_res / 2, max_iterations=max_outer, lm_max_iterations=lm_iters,
-                                max_surface_features=-1, time_kernels=1)
+                                max_surface_features=-1, time_kernels=2 if args.time_all_kernels else 1)
     if world > 1:
         uid = [binding.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)

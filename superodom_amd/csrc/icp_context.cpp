@@ -96,6 +96,9 @@ struct so_icp_ctx {
   int32_t* d_hist = nullptr; uint32_t* d_ticket = nullptr; uint32_t* d_nkept = nullptr; uint32_t* d_fbcount = nullptr;
   LmSums* d_sums = nullptr; double* d_partials = nullptr;
   LmSums* h_sums = nullptr; uint32_t* h_u32 = nullptr;  // pinned
+  DevBuf d_state_buf; DevState* d_state = nullptr; DevState* h_state = nullptr;  // device-resident registration state + pinned mirror
+  int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
+  int sync_per_outer = 1;  // 1: read back reg_done after every outer iteration and stop enqueuing (eager mode)
   std::vector<DevBuf> resident_scans;  // so_icp_upload_scan
   // Seam B scratch
   DevBuf d_q, d_nbr, d_d2, d_idx, d_found, d_fblist;
@@ -107,6 +110,7 @@ struct so_icp_ctx {
   // timing
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<EventSpan> spans;
+  bool span_open = false;
   so_icp_timing timing{};
   // RCCL
   Rccl rccl; void* comm = nullptr;
@@ -140,15 +144,19 @@ hipEvent_t next_event(so_icp_ctx* c) {
   }
   return c->ev_pool[c->ev_used++];
 }
+// time_kernels: 1 = bracket only the dominant (k-NN) kernel -- cheap enough to stay on inside a timed region;
+//               2 = bracket every kernel (events cost a few microseconds of pipeline bubble each)
 void span_begin(so_icp_ctx* c, int kind, uint32_t units) {
-  if (!c->cfg.time_kernels) return;
+  if (!c->cfg.time_kernels || (c->cfg.time_kernels == 1 && kind != 0)) return;
   EventSpan s{kind, next_event(c), next_event(c), units};
   if (!s.a || !s.b) return;
   (void)hipEventRecord(s.a, c->stream);
   c->spans.push_back(s);
+  c->span_open = true;
 }
 void span_end(so_icp_ctx* c) {
-  if (!c->cfg.time_kernels || c->spans.empty()) return;
+  if (!c->span_open || c->spans.empty()) return;
+  c->span_open = false;
   (void)hipEventRecord(c->spans.back().b, c->stream);
 }
 void spans_collect(so_icp_ctx* c) {  // stream must be idle
@@ -212,6 +220,8 @@ EvalParams eval_params(float plane_res, int variant) {
   const double a = (double)sqrtf(3 * plane_res);  // std::sqrt(float) then TukeyLoss(double a) (LidarSlam.cpp:271)
   ep.a2 = a * a;
   ep.variant = variant;
+  static const int ablate = std::getenv("SOICP_ABLATE") ? std::atoi(std::getenv("SOICP_ABLATE")) : 0;
+  ep.ablate = ablate;
   return ep;
 }
 
@@ -254,24 +264,12 @@ void yaw_correction(double T[7], const double last[7], double yaw_ratio) {
   for (int i = 0; i < 4; ++i) T[3 + i] = q[i] / n;
 }
 
-// one fused evaluation at `pose`: kernel -> (all-reduce) -> pinned host copy
-int evaluate_at(so_icp_ctx* c, const double pose[7], uint32_t n_kept, LmSums& out) {
-  const Pose P = pose_from_array(pose);
-  CorrBuffers corr{c->d_nd.as<double4>(), c->d_coeff.as<double>(), c->d_status.as<uint8_t>()};
-  span_begin(c, 1, n_kept);
-  launch_eval(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), corr, n_kept, P,
-              eval_params(c->map.plane_res(), c->cfg.tukey_variant), c->d_partials, c->d_ticket, c->d_hist, c->d_sums, c->stream);
-  span_end(c);
-  if (c->comm) {  // per-evaluation collective: 45 fp64 summed over the shards (xGMI, latency-bound)
-    const int rc = c->rccl.AllReduce(c->d_sums, c->d_sums, sizeof(LmSums) / sizeof(double), kNcclDouble, kNcclSum, c->comm, c->stream);
-    if (rc != 0) return fail(c, SO_ICP_E_RCCL, std::string("ncclAllReduce: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(rc) : "?"));
-  }
-  HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(LmSums), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  out = *c->h_sums;
-  return SO_ICP_OK;
-}
-
+// LidarSLAM::performLocalizationAndMapping (LidarSlam.cpp:107-152) with the loop state resident on the device:
+// the host enqueues, per outer iteration, the STATIC sequence
+//     clear histograms -> knn_plane -> [ eval(slot) -> (all-reduce) -> lm_step(slot) ] x (1 + lm_max)
+// and every kernel consults DevState (reg_done / lm_more) to turn itself into a no-op once the controller has
+// finished -- no host round trip per evaluation.  One small read-back per outer iteration (or one per
+// registration with SOICP_SYNC_PER_OUTER=0) tells the host when to stop enqueuing.
 int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pose_in[7], double pose_out[7], so_icp_stats* st) {
   const auto t_begin = std::chrono::steady_clock::now();
   so_icp_stats local;
@@ -294,87 +292,110 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   if (rc) return rc;
   const auto t_icp = std::chrono::steady_clock::now();  // TicToc t_opt, LidarSlam.cpp:118
 
-  // ---- once per registration: sampling, spatial sort (locality survives the small pose updates) ----
-  uint32_t n_kept = 0, n_chunks = 0;
-  if (c->cfg.time_kernels) HIP_TRY(c, hipMemsetAsync(c->d_hist + 16, 0, 4 * sizeof(int32_t), c->stream));
+  const int max_outer = std::min(c->cfg.max_iterations > 0 ? c->cfg.max_iterations : 4, SO_ICP_MAX_OUTER);
+  const int lm_max = std::min(c->cfg.lm_max_iterations > 0 ? c->cfg.lm_max_iterations : 4, 16);
+  DevState* ds = c->d_state;
+  hipStream_t s = c->stream;
+  // ---- host -> device: the guess and the loop bounds (one 64-byte copy), then the device-side prologue
+  std::memcpy(c->h_state->pose_in, pose_in, sizeof(T));
+  c->h_state->max_outer = max_outer; c->h_state->lm_max = lm_max;
+  HIP_TRY(c, hipMemcpyAsync(ds, c->h_state, kDevStateHostBytes, hipMemcpyHostToDevice, s));
+  launch_reg_begin(ds, s);
+  // ---- once per registration: sampling rule, spatial sort (locality survives the small pose updates), chunk list
   if (n) {
     span_begin(c, 2, (uint32_t)n);
-    HIP_TRY(c, hipMemsetAsync(c->d_nkept, 0, 8, c->stream));  // n_kept, n_chunks
-    launch_scan_keys(d_scan, (uint32_t)n, pose_from_array(T), c->view, c->cfg.max_surface_features, c->cfg.rank,
-                     c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_nkept, c->stream);
+    launch_scan_keys(d_scan, (uint32_t)n, ds, c->view, c->cfg.max_surface_features, c->cfg.rank, c->cfg.world_size,
+                     c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), ds, s);
     launch_sort_pairs(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->d_keys0.as<uint32_t>(), c->d_keys1.as<uint32_t>(),
-                      c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, c->stream);
-    HIP_TRY(c, hipMemcpyAsync(c->h_u32, c->d_nkept, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    n_kept = c->h_u32[0];
-    launch_chunk_heads(c->d_keys1.as<uint32_t>(), n_kept, c->d_chunks.as<uint32_t>(), c->d_nkept + 1, c->stream);
-    HIP_TRY(c, hipMemcpyAsync(c->h_u32 + 1, c->d_nkept + 1, 4, hipMemcpyDeviceToHost, c->stream));
-    launch_gather_scan(d_scan, c->d_vals1.as<uint32_t>(), n_kept, c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->stream);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    n_chunks = c->h_u32[1];
+                      c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, s);
+    launch_chunk_heads(c->d_keys1.as<uint32_t>(), (uint32_t)n, c->d_chunks.as<uint32_t>(), ds, s);
+    launch_gather_scan(d_scan, c->d_vals1.as<uint32_t>(), c->d_keys1.as<uint32_t>(), (uint32_t)n, c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
     span_end(c);
   }
-
-  const int max_outer = std::min(c->cfg.max_iterations > 0 ? c->cfg.max_iterations : 4, SO_ICP_MAX_OUTER);
-  const int lm_max = c->cfg.lm_max_iterations > 0 ? c->cfg.lm_max_iterations : 4;
   const MatchParams mp = match_params(c->map.plane_res());
+  const EvalParams ep = eval_params(c->map.plane_res(), c->cfg.tukey_variant);
   CorrBuffers corr{c->d_nd.as<double4>(), c->d_coeff.as<double>(), c->d_status.as<uint8_t>()};
-  LmState S;
-  std::memset(&S, 0, sizeof(S));
-  bool final_sums_valid = false;
+  std::vector<size_t> knn_span_of_outer, eval_span_first;
   for (int it = 0; it < max_outer; ++it) {
-    so_icp_iter_stats& is = st->iterations[it];
-    st->n_iterations = it + 1;
-    // processPlannerFeatures: every (kept) query in parallel (LidarSlam.cpp:323-344)
-    HIP_TRY(c, hipMemsetAsync(c->d_hist, 0, 16 * sizeof(int32_t), c->stream));  // ResetDistanceParameters, :847-852
-    span_begin(c, 0, n_kept);
-    launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), n_kept, c->d_keys1.as<uint32_t>(), c->d_chunks.as<uint32_t>(),
-                     n_chunks, pose_from_array(T), c->view, mp, corr, c->d_hist, c->stream);
+    // ResetDistanceParameters (LidarSlam.cpp:847-852); the 4 statistics slots of every replica are cleared too
+    HIP_TRY(c, hipMemsetAsync(c->d_hist, 0, kHistReplicas * kHistStride * sizeof(int32_t), s));
+    // processPlannerFeatures: every kept query in parallel (LidarSlam.cpp:323-344)
+    knn_span_of_outer.push_back(c->spans.size());
+    span_begin(c, 0, (uint32_t)n);
+    launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->d_keys1.as<uint32_t>(),
+                     c->d_chunks.as<uint32_t>(), ds, c->view, mp, corr, c->d_hist, s);
     span_end(c);
-    // setupOptimizationProblem + solveOptimizationProblem (LidarSlam.cpp:213-240)
-    double prev[7];
-    std::memcpy(prev, T, sizeof(T));
-    LmSums sums;
-    rc = evaluate_at(c, T, n_kept, sums);
-    if (rc) return rc;
-    for (int h = 0; h < SO_ICP_N_REJECT; ++h) is.reject_hist[h] = (int32_t)sums.hist[h];
-    for (int h = 0; h < SO_ICP_N_OBS; ++h) is.obs_hist[h] = (int32_t)sums.hist[7 + h];
-    double next[7];
-    int more = lm_begin(S, T, sums, lm_max, next);
-    while (more) {
-      rc = evaluate_at(c, next, n_kept, sums);
-      if (rc) return rc;
-      more = lm_feed(S, sums, next);
+    if (c->cfg.time_kernels >= 2)  // kernel statistics of this sweep (profiling mode only)
+      HIP_TRY(c, hipMemcpyAsync(c->h_hist + (size_t)it * kHistReplicas * kHistStride, c->d_hist,
+                                kHistReplicas * kHistStride * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    // setupOptimizationProblem + solveOptimizationProblem (LidarSlam.cpp:213-240): 1 + lm_max fused evaluations
+    eval_span_first.push_back(c->spans.size());
+    for (int slot = 0; slot <= lm_max; ++slot) {
+      span_begin(c, 1, (uint32_t)n);
+      const bool fuse_lm = (c->comm == nullptr);  // single device: the last workgroup of eval runs the LM controller itself
+      launch_eval(slot, fuse_lm, c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), corr, ds, ep, c->d_partials,
+                  c->d_ticket, c->d_hist, c->d_sums, s);
+      span_end(c);
+      if (!fuse_lm) {  // per-evaluation collective: 45 fp64 summed over the shards (xGMI, latency-bound), then the controller
+        const int nrc = c->rccl.AllReduce(c->d_sums, c->d_sums, sizeof(LmSums) / sizeof(double), kNcclDouble, kNcclSum, c->comm, s);
+        if (nrc != 0) return fail(c, SO_ICP_E_RCCL, std::string("ncclAllReduce: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(nrc) : "?"));
+        launch_lm_step(slot, ds, c->d_sums, s);
+      }
     }
-    std::memcpy(T, S.x, sizeof(T));  // LidarSlam.cpp:135-136
-    final_sums_valid = S.count > 0;
-    is.num_surf_from_scan = (int32_t)S.count;
-    is.lm_iterations = S.lm_iterations;
-    is.num_successful_steps = S.num_successful;
-    is.termination = S.termination;
-    is.initial_cost = S.initial_cost; is.final_cost = S.x_cost;
-    relative_motion(prev, T, is.translation_norm, is.rotation_norm);  // recordIterationStats, :242-251
-    std::memcpy(is.pose_after, T, sizeof(T));
-    std::memcpy(c->prev_obs_hist, is.obs_hist, sizeof(c->prev_obs_hist));
+    if (c->sync_per_outer || it == max_outer - 1) {
+      HIP_TRY(c, hipMemcpyAsync(&c->h_state->outer_iter, &ds->outer_iter, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(c, hipStreamSynchronize(s));
+      if (c->h_state->reg_done) break;
+    }
+  }
+  // ---- device -> host: the whole state block (pose, per-iteration statistics, final normal equations)
+  HIP_TRY(c, hipMemcpyAsync(c->h_state, ds, sizeof(DevState), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  const DevState& H = *c->h_state;
+  std::memcpy(T, H.T, sizeof(T));  // LidarSlam.cpp:135-136
+  st->n_iterations = H.n_iterations;
+  for (int it = 0; it < H.n_iterations && it < SO_ICP_MAX_OUTER; ++it) {
+    so_icp_iter_stats& is = st->iterations[it];
+    const DevIterStats& d = H.iters[it];
+    is.translation_norm = d.translation_norm; is.rotation_norm = d.rotation_norm;
+    is.num_surf_from_scan = d.num_surf; is.lm_iterations = d.lm_iterations; is.num_successful_steps = d.num_successful;
+    is.termination = d.termination; is.initial_cost = d.initial_cost; is.final_cost = d.final_cost;
+    std::memcpy(is.reject_hist, d.reject_hist, sizeof(is.reject_hist));
+    std::memcpy(is.obs_hist, d.obs_hist, sizeof(is.obs_hist));
+    std::memcpy(is.pose_after, d.pose_after, sizeof(is.pose_after));
+  }
+  if (H.n_iterations > 0) {
+    std::memcpy(c->prev_obs_hist, H.iters[H.n_iterations - 1].obs_hist, sizeof(c->prev_obs_hist));
     c->have_hist = true;
-    if (S.num_successful == 1 || it == max_outer - 1) break;  // LidarSlam.cpp:141
   }
-  if (final_sums_valid) {  // normal equations at the returned pose (S.H/S.g always belong to S.x)
-    std::memcpy(st->JtJ, S.H, sizeof(st->JtJ));
-    std::memcpy(st->Jtr, S.g, sizeof(st->Jtr));
-  }
+  std::memcpy(st->JtJ, H.JtJ, sizeof(st->JtJ));
+  std::memcpy(st->Jtr, H.Jtr, sizeof(st->Jtr));
   yaw_correction(T, T_last, c->cfg.yaw_ratio);  // performPostOptimizationProcessing, :155-157
   st->time_elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_icp).count();  // :199-200
   relative_motion(T_init, T, st->total_translation, st->total_rotation);
   relative_motion(T_last, T, st->translation_from_last, st->rotation_from_last);
   st->prediction_source = 0;
   std::memcpy(pose_out, T, sizeof(T));
-  if (c->cfg.time_kernels) {
-    HIP_TRY(c, hipMemcpyAsync(c->h_u32 + 4, c->d_hist + 16, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->timing.knn_group_passes += c->h_u32[4]; c->timing.knn_fallback_lanes += c->h_u32[5];
-    c->timing.knn_candidates_scanned += (int64_t)c->h_u32[6] * 16;
+  if (c->cfg.time_kernels) {  // keep only the launches that did real work (no-op launches after convergence are excluded)
+    std::vector<EventSpan> real;
+    for (size_t i = 0; i < c->spans.size(); ++i) {
+      const EventSpan& sp = c->spans[i];
+      bool keep = (sp.kind == 2);
+      for (int it = 0; it < H.n_iterations && !keep; ++it) {
+        if (sp.kind == 0 && it < (int)knn_span_of_outer.size() && i == knn_span_of_outer[it]) keep = true;
+        if (sp.kind == 1 && it < (int)eval_span_first.size() && i >= eval_span_first[it] &&
+            i < eval_span_first[it] + 1 + (size_t)std::max(H.iters[it].lm_iterations, 0)) keep = true;
+      }
+      if (keep) { EventSpan r = sp; r.units = H.n_kept; real.push_back(r); }
+    }
+    c->spans.swap(real);
     spans_collect(c);
+    for (int it = 0; it < H.n_iterations && c->cfg.time_kernels >= 2; ++it)
+      for (int r = 0; r < kHistReplicas; ++r) {
+        const int32_t* hh = c->h_hist + ((size_t)it * kHistReplicas + r) * kHistStride;
+        c->timing.knn_group_passes += hh[16]; c->timing.knn_fallback_lanes += hh[17];
+        c->timing.knn_candidates_scanned += (int64_t)hh[18] * 16;
+      }
   }
   c->timing.registrations++;
   c->timing.host_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -408,6 +429,9 @@ so_icp_ctx::~so_icp_ctx() {
                     &d_found, &d_fblist})
     b->release();
   for (DevBuf& b : resident_scans) b.release();
+  d_state_buf.release();
+  if (h_state) (void)hipHostFree(h_state);
+  if (h_hist) (void)hipHostFree(h_hist);
   if (h_sums) (void)hipHostFree(h_sums);
   if (h_u32) (void)hipHostFree(h_u32);
   for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
@@ -470,18 +494,26 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   c->map.set_resolution(cfg->line_res, cfg->plane_res);
   auto bail = [&](const std::string& m) { g_create_error = m; delete c; return (so_icp_ctx*)nullptr; };
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(std::string("hipStreamCreate: ") + hipGetErrorString(e));
-  const size_t small_bytes = 512 + sizeof(LmSums) + 256 + (size_t)kEvalBlocks * kSumsStride * sizeof(double);
+  const size_t small_bytes = 4096 + sizeof(LmSums) + 256 + (size_t)kEvalBlocks * kSumsStride * sizeof(double);
   if ((e = c->d_small.reserve(small_bytes)) != hipSuccess) return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
   if ((e = hipMemset(c->d_small.p, 0, c->d_small.cap)) != hipSuccess) return bail(std::string("hipMemset: ") + hipGetErrorString(e));
   char* base = c->d_small.as<char>();
-  c->d_hist = reinterpret_cast<int32_t*>(base);            // 16 histogram bins + 4 kernel statistics (128 B reserved)
-  c->d_ticket = reinterpret_cast<uint32_t*>(base + 128);
-  c->d_nkept = reinterpret_cast<uint32_t*>(base + 192);
-  c->d_fbcount = reinterpret_cast<uint32_t*>(base + 256);
-  c->d_sums = reinterpret_cast<LmSums*>(base + 512);
-  c->d_partials = reinterpret_cast<double*>(base + 512 + ((sizeof(LmSums) + 255) / 256) * 256);
+  c->d_hist = reinterpret_cast<int32_t*>(base);            // kHistReplicas x kHistStride ints (2 KB)
+  c->d_ticket = reinterpret_cast<uint32_t*>(base + 2048);
+  c->d_nkept = reinterpret_cast<uint32_t*>(base + 2112);   // Seam B scratch counters
+  c->d_fbcount = reinterpret_cast<uint32_t*>(base + 2176);
+  c->d_sums = reinterpret_cast<LmSums*>(base + 4096);
+  c->d_partials = reinterpret_cast<double*>(base + 4096 + ((sizeof(LmSums) + 255) / 256) * 256);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), sizeof(LmSums))) != hipSuccess) return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_u32), 64)) != hipSuccess) return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  if ((e = c->d_state_buf.reserve(sizeof(DevState))) != hipSuccess) return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
+  if ((e = hipMemset(c->d_state_buf.p, 0, sizeof(DevState))) != hipSuccess) return bail(std::string("hipMemset: ") + hipGetErrorString(e));
+  c->d_state = c->d_state_buf.as<DevState>();
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_state), sizeof(DevState))) != hipSuccess) return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  std::memset(c->h_state, 0, sizeof(DevState));
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_hist), (size_t)SO_ICP_MAX_OUTER * kHistReplicas * kHistStride * sizeof(int32_t))) != hipSuccess)
+    return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  if (const char* ev = std::getenv("SOICP_SYNC_PER_OUTER")) c->sync_per_outer = std::atoi(ev);
   return c;
 }
 

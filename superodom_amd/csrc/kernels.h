@@ -32,6 +32,7 @@ struct MatchParams {
 struct EvalParams {
   double a2;       // TukeyLoss a^2 with a = (double)sqrtf(3*planeRes)  (LidarSlam.cpp:271)
   int32_t variant; // 0: Ceres 2.0.0, 1: Ceres >= 2.1
+  int32_t ablate;  // profiling only (env SOICP_ABLATE): bit5 skip the LM controller, bit6 skip the point loop
 };
 
 // per-correspondence record written by the k-NN + plane-fit kernel, read by the evaluation kernel
@@ -41,6 +42,33 @@ struct CorrBuffers {
   uint8_t* status;  // MatchingResult
 };
 
+// ---- device-resident registration state: the outer ICP loop and the LM controller advance on the GPU, the
+// host only enqueues the (static) kernel sequence and reads this block back (no host round trip per evaluation)
+struct DevIterStats {
+  double translation_norm, rotation_norm;
+  int32_t num_surf, lm_iterations, num_successful, termination;
+  double initial_cost, final_cost;
+  int32_t reject_hist[7], obs_hist[9];
+  double pose_after[7];
+};
+struct DevState {
+  // written by the host before each registration (one small H2D copy)
+  double pose_in[7];
+  int32_t max_outer, lm_max, pad0, pad1;
+  // device-side control
+  int32_t outer_iter, reg_done, lm_more, n_iterations;
+  uint32_t n_kept, n_chunks, pad2, pad3;
+  double T[7];          // pose of the current outer iteration (T_w_lidar)
+  double eval_pose[7];  // pose the next LM evaluation is requested at
+  LmState S;
+  double JtJ[36], Jtr[6];
+  DevIterStats iters[16];
+};
+constexpr int kDevStateHostBytes = 64;  // pose_in + max_outer/lm_max
+
+constexpr int kHistReplicas = 16;    // histogram atomics are spread over replicas (contention), summed by eval_kernel
+constexpr int kHistStride = 32;      // ints per replica: reject[7] obs[9] stats[4]
+constexpr int kKnnBlocks = 1024;     // 4 workgroups per CU, waves grid-stride over the chunk list
 constexpr int kEvalBlocks = 256;     // one workgroup per CU
 constexpr int kSumsStride = 48;      // doubles per partial record (45 used)
 constexpr uint32_t kKeyDropped = 0xFFFFFFFFu;   // not sampled / not owned by this rank
@@ -48,21 +76,22 @@ constexpr uint32_t kKeyNoCube = 0xFFFFFFFEu;    // processed, but cube outside w
 
 size_t sort_temp_bytes(size_t n);
 
-void launch_scan_keys(const float* d_scan_xyz, uint32_t n, const Pose& pose, const DevMapView& map,
-                      int max_surface_features, int rank, int world, uint32_t* d_keys, uint32_t* d_vals,
-                      uint32_t* d_n_kept, hipStream_t s);
+void launch_reg_begin(DevState* st, hipStream_t s);
+void launch_scan_keys(const float* d_scan_xyz, uint32_t n, const DevState* st, const DevMapView& map,
+                      int max_surface_features, int rank, int world, uint32_t* d_keys, uint32_t* d_vals, DevState* st_rw,
+                      hipStream_t s);
 void launch_sort_pairs(void* d_temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                        const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, hipStream_t s);
-void launch_gather_scan(const float* d_scan_xyz, const uint32_t* d_perm, uint32_t n_kept, float* spx, float* spy,
-                        float* spz, hipStream_t s);
-void launch_chunk_heads(const uint32_t* d_keys_sorted, uint32_t n_kept, uint32_t* d_chunk_start, uint32_t* d_n_chunks,
-                        hipStream_t s);
-void launch_knn_plane(const float* spx, const float* spy, const float* spz, uint32_t n_kept, const uint32_t* d_keys_sorted,
-                      const uint32_t* d_chunk_start, uint32_t n_chunks, const Pose& pose, const DevMapView& map,
-                      const MatchParams& mp, CorrBuffers corr, int32_t* d_hist /*20*/, hipStream_t s);
-void launch_eval(const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, uint32_t n_kept,
-                 const Pose& pose, const EvalParams& ep, double* d_partials, uint32_t* d_ticket,
-                 const int32_t* d_hist, LmSums* d_sums, hipStream_t s);
+void launch_chunk_heads(const uint32_t* d_keys_sorted, uint32_t n, uint32_t* d_chunk_start, DevState* st, hipStream_t s);
+void launch_gather_scan(const float* d_scan_xyz, const uint32_t* d_perm, const uint32_t* d_keys_sorted, uint32_t n, float* spx,
+                        float* spy, float* spz, hipStream_t s);
+void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* d_keys_sorted,
+                      const uint32_t* d_chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
+                      CorrBuffers corr, int32_t* d_hist /*kHistReplicas*kHistStride*/, hipStream_t s);
+void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr,
+                 DevState* st, const EvalParams& ep, double* d_partials, uint32_t* d_ticket, const int32_t* d_hist,
+                 LmSums* d_sums, hipStream_t s);
+void launch_lm_step(int slot, DevState* st, const LmSums* d_sums, hipStream_t s);
 // Seam B
 void launch_knn_only(const float* d_q_xyz, uint32_t nq, int k, const DevMapView& map, float gate_d2, float* d_nbr,
                      float* d_d2, int32_t* d_idx, uint8_t* d_found, uint32_t* d_fallback_list,

@@ -64,12 +64,20 @@ __device__ __forceinline__ CellRef locate(const DevMapView& m, float qx, float q
 // ------------------------------------------------------------------------------------------------
 // scan preparation
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict__ scan, uint32_t n, Pose pose,
-                                                        DevMapView map, int max_surface_features, int rank, int world,
-                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint32_t* __restrict__ n_kept) {
+// registration prologue: pose <- host-provided guess, counters cleared (single thread)
+__global__ void reg_begin_kernel(DevState* st) {
+  for (int i = 0; i < 7; ++i) { st->T[i] = st->pose_in[i]; st->eval_pose[i] = st->pose_in[i]; }
+  st->outer_iter = 0; st->reg_done = 0; st->lm_more = 0; st->n_iterations = 0;
+  st->n_kept = 0; st->n_chunks = 0;
+}
+
+__global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict__ scan, uint32_t n,
+                                                        const DevState* __restrict__ st, DevMapView map,
+                                                        int max_surface_features, int rank, int world,
+                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const Pose pose = pose_from_array(st->pose_in);
   uint32_t key = kKeyDropped;
   bool process = true;
   if (max_surface_features > 0 && n > (uint32_t)max_surface_features) {  // calculateSamplingRate / shouldProcessPoint
@@ -94,14 +102,14 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   }
   keys[i] = key;
   vals[i] = i;
-  if (key != kKeyDropped) atomicAdd(n_kept, 1u);  // coalesced by the compiler into one add per wave
 }
 
 __global__ __launch_bounds__(256) void gather_scan_kernel(const float* __restrict__ scan, const uint32_t* __restrict__ perm,
-                                                          uint32_t n_kept, float* __restrict__ spx,
-                                                          float* __restrict__ spy, float* __restrict__ spz) {
+                                                          const uint32_t* __restrict__ keys_sorted, uint32_t n,
+                                                          float* __restrict__ spx, float* __restrict__ spy,
+                                                          float* __restrict__ spz) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_kept) return;
+  if (j >= n || keys_sorted[j] == kKeyDropped) return;
   const uint32_t i = perm[j];
   spx[j] = scan[3 * i]; spy[j] = scan[3 * i + 1]; spz[j] = scan[3 * i + 2];
 }
@@ -109,12 +117,27 @@ __global__ __launch_bounds__(256) void gather_scan_kernel(const float* __restric
 // Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries that share one sort key (one map
 // cell under the pose the scan was sorted with) and one 64-aligned block.  One wavefront per chunk keeps the
 // cost of a wave ~ one candidate set, whatever the query density (no straggler waves in sparse regions).
-__global__ __launch_bounds__(256) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n_kept,
-                                                          uint32_t* __restrict__ chunk_start, uint32_t* __restrict__ n_chunks) {
+__global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                           uint32_t* __restrict__ chunk_start, DevState* __restrict__ st) {
+  __shared__ uint32_t wave_cnt[16];
+  __shared__ uint32_t block_base;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_kept) return;
-  const bool head = (i == 0) || ((i & 63u) == 0) || (keys[i] != keys[i - 1]);
-  if (head) chunk_start[atomicAdd(n_chunks, 1u)] = i;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t key = i < n ? keys[i] : kKeyDropped;
+  const bool kept = key != kKeyDropped;
+  // keys are sorted and kKeyDropped is the largest value: the kept queries are the prefix [0, n_kept)
+  if (kept && (i + 1 == n || keys[i + 1] == kKeyDropped)) st->n_kept = i + 1;
+  const bool head = kept && ((i == 0) || ((i & 63u) == 0) || (key != keys[i - 1]));
+  const unsigned long long m = __ballot(head);
+  if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int w = 0; w < 16; ++w) { const uint32_t c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
+    block_base = tot ? atomicAdd(&st->n_chunks, tot) : 0u;  // one atomic per 1024 queries
+  }
+  __syncthreads();
+  if (head) chunk_start[block_base + wave_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -177,9 +200,12 @@ __device__ __forceinline__ uint32_t knn27(const DevMapView& m, const CellRef& c,
 __device__ __forceinline__ void jacobi_rot(double& app, double& aqq, double& apq, double& arp, double& arq,
                                            double& v0p, double& v0q, double& v1p, double& v1q, double& v2p, double& v2q) {
   if (apq == 0.0) return;
-  const double theta = (aqq - app) / (2.0 * apq);
-  const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  // t = tan(phi) of the annihilating rotation, smaller root: with d = aqq - app, b = 2 apq,
+  //   t = sgn(d) b / (|d| + sqrt(d^2 + b^2))   (== sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = d / b)
+  // one sqrt, one division and one rsqrt per rotation instead of three divisions and two square roots.
+  const double d = aqq - app, b2 = 2.0 * apq;
+  const double t = (d >= 0 ? b2 : -b2) / (fabs(d) + sqrt(d * d + b2 * b2));
+  const double c = rsqrt(t * t + 1.0), s = t * c;
   app -= t * apq; aqq += t * apq; apq = 0.0;
   const double rp = c * arp - s * arq, rq = s * arp + c * arq;
   arp = rp; arq = rq;
@@ -192,10 +218,10 @@ __device__ __forceinline__ void jacobi_rot(double& app, double& aqq, double& apq
 __device__ __forceinline__ void eig3_sym(double a00, double a01, double a02, double a11, double a12, double a22,
                                          double ev[3], double nrm[3]) {
   double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;  // v[row][col]
-  for (int sweep = 0; sweep < 32; ++sweep) {
+  for (int sweep = 0; sweep < 16; ++sweep) {
     const double off = a01 * a01 + a02 * a02 + a12 * a12;
     const double dg = a00 * a00 + a11 * a11 + a22 * a22;
-    if (off <= 1e-40 * dg || off == 0.0) break;
+    if (off <= 1e-30 * dg || off == 0.0) break;  // off-diagonal below 1e-15 of the diagonal: converged in fp64
     jacobi_rot(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21);  // (p,q)=(0,1), r=2
     jacobi_rot(a00, a22, a02, a01, a12, v00, v02, v10, v12, v20, v22);  // (0,2), r=1
     jacobi_rot(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22);  // (1,2), r=0
@@ -408,14 +434,18 @@ __device__ __forceinline__ uint32_t approx_key(float qx, float qy, float qz, con
 }
 
 __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
-                                                        const float* __restrict__ spz, uint32_t n_kept,
+                                                        const float* __restrict__ spz,
                                                         const uint32_t* __restrict__ skeys,
-                                                        const uint32_t* __restrict__ chunk_start, uint32_t n_chunks, Pose pose,
+                                                        const uint32_t* __restrict__ chunk_start,
+                                                        const DevState* __restrict__ st,
                                                         const float4* __restrict__ mpts,
                                                         const uint32_t* __restrict__ mcell_start, DevMapView map,
                                                         MatchParams mp, CorrBuffers corr, int32_t* __restrict__ hist) {
   __shared__ int32_t lh[20];
   __shared__ __attribute__((aligned(16))) float tiles[4][4][kGroupMaxCand];  // per wavefront: x[], y[], z[], index[] (16 KB)
+  if (st->reg_done) return;  // the registration already converged: this launch is a no-op
+  const uint32_t n_kept = st->n_kept, n_chunks = st->n_chunks;
+  const Pose pose = pose_from_array(st->T);
   if (threadIdx.x < 20) lh[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -423,11 +453,11 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   float* ty = tiles[threadIdx.x >> 6][1];
   float* tz = tiles[threadIdx.x >> 6][2];
   uint32_t* ti = reinterpret_cast<uint32_t*>(tiles[threadIdx.x >> 6][3]);
-  // one wavefront per chunk of the work list
-  const uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // one wavefront per chunk of the work list (grid-stride when the list is longer than the grid)
+  for (uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
   uint32_t j = 0;
   bool valid_q = false;
-  if (chunk < n_chunks) {
+  {
     const uint32_t start = __builtin_amdgcn_readfirstlane(chunk_start[chunk]);
     j = start + lane;
     valid_q = (j < n_kept) && ((j >> 6) == (start >> 6)) && (skeys[j] == skeys[start]);
@@ -542,7 +572,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
       cov2 = cov >= 1e15f ? big : cov * cov;
     }
   }
-  if (lane == 0 && chunk < n_chunks) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
+  if (lane == 0) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
 
   if (valid_q) {
     int status;
@@ -601,8 +631,9 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
     atomicAdd(&lh[status], 1);
     if (status == SO_MATCH_SUCCESS) { atomicAdd(&lh[7 + obs[0]], 1); atomicAdd(&lh[7 + obs[1]], 1); atomicAdd(&lh[7 + obs[2]], 1); }
   }
+  }  // chunk loop
   __syncthreads();
-  if (threadIdx.x < 20 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+  if (threadIdx.x < 20 && lh[threadIdx.x]) atomicAdd(&hist[(blockIdx.x % kHistReplicas) * kHistStride + threadIdx.x], lh[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -610,20 +641,82 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 constexpr int kNAcc = 29;  // cost, count, Jtr[6], JtJ[21]
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+// slot 0 evaluates at the outer pose T (lm_begin); slots >= 1 evaluate the candidate requested by the LM
+// controller and are no-ops once the controller has finished (or the registration has converged).
+__device__ __forceinline__ bool eval_slot_active(const DevState* st, int slot) {
+  return !st->reg_done && (slot == 0 || st->lm_more);
 }
 
-__global__ __launch_bounds__(256) void eval_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
-                                                   const float* __restrict__ spz, CorrBuffers corr, uint32_t n_kept,
-                                                   Pose pose, EvalParams ep, double* __restrict__ partials,
-                                                   uint32_t* __restrict__ ticket, const int32_t* __restrict__ hist,
-                                                   LmSums* __restrict__ out) {
-  __shared__ double red[4][kNAcc + 3];
-  __shared__ double fin[8][32];
+// The Ceres-equivalent LM controller plus the outer ICP bookkeeping (LidarSlam.cpp:119-148, 242-251).
+// Executed by ONE thread on an LDS copy of the controller state.
+__device__ void lm_control(int slot, DevState* st, LmState& S, const LmSums& sums) {
+  int more;
+  if (slot == 0) more = lm_begin(S, st->T, sums, st->lm_max, st->eval_pose);
+  else more = lm_feed(S, sums, st->eval_pose);
+  st->lm_more = more;
+  if (more) return;
+  // solve finished: T_w_lidar <- optimised pose, iteration statistics, termination rule
+  double prev[7];
+  for (int i = 0; i < 7; ++i) { prev[i] = st->T[i]; st->T[i] = S.x[i]; }
+  const int o = st->outer_iter;
+  DevIterStats& is = st->iters[o < 16 ? o : 15];
+  relative_motion(prev, S.x, is.translation_norm, is.rotation_norm);
+  is.num_surf = (int32_t)S.count; is.lm_iterations = S.lm_iterations; is.num_successful = S.num_successful;
+  is.termination = S.termination; is.initial_cost = S.initial_cost; is.final_cost = S.x_cost;
+  for (int h = 0; h < 7; ++h) is.reject_hist[h] = (int32_t)sums.hist[h];
+  for (int h = 0; h < 9; ++h) is.obs_hist[h] = (int32_t)sums.hist[7 + h];
+  for (int i = 0; i < 7; ++i) is.pose_after[i] = S.x[i];
+  st->outer_iter = o + 1;
+  st->n_iterations = o + 1;
+  if (S.num_successful == 1 || o + 1 >= st->max_outer) {  // LidarSlam.cpp:141
+    st->reg_done = 1;
+    const bool have = S.count > 0;
+    for (int i = 0; i < 36; ++i) st->JtJ[i] = have ? S.H[i] : 0.0;
+    for (int i = 0; i < 6; ++i) st->Jtr[i] = have ? S.g[i] : 0.0;
+  }
+}
+
+// cooperative copy of the controller state between global memory and LDS (sizeof(LmState) is a multiple of 8)
+__device__ __forceinline__ void copy_words(double* dst, const double* src, int n_doubles, int tid, int nthreads) {
+  for (int i = tid; i < n_doubles; i += nthreads) dst[i] = src[i];
+}
+static_assert(sizeof(LmState) % 8 == 0 && sizeof(LmSums) % 8 == 0, "controller state must be double-aligned");
+
+constexpr int kRedStride = kNAcc + 1;  // 30 doubles per record in LDS
+
+// sum 256 records of kNAcc doubles held in red[256][kRedStride]: thread (a, c) adds rows 32c..32c+31 of value a in
+// order, then thread (a, 0) adds the 8 partial sums in order -- a fixed tree, identical on every launch.
+__device__ __forceinline__ double reduce_records(double (*red)[kRedStride], double (*part)[32], int tid) {
+  const int a = tid & 31, cch = tid >> 5;
+  if (a < kNAcc) {
+    double s = 0;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) s += red[cch * 32 + r][a];
+    part[cch][a] = s;
+  }
+  __syncthreads();
+  double tot = 0;
+  if (tid < kNAcc) {
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) tot += part[cc][tid];
+  }
+  return tot;
+}
+
+__global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const float* __restrict__ spx,
+                                                   const float* __restrict__ spy, const float* __restrict__ spz,
+                                                   CorrBuffers corr, DevState* __restrict__ st, EvalParams ep,
+                                                   double* __restrict__ partials, uint32_t* __restrict__ ticket,
+                                                   const int32_t* __restrict__ hist, LmSums* __restrict__ out) {
+  __shared__ double red[256][kRedStride];  // 60 KB: per-thread accumulators, later the 256 workgroup records
+  __shared__ double part[8][32];
+  __shared__ LmSums sh_sums;
+  __shared__ LmState sh_S;
   __shared__ bool is_last;
+  if (!eval_slot_active(st, slot)) return;
+  const int tid = threadIdx.x;
+  const uint32_t n_kept = (ep.ablate & 64) ? 0u : st->n_kept;
+  const Pose pose = pose_from_array(slot == 0 ? st->T : st->eval_pose);
   double acc[kNAcc];
 #pragma unroll
   for (int a = 0; a < kNAcc; ++a) acc[a] = 0;
@@ -635,9 +728,9 @@ __global__ __launch_bounds__(256) void eval_kernel(const float* __restrict__ spx
   const double R00 = 1 - (tyy + tzz), R01 = txy - twz, R02 = txz + twy;
   const double R10 = txy + twz, R11 = 1 - (txx + tzz), R12 = tyz - twx;
   const double R20 = txz - twy, R21 = tyz + twx, R22 = 1 - (txx + tyy);
-  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_kept; j += gridDim.x * blockDim.x) {
-    const double c = corr.coeff[j];
+  for (uint32_t j = blockIdx.x * blockDim.x + tid; j < n_kept; j += gridDim.x * blockDim.x) {
     if (corr.status[j] != SO_MATCH_SUCCESS) continue;
+    const double c = corr.coeff[j];
     const double4 nd = corr.nd[j];
     const double px = (double)spx[j], py = (double)spy[j], pz = (double)spz[j];
     double wx, wy, wz;
@@ -672,47 +765,65 @@ __global__ __launch_bounds__(256) void eval_kernel(const float* __restrict__ spx
       for (int b = a; b < 6; ++b) acc[k++] += wj * J[b];
     }
   }
-  // wavefront shuffle reduction -> LDS -> one partial record per workgroup
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // workgroup reduction through LDS (transposed: no serial shuffle chains), fixed order
 #pragma unroll
-  for (int a = 0; a < kNAcc; ++a) {
-    const double v = wave_sum(acc[a]);
-    if (lane == 0) red[wave][a] = v;
-  }
+  for (int a = 0; a < kNAcc; ++a) red[tid][a] = acc[a];
   __syncthreads();
-  if (threadIdx.x < kNAcc) {
-    const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    partials[(size_t)blockIdx.x * kSumsStride + threadIdx.x] = v;
-  }
-  // last-workgroup finish (agent-scope release by the producers, acquire by the consumer)
+  const double mine = reduce_records(red, part, tid);
+  // Hand-off to the last workgroup WITHOUT release/acquire fences (each costs microseconds on gfx950): the 29
+  // partial sums are 8-byte agent-scope relaxed atomic stores (write-through, sc1), drained with vmcnt(0) by the
+  // storing wave before the arrival ticket; the consumer reads them with agent-scope relaxed atomic loads
+  // (sc1: served by L2, never a stale L1 line).  [MI355X guide, G16 "8-B agent atomics both sides"]
+  if (tid < kNAcc)
+    __hip_atomic_store(&partials[(size_t)blockIdx.x * kSumsStride + tid], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // keep the write-back ahead of the ticket (ROCm 7.2 hazard)
-    const uint32_t t = atomicAdd(ticket, 1u);
+  if (tid == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (t == gridDim.x - 1);
-    if (is_last) __threadfence();
   }
   __syncthreads();
   if (!is_last) return;
-  {
-    const int v = threadIdx.x & 31, chunk = threadIdx.x >> 5;  // 8 chunks x 32 values, fixed order
-    double s = 0;
-    if (v < kNAcc)
-      for (uint32_t b = chunk; b < gridDim.x; b += 8) s += __builtin_nontemporal_load(&partials[(size_t)b * kSumsStride + v]);
-    fin[chunk][v] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kNAcc) {
-    double s = 0;
+  // thread b fetches workgroup b's record (29 independent loads = one memory latency), same fixed tree again
 #pragma unroll
-    for (int cidx = 0; cidx < 8; ++cidx) s += fin[cidx][threadIdx.x];
-    double* o = reinterpret_cast<double*>(out);
-    o[threadIdx.x] = s;  // LmSums layout: cost, count, Jtr[6], JtJ[21]
-  } else if (threadIdx.x >= 32 && threadIdx.x < 48) {
-    reinterpret_cast<double*>(out)[kNAcc + (threadIdx.x - 32)] = (double)hist[threadIdx.x - 32];
+  for (int a = 0; a < kNAcc; ++a)
+    red[tid][a] = (tid < (int)gridDim.x)
+                      ? __hip_atomic_load(&partials[(size_t)tid * kSumsStride + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                      : 0.0;
+  __syncthreads();
+  const double total = reduce_records(red, part, tid);
+  double* o = reinterpret_cast<double*>(&sh_sums);
+  if (tid < kNAcc) {
+    o[tid] = total;  // cost, count, Jtr[6], JtJ[21]
+  } else if (tid >= 32 && tid < 48) {
+    int h = 0;
+#pragma unroll
+    for (int r = 0; r < kHistReplicas; ++r) h += hist[r * kHistStride + (tid - 32)];
+    o[kNAcc + (tid - 32)] = (double)h;
   }
-  if (threadIdx.x == 0) *ticket = 0;  // re-arm for the next launch on this stream
+  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+  __syncthreads();
+  copy_words(reinterpret_cast<double*>(out), o, (int)(sizeof(LmSums) / 8), tid, 256);
+  if (!fuse_lm) return;  // sharded map: the sums are all-reduced first, lm_step_kernel runs the controller
+  copy_words(reinterpret_cast<double*>(&sh_S), reinterpret_cast<const double*>(&st->S), (int)(sizeof(LmState) / 8), tid, 256);
+  __syncthreads();
+  if (tid == 0 && !(ep.ablate & 32)) lm_control(slot, st, sh_S, sh_sums);
+  __syncthreads();
+  copy_words(reinterpret_cast<double*>(&st->S), reinterpret_cast<const double*>(&sh_S), (int)(sizeof(LmState) / 8), tid, 256);
+}
+
+// controller as its own launch (used when the sums pass through the RCCL all-reduce between eval and control)
+__global__ __launch_bounds__(64) void lm_step_kernel(int slot, DevState* st, const LmSums* __restrict__ sums_in) {
+  __shared__ LmSums sh_sums;
+  __shared__ LmState sh_S;
+  if (!eval_slot_active(st, slot)) return;
+  const int tid = threadIdx.x;
+  copy_words(reinterpret_cast<double*>(&sh_sums), reinterpret_cast<const double*>(sums_in), (int)(sizeof(LmSums) / 8), tid, 64);
+  copy_words(reinterpret_cast<double*>(&sh_S), reinterpret_cast<const double*>(&st->S), (int)(sizeof(LmState) / 8), tid, 64);
+  __syncthreads();
+  if (tid == 0) lm_control(slot, st, sh_S, sh_sums);
+  __syncthreads();
+  copy_words(reinterpret_cast<double*>(&st->S), reinterpret_cast<const double*>(&sh_S), (int)(sizeof(LmState) / 8), tid, 64);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -810,35 +921,41 @@ size_t sort_temp_bytes(size_t n) {
   return bytes;
 }
 
-void launch_scan_keys(const float* d_scan, uint32_t n, const Pose& pose, const DevMapView& map, int max_sf, int rank,
-                      int world, uint32_t* keys, uint32_t* vals, uint32_t* n_kept, hipStream_t s) {
+void launch_reg_begin(DevState* st, hipStream_t s) { hipLaunchKernelGGL(reg_begin_kernel, dim3(1), dim3(1), 0, s, st); }
+void launch_scan_keys(const float* d_scan, uint32_t n, const DevState* st, const DevMapView& map, int max_sf, int rank,
+                      int world, uint32_t* keys, uint32_t* vals, DevState* st_rw, hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, pose, map, max_sf, rank, world, keys, vals, n_kept);
+  (void)st_rw;
+  hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, map, max_sf, rank, world, keys, vals);
 }
 void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo,
                        uint32_t n, hipStream_t s) {
   if (!n) return;
   (void)rocprim::radix_sort_pairs(tmp, tmp_bytes, ki, ko, vi, vo, (size_t)n, 0, 32, s);
 }
-void launch_gather_scan(const float* d_scan, const uint32_t* perm, uint32_t n_kept, float* spx, float* spy, float* spz, hipStream_t s) {
-  if (!n_kept) return;
-  hipLaunchKernelGGL(gather_scan_kernel, grid_for(n_kept, 256), dim3(256), 0, s, d_scan, perm, n_kept, spx, spy, spz);
+void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n, uint32_t* chunk_start, DevState* st, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(chunk_heads_kernel, grid_for(n, 1024), dim3(1024), 0, s, keys_sorted, n, chunk_start, st);
 }
-void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n_kept, uint32_t* chunk_start, uint32_t* n_chunks, hipStream_t s) {
-  if (!n_kept) return;
-  hipLaunchKernelGGL(chunk_heads_kernel, grid_for(n_kept, 256), dim3(256), 0, s, keys_sorted, n_kept, chunk_start, n_chunks);
+void launch_gather_scan(const float* d_scan, const uint32_t* perm, const uint32_t* keys_sorted, uint32_t n, float* spx, float* spy,
+                        float* spz, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(gather_scan_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, perm, keys_sorted, n, spx, spy, spz);
 }
-void launch_knn_plane(const float* spx, const float* spy, const float* spz, uint32_t n_kept, const uint32_t* keys_sorted,
-                      const uint32_t* chunk_start, uint32_t n_chunks, const Pose& pose, const DevMapView& map,
-                      const MatchParams& mp, CorrBuffers corr, int32_t* hist, hipStream_t s) {
-  if (!n_kept || !n_chunks) return;
-  hipLaunchKernelGGL(knn_plane_kernel, dim3((n_chunks + 3) / 4), dim3(256), 0, s, spx, spy, spz, n_kept, keys_sorted, chunk_start,
-                     n_chunks, pose, map.pts, map.cell_start, map, mp, corr, hist);
+void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* keys_sorted,
+                      const uint32_t* chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
+                      CorrBuffers corr, int32_t* hist, hipStream_t s) {
+  hipLaunchKernelGGL(knn_plane_kernel, dim3(kKnnBlocks), dim3(256), 0, s, spx, spy, spz, keys_sorted, chunk_start, st, map.pts,
+                     map.cell_start, map, mp, corr, hist);
 }
-void launch_eval(const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, uint32_t n_kept,
-                 const Pose& pose, const EvalParams& ep, double* partials, uint32_t* ticket, const int32_t* hist,
-                 LmSums* sums, hipStream_t s) {
-  hipLaunchKernelGGL(eval_kernel, dim3(kEvalBlocks), dim3(256), 0, s, spx, spy, spz, corr, n_kept, pose, ep, partials, ticket, hist, sums);
+void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr,
+                 DevState* st, const EvalParams& ep, double* partials, uint32_t* ticket, const int32_t* hist, LmSums* sums,
+                 hipStream_t s) {
+  hipLaunchKernelGGL(eval_kernel, dim3(kEvalBlocks), dim3(256), 0, s, slot, fuse_lm ? 1 : 0, spx, spy, spz, corr, st, ep, partials,
+                     ticket, hist, sums);
+}
+void launch_lm_step(int slot, DevState* st, const LmSums* sums, hipStream_t s) {
+  hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, s, slot, st, sums);
 }
 void launch_knn_only(const float* q, uint32_t nq, int k, const DevMapView& map, float gate_d2, float* nbr, float* d2,
                      int32_t* idx, uint8_t* found, uint32_t* fb_list, uint32_t* fb_count, hipStream_t s) {

@@ -15,6 +15,12 @@
 #pragma once
 #include "so_math.h"
 
+#if defined(__HIP__)
+#define SO_UNROLL _Pragma("unroll")
+#else
+#define SO_UNROLL
+#endif
+
 namespace soicp {
 
 struct LmSums {      // == so_icp_sums (include/so_icp.h), 45 doubles
@@ -42,45 +48,59 @@ struct LmConst {
 
 SO_HD void lm_unpack(const LmSums& s, double H[36], double g[6]) {
   int k = 0;
+  SO_UNROLL
   for (int i = 0; i < 6; ++i)
+    SO_UNROLL
     for (int j = i; j < 6; ++j) { H[6 * i + j] = s.JtJ[k]; H[6 * j + i] = s.JtJ[k]; ++k; }
+  SO_UNROLL
   for (int i = 0; i < 6; ++i) g[i] = s.Jtr[i];
 }
 
 // | x - Plus(x, -g) |_inf : TrustRegionMinimizer::EvaluateGradientAndJacobian
 SO_HD double lm_gradient_max_norm(const double x[7], const double g[6]) {
   double ng[6], xp[7], m = 0;
+  SO_UNROLL
   for (int i = 0; i < 6; ++i) ng[i] = -g[i];
   pose_plus(x, ng, xp);
+  SO_UNROLL
   for (int i = 0; i < 7; ++i) { double v = fabs(x[i] - xp[i]); if (v > m) m = v; }
   return m;
 }
 
 // Cholesky solve of a 6x6 SPD system; returns false when a pivot is not positive / result not finite.
 SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
+  SO_UNROLL
   for (int j = 0; j < 6; ++j) {
     double d = A[6 * j + j];
+    SO_UNROLL
     for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
     if (!(d > 0.0)) return false;
     d = sqrt(d);
     A[6 * j + j] = d;
+    SO_UNROLL
     for (int i = j + 1; i < 6; ++i) {
       double s = A[6 * i + j];
+      SO_UNROLL
       for (int k = 0; k < j; ++k) s -= A[6 * i + k] * A[6 * j + k];
       A[6 * i + j] = s / d;
     }
   }
   double z[6];
+  SO_UNROLL
   for (int i = 0; i < 6; ++i) {
     double s = b[i];
+    SO_UNROLL
     for (int k = 0; k < i; ++k) s -= A[6 * i + k] * z[k];
     z[i] = s / A[6 * i + i];
   }
+  SO_UNROLL
   for (int i = 5; i >= 0; --i) {
     double s = z[i];
+    SO_UNROLL
     for (int k = i + 1; k < 6; ++k) s -= A[6 * k + i] * y[k];
     y[i] = s / A[6 * i + i];
   }
+  SO_UNROLL
   for (int i = 0; i < 6; ++i) if (!isfinite(y[i])) return false;
   return true;
 }
@@ -95,6 +115,7 @@ SO_HD int lm_propose(LmState& S, double next_pose[7]) {
     S.lm_iterations = S.iter;
     // jacobian_ is column-scaled: Hs = S H S, gs = S g
     if (!S.reuse_diagonal) {
+      SO_UNROLL
       for (int j = 0; j < 6; ++j) {
         double v = S.H[7 * j] * S.scale[j] * S.scale[j];
         v = v < LmConst::kMinLmDiagonal ? LmConst::kMinLmDiagonal : v;
@@ -102,8 +123,10 @@ SO_HD int lm_propose(LmState& S, double next_pose[7]) {
       }
     }
     double A[36], Hs[36], gs[6], y[6], step[6];
+    SO_UNROLL
     for (int i = 0; i < 6; ++i) {
       gs[i] = S.g[i] * S.scale[i];
+      SO_UNROLL
       for (int j = 0; j < 6; ++j) { Hs[6 * i + j] = S.H[6 * i + j] * S.scale[i] * S.scale[j]; A[6 * i + j] = Hs[6 * i + j]; }
       A[7 * i] += S.diag[i] / S.radius;  // lm_diagonal^2
     }
@@ -112,12 +135,15 @@ SO_HD int lm_propose(LmState& S, double next_pose[7]) {
     double mcc = 0;
     if (ok) {
       double sHs = 0, sg = 0;
+      SO_UNROLL
       for (int i = 0; i < 6; ++i) {
         step[i] = -y[i];
         sg += step[i] * gs[i];
       }
+      SO_UNROLL
       for (int i = 0; i < 6; ++i) {
         double r = 0;
+        SO_UNROLL
         for (int j = 0; j < 6; ++j) r += Hs[6 * i + j] * step[j];
         sHs += step[i] * r;
       }
@@ -131,24 +157,30 @@ SO_HD int lm_propose(LmState& S, double next_pose[7]) {
     S.invalid_steps = 0;
     S.model_cost_change = mcc;
     double delta[6];
+    SO_UNROLL
     for (int i = 0; i < 6; ++i) delta[i] = step[i] * S.scale[i];
     pose_plus(S.x, delta, S.cand);
+    SO_UNROLL
     for (int i = 0; i < 7; ++i) next_pose[i] = S.cand[i];
     return 1;
   }
 }
 
 SO_HD int lm_begin(LmState& S, const double x0[7], const LmSums& sums, int max_iterations, double next_pose[7]) {
+  SO_UNROLL
   for (int i = 0; i < 7; ++i) { S.x[i] = x0[i]; S.cand[i] = x0[i]; }
   S.iter = 0; S.max_iter = max_iterations; S.reuse_diagonal = 0; S.invalid_steps = 0; S.num_successful = 0;
   S.termination = 0; S.done = 0; S.lm_iterations = 0;
   S.radius = LmConst::kInitialRadius; S.decrease_factor = 2.0; S.model_cost_change = 0;
   S.count = sums.count; S.x_cost = sums.cost; S.initial_cost = sums.cost;
   lm_unpack(sums, S.H, S.g);
+  SO_UNROLL
   for (int j = 0; j < 6; ++j) { S.scale[j] = 1.0; S.diag[j] = 0; }
   if (!(sums.count > 0)) { S.termination = 4; S.done = 1; return 0; }  // no residual blocks: nothing to minimise
+  SO_UNROLL
   for (int j = 0; j < 6; ++j) S.scale[j] = 1.0 / (1.0 + sqrt(S.H[7 * j]));  // jacobi_scaling, fixed at iteration 0
   double n2 = 0;
+  SO_UNROLL
   for (int i = 0; i < 7; ++i) n2 += S.x[i] * S.x[i];
   S.x_norm = sqrt(n2);
   if (lm_gradient_max_norm(S.x, S.g) <= LmConst::kGradientTolerance) { S.termination = 3; S.done = 1; return 0; }
@@ -160,6 +192,7 @@ SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7]) {
   const double cand_cost = sums.cost;
   // ParameterToleranceReached
   double sn = 0;
+  SO_UNROLL
   for (int i = 0; i < 7; ++i) sn += (S.x[i] - S.cand[i]) * (S.x[i] - S.cand[i]);
   sn = sqrt(sn);
   if (sn <= LmConst::kParameterTolerance * (S.x_norm + LmConst::kParameterTolerance)) { S.termination = 2; S.done = 1; return 0; }
@@ -168,8 +201,10 @@ SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7]) {
   if (fabs(cost_change) <= LmConst::kFunctionTolerance * S.x_cost) { S.termination = 1; S.done = 1; return 0; }
   const double rel = cost_change / S.model_cost_change;  // TrustRegionStepEvaluator::StepQuality, monotonic
   if (rel > LmConst::kMinRelativeDecrease) {             // HandleSuccessfulStep
+    SO_UNROLL
     for (int i = 0; i < 7; ++i) S.x[i] = S.cand[i];
     double n2 = 0;
+    SO_UNROLL
     for (int i = 0; i < 7; ++i) n2 += S.x[i] * S.x[i];
     S.x_norm = sqrt(n2);
     S.x_cost = cand_cost;
