@@ -405,32 +405,45 @@ constexpr int kKeyIdxBits = 9;
 constexpr uint32_t kKeyIdxMask = (1u << kKeyIdxBits) - 1u;
 constexpr uint32_t kGroupMaxCand = 1u << kKeyIdxBits;
 
-// v_med3_u32 has no clang builtin; it is a pure VALU op (no memory, no wait states needed).
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t r;
-  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+// v_med3_i32 has no clang builtin; it is a pure VALU op (no memory, no wait states needed).
+__device__ __forceinline__ int32_t imed3(int32_t a, int32_t b, int32_t c) {
+  int32_t r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
 
+// Keys are float bit patterns compared as SIGNED integers: for non-negative floats that is the float order, and a
+// (rounding-induced) slightly negative approximate d2 sorts in front of everything, which is what we want.
+constexpr int32_t kKeyEmpty = 0x7FFFFFFF;
+
 struct Net8 {  // ascending: a0 <= a1 <= ... <= a7
-  uint32_t a0, a1, a2, a3, a4, a5, a6, a7;
-  __device__ __forceinline__ void init() { a0 = a1 = a2 = a3 = a4 = a5 = a6 = a7 = 0xFFFFFFFFu; }
-  __device__ __forceinline__ void push(uint32_t k) {  // new a_s = med3(a_{s-1}, a_s, k); a0 = min(a0, k)
-    a7 = umed3(a6, a7, k);
-    a6 = umed3(a5, a6, k);
-    a5 = umed3(a4, a5, k);
-    a4 = umed3(a3, a4, k);
-    a3 = umed3(a2, a3, k);
-    a2 = umed3(a1, a2, k);
-    a1 = umed3(a0, a1, k);
+  int32_t a0, a1, a2, a3, a4, a5, a6, a7;
+  __device__ __forceinline__ void init() { a0 = a1 = a2 = a3 = a4 = a5 = a6 = a7 = kKeyEmpty; }
+  __device__ __forceinline__ void push(int32_t k) {  // new a_s = med3(a_{s-1}, a_s, k); a0 = min(a0, k)
+    a7 = imed3(a6, a7, k);
+    a6 = imed3(a5, a6, k);
+    a5 = imed3(a4, a5, k);
+    a4 = imed3(a3, a4, k);
+    a3 = imed3(a2, a3, k);
+    a2 = imed3(a1, a2, k);
+    a1 = imed3(a0, a1, k);
     a0 = a0 < k ? a0 : k;
   }
 };
 
-__device__ __forceinline__ uint32_t approx_key(float qx, float qy, float qz, const float4 c, uint32_t jloc) {
-  const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-  const float d2a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-  return (__float_as_uint(d2a) & ~kKeyIdxMask) | jloc;
+// Approximate d2 in BLOCK-LOCAL coordinates (origin = centre of the group's home cell, |coords| <= ~2 m):
+//   d2a = (|c|^2 + |q|^2) - 2 q.c      -> 1 add + 3 fma per candidate instead of 3 sub + mul + 2 fma.
+// |c|^2 is precomputed at staging time, -2q and |q|^2 once per lane per group.  With magnitudes <= ~8 the fp32
+// rounding error is <= ~4e-6 m^2 (absolute); the certification margin below accounts for it (kApproxAbsErr).
+constexpr float kApproxAbsErr = 2e-5f;
+__device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz, float qq, float cx, float cy, float cz,
+                                              float cc, uint32_t jloc, uint32_t keep_mask) {
+  float v = cc + qq;
+  v = __builtin_fmaf(m2qx, cx, v);
+  v = __builtin_fmaf(m2qy, cy, v);
+  v = __builtin_fmaf(m2qz, cz, v);
+  // v_bfi_b32: distance bits where keep_mask is set, the candidate's position in the tile elsewhere
+  return (int32_t)((__float_as_uint(v) & keep_mask) | (jloc & ~keep_mask));
 }
 
 __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
                                                         const uint32_t* __restrict__ mcell_start, DevMapView map,
                                                         MatchParams mp, CorrBuffers corr, int32_t* __restrict__ hist) {
   __shared__ int32_t lh[20];
-  __shared__ __attribute__((aligned(16))) float tiles[4][4][kGroupMaxCand];  // per wavefront: x[], y[], z[], index[] (16 KB)
+  __shared__ __attribute__((aligned(16))) float tiles[4][4][kGroupMaxCand + 4];  // per wavefront: x[], y[], z[], |c|^2 (block-local)
   if (st->reg_done) return;  // the registration already converged: this launch is a no-op
   const uint32_t n_kept = st->n_kept, n_chunks = st->n_chunks;
   const Pose pose = pose_from_array(st->T);
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   float* tx = tiles[threadIdx.x >> 6][0];
   float* ty = tiles[threadIdx.x >> 6][1];
   float* tz = tiles[threadIdx.x >> 6][2];
-  uint32_t* ti = reinterpret_cast<uint32_t*>(tiles[threadIdx.x >> 6][3]);
+  float* tc = tiles[threadIdx.x >> 6][3];
   // one wavefront per chunk of the work list (grid-stride when the list is longer than the grid)
   for (uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
   uint32_t j = 0;
@@ -465,22 +478,24 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   double pw[3] = {0, 0, 0};
   float qx = 0, qy = 0, qz = 0;
   float ux = 0, uy = 0, uz = 0;  // cube-local coordinates of the query (for the coverage test)
+  int wcube0 = 0, wcube1 = 0, wcube2 = 0;  // world id of the query's cube
   CellRef c;
   c.slot = -1; c.cx = c.cy = c.cz = 0;
   if (valid_q) {
     quat_rotate<double>(pose.q, (double)spx[j], (double)spy[j], (double)spz[j], pw[0], pw[1], pw[2]);  // LidarSlam.cpp:397-398
     pw[0] += pose.t[0]; pw[1] += pose.t[1]; pw[2] += pose.t[2];
     qx = (float)pw[0]; qy = (float)pw[1]; qz = (float)pw[2];                                            // LidarSlam.cpp:728-731
-    int w[3];
+    int w[3] = {0, 0, 0};
     c = locate(map, qx, qy, qz, w);
     if (c.slot >= 0) {
       ux = (float)((double)qx - (w[0] * 50.0 - 25.0)); uy = (float)((double)qy - (w[1] * 50.0 - 25.0)); uz = (float)((double)qz - (w[2] * 50.0 - 25.0));
+      wcube0 = w[0]; wcube1 = w[1]; wcube2 = w[2];
     }
   }
   const uint32_t ckey = (valid_q && c.slot >= 0) ? (((uint32_t)c.slot << 18) | ((uint32_t)c.cz << 12) | ((uint32_t)c.cy << 6) | (uint32_t)c.cx)
                                                  : 0xFFFFFFFFu;
   uint32_t g0 = 0xFFFFFFFFu, g1 = g0, g2 = g0, g3 = g0, g4 = g0, g5 = g0, g6 = g0, g7 = g0;  // canonical indices of the 8 survivors
-  uint32_t k8 = 0xFFFFFFFFu;   // 8th key of the lane's group pass
+  int32_t k8 = kKeyEmpty;      // 8th key of the lane's group pass
   float cov2 = 0.f;            // squared distance from the query to the boundary of the scanned block
   bool need_exact = false;
   const int nc = map.nc;
@@ -533,39 +548,60 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
       continue;
     }
     n_scanned += total;
-    // stage the group's candidates into this wave's LDS tile with coalesced 16-byte loads; .w carries the canonical index
+    // block-local frame: origin at the centre of the group's home cell (world coordinates, fp64)
+    const double ox = ((int)__builtin_amdgcn_readlane(wcube0, leader) * 50.0 - 25.0) + ((double)gx + 0.5) * (double)cell;
+    const double oy = ((int)__builtin_amdgcn_readlane(wcube1, leader) * 50.0 - 25.0) + ((double)gy + 0.5) * (double)cell;
+    const double oz = ((int)__builtin_amdgcn_readlane(wcube2, leader) * 50.0 - 25.0) + ((double)gz + 0.5) * (double)cell;
+    // stage the group's candidates into this wave's LDS tile with coalesced 16-byte loads
     __builtin_amdgcn_wave_barrier();
     if (!(mp.ablate & 16))
-    for (uint32_t t = lane; t < total; t += 64) {
-      uint32_t idx = rbeg[0] + t;
+    for (uint32_t t = lane; t < total + 4; t += 64) {
+      float lx = 0.f, ly = 0.f, lz = 0.f, lc = 3.0e38f;  // padding entries lose against every real candidate
+      if (t < total) {
+        uint32_t idx = rbeg[0] + t;
 #pragma unroll
-      for (int r = 1; r < 9; ++r) idx = (t >= roff[r]) ? (rbeg[r] - roff[r] + t) : idx;
-      const float4 p = mpts[idx];
-      tx[t] = p.x; ty[t] = p.y; tz[t] = p.z; ti[t] = idx;
+        for (int r = 1; r < 9; ++r) idx = (t >= roff[r]) ? (rbeg[r] - roff[r] + t) : idx;
+        const float4 p = mpts[idx];
+        lx = (float)((double)p.x - ox); ly = (float)((double)p.y - oy); lz = (float)((double)p.z - oz);
+        lc = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+      }
+      tx[t] = lx; ty[t] = ly; tz[t] = lz; tc[t] = lc;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const float lqx = (float)((double)qx - ox), lqy = (float)((double)qy - oy), lqz = (float)((double)qz - oz);
+    const float m2qx = -2.f * lqx, m2qy = -2.f * lqy, m2qz = -2.f * lqz;
+    const float qq = __builtin_fmaf(lqz, lqz, __builtin_fmaf(lqy, lqy, lqx * lqx));
+    const uint32_t keep = ~kKeyIdxMask;
     Net8 net;
     net.init();
     if (!(mp.ablate & 8)) {
-      uint32_t jl = 0;
-      for (; jl + 4 <= total; jl += 4) {  // uniform addresses: three broadcast ds_read_b128 feed four candidates
-        const float4 X = *reinterpret_cast<const float4*>(tx + jl);
-        const float4 Y = *reinterpret_cast<const float4*>(ty + jl);
-        const float4 Z = *reinterpret_cast<const float4*>(tz + jl);
-        net.push(approx_key(qx, qy, qz, make_float4(X.x, Y.x, Z.x, 0.f), jl));
-        net.push(approx_key(qx, qy, qz, make_float4(X.y, Y.y, Z.y, 0.f), jl + 1));
-        net.push(approx_key(qx, qy, qz, make_float4(X.z, Y.z, Z.z, 0.f), jl + 2));
-        net.push(approx_key(qx, qy, qz, make_float4(X.w, Y.w, Z.w, 0.f), jl + 3));
+      // uniform addresses: four broadcast ds_read_b128 feed four candidates; the next quad is fetched while this one
+      // runs through the selection network (software pipeline, no wait between LDS issue and use)
+      float4 X = *reinterpret_cast<const float4*>(tx), Y = *reinterpret_cast<const float4*>(ty);
+      float4 Z = *reinterpret_cast<const float4*>(tz), C = *reinterpret_cast<const float4*>(tc);
+      for (uint32_t jl = 0; jl < total; jl += 4) {
+        const uint32_t nx = (jl + 4 < total) ? jl + 4 : jl;  // last iteration re-reads (harmless)
+        const float4 Xn = *reinterpret_cast<const float4*>(tx + nx), Yn = *reinterpret_cast<const float4*>(ty + nx);
+        const float4 Zn = *reinterpret_cast<const float4*>(tz + nx), Cn = *reinterpret_cast<const float4*>(tc + nx);
+        net.push(approx_key(m2qx, m2qy, m2qz, qq, X.x, Y.x, Z.x, C.x, jl, keep));
+        net.push(approx_key(m2qx, m2qy, m2qz, qq, X.y, Y.y, Z.y, C.y, jl + 1, keep));
+        net.push(approx_key(m2qx, m2qy, m2qz, qq, X.z, Y.z, Z.z, C.z, jl + 2, keep));
+        net.push(approx_key(m2qx, m2qy, m2qz, qq, X.w, Y.w, Z.w, C.w, jl + 3, keep));
+        X = Xn; Y = Yn; Z = Zn; C = Cn;
       }
-      for (; jl < total; ++jl) net.push(approx_key(qx, qy, qz, make_float4(tx[jl], ty[jl], tz[jl], 0.f), jl));
     }
-    // survivors' canonical indices come straight out of the tile
-    const uint32_t ks[8] = {net.a0, net.a1, net.a2, net.a3, net.a4, net.a5, net.a6, net.a7};
+    // survivors: position in the tile -> canonical index through the row table (all lanes compute, owners commit)
+    const int32_t ks[8] = {net.a0, net.a1, net.a2, net.a3, net.a4, net.a5, net.a6, net.a7};
     uint32_t gi[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-      gi[t] = (ks[t] == 0xFFFFFFFFu) ? 0xFFFFFFFFu : ti[ks[t] & kKeyIdxMask];
+    for (int t = 0; t < 8; ++t) {
+      const uint32_t jl = (uint32_t)ks[t] & kKeyIdxMask;
+      uint32_t idx = rbeg[0] + jl;
+#pragma unroll
+      for (int r = 1; r < 9; ++r) idx = (jl >= roff[r]) ? (rbeg[r] - roff[r] + jl) : idx;
+      gi[t] = (ks[t] == kKeyEmpty || jl >= total) ? 0xFFFFFFFFu : idx;
+    }
     if (mine) {
       g0 = gi[0]; g1 = gi[1]; g2 = gi[2]; g3 = gi[3]; g4 = gi[4]; g5 = gi[5]; g6 = gi[6]; g7 = gi[7];
       k8 = net.a7;
@@ -594,10 +630,10 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
           }
         }
         // Every candidate that was NOT re-ranked has exact d2 >= R2:
-        //   in-block outsiders: approximate d2 >= L (8th key, index bits cleared), exact >= L (1 - 4e-7);
+        //   in-block outsiders: approximate d2 >= L (8th key, index bits cleared), exact >= L - kApproxAbsErr;
         //   points of the cube outside the block: farther than the block boundary (cov2).
         double R2 = (double)cov2 * (1.0 - 1e-6);
-        if (k8 != 0xFFFFFFFFu) R2 = fmin(R2, (double)__uint_as_float(k8 & ~kKeyIdxMask) * (1.0 - 1e-6));
+        if (k8 != kKeyEmpty) R2 = fmin(R2, (double)__uint_as_float((uint32_t)k8 & ~kKeyIdxMask) * (1.0 - 1e-6) - (double)kApproxAbsErr);
         const bool have5 = top.b4 != ~0ull;
         const double d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
         if (have5 && d5 < R2) {

@@ -148,3 +148,74 @@ def test_determinism_bitwise(gpu_slam_factory, oracle):
     _, p1, s1 = slam.register(scan, guess)
     _, p2, s2 = slam.register(scan, guess)
     assert np.array_equal(p1, p2), "fixed-order reductions: repeated registrations must agree bit for bit"
+
+
+def test_rccl_path_world1_matches_oracle(oracle, gpu_slam_factory, soicp):
+    """The N>1 code path (eval -> ncclAllReduce(45 fp64) -> lm_step_kernel) on a 1-rank RCCL communicator."""
+    sc, slam, om = _setup("tiny", oracle, gpu_slam_factory, max_iterations=5)
+    try:
+        uid = soicp.comm_unique_id()
+        slam.comm_init(uid)
+    except soicp.SoIcpError as e:
+        pytest.fail(f"RCCL communicator could not be created: {e}")
+    for i in (0, 4):
+        scan, guess = sc.scan(i), sc.guess(i)
+        rc, pose, st = slam.register(scan, guess)
+        orc, opose, ost, _ = om.register(scan, guess, oracle.default_config(max_iterations=5))
+        assert rc == orc == 0 and st.n_iterations == ost.n_iterations
+        for it in range(st.n_iterations):
+            assert st.iterations[it].lm_iterations == ost.iters[it].lm_iterations
+            assert list(st.iterations[it].obs_hist) == list(ost.iters[it].obs_hist)
+        ok, dt, dr = pose_close(pose, opose, 1e-8, 1e-8)
+        assert ok, (dt, dr)
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[2] sizes (131 072-pt scan vs 2M-pt map): size-independent properties."""
+    import oracle_py
+    from superodom_amd import binding
+    sc = synth.Scene("os1_128_2m")
+    slam = binding.LidarSlamGpu(plane_res=sc.plane_res, max_surface_features=-1, max_iterations=5)
+    assert slam.add_surf_point_cloud(sc.map_points) == 2_000_000 == slam.map_size()
+    scan, gt = sc.scan(1), sc.gt_pose(1)
+    assert len(scan) == 131072
+    # (1) convergence basin: different guesses land on the same pose
+    poses = []
+    for seed in (1001, 2001, 3001):
+        rc, pose, st = slam.register(scan, synth.perturb_pose(gt, seed, 0.10, 1.0))
+        assert rc == 0 and 1 <= st.n_iterations <= 5
+        poses.append(pose)
+        e = synth.pose_error(pose, gt)
+        assert e[0] < 0.01 and e[1] < 0.002, e
+    for p in poses[1:]:
+        d = synth.pose_error(p, poses[0])
+        assert d[0] < 2e-3 and d[1] < 2e-4, d
+    # (2) idempotence: registering from the converged pose moves it by less than the tolerance of record
+    rc, pose2, st2 = slam.register(scan, poses[0])
+    d = synth.pose_error(pose2, poses[0])
+    assert d[0] < 1e-3 and d[1] < 1e-4, d
+    # (3) bitwise determinism at full size
+    rc, pose3, _ = slam.register(scan, synth.perturb_pose(gt, 1001, 0.10, 1.0))
+    assert np.array_equal(pose3, poses[0])
+    # (4) Seam B at full size: sortedness, cube restriction, and exactness against numpy brute force on a sample
+    R = synth.quat_to_R(gt[3:])
+    q = (scan[::16] @ R.T + gt[:3]).astype(np.float32)
+    found, nbr, d2, idx = slam.nearest_k_search_surf(q, 5)
+    assert found.all() and (np.diff(d2, axis=1) >= 0).all()
+    assert (np.floor((nbr + 25.0) / 50.0) == np.floor((q + 25.0) / 50.0)[:, None, :]).all()
+    mp = slam.export_map()
+    cube_of = np.floor((mp.astype(np.float64) + 25.0) / 50.0).astype(np.int64)
+    rng = np.random.default_rng(0)
+    for i in rng.integers(0, len(q), 40):
+        cq = np.floor((q[i].astype(np.float64) + 25.0) / 50.0).astype(np.int64)
+        cand = mp[(cube_of == cq).all(1)]
+        diff = (q[i] - cand).astype(np.float32).astype(np.float64)
+        dd = ((diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]).astype(np.float32)
+        assert np.array_equal(np.sort(dd)[:5].view(np.uint32), d2[i].view(np.uint32))
+    # (5) the full-size registration agrees with the CPU oracle (one scan, all host cores)
+    om = oracle_py.OracleMap(plane_res=sc.plane_res)
+    om.add_surf(mp, raw=True)
+    guess = synth.perturb_pose(gt, 1001, 0.10, 1.0)
+    orc, opose, ost, _ = om.register(scan, guess, oracle_py.default_config(max_iterations=5))
+    ok, dt, dr = pose_close(poses[0], opose, TOL_T, TOL_R)
+    assert ok and dt < 1e-8 and dr < 1e-8, (dt, dr)
