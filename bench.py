@@ -119,10 +119,22 @@ def main():
     value = args.steps / t_max
     # ---- roofline of the dominant kernel (k-NN + plane fit): algorithmic bytes per launch
     #      B_knn = 12*Q (query xyz in) + 12*M_t (map xyz in) + 24*Q (n,d,w,status record out)
+    #      M_t = map points in the 50 m cubes the scan touches, NOT the whole map
     knn_ms = tm.knn_ms_total / max(tm.knn_launches, 1)
     q_per_launch = tm.knn_queries / max(tm.knn_launches, 1)
-    m_per_launch = tm.knn_map_points / max(tm.knn_launches, 1)
+    map_xyz = slam.export_map() if world == 1 else sc.map_points
+    map_cube = np.floor((map_xyz.astype(np.float64) + 25.0) / 50.0).astype(np.int64)
+    cube_key = lambda c: (c[:, 0] + 64) * 16384 + (c[:, 1] + 64) * 128 + (c[:, 2] + 64)
+    mkeys = cube_key(map_cube)
+    m_t = []
+    for i in range(args.scans):
+        R = synth.quat_to_R(guesses[i][3:])
+        w = scans[i].astype(np.float64) @ R.T + guesses[i][:3]
+        touched = np.unique(cube_key(np.floor((w + 25.0) / 50.0).astype(np.int64)))
+        m_t.append(int(np.isin(mkeys, touched).sum()))
+    m_per_launch = float(np.mean(m_t)) / world
     b_knn = 12.0 * q_per_launch + 12.0 * m_per_launch + 24.0 * q_per_launch
+    b_knn_whole_map = 36.0 * q_per_launch + 12.0 * tm.knn_map_points / max(tm.knn_launches, 1)
     achieved = b_knn / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")  # PMC pass result (bytes per launch), see profiles/README.md
@@ -150,7 +162,10 @@ def main():
                      "pose_error_vs_ground_truth_m_rad": [max(e[0] for e in errs), max(e[1] for e in errs)]},
         "roofline": {"bound": "hbm", "kernel": "knn_plane_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": b_knn, "avg_launch_ms": knn_ms, "launches": int(tm.knn_launches)},
+                     "algorithmic_bytes_per_launch": b_knn, "avg_launch_ms": knn_ms, "launches": int(tm.knn_launches),
+                     "queries_per_launch": q_per_launch, "map_points_in_touched_cubes": m_per_launch,
+                     "note": "B = 36*Q + 12*M_t (SURVEY 8d); with M_t = whole map (BASELINE.md table) B would be %.0f and frac %.4f"
+                             % (b_knn_whole_map, (b_knn_whole_map / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if knn_ms > 0 else 0.0)},
         "kernels": {"knn_plane_ms_per_step": tm.knn_ms_total / args.steps, "eval_ms_per_step": tm.eval_ms_total / args.steps,
                     "prep_sort_ms_per_step": tm.prep_ms_total / args.steps,
                     "eval_avg_launch_ms": eval_ms, "eval_launches_per_step": tm.eval_launches / args.steps,

@@ -192,6 +192,7 @@ int upload_map(so_icp_ctx* c) {
   v.nc = m.nc; v.ncell1 = (uint32_t)((size_t)m.nc * m.nc * m.nc + 1); v.inv_cell = 1.0 / m.cell;
   v.origin[0] = c->map.origin()[0]; v.origin[1] = c->map.origin()[1]; v.origin[2] = c->map.origin()[2];
   v.n_points = (uint32_t)n;
+  v.n_slots = (uint32_t)m.n_slots;
   c->uploaded_version = c->map.version();
   return SO_ICP_OK;
 }
@@ -307,9 +308,9 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     launch_scan_keys(d_scan, (uint32_t)n, ds, c->view, c->cfg.max_surface_features, c->cfg.rank, c->cfg.world_size,
                      c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), ds, s);
     launch_sort_pairs(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->d_keys0.as<uint32_t>(), c->d_keys1.as<uint32_t>(),
-                      c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, s);
-    launch_chunk_heads(c->d_keys1.as<uint32_t>(), (uint32_t)n, c->d_chunks.as<uint32_t>(), ds, s);
-    launch_gather_scan(d_scan, c->d_vals1.as<uint32_t>(), c->d_keys1.as<uint32_t>(), (uint32_t)n, c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
+                      c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, key_bits(c->view.n_slots), s);
+    launch_chunk_heads(c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_chunks.as<uint32_t>(), ds, s);
+    launch_gather_scan(d_scan, c->d_vals1.as<uint32_t>(), c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
     span_end(c);
   }
   const MatchParams mp = match_params(c->map.plane_res());

@@ -20,6 +20,7 @@ struct DevMapView {
   double inv_cell;
   int32_t origin[3];
   uint32_t n_points;
+  uint32_t n_slots;            // occupied cubes (tables); sort keys use slot ids n_slots / n_slots+1 for the two specials
 };
 
 struct MatchParams {
@@ -71,8 +72,13 @@ constexpr int kHistStride = 32;      // ints per replica: reject[7] obs[9] stats
 constexpr int kKnnBlocks = 1024;     // 4 workgroups per CU, waves grid-stride over the chunk list
 constexpr int kEvalBlocks = 256;     // one workgroup per CU
 constexpr int kSumsStride = 48;      // doubles per partial record (45 used)
-constexpr uint32_t kKeyDropped = 0xFFFFFFFFu;   // not sampled / not owned by this rank
-constexpr uint32_t kKeyNoCube = 0xFFFFFFFEu;    // processed, but cube outside window / no tree
+// sort key = (cube slot << 18) | Morton(cell).  Two special "slots" sort behind every real cube:
+//   n_slots     : processed query whose cube is outside the window / has no tree (NOT_ENOUGH_NEIGHBORS)
+//   n_slots + 1 : query not sampled / not owned by this rank (dropped)
+// so that only 18 + log2(n_slots + 2) key bits take part in the radix sort.
+inline uint32_t key_nocube(uint32_t n_slots) { return n_slots << 18; }
+inline uint32_t key_dropped(uint32_t n_slots) { return (n_slots + 1u) << 18; }
+inline int key_bits(uint32_t n_slots) { int b = 0; while ((1u << b) <= n_slots + 1u) ++b; return 18 + b; }
 
 size_t sort_temp_bytes(size_t n);
 
@@ -81,10 +87,11 @@ void launch_scan_keys(const float* d_scan_xyz, uint32_t n, const DevState* st, c
                       int max_surface_features, int rank, int world, uint32_t* d_keys, uint32_t* d_vals, DevState* st_rw,
                       hipStream_t s);
 void launch_sort_pairs(void* d_temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                       const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, hipStream_t s);
-void launch_chunk_heads(const uint32_t* d_keys_sorted, uint32_t n, uint32_t* d_chunk_start, DevState* st, hipStream_t s);
-void launch_gather_scan(const float* d_scan_xyz, const uint32_t* d_perm, const uint32_t* d_keys_sorted, uint32_t n, float* spx,
-                        float* spy, float* spz, hipStream_t s);
+                       const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, int end_bit, hipStream_t s);
+void launch_chunk_heads(const uint32_t* d_keys_sorted, uint32_t n, uint32_t dropped_key, uint32_t* d_chunk_start, DevState* st,
+                        hipStream_t s);
+void launch_gather_scan(const float* d_scan_xyz, const uint32_t* d_perm, const uint32_t* d_keys_sorted, uint32_t n,
+                        uint32_t dropped_key, float* spx, float* spy, float* spz, hipStream_t s);
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* d_keys_sorted,
                       const uint32_t* d_chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
                       CorrBuffers corr, int32_t* d_hist /*kHistReplicas*kHistStride*/, hipStream_t s);

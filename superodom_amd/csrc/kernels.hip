@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Pose pose = pose_from_array(st->pose_in);
-  uint32_t key = kKeyDropped;
+  const uint32_t kDropped = (map.n_slots + 1u) << 18, kNoCube = map.n_slots << 18;
+  uint32_t key = kDropped;
   bool process = true;
   if (max_surface_features > 0 && n > (uint32_t)max_surface_features) {  // calculateSamplingRate / shouldProcessPoint
     const double rate = 1.0 * max_surface_features / n;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
     int w[3];
     const CellRef c = locate(map, qx, qy, qz, w);
     if (c.slot < 0) {
-      key = (rank == 0) ? kKeyNoCube : kKeyDropped;  // counted once (NOT_ENOUGH_NEIGHBORS) by rank 0
+      key = (rank == 0) ? kNoCube : kDropped;  // counted once (NOT_ENOUGH_NEIGHBORS) by rank 0
     } else {
       int owner = 0;
       if (world > 1) owner = (int)(brick_hash(w[0], w[1], w[2], c.cx / kBrickCells, c.cy / kBrickCells, c.cz / kBrickCells) % (uint32_t)world);
@@ -106,10 +107,10 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void gather_scan_kernel(const float* __restrict__ scan, const uint32_t* __restrict__ perm,
                                                           const uint32_t* __restrict__ keys_sorted, uint32_t n,
-                                                          float* __restrict__ spx, float* __restrict__ spy,
-                                                          float* __restrict__ spz) {
+                                                          uint32_t dropped_key, float* __restrict__ spx,
+                                                          float* __restrict__ spy, float* __restrict__ spz) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n || keys_sorted[j] == kKeyDropped) return;
+  if (j >= n || keys_sorted[j] == dropped_key) return;
   const uint32_t i = perm[j];
   spx[j] = scan[3 * i]; spy[j] = scan[3 * i + 1]; spz[j] = scan[3 * i + 2];
 }
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void gather_scan_kernel(const float* __restric
 // Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries that share one sort key (one map
 // cell under the pose the scan was sorted with) and one 64-aligned block.  One wavefront per chunk keeps the
 // cost of a wave ~ one candidate set, whatever the query density (no straggler waves in sparse regions).
-__global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+__global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t kKeyDropped,
                                                            uint32_t* __restrict__ chunk_start, DevState* __restrict__ st) {
   __shared__ uint32_t wave_cnt[16];
   __shared__ uint32_t block_base;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t key = i < n ? keys[i] : kKeyDropped;
   const bool kept = key != kKeyDropped;
-  // keys are sorted and kKeyDropped is the largest value: the kept queries are the prefix [0, n_kept)
+  // keys are sorted and the dropped key is the largest value: the kept queries are the prefix [0, n_kept)
   if (kept && (i + 1 == n || keys[i + 1] == kKeyDropped)) st->n_kept = i + 1;
   const bool head = kept && ((i == 0) || ((i & 63u) == 0) || (key != keys[i - 1]));
   const unsigned long long m = __ballot(head);
@@ -950,10 +951,13 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
+// rocPRIM picks block sort + merge passes for ~131 k pairs (measured 65 us per registration); forcing Onesweep
+// (merge_sort_limit = 0) was measured SLOWER (120 us: look-back state memsets + 8-bit passes), so the default stays.
+using SortConfig = rocprim::default_config;
 size_t sort_temp_bytes(size_t n) {
   size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
+  (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                              (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
   return bytes;
 }
 
@@ -965,18 +969,19 @@ void launch_scan_keys(const float* d_scan, uint32_t n, const DevState* st, const
   hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, map, max_sf, rank, world, keys, vals);
 }
 void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo,
-                       uint32_t n, hipStream_t s) {
+                       uint32_t n, int end_bit, hipStream_t s) {
   if (!n) return;
-  (void)rocprim::radix_sort_pairs(tmp, tmp_bytes, ki, ko, vi, vo, (size_t)n, 0, 32, s);
+  (void)rocprim::radix_sort_pairs<SortConfig>(tmp, tmp_bytes, ki, ko, vi, vo, (size_t)n, 0, (unsigned)end_bit, s);
 }
-void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n, uint32_t* chunk_start, DevState* st, hipStream_t s) {
+void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n, uint32_t dropped_key, uint32_t* chunk_start, DevState* st,
+                        hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(chunk_heads_kernel, grid_for(n, 1024), dim3(1024), 0, s, keys_sorted, n, chunk_start, st);
+  hipLaunchKernelGGL(chunk_heads_kernel, grid_for(n, 1024), dim3(1024), 0, s, keys_sorted, n, dropped_key, chunk_start, st);
 }
-void launch_gather_scan(const float* d_scan, const uint32_t* perm, const uint32_t* keys_sorted, uint32_t n, float* spx, float* spy,
-                        float* spz, hipStream_t s) {
+void launch_gather_scan(const float* d_scan, const uint32_t* perm, const uint32_t* keys_sorted, uint32_t n, uint32_t dropped_key,
+                        float* spx, float* spy, float* spz, hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(gather_scan_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, perm, keys_sorted, n, spx, spy, spz);
+  hipLaunchKernelGGL(gather_scan_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, perm, keys_sorted, n, dropped_key, spx, spy, spz);
 }
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* keys_sorted,
                       const uint32_t* chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,

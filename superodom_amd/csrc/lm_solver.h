@@ -69,6 +69,7 @@ SO_HD double lm_gradient_max_norm(const double x[7], const double g[6]) {
 
 // Cholesky solve of a 6x6 SPD system; returns false when a pivot is not positive / result not finite.
 SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
+  double inv[6];  // reciprocal pivots: one division per column instead of one per element
   SO_UNROLL
   for (int j = 0; j < 6; ++j) {
     double d = A[6 * j + j];
@@ -77,12 +78,13 @@ SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
     if (!(d > 0.0)) return false;
     d = sqrt(d);
     A[6 * j + j] = d;
+    inv[j] = 1.0 / d;
     SO_UNROLL
     for (int i = j + 1; i < 6; ++i) {
       double s = A[6 * i + j];
       SO_UNROLL
       for (int k = 0; k < j; ++k) s -= A[6 * i + k] * A[6 * j + k];
-      A[6 * i + j] = s / d;
+      A[6 * i + j] = s * inv[j];
     }
   }
   double z[6];
@@ -91,14 +93,14 @@ SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
     double s = b[i];
     SO_UNROLL
     for (int k = 0; k < i; ++k) s -= A[6 * i + k] * z[k];
-    z[i] = s / A[6 * i + i];
+    z[i] = s * inv[i];
   }
   SO_UNROLL
   for (int i = 5; i >= 0; --i) {
     double s = z[i];
     SO_UNROLL
     for (int k = i + 1; k < 6; ++k) s -= A[6 * k + i] * y[k];
-    y[i] = s / A[6 * i + i];
+    y[i] = s * inv[i];
   }
   SO_UNROLL
   for (int i = 0; i < 6; ++i) if (!isfinite(y[i])) return false;
@@ -210,7 +212,8 @@ SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7]) {
     S.x_cost = cand_cost;
     lm_unpack(sums, S.H, S.g);
     S.num_successful++;
-    double f = 1.0 - pow(2.0 * rel - 1.0, 3);  // LevenbergMarquardtStrategy::StepAccepted
+    const double u = 2.0 * rel - 1.0;
+    double f = 1.0 - u * u * u;  // LevenbergMarquardtStrategy::StepAccepted: 1 - pow(2 rho - 1, 3)
     if (f < 1.0 / 3.0) f = 1.0 / 3.0;
     S.radius = S.radius / f;
     if (S.radius > LmConst::kMaxRadius) S.radius = LmConst::kMaxRadius;
