@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--workload", default="os1_128_2m")
     ap.add_argument("--scans", type=int, default=4, help="distinct synthetic scans cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-outer", type=int, default=5, help="LocalizationICPMaxIter (5 = config of record)")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every kernel (adds bubbles)")
     ap.add_argument("--cpu-sample", type=int, default=1, help="registrations timed for the CPU baseline")
     args = ap.parse_args()
@@ -59,7 +60,7 @@ def main():
 
     # ---------------- synthetic workload (seeded) ----------------
     sc = synth.Scene(args.workload)
-    max_outer, lm_iters = 5, 4
+    max_outer, lm_iters = args.max_outer, 4
     slam = binding.LidarSlamGpu(device_id=local_rank, rank=rank, world_size=world, plane_res=sc.plane_res,
                                 line_res=sc.plane_res / 2, max_iterations=max_outer, lm_max_iterations=lm_iters,
                                 max_surface_features=-1, time_kernels=2 if args.time_all_kernels else 1)

@@ -71,6 +71,7 @@ constexpr int kHistReplicas = 16;    // histogram atomics are spread over replic
 constexpr int kHistStride = 32;      // ints per replica: reject[7] obs[9] stats[4]
 constexpr int kKnnBlocks = 1024;     // 4 workgroups per CU, waves grid-stride over the chunk list
 constexpr int kEvalBlocks = 256;     // one workgroup per CU
+constexpr int kFitBlocksMax = 256;   // plane-fit + first evaluation: one query per thread up to 131072 queries
 constexpr int kSumsStride = 48;      // doubles per partial record (45 used)
 // sort key = (cube slot << 18) | Morton(cell).  Two special "slots" sort behind every real cube:
 //   n_slots     : processed query whose cube is outside the window / has no tree (NOT_ENOUGH_NEIGHBORS)
@@ -94,10 +95,12 @@ void launch_gather_scan(const float* d_scan_xyz, const uint32_t* d_perm, const u
                         uint32_t dropped_key, float* spx, float* spy, float* spz, hipStream_t s);
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* d_keys_sorted,
                       const uint32_t* d_chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
-                      CorrBuffers corr, int32_t* d_hist /*kHistReplicas*kHistStride*/, hipStream_t s);
+                      CorrBuffers corr, uint32_t* d_nbr5 /*5 canonical indices per query*/,
+                      int32_t* d_hist /*kHistReplicas*kHistStride*/, hipStream_t s);
 void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr,
-                 DevState* st, const EvalParams& ep, double* d_partials, uint32_t* d_ticket, const int32_t* d_hist,
-                 LmSums* d_sums, hipStream_t s);
+                 DevState* st, const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist,
+                 LmSums* d_sums, const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper,
+                 hipStream_t s);
 void launch_lm_step(int slot, DevState* st, const LmSums* d_sums, hipStream_t s);
 // Seam B
 void launch_knn_only(const float* d_q_xyz, uint32_t nq, int k, const DevMapView& map, float gate_d2, float* d_nbr,

@@ -29,6 +29,7 @@ namespace soicp {
 #define SO_MATCH_BAD_PCA 3
 #define SO_MATCH_INVALID 4
 #define SO_MATCH_MSE 5
+#define SO_MATCH_PENDING 255  // k-NN done, plane fit not yet (internal hand-off between the two kernels)
 
 // ------------------------------------------------------------------------------------------------
 // map addressing
@@ -38,13 +39,24 @@ struct CellRef {
   int cx, cy, cz;  // cell inside the cube
 };
 
+// int((c + 25.0) / 50.0) for a FLOAT-valued c without the fp64 division: c + 25.0 is exact in double and, unless it
+// is an exact multiple of 50, differs from one by at least a float ulp (>= 2^-24 relative), far more than the 2^-53
+// error of multiplying by 0.02; on exact multiples the product rounds to the same integer side.  So the truncation
+// is identical to the reference's division for every float input (LocalMap.h:488-497).
+__device__ __forceinline__ int cube_coord_f(float c, int origin) {
+  const double s = (double)c + 25.0;
+  int i = (int)(s * 0.02) + origin;
+  if (s < 0) i--;
+  return i;
+}
+
 // cube index exactly as LocalMap::nearestKSearchSurf (LocalMap.h:488-507); then the cell of the
 // hashed-voxel grid inside that cube.
 __device__ __forceinline__ CellRef locate(const DevMapView& m, float qx, float qy, float qz, int* wcube = nullptr) {
   CellRef r;
-  const int ci = cube_coord((double)qx, m.origin[0]);
-  const int cj = cube_coord((double)qy, m.origin[1]);
-  const int ck = cube_coord((double)qz, m.origin[2]);
+  const int ci = cube_coord_f(qx, m.origin[0]);
+  const int cj = cube_coord_f(qy, m.origin[1]);
+  const int ck = cube_coord_f(qz, m.origin[2]);
   r.slot = -1; r.cx = r.cy = r.cz = 0;
   if (!(ci >= 0 && ci < 21 && cj >= 0 && cj < 21 && ck >= 0 && ck < 11)) return r;
   r.slot = m.cube_slot[ci + 21 * cj + 21 * 21 * ck];
@@ -385,7 +397,7 @@ __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const d
 }
 
 // ------------------------------------------------------------------------------------------------
-// knn_plane_kernel -- wave-cooperative, cell-grouped 5-NN + plane fit.
+// knn_plane_kernel -- wave-cooperative, cell-grouped exact 5-NN (the plane fit follows in plane_eval_kernel).
 //
 // A wavefront owns 64 consecutive queries of the spatially sorted scan.  Queries that fall into the
 // same map cell share the same 27-cell candidate set, so the wave walks its lanes cell-group by
@@ -402,9 +414,10 @@ __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const d
 // cannot be certified (8 near-equidistant candidates, or a group with more than 1024 candidates) falls
 // back to the per-lane exact scan knn27().  Result: bit-identical neighbour lists to the oracle.
 // ------------------------------------------------------------------------------------------------
-constexpr int kKeyIdxBits = 9;
+constexpr int kKeyIdxBits = 11;                                  // a key addresses up to 2048 candidates of one group
 constexpr uint32_t kKeyIdxMask = (1u << kKeyIdxBits) - 1u;
 constexpr uint32_t kGroupMaxCand = 1u << kKeyIdxBits;
+constexpr uint32_t kTileCand = 512;                               // candidates staged in LDS at a time (8 KB per wavefront)
 
 // v_med3_i32 has no clang builtin; it is a pure VALU op (no memory, no wait states needed).
 __device__ __forceinline__ int32_t imed3(int32_t a, int32_t b, int32_t c) {
@@ -437,6 +450,19 @@ struct Net8 {  // ascending: a0 <= a1 <= ... <= a7
 // |c|^2 is precomputed at staging time, -2q and |q|^2 once per lane per group.  With magnitudes <= ~8 the fp32
 // rounding error is <= ~4e-6 m^2 (absolute); the certification margin below accounts for it (kApproxAbsErr).
 constexpr float kApproxAbsErr = 2e-5f;
+typedef float float2v __attribute__((ext_vector_type(2)));
+// two candidates per instruction: v_pk_add_f32 + 3 x v_pk_fma_f32 (packed fp32 runs at twice the scalar fp32 rate)
+__device__ __forceinline__ float2v approx_d2_pair(float2v m2qx, float2v m2qy, float2v m2qz, float2v qq, float2v cx, float2v cy,
+                                                  float2v cz, float2v cc) {
+  float2v v = cc + qq;
+  v = __builtin_elementwise_fma(m2qx, cx, v);
+  v = __builtin_elementwise_fma(m2qy, cy, v);
+  v = __builtin_elementwise_fma(m2qz, cz, v);
+  return v;
+}
+__device__ __forceinline__ int32_t make_key(float d2a, uint32_t jloc, uint32_t keep_mask) {
+  return (int32_t)((__float_as_uint(d2a) & keep_mask) | (jloc & ~keep_mask));  // v_bfi_b32
+}
 __device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz, float qq, float cx, float cy, float cz,
                                               float cc, uint32_t jloc, uint32_t keep_mask) {
   float v = cc + qq;
@@ -454,9 +480,11 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
                                                         const DevState* __restrict__ st,
                                                         const float4* __restrict__ mpts,
                                                         const uint32_t* __restrict__ mcell_start, DevMapView map,
-                                                        MatchParams mp, CorrBuffers corr, int32_t* __restrict__ hist) {
+                                                        MatchParams mp, CorrBuffers corr, uint32_t* __restrict__ nbr5,
+                                                        int32_t* __restrict__ hist) {
   __shared__ int32_t lh[20];
-  __shared__ __attribute__((aligned(16))) float tiles[4][4][kGroupMaxCand + 4];  // per wavefront: x[], y[], z[], |c|^2 (block-local)
+  __shared__ __attribute__((aligned(16))) float tiles[4][4][kTileCand + 4];  // per wavefront: x[], y[], z[], |c|^2 (block-local)
+  __shared__ uint32_t rowtab[4][2][36];  // per wavefront: exclusive candidate offsets [33] and first canonical index [32] of the block's x-runs
   if (st->reg_done) return;  // the registration already converged: this launch is a no-op
   const uint32_t n_kept = st->n_kept, n_chunks = st->n_chunks;
   const Pose pose = pose_from_array(st->T);
@@ -467,6 +495,8 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   float* ty = tiles[threadIdx.x >> 6][1];
   float* tz = tiles[threadIdx.x >> 6][2];
   float* tc = tiles[threadIdx.x >> 6][3];
+  uint32_t* rowoff = rowtab[threadIdx.x >> 6][0];
+  uint32_t* rowbeg = rowtab[threadIdx.x >> 6][1];
   // one wavefront per chunk of the work list (grid-stride when the list is longer than the grid)
   for (uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
   uint32_t j = 0;
@@ -501,7 +531,16 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   bool need_exact = false;
   const int nc = map.nc;
   const float cell = (float)(1.0 / map.inv_cell);
-  const float join_cov = 0.58f * cell;  // join a neighbouring group only if its block still covers this much
+  const float inv_cellf = (float)map.inv_cell;
+  // radius every lane's block must cover: the reference's gate sqrt(3*planeRes) (LidarSlam.cpp:526,741) plus a margin
+  const float r_cover = sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f;
+  // per-lane cell range that contains the lane's gate ball (clamped to the cube: nothing of the cube lies beyond it)
+  int lo_x = 0, lo_y = 0, lo_z = 0, hi_x = 0, hi_y = 0, hi_z = 0;
+  if (ckey != 0xFFFFFFFFu) {
+    lo_x = max(0, (int)floorf((ux - r_cover) * inv_cellf)); hi_x = min(nc - 1, (int)floorf((ux + r_cover) * inv_cellf));
+    lo_y = max(0, (int)floorf((uy - r_cover) * inv_cellf)); hi_y = min(nc - 1, (int)floorf((uy + r_cover) * inv_cellf));
+    lo_z = max(0, (int)floorf((uz - r_cover) * inv_cellf)); hi_z = min(nc - 1, (int)floorf((uz + r_cover) * inv_cellf));
+  }
   bool pending = (ckey != 0xFFFFFFFFu);
   unsigned long long todo = __ballot(pending);
   if (mp.ablate & 2) todo = 0;
@@ -509,87 +548,108 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   uint32_t n_scanned = 0;
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t k = __builtin_amdgcn_readlane(ckey, leader);  // wave-uniform (SGPR) cell key of this group
-    const int gslot = (int)(k >> 18), gz = (int)((k >> 12) & 63u), gy = (int)((k >> 6) & 63u), gx = (int)(k & 63u);
-    const int x0 = gx > 0 ? gx - 1 : 0, x1 = gx < nc - 1 ? gx + 1 : nc - 1;
-    const int y0 = gy > 0 ? gy - 1 : 0, y1 = gy < nc - 1 ? gy + 1 : nc - 1;
-    const int z0 = gz > 0 ? gz - 1 : 0, z1 = gz < nc - 1 ? gz + 1 : nc - 1;
-    // coverage of the block [x0..x1]x[y0..y1]x[z0..z1] around this lane's query: nothing of the query's cube lies
-    // outside the block closer than `cov` (block faces that coincide with a cube face do not limit it)
-    const float big = 1e30f;
-    float cov = big;
-    cov = fminf(cov, x0 > 0 ? ux - (float)x0 * cell : big);
-    cov = fminf(cov, x1 < nc - 1 ? (float)(x1 + 1) * cell - ux : big);
-    cov = fminf(cov, y0 > 0 ? uy - (float)y0 * cell : big);
-    cov = fminf(cov, y1 < nc - 1 ? (float)(y1 + 1) * cell - uy : big);
-    cov = fminf(cov, z0 > 0 ? uz - (float)z0 * cell : big);
-    cov = fminf(cov, z1 < nc - 1 ? (float)(z1 + 1) * cell - uz : big);
-    const bool mine = pending && ((ckey == k) || ((int)(ckey >> 18) == gslot && cov >= join_cov));
+    const uint32_t k = __builtin_amdgcn_readlane(ckey, leader);  // wave-uniform (SGPR) cell key of the leader
+    const int gslot = (int)(k >> 18);
+    // ---- group = every pending lane of the leader's cube; block = union of the lanes' gate-ball cell ranges.
+    //      A chunk is spatially compact (its queries shared one cell when the scan was sorted and a rigid pose update
+    //      keeps them together), so the union is 3..4 cells per axis.  If it is too large for the tile the group
+    //      shrinks to the lanes of the leader's own cell (block <= 27 cells).
+    bool mine = pending && ((int)(ckey >> 18) == gslot);
+    int bx0, bx1, by0, by1, bz0, bz1;
+    uint32_t total = 0;
+    uint32_t vb = 0, vl = 0;
+    int nrows = 0, nyr = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (attempt == 1) mine = mine && (ckey == k);
+      bx0 = __builtin_amdgcn_readlane(lo_x, leader); bx1 = __builtin_amdgcn_readlane(hi_x, leader);
+      by0 = __builtin_amdgcn_readlane(lo_y, leader); by1 = __builtin_amdgcn_readlane(hi_y, leader);
+      bz0 = __builtin_amdgcn_readlane(lo_z, leader); bz1 = __builtin_amdgcn_readlane(hi_z, leader);
+      while (__ballot(mine && lo_x < bx0)) --bx0;   // wave-uniform min / max over the group, a few ballots each
+      while (__ballot(mine && hi_x > bx1)) ++bx1;
+      while (__ballot(mine && lo_y < by0)) --by0;
+      while (__ballot(mine && hi_y > by1)) ++by1;
+      while (__ballot(mine && lo_z < bz0)) --bz0;
+      while (__ballot(mine && hi_z > bz1)) ++bz1;
+      nyr = by1 - by0 + 1;
+      nrows = nyr * (bz1 - bz0 + 1);
+      total = 0xFFFFFFFFu;
+      if (nrows <= 32) {  // row table: lane r fetches the bounds of x-run r, prefix sums by shuffles
+        vb = 0; vl = 0;
+        if (lane < nrows) {
+          const int z = bz0 + lane / nyr, y = by0 + lane % nyr;
+          const uint32_t* row = mcell_start + (size_t)gslot * map.ncell1 + ((size_t)z * nc + y) * nc;
+          vb = row[bx0]; vl = row[bx1 + 1] - vb;
+        }
+        uint32_t inc = vl;  // inclusive scan over lanes 0..31
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        total = __builtin_amdgcn_readlane(inc, 31);
+        if (lane < 32) { rowoff[lane] = inc - vl; rowbeg[lane] = vb; }
+        if (lane == 0) rowoff[32] = total;
+      }
+      if (total <= kGroupMaxCand) break;
+    }
     pending = pending && !mine;
     todo = __ballot(pending);
     ++n_groups;
-    // row table: lane r (0..8) fetches the bounds of x-run r; prefix sums by readlane
-    uint32_t vb = 0, vl = 0;
-    if (lane < 9) {
-      const int z = gz + (lane / 3 - 1), y = gy + (lane % 3 - 1);
-      if (z >= 0 && z < nc && y >= 0 && y < nc) {
-        const uint32_t* row = mcell_start + (size_t)gslot * map.ncell1 + ((size_t)z * nc + y) * nc;
-        vb = row[x0]; vl = row[x1 + 1] - vb;
-      }
-    }
-    uint32_t rbeg[9], roff[9];
-    uint32_t total = 0;
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      rbeg[r] = __builtin_amdgcn_readlane(vb, r); roff[r] = total;
-      total += __builtin_amdgcn_readlane(vl, r);
-    }
-    if (total > kGroupMaxCand) {  // uniform: too many candidates for the 10-bit position field
+    if (total > kGroupMaxCand) {  // still too many candidates for the tile: exact per-lane scan for these lanes
       need_exact = need_exact || mine;
       continue;
     }
     n_scanned += total;
-    // block-local frame: origin at the centre of the group's home cell (world coordinates, fp64)
+    const int gz = (bz0 + bz1) >> 1, gy = (by0 + by1) >> 1, gx = (bx0 + bx1) >> 1;
+    // block-local frame: origin at the centre of the block's middle cell (world coordinates, fp64)
     const double ox = ((int)__builtin_amdgcn_readlane(wcube0, leader) * 50.0 - 25.0) + ((double)gx + 0.5) * (double)cell;
     const double oy = ((int)__builtin_amdgcn_readlane(wcube1, leader) * 50.0 - 25.0) + ((double)gy + 0.5) * (double)cell;
     const double oz = ((int)__builtin_amdgcn_readlane(wcube2, leader) * 50.0 - 25.0) + ((double)gz + 0.5) * (double)cell;
-    // stage the group's candidates into this wave's LDS tile with coalesced 16-byte loads
-    __builtin_amdgcn_wave_barrier();
-    if (!(mp.ablate & 16))
-    for (uint32_t t = lane; t < total + 4; t += 64) {
-      float lx = 0.f, ly = 0.f, lz = 0.f, lc = 3.0e38f;  // padding entries lose against every real candidate
-      if (t < total) {
-        uint32_t idx = rbeg[0] + t;
-#pragma unroll
-        for (int r = 1; r < 9; ++r) idx = (t >= roff[r]) ? (rbeg[r] - roff[r] + t) : idx;
-        const float4 p = mpts[idx];
-        lx = (float)((double)p.x - ox); ly = (float)((double)p.y - oy); lz = (float)((double)p.z - oz);
-        lc = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
-      }
-      tx[t] = lx; ty[t] = ly; tz[t] = lz; tc[t] = lc;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     const float lqx = (float)((double)qx - ox), lqy = (float)((double)qy - oy), lqz = (float)((double)qz - oz);
     const float m2qx = -2.f * lqx, m2qy = -2.f * lqy, m2qz = -2.f * lqz;
     const float qq = __builtin_fmaf(lqz, lqz, __builtin_fmaf(lqy, lqy, lqx * lqx));
     const uint32_t keep = ~kKeyIdxMask;
+    const float2v pqx = {m2qx, m2qx}, pqy = {m2qy, m2qy}, pqz = {m2qz, m2qz}, pqq = {qq, qq};
     Net8 net;
     net.init();
-    if (!(mp.ablate & 8)) {
-      // uniform addresses: four broadcast ds_read_b128 feed four candidates; the next quad is fetched while this one
-      // runs through the selection network (software pipeline, no wait between LDS issue and use)
-      float4 X = *reinterpret_cast<const float4*>(tx), Y = *reinterpret_cast<const float4*>(ty);
-      float4 Z = *reinterpret_cast<const float4*>(tz), C = *reinterpret_cast<const float4*>(tc);
-      for (uint32_t jl = 0; jl < total; jl += 4) {
-        const uint32_t nx = (jl + 4 < total) ? jl + 4 : jl;  // last iteration re-reads (harmless)
-        const float4 Xn = *reinterpret_cast<const float4*>(tx + nx), Yn = *reinterpret_cast<const float4*>(ty + nx);
-        const float4 Zn = *reinterpret_cast<const float4*>(tz + nx), Cn = *reinterpret_cast<const float4*>(tc + nx);
-        net.push(approx_key(m2qx, m2qy, m2qz, qq, X.x, Y.x, Z.x, C.x, jl, keep));
-        net.push(approx_key(m2qx, m2qy, m2qz, qq, X.y, Y.y, Z.y, C.y, jl + 1, keep));
-        net.push(approx_key(m2qx, m2qy, m2qz, qq, X.z, Y.z, Z.z, C.z, jl + 2, keep));
-        net.push(approx_key(m2qx, m2qy, m2qz, qq, X.w, Y.w, Z.w, C.w, jl + 3, keep));
-        X = Xn; Y = Yn; Z = Zn; C = Cn;
+    // The group's candidate enumeration [0, total) is streamed through the LDS tile in pieces of kTileCand; the
+    // selection network simply continues across pieces (keys carry the position in the whole enumeration).
+    for (uint32_t base = 0; base < total; base += kTileCand) {
+      const uint32_t cnt = (total - base < kTileCand) ? total - base : kTileCand;
+      // stage with coalesced 16-byte loads (position -> row by a 5-step binary search over the row offsets)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (!(mp.ablate & 16))
+      for (uint32_t t = lane; t < cnt + 4; t += 64) {
+        float lx = 0.f, ly = 0.f, lz = 0.f, lc = 3.0e38f;  // padding entries lose against every real candidate
+        if (t < cnt) {
+          const uint32_t e = base + t;
+          int r = 0;
+#pragma unroll
+          for (int step = 16; step >= 1; step >>= 1) r = (r + step < 32 && rowoff[r + step] <= e) ? r + step : r;
+          const float4 p = mpts[rowbeg[r] + (e - rowoff[r])];
+          lx = (float)((double)p.x - ox); ly = (float)((double)p.y - oy); lz = (float)((double)p.z - oz);
+          lc = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+        }
+        tx[t] = lx; ty[t] = ly; tz[t] = lz; tc[t] = lc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (!(mp.ablate & 8)) {
+        // uniform addresses: four broadcast ds_read_b128 feed four candidates; the next quad is fetched while this one
+        // runs through the selection network (software pipeline, no wait between LDS issue and use)
+        float4 X = *reinterpret_cast<const float4*>(tx), Y = *reinterpret_cast<const float4*>(ty);
+        float4 Z = *reinterpret_cast<const float4*>(tz), C = *reinterpret_cast<const float4*>(tc);
+        for (uint32_t jl = 0; jl < cnt; jl += 4) {
+          const uint32_t nx = (jl + 4 < cnt) ? jl + 4 : jl;  // last iteration re-reads (harmless)
+          const float4 Xn = *reinterpret_cast<const float4*>(tx + nx), Yn = *reinterpret_cast<const float4*>(ty + nx);
+          const float4 Zn = *reinterpret_cast<const float4*>(tz + nx), Cn = *reinterpret_cast<const float4*>(tc + nx);
+          const float2v d01 = approx_d2_pair(pqx, pqy, pqz, pqq, float2v{X.x, X.y}, float2v{Y.x, Y.y}, float2v{Z.x, Z.y}, float2v{C.x, C.y});
+          const float2v d23 = approx_d2_pair(pqx, pqy, pqz, pqq, float2v{X.z, X.w}, float2v{Y.z, Y.w}, float2v{Z.z, Z.w}, float2v{C.z, C.w});
+          const uint32_t e = base + jl;
+          net.push(make_key(d01.x, e, keep));
+          net.push(make_key(d01.y, e + 1, keep));
+          net.push(make_key(d23.x, e + 2, keep));
+          net.push(make_key(d23.y, e + 3, keep));
+          X = Xn; Y = Yn; Z = Zn; C = Cn;
+        }
       }
     }
     // survivors: position in the tile -> canonical index through the row table (all lanes compute, owners commit)
@@ -598,23 +658,21 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const uint32_t jl = (uint32_t)ks[t] & kKeyIdxMask;
-      uint32_t idx = rbeg[0] + jl;
+      int r = 0;
 #pragma unroll
-      for (int r = 1; r < 9; ++r) idx = (jl >= roff[r]) ? (rbeg[r] - roff[r] + jl) : idx;
-      gi[t] = (ks[t] == kKeyEmpty || jl >= total) ? 0xFFFFFFFFu : idx;
+      for (int step = 16; step >= 1; step >>= 1) r = (r + step < 32 && rowoff[r + step] <= jl) ? r + step : r;
+      gi[t] = (ks[t] == kKeyEmpty || jl >= total) ? 0xFFFFFFFFu : rowbeg[r] + (jl - rowoff[r]);
     }
     if (mine) {
       g0 = gi[0]; g1 = gi[1]; g2 = gi[2]; g3 = gi[3]; g4 = gi[4]; g5 = gi[5]; g6 = gi[6]; g7 = gi[7];
       k8 = net.a7;
-      cov2 = cov >= 1e15f ? big : cov * cov;
+      cov2 = 1e30f;  // the block contains the lane's whole gate ball by construction
     }
   }
   if (lane == 0) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
 
   if (valid_q) {
     int status;
-    double nd[4] = {0, 0, 0, 0}, coeff = 0;
-    int obs[3] = {0, 0, 0};
     if (c.slot < 0) {
       status = SO_MATCH_NOT_ENOUGH;  // LidarSlam.cpp:736-739
     } else {
@@ -654,23 +712,17 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
       if ((mp.ablate & 1) || too_far_certain || top.b4 == ~0ull || (double)d2_4 > (double)mp.sq_max_dist_f) {
         status = SO_MATCH_TOO_FAR;   // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
       } else {
-        float nb[15];
-        const uint32_t id[5] = {(uint32_t)top.b0, (uint32_t)top.b1, (uint32_t)top.b2, (uint32_t)top.b3, (uint32_t)top.b4};
-#pragma unroll
-        for (int t = 0; t < 5; ++t) { const float4 p = mpts[id[t]]; nb[3 * t] = p.x; nb[3 * t + 1] = p.y; nb[3 * t + 2] = p.z; }
-        status = plane_from_neighbours(nb, pw, pose, mp, nd, coeff, obs);
+        status = SO_MATCH_PENDING;   // five neighbours inside the gate: the plane fit runs in plane_eval_kernel
+        uint32_t* o = nbr5 + (size_t)5 * j;
+        o[0] = (uint32_t)top.b0; o[1] = (uint32_t)top.b1; o[2] = (uint32_t)top.b2; o[3] = (uint32_t)top.b3; o[4] = (uint32_t)top.b4;
       }
     }
-    if (status != SO_MATCH_SUCCESS) { coeff = 0; nd[0] = nd[1] = nd[2] = nd[3] = 0; }
-    corr.nd[j] = make_double4(nd[0], nd[1], nd[2], nd[3]);
-    corr.coeff[j] = coeff;
     corr.status[j] = (uint8_t)status;
-    atomicAdd(&lh[status], 1);
-    if (status == SO_MATCH_SUCCESS) { atomicAdd(&lh[7 + obs[0]], 1); atomicAdd(&lh[7 + obs[1]], 1); atomicAdd(&lh[7 + obs[2]], 1); }
   }
   }  // chunk loop
   __syncthreads();
-  if (threadIdx.x < 20 && lh[threadIdx.x]) atomicAdd(&hist[(blockIdx.x % kHistReplicas) * kHistStride + threadIdx.x], lh[threadIdx.x]);
+  if (threadIdx.x >= 16 && threadIdx.x < 20 && lh[threadIdx.x])  // kernel statistics only; the histograms are built by plane_eval_kernel
+    atomicAdd(&hist[(blockIdx.x % kHistReplicas) * kHistStride + threadIdx.x], lh[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,7 +738,7 @@ __device__ __forceinline__ bool eval_slot_active(const DevState* st, int slot) {
 
 // The Ceres-equivalent LM controller plus the outer ICP bookkeeping (LidarSlam.cpp:119-148, 242-251).
 // Executed by ONE thread on an LDS copy of the controller state.
-__device__ void lm_control(int slot, DevState* st, LmState& S, const LmSums& sums) {
+__device__ __attribute__((noinline)) void lm_control(int slot, DevState* st, LmState& S, const LmSums& sums) {
   int more;
   if (slot == 0) more = lm_begin(S, st->T, sums, st->lm_max, st->eval_pose);
   else more = lm_feed(S, sums, st->eval_pose);
@@ -740,18 +792,31 @@ __device__ __forceinline__ double reduce_records(double (*red)[kRedStride], doub
   return tot;
 }
 
+// FIT = true : the slot-0 launch of an outer iteration.  Dense over the queries (full lane occupancy for the heavy
+//              fp64 work): plane fit from the five neighbour indices left by knn_plane_kernel (PCA gate, 5x3 LS
+//              plane, inlier gate, coefficient, observability labels -> correspondence record + histograms), then
+//              the first evaluation at the outer pose.
+// FIT = false: evaluations at the poses requested by the LM controller.
+template <bool FIT>
 __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const float* __restrict__ spx,
                                                    const float* __restrict__ spy, const float* __restrict__ spz,
                                                    CorrBuffers corr, DevState* __restrict__ st, EvalParams ep,
                                                    double* __restrict__ partials, uint32_t* __restrict__ ticket,
-                                                   const int32_t* __restrict__ hist, LmSums* __restrict__ out) {
-  __shared__ double red[256][kRedStride];  // 60 KB: per-thread accumulators, later the 256 workgroup records
+                                                   int32_t* __restrict__ hist, LmSums* __restrict__ out,
+                                                   const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
+                                                   MatchParams mp) {
+  __shared__ double red[256][kRedStride];  // 60 KB: per-thread accumulators, later the workgroup records
   __shared__ double part[8][32];
   __shared__ LmSums sh_sums;
   __shared__ LmState sh_S;
+  __shared__ int32_t lh[16];
   __shared__ bool is_last;
   if (!eval_slot_active(st, slot)) return;
   const int tid = threadIdx.x;
+  if (FIT) {
+    if (tid < 16) lh[tid] = 0;
+    __syncthreads();
+  }
   const uint32_t n_kept = (ep.ablate & 64) ? 0u : st->n_kept;
   const Pose pose = pose_from_array(slot == 0 ? st->T : st->eval_pose);
   double acc[kNAcc];
@@ -766,13 +831,35 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
   const double R10 = txy + twz, R11 = 1 - (txx + tzz), R12 = tyz - twx;
   const double R20 = txz - twy, R21 = tyz + twx, R22 = 1 - (txx + tyy);
   for (uint32_t j = blockIdx.x * blockDim.x + tid; j < n_kept; j += gridDim.x * blockDim.x) {
-    if (corr.status[j] != SO_MATCH_SUCCESS) continue;
-    const double c = corr.coeff[j];
-    const double4 nd = corr.nd[j];
+    int status = corr.status[j];
+    if (!FIT && status != SO_MATCH_SUCCESS) continue;
     const double px = (double)spx[j], py = (double)spy[j], pz = (double)spz[j];
     double wx, wy, wz;
-    quat_rotate<double>(pose.q, px, py, pz, wx, wy, wz);                   // lidarOptimization.cpp:59
+    quat_rotate<double>(pose.q, px, py, pz, wx, wy, wz);                   // lidarOptimization.cpp:59 == LidarSlam.cpp:397-398
     wx += pose.t[0]; wy += pose.t[1]; wz += pose.t[2];
+    double c;
+    double4 nd;
+    if (FIT) {
+      double fnd[4] = {0, 0, 0, 0}, fc = 0;
+      int obs[3] = {0, 0, 0};
+      if (status == SO_MATCH_PENDING) {
+        float nb[15];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { const float4 p = mpts[nbr5[(size_t)5 * j + t]]; nb[3 * t] = p.x; nb[3 * t + 1] = p.y; nb[3 * t + 2] = p.z; }
+        const double pw[3] = {wx, wy, wz};
+        status = plane_from_neighbours(nb, pw, pose, mp, fnd, fc, obs);
+      }
+      if (status != SO_MATCH_SUCCESS) { fc = 0; fnd[0] = fnd[1] = fnd[2] = fnd[3] = 0; }
+      nd = make_double4(fnd[0], fnd[1], fnd[2], fnd[3]);
+      c = fc;
+      corr.nd[j] = nd; corr.coeff[j] = c; corr.status[j] = (uint8_t)status;
+      atomicAdd(&lh[status], 1);                                          // MatchRejectionHistogramPlane, LidarSlam.cpp:341
+      if (status == SO_MATCH_SUCCESS) { atomicAdd(&lh[7 + obs[0]], 1); atomicAdd(&lh[7 + obs[1]], 1); atomicAdd(&lh[7 + obs[2]], 1); }
+      if (status != SO_MATCH_SUCCESS) continue;
+    } else {
+      c = corr.coeff[j];
+      nd = corr.nd[j];
+    }
     const double r = nd.x * wx + nd.y * wy + nd.z * wz + nd.w;             // lidarOptimization.cpp:61
     // ScaledLoss(TukeyLoss(a), c): rho, rho' [UPSTREAM ceres loss_function.cc]; corrector with rho''<=0
     const double s = r * r;
@@ -813,6 +900,8 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
   // (sc1: served by L2, never a stale L1 line).  [MI355X guide, G16 "8-B agent atomics both sides"]
   if (tid < kNAcc)
     __hip_atomic_store(&partials[(size_t)blockIdx.x * kSumsStride + tid], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (FIT && tid >= 32 && tid < 48 && lh[tid - 32])  // histograms: device-scope atomics on 16 replicas, visible before the ticket
+    __hip_atomic_fetch_add(&hist[(blockIdx.x % kHistReplicas) * kHistStride + (tid - 32)], lh[tid - 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
@@ -823,10 +912,12 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
   if (!is_last) return;
   // thread b fetches workgroup b's record (29 independent loads = one memory latency), same fixed tree again
 #pragma unroll
-  for (int a = 0; a < kNAcc; ++a)
-    red[tid][a] = (tid < (int)gridDim.x)
-                      ? __hip_atomic_load(&partials[(size_t)tid * kSumsStride + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                      : 0.0;
+  for (int a = 0; a < kNAcc; ++a) {
+    double v = 0.0;
+    for (uint32_t b = tid; b < gridDim.x; b += 256)  // fixed order: record tid, tid+256, ...
+      v += __hip_atomic_load(&partials[(size_t)b * kSumsStride + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[tid][a] = v;
+  }
   __syncthreads();
   const double total = reduce_records(red, part, tid);
   double* o = reinterpret_cast<double*>(&sh_sums);
@@ -835,7 +926,8 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
   } else if (tid >= 32 && tid < 48) {
     int h = 0;
 #pragma unroll
-    for (int r = 0; r < kHistReplicas; ++r) h += hist[r * kHistStride + (tid - 32)];
+    for (int r = 0; r < kHistReplicas; ++r)
+      h += __hip_atomic_load(&hist[r * kHistStride + (tid - 32)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     o[kNAcc + (tid - 32)] = (double)h;
   }
   if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
@@ -985,15 +1077,22 @@ void launch_gather_scan(const float* d_scan, const uint32_t* perm, const uint32_
 }
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* keys_sorted,
                       const uint32_t* chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
-                      CorrBuffers corr, int32_t* hist, hipStream_t s) {
+                      CorrBuffers corr, uint32_t* nbr5, int32_t* hist, hipStream_t s) {
   hipLaunchKernelGGL(knn_plane_kernel, dim3(kKnnBlocks), dim3(256), 0, s, spx, spy, spz, keys_sorted, chunk_start, st, map.pts,
-                     map.cell_start, map, mp, corr, hist);
+                     map.cell_start, map, mp, corr, nbr5, hist);
 }
 void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr,
-                 DevState* st, const EvalParams& ep, double* partials, uint32_t* ticket, const int32_t* hist, LmSums* sums,
-                 hipStream_t s) {
-  hipLaunchKernelGGL(eval_kernel, dim3(kEvalBlocks), dim3(256), 0, s, slot, fuse_lm ? 1 : 0, spx, spy, spz, corr, st, ep, partials,
-                     ticket, hist, sums);
+                 DevState* st, const EvalParams& ep, double* partials, uint32_t* ticket, int32_t* hist, LmSums* sums,
+                 const DevMapView& map, const uint32_t* nbr5, const MatchParams& mp, uint32_t n_upper, hipStream_t s) {
+  if (slot == 0) {  // plane fit + first evaluation, dense over the queries
+    uint32_t blocks = (n_upper + 255u) / 256u;
+    blocks = blocks < 1 ? 1 : (blocks > (uint32_t)kFitBlocksMax ? (uint32_t)kFitBlocksMax : blocks);
+    hipLaunchKernelGGL(eval_kernel<true>, dim3(blocks), dim3(256), 0, s, slot, fuse_lm ? 1 : 0, spx, spy, spz, corr, st, ep, partials,
+                       ticket, hist, sums, map.pts, nbr5, mp);
+  } else {
+    hipLaunchKernelGGL(eval_kernel<false>, dim3(kEvalBlocks), dim3(256), 0, s, slot, fuse_lm ? 1 : 0, spx, spy, spz, corr, st, ep,
+                       partials, ticket, hist, sums, map.pts, nbr5, mp);
+  }
 }
 void launch_lm_step(int slot, DevState* st, const LmSums* sums, hipStream_t s) {
   hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, s, slot, st, sums);
