@@ -219,3 +219,25 @@ def test_full_size_properties():
     orc, opose, ost, _ = om.register(scan, guess, oracle_py.default_config(max_iterations=5))
     ok, dt, dr = pose_close(poses[0], opose, TOL_T, TOL_R)
     assert ok and dt < 1e-8 and dr < 1e-8, (dt, dr)
+
+
+def test_sharded_map_covers_every_query_exactly_once(oracle, gpu_slam_factory):
+    """Two shard contexts (rank 0/1 of world 2) on one device, no communicator: the first outer iteration's
+    rejection/observability histograms depend only on the input pose, so the per-rank histograms must ADD UP to
+    the single-context ones -- every query is matched by exactly one rank against a shard that holds all the
+    cells its gate ball needs (brick-hash ownership + one-cell halo)."""
+    sc, full, om = _setup("small", oracle, gpu_slam_factory, max_iterations=1)
+    scan, guess = sc.scan(3), sc.guess(3)
+    rc, _, st = full.register(scan, guess)
+    want_rej = np.array(list(st.iterations[0].reject_hist)); want_obs = np.array(list(st.iterations[0].obs_hist))
+    got_rej = np.zeros(7, int); got_obs = np.zeros(9, int); sizes = []
+    for rank in (0, 1):
+        sh = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=1,
+                              rank=rank, world_size=2)
+        sh.add_surf_point_cloud(sc.map_points)
+        total, mine = sh.map_size(this_rank=True)
+        sizes.append(mine)
+        rc, _, s2 = sh.register(scan, guess)
+        got_rej += np.array(list(s2.iterations[0].reject_hist)); got_obs += np.array(list(s2.iterations[0].obs_hist))
+    assert np.array_equal(got_rej, want_rej) and np.array_equal(got_obs, want_obs)
+    assert all(0 < m < total for m in sizes), "each rank holds a strict subset of the map"
