@@ -1,0 +1,297 @@
+// device_map.cpp -- see device_map.h.  Host C++ driving map_kernels.hip; bookkeeping mirrors
+// include/super_odometry/LidarProcess/LocalMap.h (paths relative to /root/reference/super_odometry/).
+#include "device_map.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace soicp {
+
+#define DM_TRY(expr)                                                      \
+  do {                                                                    \
+    hipError_t e__ = (expr);                                              \
+    if (e__ != hipSuccess) {                                              \
+      err = std::string(#expr) + ": " + hipGetErrorString(e__);           \
+      return -2;                                                          \
+    }                                                                     \
+  } while (0)
+
+static inline int cidx(int i, int j, int k) { return i + kMapW * j + kMapW * kMapH * k; }
+
+DeviceMap::~DeviceMap() {
+  for (void* p : {(void*)d_pool_, (void*)d_cell_start_, (void*)d_cube_slot_, (void*)d_wpts_, (void*)d_cent_, (void*)d_k0_, (void*)d_k1_,
+                  (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, d_temp_, (void*)d_cube_of_, (void*)d_touched_,
+                  (void*)d_touched_id_, (void*)d_small_, (void*)d_stage_})
+    if (p) (void)hipFree(p);
+  if (h_touched_) (void)hipHostFree(h_touched_);
+  if (h_small_) (void)hipHostFree(h_small_);
+}
+
+void DeviceMap::clear() {
+  std::fill(cube_slot_.begin(), cube_slot_.end(), -1);
+  std::fill(slot_cube_.begin(), slot_cube_.end(), -1);
+  std::fill(slot_count_.begin(), slot_count_.end(), 0u);
+  slot_table_dirty_ = true;
+}
+
+void DeviceMap::set_origin(const double t[3]) {  // LocalMap.h:146-164
+  for (int a = 0; a < 3; ++a) origin_[a] = -cube_coord(t[a], 0);
+  slot_table_dirty_ = true;
+}
+
+int DeviceMap::alloc_slot(int cube) {
+  for (size_t s = 0; s < slot_cube_.size(); ++s)
+    if (slot_cube_[s] < 0) { slot_cube_[s] = cube; slot_count_[s] = 0; cube_slot_[cube] = (int)s; slot_table_dirty_ = true; return (int)s; }
+  slot_cube_.push_back(cube); slot_count_.push_back(0);
+  cube_slot_[cube] = (int)slot_cube_.size() - 1;
+  slot_table_dirty_ = true;
+  return cube_slot_[cube];
+}
+
+// LocalMap::shiftMap, LocalMap.h:169-287: the block array rolls so that the sensor's block stays >= 3 blocks from the
+// border; blocks leaving the window are dropped.  Here a block is just its slot id -- no point data moves.
+void DeviceMap::shift(const double t[3], int pos[3]) {
+  int c[3] = {cube_coord(t[0], origin_[0]), cube_coord(t[1], origin_[1]), cube_coord(t[2], origin_[2])};
+  const int dim[3] = {kMapW, kMapH, kMapD};
+  auto at = [&](int i, int j, int k) -> int32_t& { return cube_slot_[cidx(i, j, k)]; };
+  auto drop = [&](int32_t& s) { if (s >= 0) { slot_cube_[s] = -1; slot_count_[s] = 0; } s = -1; };
+  bool moved = false;
+  for (int axis = 0; axis < 3; ++axis) {
+    while (c[axis] < 3 || c[axis] >= dim[axis] - 3) {
+      const int dir = c[axis] < 3 ? +1 : -1;  // +1: contents move towards higher indices
+      for (int u = 0; u < dim[(axis + 1) % 3]; ++u) for (int v = 0; v < dim[(axis + 2) % 3]; ++v) {
+        auto cell = [&](int w) -> int32_t& {
+          int ijk[3]; ijk[axis] = w; ijk[(axis + 1) % 3] = u; ijk[(axis + 2) % 3] = v;
+          return at(ijk[0], ijk[1], ijk[2]);
+        };
+        if (dir > 0) { drop(cell(dim[axis] - 1)); for (int w = dim[axis] - 1; w >= 1; --w) cell(w) = cell(w - 1); cell(0) = -1; }
+        else { drop(cell(0)); for (int w = 0; w < dim[axis] - 1; ++w) cell(w) = cell(w + 1); cell(dim[axis] - 1) = -1; }
+      }
+      c[axis] += dir; origin_[axis] += dir; moved = true;
+    }
+  }
+  if (moved) {
+    for (int cube = 0; cube < kMapNum; ++cube) if (cube_slot_[cube] >= 0) slot_cube_[cube_slot_[cube]] = cube;
+    slot_table_dirty_ = true;
+  }
+  pos[0] = c[0]; pos[1] = c[1]; pos[2] = c[2];
+}
+
+int DeviceMap::count_5x5(const int pos[3]) const {  // LocalMap.h:292-318
+  int n = 0;
+  for (int i = pos[0] - 2; i <= pos[0] + 2; ++i) for (int j = pos[1] - 2; j <= pos[1] + 2; ++j) for (int k = pos[2] - 1; k <= pos[2] + 1; ++k)
+    if (i >= 0 && i < kMapW && j >= 0 && j < kMapH && k >= 0 && k < kMapD && cube_slot_[cidx(i, j, k)] >= 0)
+      n += (int)slot_count_[cube_slot_[cidx(i, j, k)]];
+  return n;
+}
+
+size_t DeviceMap::size() const {
+  size_t n = 0;
+  for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) n += slot_count_[s];
+  return n;
+}
+
+int DeviceMap::ensure_pool(int slots_needed, std::string& err) {
+  if (slots_needed <= slots_alloc_) return 0;
+  if (slots_needed > 4096) { err = "DeviceMap: more than 4096 occupied cubes"; return -1; }
+  int want = std::max(16, slots_alloc_ * 2);
+  while (want < slots_needed) want *= 2;
+  float4* np = nullptr; uint32_t* nt = nullptr;
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&np), (size_t)want * kCapPerSlot * sizeof(float4) + 64));
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&nt), (size_t)want * ncell1_ * sizeof(uint32_t)));
+  if (slots_alloc_) {
+    DM_TRY(hipMemcpyAsync(np, d_pool_, (size_t)slots_alloc_ * kCapPerSlot * sizeof(float4), hipMemcpyDeviceToDevice, stream_));
+    DM_TRY(hipMemcpyAsync(nt, d_cell_start_, (size_t)slots_alloc_ * ncell1_ * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_));
+    DM_TRY(hipStreamSynchronize(stream_));
+    (void)hipFree(d_pool_); (void)hipFree(d_cell_start_);
+  }
+  d_pool_ = np; d_cell_start_ = nt; slots_alloc_ = want;
+  if (!d_cube_slot_) DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cube_slot_), kMapNum * sizeof(int32_t)));
+  slot_table_dirty_ = true;
+  return 0;
+}
+
+int DeviceMap::ensure_work(size_t total, std::string& err) {
+  if (!d_touched_) {
+    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_touched_), kMapNum));
+    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_touched_id_), kMapNum));
+    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_small_), 64 * sizeof(uint32_t)));
+    DM_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_touched_), kMapNum));
+    DM_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small_), 64 * sizeof(uint32_t)));
+  }
+  if (total <= work_cap_) return 0;
+  const size_t cap = total + total / 4 + 1024;
+  for (void* p : {(void*)d_wpts_, (void*)d_cent_, (void*)d_k0_, (void*)d_k1_, (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, d_temp_})
+    if (p) (void)hipFree(p);
+  d_wpts_ = d_cent_ = nullptr; d_k0_ = d_k1_ = d_v0_ = d_v1_ = d_flags_ = d_pos_ = nullptr; d_temp_ = nullptr; work_cap_ = 0;
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_wpts_), cap * sizeof(float4)));
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cent_), cap * sizeof(float4)));
+  for (uint32_t** p : {&d_k0_, &d_k1_, &d_v0_, &d_v1_, &d_flags_, &d_pos_}) DM_TRY(hipMalloc(reinterpret_cast<void**>(p), cap * sizeof(uint32_t)));
+  temp_bytes_ = map_sort_temp_bytes(cap) + 256;
+  DM_TRY(hipMalloc(&d_temp_, temp_bytes_));
+  work_cap_ = cap;
+  return 0;
+}
+
+bool DeviceMap::view(DevMapView& v, std::string& err) {
+  if (ensure_pool(std::max<int>(1, (int)slot_cube_.size()), err)) return false;
+  if (slot_table_dirty_) {
+    if (hipMemcpyAsync(d_cube_slot_, cube_slot_.data(), kMapNum * sizeof(int32_t), hipMemcpyHostToDevice, stream_) != hipSuccess ||
+        hipStreamSynchronize(stream_) != hipSuccess) { err = "DeviceMap: cube_slot upload failed"; return false; }
+    slot_table_dirty_ = false;
+  }
+  v.pts = d_pool_; v.cell_start = d_cell_start_; v.cube_slot = d_cube_slot_;
+  v.nc = nc_; v.ncell1 = ncell1_; v.inv_cell = 1.0 / cell_;
+  v.origin[0] = origin_[0]; v.origin[1] = origin_[1]; v.origin[2] = origin_[2];
+  v.n_points = (uint32_t)size();
+  v.n_slots = (uint32_t)std::max<size_t>(1, slot_cube_.size());
+  return true;
+}
+
+int DeviceMap::set_resolution(float line_res, float plane_res) {
+  line_res_ = line_res;
+  if (plane_res == plane_res_ && nc_ > 1) return 0;
+  // planeRes decides the leaf of the voxel filter and the cell of the index.  Existing points keep their positions
+  // (the reference re-filters a block only when it is touched again); the tables are rebuilt for the new cell size.
+  std::vector<float> keep;
+  std::string err;
+  const bool had = size() > 0;
+  if (had) {
+    keep.resize(size() * 3);
+    const int zero[3] = {0, 0, 0};
+    export_points(keep.data(), size(), false, zero, err);
+  }
+  plane_res_ = plane_res;
+  double cell;
+  nc_ = cells_per_cube(plane_res, &cell);
+  cell_ = cell;
+  const uint32_t new_ncell1 = (uint32_t)((size_t)nc_ * nc_ * nc_ + 1);
+  if (new_ncell1 != ncell1_ || !d_cell_start_) {  // table geometry changed: drop the device tables (pool is re-filled below)
+    if (d_pool_) (void)hipFree(d_pool_);
+    if (d_cell_start_) (void)hipFree(d_cell_start_);
+    d_pool_ = nullptr; d_cell_start_ = nullptr; slots_alloc_ = 0;
+    ncell1_ = new_ncell1;
+  }
+  if (had) {
+    const std::vector<int32_t> cs = cube_slot_;
+    clear();
+    // re-insert: every leaf of the old grid holds one point; with a different leaf size the touched-block filter of the
+    // reference would merge them the same way on its next insert
+    add_surf_host(keep.data(), keep.size() / 3, 3, err);
+  }
+  return 0;
+}
+
+int DeviceMap::add_surf_host(const float* xyz, size_t n, size_t stride_floats, std::string& err) {
+  if (!n) return 0;
+  if (stride_floats == 0) stride_floats = 3;
+  if (n * stride_floats > stage_cap_) {
+    if (d_stage_) (void)hipFree(d_stage_);
+    d_stage_ = nullptr; stage_cap_ = 0;
+    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_stage_), (n * stride_floats + 1024) * sizeof(float)));
+    stage_cap_ = n * stride_floats + 1024;
+  }
+  DM_TRY(hipMemcpyAsync(d_stage_, xyz, n * stride_floats * sizeof(float), hipMemcpyHostToDevice, stream_));
+  return add_surf_dev(d_stage_, n, stride_floats, err);
+}
+
+int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, std::string& err) {
+  if (!n) return 0;
+  if (stride_floats == 0) stride_floats = 3;
+  if (nc_ <= 1 && ncell1_ <= 2) { double cell; nc_ = cells_per_cube(plane_res_, &cell); cell_ = cell; ncell1_ = (uint32_t)((size_t)nc_ * nc_ * nc_ + 1); }
+  if (ensure_work(n, err)) return -2;
+  if (n > new_cap_) {
+    if (d_cube_of_) (void)hipFree(d_cube_of_);
+    d_cube_of_ = nullptr; new_cap_ = 0;
+    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cube_of_), (n + 1024) * sizeof(int32_t)));
+    new_cap_ = n + 1024;
+  }
+  // 1. cube of every new point + touched flags (one small read-back)
+  DM_TRY(hipMemsetAsync(d_touched_, 0, kMapNum, stream_));
+  DM_TRY(hipMemsetAsync(d_small_ + 48, 0, sizeof(uint32_t), stream_));
+  launch_world_cube(d_xyz, (uint32_t)n, (uint32_t)stride_floats, origin_, d_cube_of_, d_touched_, d_small_ + 48, stream_);
+  DM_TRY(hipMemcpyAsync(h_touched_, d_touched_, kMapNum, hipMemcpyDeviceToHost, stream_));
+  DM_TRY(hipMemcpyAsync(h_small_ + 48, d_small_ + 48, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+  DM_TRY(hipStreamSynchronize(stream_));
+  const int inserted_total = (int)h_small_[48];  // points inside the 21x21x11 window (LocalMap.h:605)
+  std::vector<int> touched;
+  for (int cube = 0; cube < kMapNum; ++cube) if (h_touched_[cube]) touched.push_back(cube);
+  if (touched.empty()) return 0;
+  for (int cube : touched) if (cube_slot_[cube] < 0) alloc_slot(cube);
+  if (ensure_pool((int)slot_cube_.size(), err)) return -2;
+  const float inv_leaf = 1.0f / plane_res_;
+  std::vector<int8_t> tid(kMapNum);
+  // 2. rounds of at most kMaxTouched cubes
+  for (size_t r0 = 0; r0 < touched.size(); r0 += kMaxTouched) {
+    MapInsertArgs a{};
+    MapTouched& tt = a.tt;
+    tt.n = (int)std::min<size_t>(kMaxTouched, touched.size() - r0);
+    std::fill(tid.begin(), tid.end(), (int8_t)-1);
+    uint32_t n_old = 0;
+    for (int t = 0; t < tt.n; ++t) {
+      const int cube = touched[r0 + t];
+      const int s = cube_slot_[cube];
+      tid[cube] = (int8_t)t;
+      tt.slot[t] = (uint32_t)s;
+      tt.old_prefix[t] = n_old;
+      n_old += slot_count_[s];
+      const int ci = cube % kMapW, cj = (cube / kMapW) % kMapH, ck = cube / (kMapW * kMapH);
+      const int w[3] = {ci - origin_[0], cj - origin_[1], ck - origin_[2]};
+      for (int ax = 0; ax < 3; ++ax) {
+        tt.cube_min[t][ax] = w[ax] * kCube - kHalfCube;
+        tt.leaf_lo[t][ax] = (int)std::floor((float)tt.cube_min[t][ax] * inv_leaf) - 2;
+      }
+    }
+    for (int t = tt.n; t <= kMaxTouched; ++t) tt.old_prefix[t] = n_old;
+    for (int t = tt.n; t < kMaxTouched; ++t) tt.slot[t] = 0;
+    if (ensure_work((size_t)n_old + n, err)) return -2;
+    DM_TRY(hipMemcpyAsync(d_touched_id_, tid.data(), kMapNum, hipMemcpyHostToDevice, stream_));
+    DM_TRY(hipMemsetAsync(d_small_, 0, 48 * sizeof(uint32_t), stream_));
+    a.d_xyz = d_xyz; a.n_new = (uint32_t)n; a.stride_floats = (uint32_t)stride_floats; a.n_old = n_old;
+    a.d_cube_of = d_cube_of_; a.d_touched_id = d_touched_id_; a.inv_leaf = inv_leaf;
+    a.nc = nc_; a.ncell1 = ncell1_; a.inv_cell = 1.0 / cell_;
+    a.pool = d_pool_; a.cap = kCapPerSlot; a.cell_start = d_cell_start_;
+    a.wpts = d_wpts_; a.cent = d_cent_;
+    a.keys0 = d_k0_; a.keys1 = d_k1_; a.vals0 = d_v0_; a.vals1 = d_v1_; a.flags = d_flags_; a.pos = d_pos_;
+    a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
+    a.temp = d_temp_; a.temp_bytes = temp_bytes_;
+    launch_map_insert(a, stream_);
+    DM_TRY(hipMemcpyAsync(h_small_, d_small_, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+    DM_TRY(hipStreamSynchronize(stream_));  // also keeps `tid` / the staging buffer alive long enough
+    for (int t = 0; t < tt.n; ++t) {
+      const uint32_t cnt = h_small_[8 + t];
+      if (cnt > kCapPerSlot) { err = "DeviceMap: a 50 m cube exceeds the per-cube capacity of 1M points"; return -1; }
+      slot_count_[tt.slot[t]] = cnt;
+    }
+  }
+  return inserted_total;
+}
+
+size_t DeviceMap::export_points(float* xyz, size_t cap, bool only_5x5, const int pos[3], std::string& err) {
+  size_t n = 0;
+  for (int cube = 0; cube < kMapNum; ++cube) {  // ascending cube index, canonical order inside the cube
+    const int s = cube_slot_[cube];
+    if (s < 0 || slot_count_[s] == 0) continue;
+    if (only_5x5) {
+      const int ci = cube % kMapW, cj = (cube / kMapW) % kMapH, ck = cube / (kMapW * kMapH);
+      if (std::abs(ci - pos[0]) > 2 || std::abs(cj - pos[1]) > 2 || std::abs(ck - pos[2]) > 1) continue;
+    }
+    const uint32_t cnt = slot_count_[s];
+    if (xyz && n + cnt <= cap) {
+      if ((size_t)cnt * 3 > stage_cap_) {
+        if (d_stage_) (void)hipFree(d_stage_);
+        d_stage_ = nullptr; stage_cap_ = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&d_stage_), ((size_t)cnt * 3 + 1024) * sizeof(float)) != hipSuccess) { err = "DeviceMap: export staging alloc failed"; return n; }
+        stage_cap_ = (size_t)cnt * 3 + 1024;
+      }
+      launch_gather_export(d_pool_, kCapPerSlot, (uint32_t)s, cnt, d_stage_, stream_);
+      if (hipMemcpyAsync(xyz + 3 * n, d_stage_, (size_t)cnt * 12, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+          hipStreamSynchronize(stream_) != hipSuccess) { err = "DeviceMap: export copy failed"; return n; }
+    }
+    n += cnt;
+  }
+  return n;
+}
+
+}  // namespace soicp

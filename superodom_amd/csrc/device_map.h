@@ -1,0 +1,64 @@
+// device_map.h -- the HBM-resident LocalMap (world_size == 1): the device pool is the authoritative store, the host
+// keeps only the block bookkeeping of include/super_odometry/LidarProcess/LocalMap.h (origin_, which block holds data,
+// per-block point counts).  Layout: every occupied 50 m cube owns a fixed region ("slot") of kCapPerSlot points in
+// one pool of {x,y,z,0} records plus its nc^3+1 cell table; canonical index = slot * kCapPerSlot + position, so a map
+// insert rewrites only the touched cubes and shiftMap is pure bookkeeping.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "local_map.h"
+#include "map_kernels.h"
+
+namespace soicp {
+
+constexpr uint32_t kCapPerSlot = 1u << 20;  // points per cube region (16 MB); 4096 slots keep indices in 32 bits
+
+class DeviceMap {
+ public:
+  explicit DeviceMap(hipStream_t s) : stream_(s) { origin_[0] = 10; origin_[1] = 10; origin_[2] = 5; cube_slot_.assign(kMapNum, -1); }
+  ~DeviceMap();
+  int set_resolution(float line_res, float plane_res);  // changing planeRes re-bins the map (download, re-insert)
+  float plane_res() const { return plane_res_; }
+  const int* origin() const { return origin_; }
+  void set_origin(const double t[3]);
+  void shift(const double t[3], int pos[3]);
+  int count_5x5(const int pos[3]) const;
+  size_t size() const;
+  void clear();
+  // LocalMap::addSurfPointCloud on the device.  d_xyz: device pointer, stride in floats.  Returns #points inside the window or <0.
+  int add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, std::string& err);
+  int add_surf_host(const float* xyz, size_t n, size_t stride_floats, std::string& err);
+  size_t export_points(float* xyz, size_t cap, bool only_5x5, const int pos[3], std::string& err);
+  bool view(DevMapView& v, std::string& err);  // refreshes the device cube_slot table when the bookkeeping changed
+  bool supported_resolution(float plane_res) const { return plane_res >= 0.0999f; }
+
+ private:
+  int ensure_pool(int slots_needed, std::string& err);
+  int ensure_work(size_t total, std::string& err);
+  int alloc_slot(int cube);
+  hipStream_t stream_;
+  int origin_[3];
+  float line_res_ = 0.2f, plane_res_ = 0.4f;
+  int nc_ = 1; double cell_ = 50.0; uint32_t ncell1_ = 2;
+  std::vector<int32_t> cube_slot_;   // kMapNum: slot or -1
+  std::vector<int32_t> slot_cube_;   // slot -> cube or -1 (free)
+  std::vector<uint32_t> slot_count_;
+  bool slot_table_dirty_ = true;
+  // device
+  float4* d_pool_ = nullptr; uint32_t* d_cell_start_ = nullptr; int32_t* d_cube_slot_ = nullptr; int slots_alloc_ = 0;
+  // work buffers
+  size_t work_cap_ = 0; size_t new_cap_ = 0;
+  float4 *d_wpts_ = nullptr, *d_cent_ = nullptr;
+  uint32_t *d_k0_ = nullptr, *d_k1_ = nullptr, *d_v0_ = nullptr, *d_v1_ = nullptr, *d_flags_ = nullptr, *d_pos_ = nullptr;
+  void* d_temp_ = nullptr; size_t temp_bytes_ = 0;
+  int32_t* d_cube_of_ = nullptr; uint8_t* d_touched_ = nullptr; int8_t* d_touched_id_ = nullptr; uint32_t* d_small_ = nullptr;
+  float* d_stage_ = nullptr; size_t stage_cap_ = 0;  // host->device staging of new points / export
+  uint8_t* h_touched_ = nullptr; uint32_t* h_small_ = nullptr;  // pinned
+};
+
+}  // namespace soicp

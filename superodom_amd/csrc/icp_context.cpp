@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -20,6 +21,7 @@
 #include "../../include/so_icp.h"
 #include "kernels.h"
 #include "lm_solver.h"
+#include "device_map.h"
 #include "local_map.h"
 #include "so_math.h"
 
@@ -83,7 +85,9 @@ struct so_icp_ctx {
   so_icp_config cfg;
   std::string err;
   bool host_only = false;  // device_id < 0: LocalMap bookkeeping only, every compute entry point fails
-  LocalMap map;
+  LocalMap map;                     // host LocalMap: host-only contexts and sharded (world_size > 1) contexts
+  std::unique_ptr<DeviceMap> dmap;  // HBM-resident LocalMap with GPU insert (world_size == 1)
+  DevBuf d_world;                   // world-frame copy of the scan for the map insert
   CanonicalMap cm;
   uint64_t uploaded_version = 0;
   hipStream_t stream = nullptr;
@@ -171,7 +175,13 @@ void spans_collect(so_icp_ctx* c) {  // stream must be idle
   c->ev_used = 0;
 }
 
+float map_plane_res(const so_icp_ctx* c) { return c->dmap ? c->dmap->plane_res() : c->map.plane_res(); }
+void map_shift(so_icp_ctx* c, const double t[3], int pos[3]) { if (c->dmap) c->dmap->shift(t, pos); else c->map.shift(t, pos); }
+int map_count_5x5(const so_icp_ctx* c, const int pos[3]) { return c->dmap ? c->dmap->count_5x5(pos) : c->map.count_5x5(pos); }
+const int* map_origin(const so_icp_ctx* c) { return c->dmap ? c->dmap->origin() : c->map.origin(); }
+
 int upload_map(so_icp_ctx* c) {
+  if (c->dmap) return c->dmap->view(c->view, c->err) ? SO_ICP_OK : SO_ICP_E_HIP;
   if (c->uploaded_version == c->map.version()) return SO_ICP_OK;
   c->map.build_canonical(c->cfg.rank, c->cfg.world_size, c->cm);
   const CanonicalMap& m = c->cm;
@@ -282,9 +292,9 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   std::memcpy(pose_out, pose_in, sizeof(T));
   if (c->have_hist) uncertainty_from_hist(c->prev_obs_hist, st->uncertainty);  // LidarSlam.cpp:47
   int pos[3];
-  c->map.shift(T, pos);                                                       // LidarSlam.cpp:363
+  map_shift(c, T, pos);                                                       // LidarSlam.cpp:363
   st->pos_in_localmap[0] = pos[0]; st->pos_in_localmap[1] = pos[1]; st->pos_in_localmap[2] = pos[2];
-  st->laser_cloud_surf_from_map_num = c->map.count_5x5(pos);                  // LidarSlam.cpp:367
+  st->laser_cloud_surf_from_map_num = map_count_5x5(c, pos);                  // LidarSlam.cpp:367
   st->laser_cloud_surf_stack_num = (int32_t)n;
   st->startup_count = c->startup_count;
   if (!(st->laser_cloud_surf_from_map_num > 50)) return SO_ICP_NOT_ENOUGH_MAP_FEATURES;  // LidarSlam.cpp:113-116
@@ -314,8 +324,8 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     launch_gather_scan(d_scan, c->d_vals1.as<uint32_t>(), c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
     span_end(c);
   }
-  const MatchParams mp = match_params(c->map.plane_res());
-  const EvalParams ep = eval_params(c->map.plane_res(), c->cfg.tukey_variant);
+  const MatchParams mp = match_params(map_plane_res(c));
+  const EvalParams ep = eval_params(map_plane_res(c), c->cfg.tukey_variant);
   CorrBuffers corr{c->d_nd.as<double4>(), c->d_coeff.as<double>(), c->d_status.as<uint8_t>()};
   std::vector<size_t> knn_span_of_outer, eval_span_first;
   for (int it = 0; it < max_outer; ++it) {
@@ -430,7 +440,7 @@ int upload_scan_impl(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_by
 
 so_icp_ctx::~so_icp_ctx() {
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
-  for (DevBuf* b : {&d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1, &d_chunks,
+  for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1, &d_chunks,
                     &d_sort_tmp, &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist})
     b->release();
@@ -520,6 +530,12 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_hist), (size_t)SO_ICP_MAX_OUTER * kHistReplicas * kHistStride * sizeof(int32_t))) != hipSuccess)
     return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if (const char* ev = std::getenv("SOICP_SYNC_PER_OUTER")) c->sync_per_outer = std::atoi(ev);
+  const bool want_dmap = cfg->world_size == 1 && !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
+  if (want_dmap) {
+    c->dmap = std::make_unique<DeviceMap>(c->stream);
+    if (!c->dmap->supported_resolution(cfg->plane_res)) c->dmap.reset();  // leaf keys hold 9 bits per axis
+    else c->dmap->set_resolution(cfg->line_res, cfg->plane_res);
+  }
   return c;
 }
 
@@ -533,6 +549,8 @@ void so_icp_destroy(so_icp_ctx* ctx) {
 
 int so_icp_set_resolution(so_icp_ctx* c, float line_res, float plane_res) {
   if (!c || !(plane_res > 0) || !(line_res > 0)) return SO_ICP_E_INVALID;
+  if (c->dmap && !c->dmap->supported_resolution(plane_res)) return fail(c, SO_ICP_E_UNSUPPORTED, "device map needs plane_res >= 0.1");
+  if (c->dmap) { NEED_DEVICE(c); HIP_TRY(c, hipSetDevice(c->cfg.device_id)); c->dmap->set_resolution(line_res, plane_res); }
   if (plane_res != c->map.plane_res()) c->uploaded_version = 0;  // cell size follows planeRes
   c->map.set_resolution(line_res, plane_res);
   c->cfg.line_res = line_res; c->cfg.plane_res = plane_res;
@@ -543,46 +561,53 @@ int so_icp_set_max_iterations(so_icp_ctx* c, int v) { if (!c || v < 1) return SO
 
 int so_icp_map_set_origin(so_icp_ctx* c, const double t[3], int o[3]) {
   if (!c || !t) return SO_ICP_E_INVALID;
-  c->map.set_origin(t);
-  if (o) { o[0] = c->map.origin()[0]; o[1] = c->map.origin()[1]; o[2] = c->map.origin()[2]; }
+  if (c->dmap) c->dmap->set_origin(t); else c->map.set_origin(t);
+  if (o) { o[0] = map_origin(c)[0]; o[1] = map_origin(c)[1]; o[2] = map_origin(c)[2]; }
   return SO_ICP_OK;
 }
 int so_icp_map_get_origin(so_icp_ctx* c, int o[3]) {
   if (!c || !o) return SO_ICP_E_INVALID;
-  o[0] = c->map.origin()[0]; o[1] = c->map.origin()[1]; o[2] = c->map.origin()[2];
+  o[0] = map_origin(c)[0]; o[1] = map_origin(c)[1]; o[2] = map_origin(c)[2];
   return SO_ICP_OK;
 }
 int so_icp_map_shift(so_icp_ctx* c, const double t[3], int pos[3]) {
   if (!c || !t || !pos) return SO_ICP_E_INVALID;
-  c->map.shift(t, pos);
+  map_shift(c, t, pos);
   return SO_ICP_OK;
 }
 int so_icp_map_add_surf(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes) {
   if (!c || (!xyz && n)) return SO_ICP_E_INVALID;
   if (stride_bytes == 0) stride_bytes = 12;
   if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
+  if (c->dmap) {  // bin + VoxelGrid + index rebuild on the device (map_kernels.hip)
+    HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+    const int r = c->dmap->add_surf_host(xyz, n, stride_bytes / 4, c->err);
+    return r < 0 ? SO_ICP_E_HIP : r;
+  }
   return c->map.add_surf(xyz, n, stride_bytes / 4);
 }
 int so_icp_map_count_5x5(so_icp_ctx* c, const int pos[3], int* n_edge, int* n_surf) {
   if (!c || !pos) return SO_ICP_E_INVALID;
   if (n_edge) *n_edge = 0;
-  if (n_surf) *n_surf = c->map.count_5x5(pos);
+  if (n_surf) *n_surf = map_count_5x5(c, pos);
   return SO_ICP_OK;
 }
 int so_icp_map_export(so_icp_ctx* c, float* xyz, size_t cap, size_t* n_out, int only_5x5, const int pos[3]) {
   if (!c || (only_5x5 && !pos)) return SO_ICP_E_INVALID;
   const int zero[3] = {0, 0, 0};
-  const size_t n = c->map.export_points(xyz, cap, only_5x5 != 0, pos ? pos : zero);
+  if (c->dmap) HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  const size_t n = c->dmap ? c->dmap->export_points(xyz, cap, only_5x5 != 0, pos ? pos : zero, c->err)
+                           : c->map.export_points(xyz, cap, only_5x5 != 0, pos ? pos : zero);
   if (n_out) *n_out = n;
   return SO_ICP_OK;
 }
 int so_icp_map_size(so_icp_ctx* c, size_t* n, size_t* n_rank) {
   if (!c) return SO_ICP_E_INVALID;
-  if (n) *n = c->map.size();
+  if (n) *n = c->dmap ? c->dmap->size() : c->map.size();
   if (n_rank) { NEED_DEVICE(c); const int rc = upload_map(c); if (rc) return rc; *n_rank = c->view.n_points; }
   return SO_ICP_OK;
 }
-int so_icp_map_clear(so_icp_ctx* c) { if (!c) return SO_ICP_E_INVALID; c->map.clear(); return SO_ICP_OK; }
+int so_icp_map_clear(so_icp_ctx* c) { if (!c) return SO_ICP_E_INVALID; if (c->dmap) c->dmap->clear(); else c->map.clear(); return SO_ICP_OK; }
 
 int so_icp_knn_surf(so_icp_ctx* c, const float* q, size_t nq, int k, float* nbr, float* d2, int32_t* idx, uint8_t* found) {
   if (!c || (!q && nq) || !nbr || !d2 || !found) return SO_ICP_E_INVALID;
@@ -598,7 +623,7 @@ int so_icp_knn_surf(so_icp_ctx* c, const float* q, size_t nq, int k, float* nbr,
   HIP_TRY(c, hipMemcpyAsync(c->d_q.p, q, nq * 12, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_fbcount, 0, 4, c->stream));
   // the 27-cell block certainly covers a ball of one cell edge around the query
-  const double cover = c->cm.cell * (1.0 - 1e-5);
+  const double cover = (1.0 / c->view.inv_cell) * (1.0 - 1e-5);
   const float gate = (float)(cover * cover);
   launch_knn_only(c->d_q.as<float>(), (uint32_t)nq, k, c->view, gate, c->d_nbr.as<float>(), c->d_d2.as<float>(), c->d_idx.as<int32_t>(),
                   c->d_found.as<uint8_t>(), c->d_fblist.as<uint32_t>(), c->d_fbcount, c->stream);
@@ -668,12 +693,17 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
       quat_rotate<double>(T + 3, (double)xyz[i * sf], (double)xyz[i * sf + 1], (double)xyz[i * sf + 2], ox, oy, oz);
       w[3 * i] = (float)(ox + T[0]); w[3 * i + 1] = (float)(oy + T[1]); w[3 * i + 2] = (float)(oz + T[2]);
     }
-    c->map.add_surf(w.data(), n, 3);
+    if (c->dmap) c->dmap->add_surf_host(w.data(), n, 3, c->err); else c->map.add_surf(w.data(), n, 3);
+  };
+  auto transform_and_add_dev = [&](const double T[7]) -> int {  // same, entirely on the device (scan already resident in d_scan_own)
+    HIP_TRY(c, c->d_world.reserve((n + 64) * 12));
+    launch_transform_scan(c->d_scan_own.as<float>(), (uint32_t)n, pose_from_array(T), c->d_world.as<float>(), c->stream);
+    return c->dmap->add_surf_dev(c->d_world.as<float>(), n, 3, c->err) < 0 ? SO_ICP_E_HIP : SO_ICP_OK;
   };
   if (!initialization) {  // initializeMapping, LidarSlam.cpp:83-94
     std::memcpy(pose_out, T_in, 7 * sizeof(double));
     if (st) std::memset(st, 0, sizeof(*st));
-    c->map.set_origin(T_in);
+    if (c->dmap) c->dmap->set_origin(T_in); else c->map.set_origin(T_in);
     transform_and_add(T_in);
     c->last_time = time_laser_odometry;
     return SO_ICP_MAP_SEEDED;
@@ -686,7 +716,8 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   const double dt = time_laser_odometry - c->last_time;
   if (st->translation_from_last / dt > c->cfg.velocity_failure_threshold) c->startup_count = 5;
   st->startup_count = c->startup_count;
-  transform_and_add(pose_out);  // LidarSlam.cpp:163-167
+  if (c->dmap) { const int r = transform_and_add_dev(pose_out); if (r) return r; }  // LidarSlam.cpp:163-167
+  else transform_and_add(pose_out);
   c->last_time = time_laser_odometry;
   return SO_ICP_OK;
 }

@@ -127,21 +127,28 @@ __global__ __launch_bounds__(256) void gather_scan_kernel(const float* __restric
   spx[j] = scan[3 * i]; spy[j] = scan[3 * i + 1]; spz[j] = scan[3 * i + 2];
 }
 
-// Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries that share one sort key (one map
-// cell under the pose the scan was sorted with) and one 64-aligned block.  One wavefront per chunk keeps the
-// cost of a wave ~ one candidate set, whatever the query density (no straggler waves in sparse regions).
+// Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries of one 64-aligned block, handled by one
+// wavefront.  A block whose queries fall into at most kMaxKeysPerChunk different map cells is ONE chunk (its lanes'
+// gate balls are covered by one union block of cells); a block that scatters over more cells (sparse far-range
+// returns) is split at every key change, so that the cost of a wave stays ~ one candidate set whatever the query
+// density (no straggler waves).  Descriptor = start | (count-1) << 26.
+constexpr int kMaxKeysPerChunk = 1;  // measured: merging up to 8 cells per chunk halves the wave count and DOUBLES the kernel time (latency-bound)
 __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t kKeyDropped,
                                                            uint32_t* __restrict__ chunk_start, DevState* __restrict__ st) {
   __shared__ uint32_t wave_cnt[16];
   __shared__ uint32_t block_base;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // one wavefront == one 64-aligned block of queries
   const uint32_t key = i < n ? keys[i] : kKeyDropped;
   const bool kept = key != kKeyDropped;
   // keys are sorted and the dropped key is the largest value: the kept queries are the prefix [0, n_kept)
   if (kept && (i + 1 == n || keys[i + 1] == kKeyDropped)) st->n_kept = i + 1;
-  const bool head = kept && ((i == 0) || ((i & 63u) == 0) || (key != keys[i - 1]));
-  const unsigned long long m = __ballot(head);
+  const unsigned long long kept_m = __ballot(kept);
+  const bool key_head = kept && ((lane == 0) || (key != keys[i - 1]));
+  const unsigned long long key_m = __ballot(key_head);
+  const bool merge = __popcll(key_m) <= kMaxKeysPerChunk;
+  const unsigned long long m = merge ? (kept_m & 1ull) : key_m;  // heads of this block
+  const bool head = (m >> lane) & 1ull;
   if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -150,7 +157,12 @@ __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __res
     block_base = tot ? atomicAdd(&st->n_chunks, tot) : 0u;  // one atomic per 1024 queries
   }
   __syncthreads();
-  if (head) chunk_start[block_base + wave_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+  if (head) {
+    const unsigned long long later = (lane == 63) ? 0ull : (m >> (lane + 1));
+    const int end = later ? lane + 1 + (__ffsll((long long)later) - 1) : (int)__popcll(kept_m);  // next head or end of the kept lanes
+    const uint32_t count = (uint32_t)(end - lane);
+    chunk_start[block_base + wave_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i | ((count - 1u) << 26);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -502,9 +514,10 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   uint32_t j = 0;
   bool valid_q = false;
   {
-    const uint32_t start = __builtin_amdgcn_readfirstlane(chunk_start[chunk]);
+    const uint32_t desc = __builtin_amdgcn_readfirstlane(chunk_start[chunk]);
+    const uint32_t start = desc & 0x03FFFFFFu, count = (desc >> 26) + 1u;
     j = start + lane;
-    valid_q = (j < n_kept) && ((j >> 6) == (start >> 6)) && (skeys[j] == skeys[start]);
+    valid_q = (lane < (int)count) && (j < n_kept);
   }
   double pw[3] = {0, 0, 0};
   float qx = 0, qy = 0, qz = 0;
@@ -559,8 +572,11 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
     uint32_t total = 0;
     uint32_t vb = 0, vl = 0;
     int nrows = 0, nyr = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-      if (attempt == 1) mine = mine && (ckey == k);
+    const int lcx = (int)(k & 63u), lcy = (int)((k >> 6) & 63u), lcz = (int)((k >> 12) & 63u);
+    for (int attempt = 0; attempt < 3; ++attempt) {
+      if (attempt == 1)
+        mine = mine && abs(c.cx - lcx) <= 1 && abs(c.cy - lcy) <= 1 && abs(c.cz - lcz) <= 1;
+      if (attempt == 2) mine = mine && (ckey == k);
       bx0 = __builtin_amdgcn_readlane(lo_x, leader); bx1 = __builtin_amdgcn_readlane(hi_x, leader);
       by0 = __builtin_amdgcn_readlane(lo_y, leader); by1 = __builtin_amdgcn_readlane(hi_y, leader);
       bz0 = __builtin_amdgcn_readlane(lo_z, leader); bz1 = __builtin_amdgcn_readlane(hi_z, leader);

@@ -1,0 +1,45 @@
+// map_kernels.h -- launch interface of the device-resident LocalMap update (map_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "so_math.h"
+
+namespace soicp {
+
+constexpr int kMaxTouched = 32;  // cubes handled by one insert round (5 key bits)
+
+// the cubes one insert round touches (passed by value to the kernels)
+struct MapTouched {
+  int32_t n;
+  uint32_t slot[kMaxTouched];            // pool slot of touched cube t
+  uint32_t old_prefix[kMaxTouched + 1];  // exclusive prefix of the cubes' current point counts
+  int32_t leaf_lo[kMaxTouched][3];       // floor(cube_min * inv_leaf) - 1: common leaf offset of the cube
+  double cube_min[kMaxTouched][3];       // world coordinates of the cube's min corner
+};
+
+struct MapInsertArgs {
+  MapTouched tt;
+  const float* d_xyz;        // new world-frame points (device)
+  uint32_t n_new, stride_floats, n_old;
+  const int32_t* d_cube_of;  // per new point: cube index or -1
+  const int8_t* d_touched_id;  // cube -> t of THIS round, -1 otherwise
+  float inv_leaf;
+  int32_t nc; uint32_t ncell1; double inv_cell;
+  float4* pool; uint32_t cap; uint32_t* cell_start;
+  float4* wpts; float4* cent;
+  uint32_t *keys0, *keys1, *vals0, *vals1, *flags, *pos;
+  uint32_t* d_n_cent; uint32_t* d_counts;  // [1], [kMaxTouched]
+  void* temp; size_t temp_bytes;
+};
+
+size_t map_sort_temp_bytes(size_t n);
+void launch_world_cube(const float* d_xyz, uint32_t n, uint32_t stride_floats, const int origin[3], int32_t* d_cube_of,
+                       uint8_t* d_touched, uint32_t* d_n_inside, hipStream_t s);
+void launch_transform_scan(const float* d_scan, uint32_t n, const Pose& pose, float* d_out, hipStream_t s);
+void launch_map_insert(const MapInsertArgs& a, hipStream_t s);
+void launch_gather_export(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, float* d_out, hipStream_t s);
+
+}  // namespace soicp

@@ -1,0 +1,239 @@
+// map_kernels.hip -- device-resident LocalMap update: the GPU counterpart of
+//   LocalMap::addSurfPointCloud   include/super_odometry/LidarProcess/LocalMap.h:591-645
+//     (bin the world-frame points into 50 m cubes, pcl::VoxelGrid(planeRes) per touched cube, rebuild the index)
+// which the reference executes on the CPU after every scan (transformAndAddToMap, LidarSlam.cpp:60-80,163-167).
+//
+// Pipeline (all on the context's stream, two small read-backs):
+//   world_cube_kernel     cube index per point (the int((c+25)/50), "--" rule) + touched-cube flags
+//   gather_old_kernel     the touched cubes' current points become the head of the working set (old first: a leaf
+//                         holds at most one old centroid, and PCL accumulates in input order)
+//   append_new_kernel     the new points follow in input order; key = (touched-cube id, leaf z, y, x)
+//   rocPRIM stable sort   by leaf key
+//   leaf_centroid_kernel  one thread per leaf head: float sums IN ORDER, centroid = sum / count  (VoxelGrid semantics)
+//   cell_key_kernel       key2 = (touched-cube id, cell z, y, x) of each centroid; rocPRIM stable sort
+//   scatter_kernel        centroids into the cube's region of the point pool (canonical order = cell, then leaf)
+//   table_kernel          per-cube prefix table by binary search (cell -> first canonical index)
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "map_kernels.h"
+#include "so_math.h"
+
+namespace soicp {
+
+__device__ __forceinline__ int cube_coord_f(float c, int origin) {  // == int((c + 25.0) / 50.0) (+origin), "--" if negative
+  const double s = (double)c + 25.0;                                 // (exact for float inputs, see kernels.hip)
+  int i = (int)(s * 0.02) + origin;
+  if (s < 0) i--;
+  return i;
+}
+
+// LocalMap.h:596-610
+__global__ __launch_bounds__(256) void world_cube_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats,
+                                                         int o0, int o1, int o2, int32_t* __restrict__ cube_of,
+                                                         uint8_t* __restrict__ touched, uint32_t* __restrict__ n_inside) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  int cube = -1;
+  if (i < n) {
+    const float* p = xyz + (size_t)i * stride_floats;
+    const int ci = cube_coord_f(p[0], o0), cj = cube_coord_f(p[1], o1), ck = cube_coord_f(p[2], o2);
+    if (ci >= 0 && ci < 21 && cj >= 0 && cj < 21 && ck >= 0 && ck < 11) {
+      cube = ci + 21 * cj + 21 * 21 * ck;
+      touched[cube] = 1;
+    }
+    cube_of[i] = cube;
+  }
+  const unsigned long long m = __ballot(cube >= 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_inside, (uint32_t)__popcll(m));  // off the ICP critical path
+}
+
+// scan + world transform in one pass (transformAndAddToMap, LidarSlam.cpp:60-80; TransformPoint, superodom_utils.h:119-123)
+__global__ __launch_bounds__(256) void transform_scan_kernel(const float* __restrict__ scan, uint32_t n, Pose pose,
+                                                             float* __restrict__ out_xyz) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double wx, wy, wz;
+  quat_rotate<double>(pose.q, (double)scan[3 * i], (double)scan[3 * i + 1], (double)scan[3 * i + 2], wx, wy, wz);
+  out_xyz[3 * i] = (float)(wx + pose.t[0]); out_xyz[3 * i + 1] = (float)(wy + pose.t[1]); out_xyz[3 * i + 2] = (float)(wz + pose.t[2]);
+}
+
+// leaf coordinate = floor(v * inv_leaf) evaluated in FLOAT exactly like pcl::VoxelGrid; an arbitrary common offset per
+// cube keeps the lexicographic (z, y, x) order, which is all VoxelGrid's linear leaf index is used for.
+__device__ __forceinline__ uint32_t leaf_key(float x, float y, float z, float inv_leaf, int lo0, int lo1, int lo2, uint32_t tid) {
+  const int l0 = (int)floorf(x * inv_leaf) - lo0, l1 = (int)floorf(y * inv_leaf) - lo1, l2 = (int)floorf(z * inv_leaf) - lo2;
+  return (tid << 27) | ((uint32_t)(l2 & 511) << 18) | ((uint32_t)(l1 & 511) << 9) | (uint32_t)(l0 & 511);
+}
+
+__global__ __launch_bounds__(256) void gather_old_kernel(MapTouched tt, const float4* __restrict__ pool, uint32_t cap, float inv_leaf,
+                                                         uint32_t n_old, float4* __restrict__ wpts, uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ vals) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_old) return;
+  int t = 0;
+#pragma unroll
+  for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
+  const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
+  wpts[e] = p;
+  keys[e] = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t);
+  vals[e] = e;
+}
+
+__global__ __launch_bounds__(256) void append_new_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats,
+                                                         const int32_t* __restrict__ cube_of, const int8_t* __restrict__ touched_id,
+                                                         MapTouched tt, float inv_leaf, uint32_t n_old, float4* __restrict__ wpts,
+                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = xyz + (size_t)i * stride_floats;
+  const int cube = cube_of[i];
+  const uint32_t e = n_old + i;
+  wpts[e] = make_float4(p[0], p[1], p[2], 0.f);
+  vals[e] = e;
+  if (cube < 0) { keys[e] = 0xFFFFFFFFu; return; }  // outside the 21x21x11 window: dropped (LocalMap.h:605)
+  const int t = touched_id[cube];
+  if (t < 0) { keys[e] = 0xFFFFFFFFu; return; }     // a cube handled by another round of this insert
+  keys[e] = leaf_key(p[0], p[1], p[2], inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t);
+}
+
+__global__ __launch_bounds__(256) void leaf_flags_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flags[i] = (keys[i] != 0xFFFFFFFFu && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
+}
+
+// one thread per leaf: accumulate the leaf's points in (stable-sorted) input order in float, divide by float(count)
+// (pcl::CentroidPoint / AccumulatorXYZ semantics); emits the cell key of the centroid for the second sort
+__global__ __launch_bounds__(256) void leaf_centroid_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                            const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
+                                                            uint32_t n, const float4* __restrict__ wpts, MapTouched tt, int nc,
+                                                            double inv_cell, float4* __restrict__ cent, uint32_t* __restrict__ keys2,
+                                                            uint32_t* __restrict__ vals2, uint32_t* __restrict__ n_cent) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == n - 1) *n_cent = pos[i] + flags[i];
+  if (!flags[i]) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  uint32_t j = i;
+  const uint32_t key = keys[i];
+  do {
+    const float4 p = wpts[vals[j]];
+    s0 += p.x; s1 += p.y; s2 += p.z;
+    ++j;
+  } while (j < n && keys[j] == key);
+  const float cnt = (float)(j - i);
+  const float cx = s0 / cnt, cy = s1 / cnt, cz = s2 / cnt;
+  const uint32_t o = pos[i];
+  cent[o] = make_float4(cx, cy, cz, 0.f);
+  const int t = (int)(key >> 27);
+  int g[3];
+  const float c3[3] = {cx, cy, cz};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {  // cell of the hashed-voxel grid: floor((p - cube_min) * inv_cell), clamped (local_map.cpp: cell_of)
+    const int v = (int)floor(((double)c3[a] - tt.cube_min[t][a]) * inv_cell);
+    g[a] = v < 0 ? 0 : (v >= nc ? nc - 1 : v);
+  }
+  keys2[o] = ((uint32_t)t << 18) | (uint32_t)((g[2] * nc + g[1]) * nc + g[0]);  // linear cell index, as in the cube's table
+  vals2[o] = o;
+}
+
+__global__ __launch_bounds__(256) void pad_keys_kernel(uint32_t* __restrict__ keys2, uint32_t* __restrict__ vals2,
+                                                       const uint32_t* __restrict__ n_cent, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || i < *n_cent) return;
+  keys2[i] = 0xFFFFFFFFu; vals2[i] = i;
+}
+
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t key) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void scatter_kernel(const uint32_t* __restrict__ keys2s, const uint32_t* __restrict__ vals2s,
+                                                      const uint32_t* __restrict__ n_cent, const float4* __restrict__ cent,
+                                                      MapTouched tt, uint32_t cap, float4* __restrict__ pool,
+                                                      uint32_t* __restrict__ counts /*[32]*/) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t m = *n_cent;
+  if (i >= m) return;
+  const uint32_t t = keys2s[i] >> 18;
+  const uint32_t beg = lower_bound_u32(keys2s, m, t << 18);
+  const uint32_t local = i - beg;
+  if (local < cap) pool[(size_t)tt.slot[t] * cap + local] = cent[vals2s[i]];
+  if (i + 1 == m || (keys2s[i + 1] >> 18) != t) counts[t] = local + 1;  // last point of this cube
+}
+
+// cell_start[slot][c] = canonical index of the first point whose cell >= c (c = nc^3: one past the cube's last point)
+__global__ __launch_bounds__(256) void table_kernel(const uint32_t* __restrict__ keys2s, const uint32_t* __restrict__ n_cent,
+                                                    MapTouched tt, uint32_t cap, uint32_t ncell1, uint32_t* __restrict__ cell_start) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = blockIdx.y;
+  if (c >= ncell1) return;
+  const uint32_t m = *n_cent;
+  const uint32_t beg = lower_bound_u32(keys2s, m, t << 18);
+  const uint32_t at = (c == ncell1 - 1) ? lower_bound_u32(keys2s, m, (t + 1) << 18) : lower_bound_u32(keys2s, m, (t << 18) | c);
+  cell_start[(size_t)tt.slot[t] * ncell1 + c] = tt.slot[t] * cap + (at - beg);
+}
+
+__global__ __launch_bounds__(256) void gather_export_kernel(const float4* __restrict__ pool, uint32_t cap, uint32_t slot, uint32_t count,
+                                                            float* __restrict__ out_xyz) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float4 p = pool[(size_t)slot * cap + i];
+  out_xyz[3 * i] = p.x; out_xyz[3 * i + 1] = p.y; out_xyz[3 * i + 2] = p.z;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
+
+size_t map_sort_temp_bytes(size_t n) {
+  size_t a = 0, b = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
+  (void)rocprim::exclusive_scan(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(), (hipStream_t)0);
+  return a > b ? a : b;
+}
+
+void launch_world_cube(const float* d_xyz, uint32_t n, uint32_t stride_floats, const int origin[3], int32_t* d_cube_of, uint8_t* d_touched,
+                       uint32_t* d_n_inside, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(world_cube_kernel, grid_for(n, 256), dim3(256), 0, s, d_xyz, n, stride_floats, origin[0], origin[1], origin[2], d_cube_of,
+                     d_touched, d_n_inside);
+}
+void launch_transform_scan(const float* d_scan, uint32_t n, const Pose& pose, float* d_out, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(transform_scan_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, pose, d_out);
+}
+void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
+  const uint32_t total = a.n_old + a.n_new;
+  if (!total) return;
+  if (a.n_old)
+    hipLaunchKernelGGL(gather_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0);
+  if (a.n_new)
+    hipLaunchKernelGGL(append_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of, a.d_touched_id,
+                       a.tt, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0);
+  size_t tb = a.temp_bytes;
+  (void)rocprim::radix_sort_pairs(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 0, 32, s);  // stable
+  hipLaunchKernelGGL(leaf_flags_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, total, a.flags);
+  tb = a.temp_bytes;
+  (void)rocprim::exclusive_scan(a.temp, tb, a.flags, a.pos, 0u, (size_t)total, rocprim::plus<uint32_t>(), s);
+  hipLaunchKernelGGL(leaf_centroid_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.flags, a.pos, total, a.wpts, a.tt, a.nc,
+                     a.inv_cell, a.cent, a.keys0, a.vals0, a.d_n_cent);
+  hipLaunchKernelGGL(pad_keys_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals0, a.d_n_cent, total);
+  tb = a.temp_bytes;
+  (void)rocprim::radix_sort_pairs(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 0, 32, s);  // stable: leaf order inside a cell
+  hipLaunchKernelGGL(scatter_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.d_n_cent, a.cent, a.tt, a.cap, a.pool, a.d_counts);
+  hipLaunchKernelGGL(table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.keys1, a.d_n_cent, a.tt, a.cap, a.ncell1, a.cell_start);
+}
+void launch_gather_export(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, float* d_out, hipStream_t s) {
+  if (!count) return;
+  hipLaunchKernelGGL(gather_export_kernel, grid_for(count, 256), dim3(256), 0, s, pool, cap, slot, count, d_out);
+}
+
+}  // namespace soicp

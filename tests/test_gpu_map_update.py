@@ -1,0 +1,103 @@
+"""-m gpu: the device-resident LocalMap (superodom_amd/csrc/device_map.cpp + map_kernels.hip) against the oracle's
+LocalMap restatement: GPU bin + VoxelGrid + index rebuild must reproduce addSurfPointCloud POINT FOR POINT
+(float centroids accumulated in input order), shiftMap must keep/drop exactly the same blocks."""
+import time
+
+import numpy as np
+import pytest
+
+from helpers import noisy_planes_cloud
+from superodom_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_points(a, b):
+    return a.shape == b.shape and np.array_equal(a[np.lexsort(a.T)], b[np.lexsort(b.T)])
+
+
+def test_incremental_inserts_and_window_roll_match_oracle(oracle, gpu_slam_factory):
+    rng = np.random.default_rng(1)
+    slam = gpu_slam_factory(plane_res=0.2)
+    om = oracle.OracleMap(plane_res=0.2)
+    t0 = np.array([130.0, -80.0, 3.0])
+    assert list(slam.set_origin(t0)) == list(om.set_origin(t0))
+    assert list(slam.shift_map(t0)) == list(om.shift(t0))
+    for step in range(4):  # repeated inserts re-filter the touched cubes together with their old centroids
+        pts = np.concatenate([noisy_planes_cloud(6000, rng, offset=(t0[0] + dx, t0[1] + dy, 0)) for dx in (-30, 20) for dy in (-10, 35)])
+        assert slam.add_surf_point_cloud(pts) == om.add_surf(pts)
+        assert slam.map_size() == om.size()
+        assert _same_points(slam.export_map(), om.export()), f"insert {step}: GPU VoxelGrid differs from the oracle"
+    pos = slam.shift_map(t0)
+    assert list(pos) == list(om.shift(t0)) and slam.count_5x5(pos) == om.count_5x5(pos)
+    # exported order = ascending cube index (canonical order inside): loading it raw into the oracle reproduces every k-NN
+    om2 = oracle.OracleMap(plane_res=0.2); om2.set_origin(t0); om2.shift(t0)
+    om2.add_surf(slam.export_map(), raw=True)
+    q = (slam.export_map()[::7] + rng.normal(0, 0.1, (len(slam.export_map()[::7]), 3))).astype(np.float32)
+    found, nbr, d2, idx = slam.nearest_k_search_surf(q, 5)
+    of, onbr, od2, _, _ = om2.knn(q, 5, use_grid=1)
+    assert np.array_equal(found, of) and np.array_equal(d2.view(np.uint32), od2.view(np.uint32)) and np.array_equal(nbr, onbr)
+    # roll the window: blocks move, points survive; then far away: everything is dropped
+    t1 = t0 + np.array([400.0, -260.0, 0.0])
+    assert list(slam.shift_map(t1)) == list(om.shift(t1))
+    assert list(slam.origin()) == list(om.origin()) and slam.map_size() == om.size() > 0
+    assert _same_points(slam.export_map(), om.export())
+    more = noisy_planes_cloud(5000, rng, offset=(t1[0], t1[1], 0))
+    assert slam.add_surf_point_cloud(more) == om.add_surf(more)
+    assert _same_points(slam.export_map(), om.export())
+    t2 = t1 + np.array([5000.0, 0, 0])
+    slam.shift_map(t2); om.shift(t2)
+    assert slam.map_size() == om.size() == 0
+
+
+def test_many_touched_cubes_and_points_outside_window(oracle, gpu_slam_factory):
+    rng = np.random.default_rng(2)
+    slam = gpu_slam_factory(plane_res=0.2)
+    om = oracle.OracleMap(plane_res=0.2)
+    # 7 x 7 x 2 = 98 cubes touched (> 32: several insert rounds) + points far outside the 21 x 21 x 11 window
+    pts = np.concatenate([rng.random((120000, 3)) * [340, 340, 60] - [170, 170, 20],
+                          rng.random((500, 3)) * 100 + 3000]).astype(np.float32)
+    a = slam.add_surf_point_cloud(pts); b = om.add_surf(pts)
+    assert a == b == 120000
+    assert slam.map_size() == om.size()
+    assert _same_points(slam.export_map(), om.export())
+    pos = slam.shift_map(np.zeros(3))
+    exp5 = slam.export_map(only_5x5=True, pos=pos)
+    assert len(exp5) == slam.count_5x5(pos) < slam.map_size()
+
+
+def test_plane_res_change_rebuilds_index(oracle, gpu_slam_factory):
+    sc = synth.Scene("tiny")
+    slam = gpu_slam_factory(plane_res=0.2, max_surface_features=-1, max_iterations=3)
+    slam.add_surf_point_cloud(sc.map_points)
+    slam.set_resolution(0.2, 0.4)  # auto voxel size may switch planeRes between frames (lmap.cpp:604-649)
+    om = oracle.OracleMap(plane_res=0.4)
+    om.add_surf(slam.export_map(), raw=True)
+    scan, guess = sc.scan(1), sc.guess(1)
+    rc, pose, st = slam.register(scan, guess)
+    orc, opose, ost, _ = om.register(scan, guess, oracle.default_config(max_iterations=3))
+    assert rc == orc == 0 and st.n_iterations == ost.n_iterations
+    assert list(st.iterations[0].reject_hist) == list(ost.iters[0].reject_hist)
+    d = synth.pose_error(pose, opose)
+    assert d[0] < 1e-8 and d[1] < 1e-8
+
+
+def test_full_size_localization_rate(gpu_slam_factory):
+    """Localization() end to end at BASELINE sizes: registration + GPU map insert (no host VoxelGrid, no re-upload)."""
+    sc = synth.Scene("os1_128_2m")
+    slam = gpu_slam_factory(plane_res=sc.plane_res, max_surface_features=-1, max_iterations=5)
+    assert slam.add_surf_point_cloud(sc.map_points) == 2_000_000
+    slam.shift_map(sc.gt_pose(0)[:3])
+    n0 = slam.map_size()
+    times = []
+    for i in range(1, 5):
+        scan, guess = sc.scan(i), sc.guess(i)
+        t = time.perf_counter()
+        rc, pose, st = slam.localization(True, guess, scan, 0.1 * i)
+        times.append(time.perf_counter() - t)
+        assert rc == 0
+        e = synth.pose_error(pose, sc.gt_pose(i))
+        assert e[0] < 0.01 and e[1] < 0.002
+    assert slam.map_size() > n0  # the scans added new voxels
+    assert min(times) < 0.05, f"Localization() should take milliseconds, got {times}"
+    print("localization wall times (s):", [round(t, 5) for t in times])
