@@ -212,6 +212,8 @@ int so_icp_lm_result(const so_icp_lm_state *s, double pose[7], so_icp_iter_stats
 int so_icp_get_timing(so_icp_ctx *ctx, so_icp_timing *t);
 int so_icp_reset_timing(so_icp_ctx *ctx);
 int so_icp_synchronize(so_icp_ctx *ctx);
+/* profiling aid: wall-clock stamps (100 MHz ticks) of the phases of the last fit / evaluation kernels (SOICP_ABLATE=128) */
+int so_icp_debug_stamps(so_icp_ctx *ctx, uint64_t out[16]);
 
 #ifdef __cplusplus
 }

@@ -786,6 +786,12 @@ int so_icp_lm_result(const so_icp_lm_state* s, double pose[7], so_icp_iter_stats
 
 int so_icp_get_timing(so_icp_ctx* c, so_icp_timing* t) { if (!c || !t) return SO_ICP_E_INVALID; *t = c->timing; return SO_ICP_OK; }
 int so_icp_reset_timing(so_icp_ctx* c) { if (!c) return SO_ICP_E_INVALID; std::memset(&c->timing, 0, sizeof(c->timing)); return SO_ICP_OK; }
+int so_icp_debug_stamps(so_icp_ctx* c, uint64_t out[16]) {
+  if (!c || !out) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  for (int i = 0; i < 16; ++i) out[i] = c->h_state->dbg[i];
+  return SO_ICP_OK;
+}
 int so_icp_synchronize(so_icp_ctx* c) { if (!c) return SO_ICP_E_INVALID; NEED_DEVICE(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return SO_ICP_OK; }
 
 }  // extern "C"

@@ -64,6 +64,7 @@ struct DevState {
   LmState S;
   double JtJ[36], Jtr[6];
   DevIterStats iters[16];
+  unsigned long long dbg[16];  // profiling aid (SOICP_ABLATE bit 7): wall-clock stamps of the last evaluation's phases
 };
 constexpr int kDevStateHostBytes = 64;  // pose_in + max_outer/lm_max
 

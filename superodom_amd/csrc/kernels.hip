@@ -754,18 +754,22 @@ __device__ __forceinline__ bool eval_slot_active(const DevState* st, int slot) {
 
 // The Ceres-equivalent LM controller plus the outer ICP bookkeeping (LidarSlam.cpp:119-148, 242-251).
 // Executed by ONE thread on an LDS copy of the controller state.
-__device__ __attribute__((noinline)) void lm_control(int slot, DevState* st, LmState& S, const LmSums& sums) {
+struct LmCtl {       // LDS copy of the DevState fields the controller reads (prefetched with the state: no global
+  double T[7];       // round trips inside the single-thread controller)
+  int32_t lm_max, outer_iter, max_outer, pad;
+};
+
+__device__ __attribute__((noinline)) void lm_control(int slot, DevState* st, LmState& S, const LmSums& sums, const LmCtl& ctl) {
   int more;
-  if (slot == 0) more = lm_begin(S, st->T, sums, st->lm_max, st->eval_pose);
+  if (slot == 0) more = lm_begin(S, ctl.T, sums, ctl.lm_max, st->eval_pose);
   else more = lm_feed(S, sums, st->eval_pose);
   st->lm_more = more;
   if (more) return;
   // solve finished: T_w_lidar <- optimised pose, iteration statistics, termination rule
-  double prev[7];
-  for (int i = 0; i < 7; ++i) { prev[i] = st->T[i]; st->T[i] = S.x[i]; }
-  const int o = st->outer_iter;
+  for (int i = 0; i < 7; ++i) st->T[i] = S.x[i];
+  const int o = ctl.outer_iter;
   DevIterStats& is = st->iters[o < 16 ? o : 15];
-  relative_motion(prev, S.x, is.translation_norm, is.rotation_norm);
+  relative_motion(ctl.T, S.x, is.translation_norm, is.rotation_norm);
   is.num_surf = (int32_t)S.count; is.lm_iterations = S.lm_iterations; is.num_successful = S.num_successful;
   is.termination = S.termination; is.initial_cost = S.initial_cost; is.final_cost = S.x_cost;
   for (int h = 0; h < 7; ++h) is.reject_hist[h] = (int32_t)sums.hist[h];
@@ -773,12 +777,21 @@ __device__ __attribute__((noinline)) void lm_control(int slot, DevState* st, LmS
   for (int i = 0; i < 7; ++i) is.pose_after[i] = S.x[i];
   st->outer_iter = o + 1;
   st->n_iterations = o + 1;
-  if (S.num_successful == 1 || o + 1 >= st->max_outer) {  // LidarSlam.cpp:141
+  if (S.num_successful == 1 || o + 1 >= ctl.max_outer) {  // LidarSlam.cpp:141
     st->reg_done = 1;
     const bool have = S.count > 0;
     for (int i = 0; i < 36; ++i) st->JtJ[i] = have ? S.H[i] : 0.0;
     for (int i = 0; i < 6; ++i) st->Jtr[i] = have ? S.g[i] : 0.0;
   }
+}
+
+// threads [first, first+10) fetch the controller's inputs
+__device__ __forceinline__ void load_ctl(LmCtl& ctl, const DevState* st, int tid, int first) {
+  const int k = tid - first;
+  if (k >= 0 && k < 7) ctl.T[k] = st->T[k];
+  else if (k == 7) ctl.lm_max = st->lm_max;
+  else if (k == 8) ctl.outer_iter = st->outer_iter;
+  else if (k == 9) ctl.max_outer = st->max_outer;
 }
 
 // cooperative copy of the controller state between global memory and LDS (sizeof(LmState) is a multiple of 8)
@@ -787,6 +800,8 @@ __device__ __forceinline__ void copy_words(double* dst, const double* src, int n
 }
 static_assert(sizeof(LmState) % 8 == 0 && sizeof(LmSums) % 8 == 0, "controller state must be double-aligned");
 
+constexpr int kPartStride = 256;      // partials[a][workgroup]: transposed so that the last workgroup reads it coalesced
+static_assert(kEvalBlocks <= kPartStride && kFitBlocksMax <= kPartStride && kNAcc <= kSumsStride, "partials table");
 constexpr int kRedStride = kNAcc + 1;  // 30 doubles per record in LDS
 
 // sum 256 records of kNAcc doubles held in red[256][kRedStride]: thread (a, c) adds rows 32c..32c+31 of value a in
@@ -825,10 +840,14 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
   __shared__ double part[8][32];
   __shared__ LmSums sh_sums;
   __shared__ LmState sh_S;
+  __shared__ LmCtl sh_ctl;
   __shared__ int32_t lh[16];
   __shared__ bool is_last;
   if (!eval_slot_active(st, slot)) return;
   const int tid = threadIdx.x;
+  const bool stamp = (ep.ablate & 128) != 0;
+  unsigned long long t_begin = 0, t_loop = 0, t_red = 0, t_ticket = 0, t_loaded = 0, t_sums = 0, t_lm = 0;
+  if (stamp) t_begin = wall_clock64();
   if (FIT) {
     if (tid < 16) lh[tid] = 0;
     __syncthreads();
@@ -905,6 +924,7 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
       for (int b = a; b < 6; ++b) acc[k++] += wj * J[b];
     }
   }
+  if (stamp) t_loop = wall_clock64();
   // workgroup reduction through LDS (transposed: no serial shuffle chains), fixed order
 #pragma unroll
   for (int a = 0; a < kNAcc; ++a) red[tid][a] = acc[a];
@@ -915,26 +935,44 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
   // storing wave before the arrival ticket; the consumer reads them with agent-scope relaxed atomic loads
   // (sc1: served by L2, never a stale L1 line).  [MI355X guide, G16 "8-B agent atomics both sides"]
   if (tid < kNAcc)
-    __hip_atomic_store(&partials[(size_t)blockIdx.x * kSumsStride + tid], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[(size_t)tid * kPartStride + blockIdx.x], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (FIT && tid >= 32 && tid < 48 && lh[tid - 32])  // histograms: device-scope atomics on 16 replicas, visible before the ticket
     __hip_atomic_fetch_add(&hist[(blockIdx.x % kHistReplicas) * kHistStride + (tid - 32)], lh[tid - 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (stamp) t_red = wall_clock64();
   if (tid == 0) {
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (t == gridDim.x - 1);
   }
   __syncthreads();
   if (!is_last) return;
-  // thread b fetches workgroup b's record (29 independent loads = one memory latency), same fixed tree again
+  if (stamp) t_ticket = wall_clock64();
+  // thread b fetches workgroup b's record from the transposed table partials[a][b] (coalesced: 4 lines per wave
+  // load).  The compiler serialises agent-scope atomic loads with a vmcnt(0) after each (6 us measured), so the 29
+  // sc1 loads are issued back to back, the controller state is fetched behind them, and ONE wait covers all.
+  {
+    double r[kNAcc];
+    const bool have = tid < gridDim.x;  // no divergence around the asm: a register copy before the wait would read garbage
+    const double* rec = partials + (have ? tid : 0);
 #pragma unroll
-  for (int a = 0; a < kNAcc; ++a) {
-    double v = 0.0;
-    for (uint32_t b = tid; b < gridDim.x; b += 256)  // fixed order: record tid, tid+256, ...
-      v += __hip_atomic_load(&partials[(size_t)b * kSumsStride + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    red[tid][a] = v;
+    for (int a = 0; a < kNAcc; ++a)
+      asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r[a]) : "v"(rec + a * kPartStride) : "memory");
+    if (fuse_lm) {
+      copy_words(reinterpret_cast<double*>(&sh_S), reinterpret_cast<const double*>(&st->S), (int)(sizeof(LmState) / 8), tid, 256);
+      load_ctl(sh_ctl, st, tid, 128);
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                   "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]),
+                   "+v"(r[17]), "+v"(r[18]), "+v"(r[19]), "+v"(r[20]), "+v"(r[21]), "+v"(r[22]), "+v"(r[23]), "+v"(r[24]),
+                   "+v"(r[25]), "+v"(r[26]), "+v"(r[27]), "+v"(r[28])
+                 :: "memory");
+#pragma unroll
+    for (int a = 0; a < kNAcc; ++a) red[tid][a] = have ? r[a] : 0.0;
   }
   __syncthreads();
+  if (stamp) t_loaded = wall_clock64();
   const double total = reduce_records(red, part, tid);
   double* o = reinterpret_cast<double*>(&sh_sums);
   if (tid < kNAcc) {
@@ -949,24 +987,31 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
   if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
   __syncthreads();
   copy_words(reinterpret_cast<double*>(out), o, (int)(sizeof(LmSums) / 8), tid, 256);
+  if (stamp) t_sums = wall_clock64();
   if (!fuse_lm) return;  // sharded map: the sums are all-reduced first, lm_step_kernel runs the controller
-  copy_words(reinterpret_cast<double*>(&sh_S), reinterpret_cast<const double*>(&st->S), (int)(sizeof(LmState) / 8), tid, 256);
-  __syncthreads();
-  if (tid == 0 && !(ep.ablate & 32)) lm_control(slot, st, sh_S, sh_sums);
+  if (tid == 0 && !(ep.ablate & 32)) lm_control(slot, st, sh_S, sh_sums, sh_ctl);  // sh_S / sh_ctl arrived with the partials
   __syncthreads();
   copy_words(reinterpret_cast<double*>(&st->S), reinterpret_cast<const double*>(&sh_S), (int)(sizeof(LmState) / 8), tid, 256);
+  if (stamp && tid == 0) {
+    t_lm = wall_clock64();
+    unsigned long long* d = st->dbg + (FIT ? 0 : 8);
+    d[0] = t_loop - t_begin; d[1] = t_red - t_loop; d[2] = t_ticket - t_red; d[3] = t_loaded - t_ticket; d[4] = t_sums - t_loaded;
+    d[5] = t_lm - t_sums; d[6] = t_lm - t_begin;
+  }
 }
 
 // controller as its own launch (used when the sums pass through the RCCL all-reduce between eval and control)
 __global__ __launch_bounds__(64) void lm_step_kernel(int slot, DevState* st, const LmSums* __restrict__ sums_in) {
   __shared__ LmSums sh_sums;
   __shared__ LmState sh_S;
+  __shared__ LmCtl sh_ctl;
   if (!eval_slot_active(st, slot)) return;
   const int tid = threadIdx.x;
   copy_words(reinterpret_cast<double*>(&sh_sums), reinterpret_cast<const double*>(sums_in), (int)(sizeof(LmSums) / 8), tid, 64);
   copy_words(reinterpret_cast<double*>(&sh_S), reinterpret_cast<const double*>(&st->S), (int)(sizeof(LmState) / 8), tid, 64);
+  load_ctl(sh_ctl, st, tid, 32);
   __syncthreads();
-  if (tid == 0) lm_control(slot, st, sh_S, sh_sums);
+  if (tid == 0) lm_control(slot, st, sh_S, sh_sums, sh_ctl);
   __syncthreads();
   copy_words(reinterpret_cast<double*>(&st->S), reinterpret_cast<const double*>(&sh_S), (int)(sizeof(LmState) / 8), tid, 64);
 }
