@@ -214,6 +214,9 @@ int so_icp_reset_timing(so_icp_ctx *ctx);
 int so_icp_synchronize(so_icp_ctx *ctx);
 /* profiling aid: wall-clock stamps (100 MHz ticks) of the phases of the last fit / evaluation kernels (SOICP_ABLATE=128) */
 int so_icp_debug_stamps(so_icp_ctx *ctx, uint64_t out[16]);
+/* profiling aid: per-workgroup records (16 words each, 2 sweeps x workgroups) of the k-NN kernel's phases (SOICP_ABLATE=128);
+ * call with out == NULL to query the size in 64-bit words */
+int so_icp_debug_knn_stamps(so_icp_ctx *ctx, uint64_t *out, size_t capacity_words, size_t *n_words);
 
 #ifdef __cplusplus
 }

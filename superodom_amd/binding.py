@@ -62,7 +62,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_map_size", "so_icp_map_clear", "so_icp_map_get_origin", "so_icp_knn_surf", "so_icp_register",
             "so_icp_register_dev", "so_icp_upload_scan", "so_icp_free_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
-            "so_icp_get_timing", "so_icp_reset_timing", "so_icp_synchronize", "so_icp_debug_stamps"]
+            "so_icp_get_timing", "so_icp_reset_timing", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps"]
 
 _lib = None
 
@@ -110,6 +110,7 @@ def load():
     L.so_icp_reset_timing.argtypes = [vp]
     L.so_icp_synchronize.argtypes = [vp]
     L.so_icp_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.so_icp_debug_knn_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -262,6 +263,16 @@ class LidarSlamGpu:
         out = np.zeros(16, np.uint64)
         self._check(self.L.so_icp_debug_stamps(self.h, _p(out, C.c_uint64)))
         return out
+
+    def debug_knn_stamps(self):
+        """(2, workgroups, 16) uint64 records of the k-NN kernel phases (SOICP_ABLATE=128), or None."""
+        n = C.c_size_t(0)
+        self._check(self.L.so_icp_debug_knn_stamps(self.h, None, 0, C.byref(n)))
+        if n.value == 0:
+            return None
+        out = np.zeros(n.value, np.uint64)
+        self._check(self.L.so_icp_debug_knn_stamps(self.h, _p(out, C.c_uint64), n.value, C.byref(n)))
+        return out.reshape(2, -1, 16)
 
     def synchronize(self):
         self._check(self.L.so_icp_synchronize(self.h))

@@ -96,6 +96,7 @@ struct so_icp_ctx {
   DevMapView view{};
   // scan / correspondence buffers
   DevBuf d_scan_own, d_keys0, d_keys1, d_vals0, d_vals1, d_chunks, d_sort_tmp, d_spx, d_spy, d_spz, d_nd, d_coeff, d_status, d_nbr5;
+  DevBuf d_kdbg;   // profiling only
   DevBuf d_small;  // hist[16] int32 | ticket | n_kept | fb_count | LmSums | partials
   int32_t* d_hist = nullptr; uint32_t* d_ticket = nullptr; uint32_t* d_nkept = nullptr; uint32_t* d_fbcount = nullptr;
   LmSums* d_sums = nullptr; double* d_partials = nullptr;
@@ -225,6 +226,7 @@ MatchParams match_params(float plane_res) {
   mp.max_point_dist = (double)plane_res / 2.0; // LidarSlam.cpp:820
   static const int ablate = std::getenv("SOICP_ABLATE") ? std::atoi(std::getenv("SOICP_ABLATE")) : 0;
   mp.ablate = ablate;
+  mp.kdbg = nullptr;
   return mp;
 }
 EvalParams eval_params(float plane_res, int variant) {
@@ -324,7 +326,12 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     launch_gather_scan(d_scan, c->d_vals1.as<uint32_t>(), c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
     span_end(c);
   }
-  const MatchParams mp = match_params(map_plane_res(c));
+  MatchParams mp = match_params(map_plane_res(c));
+  if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
+    HIP_TRY(c, c->d_kdbg.reserve((size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemsetAsync(c->d_kdbg.p, 0, (size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long), s));
+    mp.kdbg = c->d_kdbg.as<unsigned long long>();
+  }
   const EvalParams ep = eval_params(map_plane_res(c), c->cfg.tukey_variant);
   CorrBuffers corr{c->d_nd.as<double4>(), c->d_coeff.as<double>(), c->d_status.as<uint8_t>()};
   std::vector<size_t> knn_span_of_outer, eval_span_first;
@@ -442,7 +449,7 @@ so_icp_ctx::~so_icp_ctx() {
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1, &d_chunks,
                     &d_sort_tmp, &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
-                    &d_found, &d_fblist})
+                    &d_found, &d_fblist, &d_kdbg})
     b->release();
   for (DevBuf& b : resident_scans) b.release();
   d_state_buf.release();
@@ -790,6 +797,16 @@ int so_icp_debug_stamps(so_icp_ctx* c, uint64_t out[16]) {
   if (!c || !out) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);
   for (int i = 0; i < 16; ++i) out[i] = c->h_state->dbg[i];
+  return SO_ICP_OK;
+}
+int so_icp_debug_knn_stamps(so_icp_ctx* c, uint64_t* out, size_t capacity_words, size_t* n_words) {
+  if (!c || !n_words) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  const size_t have = c->d_kdbg.p ? (size_t)2 * kKnnBlocks * 4 * 16 : 0;
+  *n_words = have;
+  if (!out || !have) return SO_ICP_OK;
+  if (capacity_words < have) return fail(c, SO_ICP_E_INVALID, "so_icp_debug_knn_stamps: buffer too small");
+  HIP_TRY(c, hipMemcpy(out, c->d_kdbg.p, have * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return SO_ICP_OK;
 }
 int so_icp_synchronize(so_icp_ctx* c) { if (!c) return SO_ICP_E_INVALID; NEED_DEVICE(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return SO_ICP_OK; }

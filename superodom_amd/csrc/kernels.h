@@ -28,6 +28,7 @@ struct MatchParams {
   float sq_max_dist_f;    // 3 * planeRes evaluated in float (LidarSlam.cpp:526)
   double max_point_dist;  // planeRes / 2.0 (LidarSlam.cpp:820)
   int32_t ablate;         // profiling only (env SOICP_ABLATE): bit0 skip plane fit, bit1 skip scan, bit2 skip re-rank
+  unsigned long long* kdbg;  // profiling only (SOICP_ABLATE bit 7): 2 sweeps x 4*kKnnBlocks wavefront records of 16 stamps, else nullptr
 };
 
 struct EvalParams {
@@ -70,17 +71,20 @@ constexpr int kDevStateHostBytes = 64;  // pose_in + max_outer/lm_max
 
 constexpr int kHistReplicas = 16;    // histogram atomics are spread over replicas (contention), summed by eval_kernel
 constexpr int kHistStride = 32;      // ints per replica: reject[7] obs[9] stats[4]
-constexpr int kKnnBlocks = 1024;     // 4 workgroups per CU, waves grid-stride over the chunk list
+constexpr int kKnnBlocks = 2048;     // 8192 wavefronts, one per chunk (grid-stride beyond that); surplus wavefronts exit at once
 constexpr int kEvalBlocks = 256;     // one workgroup per CU
 constexpr int kFitBlocksMax = 256;   // plane-fit + first evaluation: one query per thread up to 131072 queries
 constexpr int kSumsStride = 48;      // doubles per partial record (45 used)
-// sort key = (cube slot << 18) | Morton(cell).  Two special "slots" sort behind every real cube:
+// sort key = (cube slot << 21) | Morton(half-cell: 7 bits per axis, low 3 bits = octant inside the map cell).  Two
+// special "slots" sort behind every real cube:
 //   n_slots     : processed query whose cube is outside the window / has no tree (NOT_ENOUGH_NEIGHBORS)
 //   n_slots + 1 : query not sampled / not owned by this rank (dropped)
-// so that only 18 + log2(n_slots + 2) key bits take part in the radix sort.
-inline uint32_t key_nocube(uint32_t n_slots) { return n_slots << 18; }
-inline uint32_t key_dropped(uint32_t n_slots) { return (n_slots + 1u) << 18; }
-inline int key_bits(uint32_t n_slots) { int b = 0; while ((1u << b) <= n_slots + 1u) ++b; return 18 + b; }
+// so that only 21 + log2(n_slots + 2) key bits take part in the sort.
+// (With more than 2046 occupied cubes the slot does not fit above 21 cell bits: the key falls back to whole cells.)
+inline int key_cell_bits(uint32_t n_slots) { return (n_slots + 2u <= 2048u) ? 21 : 18; }
+inline uint32_t key_nocube(uint32_t n_slots) { return n_slots << key_cell_bits(n_slots); }
+inline uint32_t key_dropped(uint32_t n_slots) { return (n_slots + 1u) << key_cell_bits(n_slots); }
+inline int key_bits(uint32_t n_slots) { int b = 0; while ((1u << b) <= n_slots + 1u) ++b; return key_cell_bits(n_slots) + b; }
 
 size_t sort_temp_bytes(size_t n);
 

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Pose pose = pose_from_array(st->pose_in);
-  const uint32_t kDropped = (map.n_slots + 1u) << 18, kNoCube = map.n_slots << 18;
+  const int cell_bits = (map.n_slots + 2u <= 2048u) ? 21 : 18;  // == key_cell_bits()
+  const uint32_t kDropped = (map.n_slots + 1u) << cell_bits, kNoCube = map.n_slots << cell_bits;
   uint32_t key = kDropped;
   bool process = true;
   if (max_surface_features > 0 && n > (uint32_t)max_surface_features) {  // calculateSamplingRate / shouldProcessPoint
@@ -110,7 +111,18 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
     } else {
       int owner = 0;
       if (world > 1) owner = (int)(brick_hash(w[0], w[1], w[2], c.cx / kBrickCells, c.cy / kBrickCells, c.cz / kBrickCells) % (uint32_t)world);
-      if (owner == rank) key = ((uint32_t)c.slot << 18) | morton3((uint32_t)c.cx, (uint32_t)c.cy, (uint32_t)c.cz);
+      if (owner == rank && cell_bits == 18) key = ((uint32_t)c.slot << 18) | morton3((uint32_t)c.cx, (uint32_t)c.cy, (uint32_t)c.cz);
+      else if (owner == rank) {
+        // Morton code of the HALF-cell: its three low bits are the octant of the cell the query sits in, so that a
+        // chunk (one key) is one octant and the near pass of the k-NN kernel needs a 2x2x2 block of cells
+        const double mn0 = w[0] * 50.0 - 25.0, mn1 = w[1] * 50.0 - 25.0, mn2 = w[2] * 50.0 - 25.0;
+        const int hmax = 2 * map.nc - 1;
+        int hx = (int)floor(((double)qx - mn0) * map.inv_cell * 2.0), hy = (int)floor(((double)qy - mn1) * map.inv_cell * 2.0);
+        int hz = (int)floor(((double)qz - mn2) * map.inv_cell * 2.0);
+        hx = min(max(hx, 2 * c.cx), min(2 * c.cx + 1, hmax)); hy = min(max(hy, 2 * c.cy), min(2 * c.cy + 1, hmax));
+        hz = min(max(hz, 2 * c.cz), min(2 * c.cz + 1, hmax));
+        key = ((uint32_t)c.slot << 21) | morton3((uint32_t)hx, (uint32_t)hy, (uint32_t)hz);
+      }
     }
   }
   keys[i] = key;
@@ -127,28 +139,43 @@ __global__ __launch_bounds__(256) void gather_scan_kernel(const float* __restric
   spx[j] = scan[3 * i]; spy[j] = scan[3 * i + 1]; spz[j] = scan[3 * i + 2];
 }
 
-// Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries of one 64-aligned block, handled by one
-// wavefront.  A block whose queries fall into at most kMaxKeysPerChunk different map cells is ONE chunk (its lanes'
-// gate balls are covered by one union block of cells); a block that scatters over more cells (sparse far-range
-// returns) is split at every key change, so that the cost of a wave stays ~ one candidate set whatever the query
-// density (no straggler waves).  Descriptor = start | (count-1) << 26.
-constexpr int kMaxKeysPerChunk = 1;  // measured: merging up to 8 cells per chunk halves the wave count and DOUBLES the kernel time (latency-bound)
+// Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries with the same key (one half-cell octant
+// of the map grid), handled by one wavefront.  Runs longer than 64 are cut every 64 queries counted from the START OF
+// THE RUN (not at 64-aligned positions of the array: alignment would cut almost every run once more and cost ~25%
+// more chunks).  A chunk's lanes therefore share one small union block of map cells and the cost of a wave is ~ one
+// candidate set whatever the query density.  Descriptor = start | (count-1) << 26.
+// (Measured before: merging several cells into one chunk halves the wave count and DOUBLES the kernel time.)
 __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t kKeyDropped,
                                                            uint32_t* __restrict__ chunk_start, DevState* __restrict__ st) {
   __shared__ uint32_t wave_cnt[16];
   __shared__ uint32_t block_base;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // one wavefront == one 64-aligned block of queries
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t key = i < n ? keys[i] : kKeyDropped;
   const bool kept = key != kKeyDropped;
   // keys are sorted and the dropped key is the largest value: the kept queries are the prefix [0, n_kept)
   if (kept && (i + 1 == n || keys[i + 1] == kKeyDropped)) st->n_kept = i + 1;
-  const unsigned long long kept_m = __ballot(kept);
-  const bool key_head = kept && ((lane == 0) || (key != keys[i - 1]));
-  const unsigned long long key_m = __ballot(key_head);
-  const bool merge = __popcll(key_m) <= kMaxKeysPerChunk;
-  const unsigned long long m = merge ? (kept_m & 1ull) : key_m;  // heads of this block
-  const bool head = (m >> lane) & 1ull;
+  bool head = false;
+  if (kept) {
+    if (i == 0 || keys[i - 1] != key) {
+      head = true;  // first query of a run
+    } else if (i >= 64 && keys[i - 64] == key) {  // inside a long run: every 64th query counted from the run's start
+      uint32_t lo = 0, hi = i - 64;               // lower_bound(key) in [0, i-64]
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+      head = ((i - lo) & 63u) == 0;
+    }
+  }
+  uint32_t count = 0;
+  if (head) {  // end of the chunk: 64 queries or the end of the run
+    if (i + 63 < n && keys[i + 63] == key) {
+      count = 64;
+    } else {
+      uint32_t lo = i + 1, hi = (i + 63 < n) ? i + 63 : n;  // first index in (i, hi] whose key differs (hi if none)
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] == key) lo = mid + 1; else hi = mid; }
+      count = lo - i;
+    }
+  }
+  const unsigned long long m = __ballot(head);
   if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -157,12 +184,8 @@ __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __res
     block_base = tot ? atomicAdd(&st->n_chunks, tot) : 0u;  // one atomic per 1024 queries
   }
   __syncthreads();
-  if (head) {
-    const unsigned long long later = (lane == 63) ? 0ull : (m >> (lane + 1));
-    const int end = later ? lane + 1 + (__ffsll((long long)later) - 1) : (int)__popcll(kept_m);  // next head or end of the kept lanes
-    const uint32_t count = (uint32_t)(end - lane);
+  if (head)
     chunk_start[block_base + wave_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i | ((count - 1u) << 26);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -429,7 +452,7 @@ __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const d
 constexpr int kKeyIdxBits = 11;                                  // a key addresses up to 2048 candidates of one group
 constexpr uint32_t kKeyIdxMask = (1u << kKeyIdxBits) - 1u;
 constexpr uint32_t kGroupMaxCand = 1u << kKeyIdxBits;
-constexpr uint32_t kTileCand = 512;                               // candidates staged in LDS at a time (8 KB per wavefront)
+constexpr uint32_t kTileCand = 256;                               // candidates staged in LDS at a time (5 KB per wavefront)
 
 // v_med3_i32 has no clang builtin; it is a pure VALU op (no memory, no wait states needed).
 __device__ __forceinline__ int32_t imed3(int32_t a, int32_t b, int32_t c) {
@@ -472,8 +495,12 @@ __device__ __forceinline__ float2v approx_d2_pair(float2v m2qx, float2v m2qy, fl
   v = __builtin_elementwise_fma(m2qz, cz, v);
   return v;
 }
-__device__ __forceinline__ int32_t make_key(float d2a, uint32_t jloc, uint32_t keep_mask) {
-  return (int32_t)((__float_as_uint(d2a) & keep_mask) | (jloc & ~keep_mask));  // v_bfi_b32
+// key = distance bits where keep_mask is set, the candidate's position elsewhere: ONE v_bfi_b32 with the (wave-uniform)
+// position in an SGPR.  (Left to itself the compiler emits v_and + v_add3 per key.)
+__device__ __forceinline__ int32_t make_key(float d2a, uint32_t jloc_uniform, uint32_t keep_mask) {
+  int32_t r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(keep_mask), "v"(d2a), "s"(jloc_uniform));
+  return r;
 }
 __device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz, float qq, float cx, float cy, float cz,
                                               float cc, uint32_t jloc, uint32_t keep_mask) {
@@ -485,7 +512,7 @@ __device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz
   return (int32_t)((__float_as_uint(v) & keep_mask) | (jloc & ~keep_mask));
 }
 
-__global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
+__global__ __launch_bounds__(256, 5) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
                                                         const float* __restrict__ spz,
                                                         const uint32_t* __restrict__ skeys,
                                                         const uint32_t* __restrict__ chunk_start,
@@ -496,6 +523,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
                                                         int32_t* __restrict__ hist) {
   __shared__ int32_t lh[20];
   __shared__ __attribute__((aligned(16))) float tiles[4][4][kTileCand + 4];  // per wavefront: x[], y[], z[], |c|^2 (block-local)
+  __shared__ uint32_t tcanon[4][kTileCand + 4];  // per wavefront: canonical map index of the staged candidate
   __shared__ uint32_t rowtab[4][2][36];  // per wavefront: exclusive candidate offsets [33] and first canonical index [32] of the block's x-runs
   if (st->reg_done) return;  // the registration already converged: this launch is a no-op
   const uint32_t n_kept = st->n_kept, n_chunks = st->n_chunks;
@@ -503,14 +531,32 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   if (threadIdx.x < 20) lh[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  float* tx = tiles[threadIdx.x >> 6][0];
-  float* ty = tiles[threadIdx.x >> 6][1];
-  float* tz = tiles[threadIdx.x >> 6][2];
-  float* tc = tiles[threadIdx.x >> 6][3];
-  uint32_t* rowoff = rowtab[threadIdx.x >> 6][0];
-  uint32_t* rowbeg = rowtab[threadIdx.x >> 6][1];
+  const int wv = threadIdx.x >> 6;
+  float* tx = tiles[wv][0];
+  float* ty = tiles[wv][1];
+  float* tz = tiles[wv][2];
+  float* tc = tiles[wv][3];
+  uint32_t* ti = tcanon[wv];
+  uint32_t* rowoff = rowtab[wv][0];
+  uint32_t* rowbeg = rowtab[wv][1];
+  const bool stamp = (mp.ablate & 128) != 0 && mp.kdbg != nullptr;
+  unsigned long long ts[4] = {0, 0, 0, 0}, acc[5] = {0, 0, 0, 0, 0}, t_first = 0, n_mine = 0, t_maxchunk = 0;
+  unsigned long long n_cand_total = 0, n_q_total = 0, n_groups_total = 0, n_pass2 = 0, max_info = 0, n_fb_total = 0;
+  if (stamp) t_first = wall_clock64();
+  const int nc = map.nc;
+  const float cell = (float)(1.0 / map.inv_cell);
+  const float inv_cellf = (float)map.inv_cell;
+  // Two search radii.  NEAR = half a cell: a query's near ball touches 2 cells per axis, and because a chunk is one
+  // HALF-cell octant of the sorted scan (scan_keys_kernel) its union block is 2x2x2 cells instead of 3x3x3 -- a third of
+  // the candidates.  A lane whose exact 5th distance lies inside the scanned block's coverage is finished (on a map
+  // voxelised at planeRes practically all of them); the others run the FULL pass with the reference's gate radius
+  // sqrt(3*planeRes) (LidarSlam.cpp:526,741), where "not found inside the gate ball" is a certain TOO_FAR.
+  const float r_gate = sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f;
+  const float r_near = 0.5f * cell;
+  const int first_pass = (r_near < 0.8f * r_gate && !(mp.ablate & 256)) ? 0 : 1;
   // one wavefront per chunk of the work list (grid-stride when the list is longer than the grid)
-  for (uint32_t chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk < n_chunks; chunk += gridDim.x * 4) {
+  for (uint32_t chunk = blockIdx.x * 4 + wv; chunk < n_chunks; chunk += gridDim.x * 4) {
+  if (stamp) ts[0] = wall_clock64();
   uint32_t j = 0;
   bool valid_q = false;
   {
@@ -538,35 +584,36 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   }
   const uint32_t ckey = (valid_q && c.slot >= 0) ? (((uint32_t)c.slot << 18) | ((uint32_t)c.cz << 12) | ((uint32_t)c.cy << 6) | (uint32_t)c.cx)
                                                  : 0xFFFFFFFFu;
+  Top5 top;
+  top.init();
+  bool resolved = (ckey == 0xFFFFFFFFu);  // no cube: nothing to search
+  bool too_far_certain = false, need_exact = false;
+  int n_groups = 0;
+  uint32_t n_scanned = 0;
+  if (stamp) { ts[1] = wall_clock64(); acc[0] += ts[1] - ts[0]; }
+  for (int pass = first_pass; pass < 2; ++pass) {
+  bool pending = !resolved && !need_exact;
+  unsigned long long todo = __ballot(pending);
+  if (mp.ablate & 2) todo = 0;
+  if (!todo) break;
+  if (stamp && pass == 1) ++n_pass2;
+  const float r_cover = pass == 0 ? r_near : r_gate;
+  // per-lane cell range that contains the lane's search ball (clamped to the cube: nothing of the cube lies beyond it)
+  const int lo_x = max(0, (int)floorf((ux - r_cover) * inv_cellf)), hi_x = min(nc - 1, (int)floorf((ux + r_cover) * inv_cellf));
+  const int lo_y = max(0, (int)floorf((uy - r_cover) * inv_cellf)), hi_y = min(nc - 1, (int)floorf((uy + r_cover) * inv_cellf));
+  const int lo_z = max(0, (int)floorf((uz - r_cover) * inv_cellf)), hi_z = min(nc - 1, (int)floorf((uz + r_cover) * inv_cellf));
   uint32_t g0 = 0xFFFFFFFFu, g1 = g0, g2 = g0, g3 = g0, g4 = g0, g5 = g0, g6 = g0, g7 = g0;  // canonical indices of the 8 survivors
   int32_t k8 = kKeyEmpty;      // 8th key of the lane's group pass
   float cov2 = 0.f;            // squared distance from the query to the boundary of the scanned block
-  bool need_exact = false;
-  const int nc = map.nc;
-  const float cell = (float)(1.0 / map.inv_cell);
-  const float inv_cellf = (float)map.inv_cell;
-  // radius every lane's block must cover: the reference's gate sqrt(3*planeRes) (LidarSlam.cpp:526,741) plus a margin
-  const float r_cover = sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f;
-  // per-lane cell range that contains the lane's gate ball (clamped to the cube: nothing of the cube lies beyond it)
-  int lo_x = 0, lo_y = 0, lo_z = 0, hi_x = 0, hi_y = 0, hi_z = 0;
-  if (ckey != 0xFFFFFFFFu) {
-    lo_x = max(0, (int)floorf((ux - r_cover) * inv_cellf)); hi_x = min(nc - 1, (int)floorf((ux + r_cover) * inv_cellf));
-    lo_y = max(0, (int)floorf((uy - r_cover) * inv_cellf)); hi_y = min(nc - 1, (int)floorf((uy + r_cover) * inv_cellf));
-    lo_z = max(0, (int)floorf((uz - r_cover) * inv_cellf)); hi_z = min(nc - 1, (int)floorf((uz + r_cover) * inv_cellf));
-  }
-  bool pending = (ckey != 0xFFFFFFFFu);
-  unsigned long long todo = __ballot(pending);
-  if (mp.ablate & 2) todo = 0;
-  int n_groups = 0;
-  uint32_t n_scanned = 0;
+  bool scanned = false;
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const uint32_t k = __builtin_amdgcn_readlane(ckey, leader);  // wave-uniform (SGPR) cell key of the leader
     const int gslot = (int)(k >> 18);
-    // ---- group = every pending lane of the leader's cube; block = union of the lanes' gate-ball cell ranges.
-    //      A chunk is spatially compact (its queries shared one cell when the scan was sorted and a rigid pose update
-    //      keeps them together), so the union is 3..4 cells per axis.  If it is too large for the tile the group
-    //      shrinks to the lanes of the leader's own cell (block <= 27 cells).
+    // ---- group = every pending lane of the leader's cube; block = union of the lanes' search-ball cell ranges.
+    //      A chunk is spatially compact (its queries shared one half-cell octant when the scan was sorted and a rigid
+    //      pose update keeps them together), so the union is 2..3 cells per axis (near pass) or 3..4 (full pass).  If
+    //      it is too large for the key's index field the group shrinks to the lanes around / of the leader's own cell.
     bool mine = pending && ((int)(ckey >> 18) == gslot);
     int bx0, bx1, by0, by1, bz0, bz1;
     uint32_t total = 0;
@@ -608,11 +655,17 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
     pending = pending && !mine;
     todo = __ballot(pending);
     ++n_groups;
-    if (total > kGroupMaxCand) {  // still too many candidates for the tile: exact per-lane scan for these lanes
+    if (total > kGroupMaxCand) {  // still too many candidates for the key's index field: exact per-lane scan for these lanes
       need_exact = need_exact || mine;
       continue;
     }
     n_scanned += total;
+    // The SIMDs are issue-bound with ~5 resident wavefronts each: a wavefront with an above-average scan (dense cells, or
+    // the full pass after a near pass) would finish long after its neighbours and set the kernel time.  Give it issue
+    // priority so that the stragglers are the light chunks instead.
+    if (n_scanned > 256u) __builtin_amdgcn_s_setprio(3);
+    else if (n_scanned > 128u) __builtin_amdgcn_s_setprio(2);
+    if (stamp) { ts[2] = wall_clock64(); acc[1] += ts[2] - ts[1]; }
     const int gz = (bz0 + bz1) >> 1, gy = (by0 + by1) >> 1, gx = (bx0 + bx1) >> 1;
     // block-local frame: origin at the centre of the block's middle cell (world coordinates, fp64)
     const double ox = ((int)__builtin_amdgcn_readlane(wcube0, leader) * 50.0 - 25.0) + ((double)gx + 0.5) * (double)cell;
@@ -635,16 +688,18 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
       if (!(mp.ablate & 16))
       for (uint32_t t = lane; t < cnt + 4; t += 64) {
         float lx = 0.f, ly = 0.f, lz = 0.f, lc = 3.0e38f;  // padding entries lose against every real candidate
+        uint32_t canon = 0xFFFFFFFFu;
         if (t < cnt) {
           const uint32_t e = base + t;
           int r = 0;
 #pragma unroll
           for (int step = 16; step >= 1; step >>= 1) r = (r + step < 32 && rowoff[r + step] <= e) ? r + step : r;
-          const float4 p = mpts[rowbeg[r] + (e - rowoff[r])];
+          canon = rowbeg[r] + (e - rowoff[r]);
+          const float4 p = mpts[canon];
           lx = (float)((double)p.x - ox); ly = (float)((double)p.y - oy); lz = (float)((double)p.z - oz);
           lc = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
         }
-        tx[t] = lx; ty[t] = ly; tz[t] = lz; tc[t] = lc;
+        tx[t] = lx; ty[t] = ly; tz[t] = lz; tc[t] = lc; ti[t] = canon;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -668,23 +723,80 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
         }
       }
     }
-    // survivors: position in the tile -> canonical index through the row table (all lanes compute, owners commit)
+    if (stamp) { ts[3] = wall_clock64(); acc[2] += ts[3] - ts[2]; }
+    // survivors: position in the enumeration -> canonical index (all lanes compute, owners commit).  A single-piece
+    // group still has its candidates' indices in LDS; a streamed one goes back through the row table.
     const int32_t ks[8] = {net.a0, net.a1, net.a2, net.a3, net.a4, net.a5, net.a6, net.a7};
     uint32_t gi[8];
+    if (total <= kTileCand) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const uint32_t jl = (uint32_t)ks[t] & kKeyIdxMask;
-      int r = 0;
+      for (int t = 0; t < 8; ++t) {
+        const uint32_t jl = (uint32_t)ks[t] & kKeyIdxMask;
+        gi[t] = (ks[t] == kKeyEmpty || jl >= total) ? 0xFFFFFFFFu : ti[jl < kTileCand ? jl : 0];
+      }
+    } else {
 #pragma unroll
-      for (int step = 16; step >= 1; step >>= 1) r = (r + step < 32 && rowoff[r + step] <= jl) ? r + step : r;
-      gi[t] = (ks[t] == kKeyEmpty || jl >= total) ? 0xFFFFFFFFu : rowbeg[r] + (jl - rowoff[r]);
+      for (int t = 0; t < 8; ++t) {
+        const uint32_t jl = (uint32_t)ks[t] & kKeyIdxMask;
+        int r = 0;
+#pragma unroll
+        for (int step = 16; step >= 1; step >>= 1) r = (r + step < 32 && rowoff[r + step] <= jl) ? r + step : r;
+        gi[t] = (ks[t] == kKeyEmpty || jl >= total) ? 0xFFFFFFFFu : rowbeg[r] + (jl - rowoff[r]);
+      }
     }
     if (mine) {
       g0 = gi[0]; g1 = gi[1]; g2 = gi[2]; g3 = gi[3]; g4 = gi[4]; g5 = gi[5]; g6 = gi[6]; g7 = gi[7];
       k8 = net.a7;
-      cov2 = 1e30f;  // the block contains the lane's whole gate ball by construction
+      scanned = true;
+      if (pass == 1) {
+        cov2 = 1e30f;  // the block contains the lane's whole gate ball by construction
+      } else {
+        // distance to the faces of the scanned block; a face on the cube's boundary has nothing of the cube behind it
+        float cv = 1e15f;
+        if (bx0 > 0) cv = fminf(cv, ux - (float)bx0 * cell);
+        if (bx1 < nc - 1) cv = fminf(cv, (float)(bx1 + 1) * cell - ux);
+        if (by0 > 0) cv = fminf(cv, uy - (float)by0 * cell);
+        if (by1 < nc - 1) cv = fminf(cv, (float)(by1 + 1) * cell - uy);
+        if (bz0 > 0) cv = fminf(cv, uz - (float)bz0 * cell);
+        if (bz1 < nc - 1) cv = fminf(cv, (float)(bz1 + 1) * cell - uz);
+        cv = fmaxf(cv - 1e-4f, 0.f);  // cell membership of a map point is decided in fp64 on its own coordinates: keep a margin
+        cov2 = cv * cv;
+      }
     }
+    if (stamp) { ts[1] = wall_clock64(); acc[3] += ts[1] - ts[3]; }
   }
+  // exact re-rank of the survivors + certification
+  if (scanned && !need_exact && !(mp.ablate & 4)) {
+    top.init();
+    const uint32_t gs[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (gs[t] != 0xFFFFFFFFu) {
+        const float4 p = mpts[gs[t]];
+        top.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, p.x, p.y, p.z)) << 32) | gs[t]);
+      }
+    }
+    // Every candidate that was NOT re-ranked has exact d2 >= R2:
+    //   in-block outsiders: approximate d2 >= L (8th key, index bits cleared), exact >= L - kApproxAbsErr;
+    //   points of the cube outside the block: farther than the block boundary (cov2).
+    double R2 = (double)cov2 * (1.0 - 1e-6);
+    if (k8 != kKeyEmpty) R2 = fmin(R2, (double)__uint_as_float((uint32_t)k8 & ~kKeyIdxMask) * (1.0 - 1e-6) - (double)kApproxAbsErr);
+    const bool have5 = top.b4 != ~0ull;
+    const double d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
+    if (have5 && d5 < R2) {
+      resolved = true;  // exact 5-NN
+    } else if (R2 > (double)mp.sq_max_dist_f) {
+      too_far_certain = true;  // the true 5th neighbour is >= R2 > gate (LidarSlam.cpp:741)
+      resolved = true;
+    } else if (pass == 1) {
+      need_exact = true;
+    }
+  } else if (scanned && (mp.ablate & 4)) {
+    resolved = true;
+  }
+  }  // pass loop
+  if (stamp) ts[2] = wall_clock64();
+  __builtin_amdgcn_s_setprio(0);
   if (lane == 0) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
 
   if (valid_q) {
@@ -692,36 +804,10 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
     if (c.slot < 0) {
       status = SO_MATCH_NOT_ENOUGH;  // LidarSlam.cpp:736-739
     } else {
-      Top5 top;
-      top.init();
-      bool too_far_certain = false;
-      if (!need_exact && !(mp.ablate & 4)) {
-        const uint32_t gs[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          if (gs[t] != 0xFFFFFFFFu) {
-            const float4 p = mpts[gs[t]];
-            top.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, p.x, p.y, p.z)) << 32) | gs[t]);
-          }
-        }
-        // Every candidate that was NOT re-ranked has exact d2 >= R2:
-        //   in-block outsiders: approximate d2 >= L (8th key, index bits cleared), exact >= L - kApproxAbsErr;
-        //   points of the cube outside the block: farther than the block boundary (cov2).
-        double R2 = (double)cov2 * (1.0 - 1e-6);
-        if (k8 != kKeyEmpty) R2 = fmin(R2, (double)__uint_as_float((uint32_t)k8 & ~kKeyIdxMask) * (1.0 - 1e-6) - (double)kApproxAbsErr);
-        const bool have5 = top.b4 != ~0ull;
-        const double d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
-        if (have5 && d5 < R2) {
-          // exact 5-NN
-        } else if (R2 > (double)mp.sq_max_dist_f) {
-          too_far_certain = true;  // the true 5th neighbour is >= R2 > gate (LidarSlam.cpp:741)
-        } else {
-          need_exact = true;
-        }
-      }
-      if (need_exact) {  // rare: exact per-lane scan of the 27 cells
+      if (need_exact || !resolved) {  // rare: exact per-lane scan of the 27 cells
         atomicAdd(&lh[17], 1);
         top.init();
+        too_far_certain = false;
         knn27(map, c, qx, qy, qz, top);
       }
       const float d2_4 = __uint_as_float((uint32_t)(top.b4 >> 32));
@@ -735,7 +821,21 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
     }
     corr.status[j] = (uint8_t)status;
   }
+  if (stamp) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[3] = wall_clock64(); acc[4] += ts[3] - ts[2]; ++n_mine;
+    const unsigned long long nfb = __popcll(__ballot(valid_q && c.slot >= 0 && (need_exact || !resolved)));
+    if (ts[3] - ts[0] > t_maxchunk) { t_maxchunk = ts[3] - ts[0]; max_info = ((unsigned long long)n_scanned << 32) | (nfb << 16) | (unsigned long long)n_groups; }
+    n_fb_total += nfb;
+    n_cand_total += n_scanned; n_groups_total += n_groups; n_q_total += __popcll(__ballot(valid_q));
+  }
   }  // chunk loop
+  if (stamp && lane == 0) {  // one record per wavefront, no atomics (they would perturb the measurement)
+    unsigned long long* d = mp.kdbg + ((size_t)(st->outer_iter & 1) * gridDim.x * 4 + blockIdx.x * 4 + wv) * 16;
+    d[0] = t_first; d[1] = wall_clock64();
+    for (int i = 0; i < 5; ++i) d[2 + i] = acc[i];
+    d[7] = n_mine; d[8] = t_maxchunk; d[9] = n_cand_total; d[10] = n_q_total; d[11] = n_groups_total; d[12] = n_pass2; d[13] = max_info; d[14] = n_fb_total;
+  }
   __syncthreads();
   if (threadIdx.x >= 16 && threadIdx.x < 20 && lh[threadIdx.x])  // kernel statistics only; the histograms are built by plane_eval_kernel
     atomicAdd(&hist[(blockIdx.x % kHistReplicas) * kHistStride + threadIdx.x], lh[threadIdx.x]);

@@ -39,6 +39,36 @@ def main():
             acc[0] += s[0:7]
             acc[1] += s[8:15]
     acc /= a.reps
+    rec = slam.debug_knn_stamps()
+    if rec is not None:
+        rec = rec.astype(np.float64)
+        for o in range(2):
+            r = rec[o]
+            r = r[r[:, 0] > 0]
+            if not len(r):
+                continue
+            t0 = r[:, 0].min()
+            busy = r[r[:, 7] > 0]
+            nch = busy[:, 7].sum()
+            ph = busy[:, 2:7].sum(axis=0) * 0.01 / nch
+            print(f"knn sweep {o}: span {(r[:, 1].max() - t0) * 0.01:.1f} us; wavefronts {len(r)} ({len(busy)} with work), chunks {int(nch)}, "
+                  f"queries {int(busy[:, 10].sum())}, candidates/chunk {busy[:, 9].sum() / nch:.0f}, groups/chunk {busy[:, 11].sum() / nch:.2f}, "
+                  f"chunks with a full pass {int(busy[:, 12].sum())}")
+            print("   per chunk (us): prologue %.2f  group_setup %.2f  stage+scan %.2f  merge+survivors %.2f  epilogue %.2f" % tuple(ph))
+            start = (busy[:, 0] - t0) * 0.01
+            life = (busy[:, 1] - busy[:, 0]) * 0.01
+            print("   workgroup start offset us: p50 %.1f p90 %.1f max %.1f | life us: p50 %.1f p90 %.1f max %.1f | max chunk %.1f us" % (
+                np.percentile(start, 50), np.percentile(start, 90), start.max(), np.percentile(life, 50), np.percentile(life, 90), life.max(),
+                busy[:, 8].max() * 0.01))
+            k = int(np.argmax(busy[:, 8]))
+            mi = int(busy[k, 13])
+            print("   slowest chunk: %.1f us, candidates scanned %d, groups(all passes) %d, fallback lanes %d | fallback lanes total %d" % (
+                busy[k, 8] * 0.01, mi >> 32, mi & 0xFFFF, (mi >> 16) & 0xFFFF, int(busy[:, 14].sum())))
+            order = np.argsort(-busy[:, 8])[:8]
+            print("   top chunks (us, cand, fb):", [(round(busy[q, 8] * 0.01, 1), int(busy[q, 13]) >> 32, (int(busy[q, 13]) >> 16) & 0xFFFF) for q in order])
+            idle = r[r[:, 7] == 0]
+            if len(idle):
+                print("   idle workgroups: start offset p50 %.1f max %.1f us" % (np.percentile((idle[:, 0] - t0) * 0.01, 50), ((idle[:, 0] - t0) * 0.01).max()))
     for k, row in zip(("fit ", "eval"), acc):
         print(k, {n: round(float(v), 2) for n, v in zip(NAMES, row)})
 
