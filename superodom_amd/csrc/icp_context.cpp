@@ -8,6 +8,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -101,7 +102,10 @@ struct so_icp_ctx {
   int32_t* d_hist = nullptr; uint32_t* d_ticket = nullptr; uint32_t* d_nkept = nullptr; uint32_t* d_fbcount = nullptr;
   LmSums* d_sums = nullptr; double* d_partials = nullptr;
   LmSums* h_sums = nullptr; uint32_t* h_u32 = nullptr;  // pinned
-  DevBuf d_state_buf; DevState* d_state = nullptr; DevState* h_state = nullptr;  // device-resident registration state + pinned mirror
+  DevBuf d_state_buf; DevState* d_state = nullptr; DevState* h_state = nullptr;  // device-resident registration state + the pinned mirror read last
+  DevState* h_ring[2] = {nullptr, nullptr}; hipEvent_t ev_outer[2] = {nullptr, nullptr};  // per-outer-iteration read-backs (double-buffered)
+  DevState* d_ring[2] = {nullptr, nullptr};  // device-side addresses of the pinned mirrors
+  bool direct_readback = true; unsigned long long reg_counter = 0;
   int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
   int sync_per_outer = 1;  // 1: read back reg_done after every outer iteration and stop enqueuing (eager mode)
   std::vector<DevBuf> resident_scans;  // so_icp_upload_scan
@@ -236,6 +240,8 @@ EvalParams eval_params(float plane_res, int variant) {
   ep.variant = variant;
   static const int ablate = std::getenv("SOICP_ABLATE") ? std::atoi(std::getenv("SOICP_ABLATE")) : 0;
   ep.ablate = ablate;
+  ep.hring[0] = ep.hring[1] = nullptr;
+  ep.seq_base = 0;
   return ep;
 }
 
@@ -310,11 +316,8 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   const int lm_max = std::min(c->cfg.lm_max_iterations > 0 ? c->cfg.lm_max_iterations : 4, 16);
   DevState* ds = c->d_state;
   hipStream_t s = c->stream;
-  // ---- host -> device: the guess and the loop bounds (one 64-byte copy), then the device-side prologue
-  std::memcpy(c->h_state->pose_in, pose_in, sizeof(T));
-  c->h_state->max_outer = max_outer; c->h_state->lm_max = lm_max;
-  HIP_TRY(c, hipMemcpyAsync(ds, c->h_state, kDevStateHostBytes, hipMemcpyHostToDevice, s));
-  launch_reg_begin(ds, s);
+  // ---- the guess and the loop bounds travel as kernel arguments of the device-side prologue (no H2D copy)
+  launch_reg_begin(ds, pose_in, max_outer, lm_max, c->d_hist, s);
   // ---- once per registration: sampling rule, spatial sort (locality survives the small pose updates), chunk list
   if (n) {
     span_begin(c, 2, (uint32_t)n);
@@ -332,12 +335,32 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     HIP_TRY(c, hipMemsetAsync(c->d_kdbg.p, 0, (size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long), s));
     mp.kdbg = c->d_kdbg.as<unsigned long long>();
   }
-  const EvalParams ep = eval_params(map_plane_res(c), c->cfg.tukey_variant);
+  EvalParams ep = eval_params(map_plane_res(c), c->cfg.tukey_variant);
+  // read-back: the controller's workgroup publishes the state block straight into the pinned mirrors (polled below);
+  // SOICP_READBACK=copy (or the controller ablated away) falls back to hipMemcpyAsync + event
+  const bool direct_rb = c->direct_readback && !(ep.ablate & 32);
+  const unsigned long long seq_base = (++c->reg_counter) << 8;
+  if (direct_rb) { ep.hring[0] = c->d_ring[0]; ep.hring[1] = c->d_ring[1]; ep.seq_base = seq_base; }
   CorrBuffers corr{c->d_nd.as<double4>(), c->d_coeff.as<double>(), c->d_status.as<uint8_t>()};
   std::vector<size_t> knn_span_of_outer, eval_span_first;
-  for (int it = 0; it < max_outer; ++it) {
-    // ResetDistanceParameters (LidarSlam.cpp:847-852); the 4 statistics slots of every replica are cleared too
-    HIP_TRY(c, hipMemsetAsync(c->d_hist, 0, kHistReplicas * kHistStride * sizeof(int32_t), s));
+  // One outer iteration = knn_plane -> [ eval(slot) -> (all-reduce -> lm_step) ] x (1 + lm_max) -> state read-back.
+  // (The histogram replicas are cleared by reg_begin and again by the controller when a solve ends:
+  //  ResetDistanceParameters, LidarSlam.cpp:847-852.)
+  // part A: correspondences + plane fit + first evaluation; part B: the remaining evaluations + read-back
+  auto enqueue_eval = [&](int slot) -> int {
+    span_begin(c, 1, (uint32_t)n);
+    const bool fuse_lm = (c->comm == nullptr);  // single device: the last workgroup of eval runs the LM controller itself
+    launch_eval(slot, fuse_lm, c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), corr, ds, ep, c->d_partials,
+                c->d_ticket, c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, s);
+    span_end(c);
+    if (!fuse_lm) {  // per-evaluation collective: 45 fp64 summed over the shards (xGMI, latency-bound), then the controller
+      const int nrc = c->rccl.AllReduce(c->d_sums, c->d_sums, sizeof(LmSums) / sizeof(double), kNcclDouble, kNcclSum, c->comm, s);
+      if (nrc != 0) return fail(c, SO_ICP_E_RCCL, std::string("ncclAllReduce: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(nrc) : "?"));
+      launch_lm_step(slot, ds, c->d_sums, c->d_hist, ep, s);
+    }
+    return SO_ICP_OK;
+  };
+  auto enqueue_outer_a = [&](int it) -> int {
     // processPlannerFeatures: every kept query in parallel (LidarSlam.cpp:323-344)
     knn_span_of_outer.push_back(c->spans.size());
     span_begin(c, 0, (uint32_t)n);
@@ -353,27 +376,63 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
                                 kHistReplicas * kHistStride * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     // setupOptimizationProblem + solveOptimizationProblem (LidarSlam.cpp:213-240): 1 + lm_max fused evaluations
     eval_span_first.push_back(c->spans.size());
-    for (int slot = 0; slot <= lm_max; ++slot) {
-      span_begin(c, 1, (uint32_t)n);
-      const bool fuse_lm = (c->comm == nullptr);  // single device: the last workgroup of eval runs the LM controller itself
-      launch_eval(slot, fuse_lm, c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), corr, ds, ep, c->d_partials,
-                  c->d_ticket, c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, s);
-      span_end(c);
-      if (!fuse_lm) {  // per-evaluation collective: 45 fp64 summed over the shards (xGMI, latency-bound), then the controller
-        const int nrc = c->rccl.AllReduce(c->d_sums, c->d_sums, sizeof(LmSums) / sizeof(double), kNcclDouble, kNcclSum, c->comm, s);
-        if (nrc != 0) return fail(c, SO_ICP_E_RCCL, std::string("ncclAllReduce: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(nrc) : "?"));
-        launch_lm_step(slot, ds, c->d_sums, s);
+    return enqueue_eval(0);
+  };
+  auto enqueue_outer_b = [&](int it) -> int {
+    for (int slot = 1; slot <= lm_max; ++slot) { const int r = enqueue_eval(slot); if (r) return r; }
+    // the whole state block (pose, per-iteration statistics, final normal equations) into this iteration's pinned mirror
+    if (!direct_rb) HIP_TRY(c, hipMemcpyAsync(c->h_ring[it & 1], ds, sizeof(DevState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));
+    return SO_ICP_OK;
+  };
+  // wait until outer iteration `it` has been reported
+  auto await_outer = [&](int it) -> int {
+    if (!direct_rb) { HIP_TRY(c, hipEventSynchronize(c->ev_outer[it & 1])); return SO_ICP_OK; }
+    volatile unsigned long long* seq = &c->h_ring[it & 1]->seq;
+    const unsigned long long want = seq_base | (unsigned long long)(it + 1);
+    for (unsigned spin = 1;; ++spin) {
+      if (*seq == want) break;
+      if ((spin & 0x3FFu) == 0 && hipEventQuery(c->ev_outer[it & 1]) == hipSuccess) {
+        // the iteration's launches have all completed: either it was a no-op (converged earlier: cannot happen for the
+        // iteration the host waits on) or a kernel failed -- report instead of spinning forever
+        if (*seq == want) break;
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (*seq == want) break;
+        return fail(c, SO_ICP_E_HIP, "registration state was not published by the device");
       }
     }
-    if (c->sync_per_outer || it == max_outer - 1) {
-      HIP_TRY(c, hipMemcpyAsync(&c->h_state->outer_iter, &ds->outer_iter, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-      HIP_TRY(c, hipStreamSynchronize(s));
-      if (c->h_state->reg_done) break;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return SO_ICP_OK;
+  };
+  // The host stays ahead of what it knows: part A of iteration it+1 (the two heavy kernels) is enqueued before the
+  // report of iteration it is awaited, so the device never idles on a host round trip; part B follows as soon as the
+  // report says "not converged" (the device is then busy with part A for tens of microseconds).  If iteration it did
+  // converge, the two speculated launches are no-ops (every kernel consults DevState::reg_done) that drain while the
+  // host post-processes.  SOICP_SYNC_PER_OUTER=0 enqueues all max_outer iterations up front instead.
+  int last = 0;
+  if (c->sync_per_outer) {
+    if ((rc = enqueue_outer_a(0)) || (rc = enqueue_outer_b(0))) return rc;
+    for (int it = 0;; ++it) {
+      if (it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
+      if ((rc = await_outer(it))) return rc;
+      last = it;
+      if (c->h_ring[it & 1]->reg_done || it + 1 >= max_outer) break;
+      if ((rc = enqueue_outer_b(it + 1))) return rc;
+    }
+  } else {
+    for (int it = 0; it < max_outer; ++it)
+      if ((rc = enqueue_outer_a(it)) || (rc = enqueue_outer_b(it))) return rc;
+    // all iterations were enqueued: the one that converges publishes last (later ones are no-ops), so wait for the stream
+    HIP_TRY(c, hipStreamSynchronize(s));
+    last = 0;
+    if (direct_rb) {
+      for (int it = 0; it < max_outer; ++it)
+        if (c->h_ring[it & 1]->seq == (seq_base | (unsigned long long)(it + 1))) last = it;
+    } else {
+      last = max_outer - 1;
     }
   }
-  // ---- device -> host: the whole state block (pose, per-iteration statistics, final normal equations)
-  HIP_TRY(c, hipMemcpyAsync(c->h_state, ds, sizeof(DevState), hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipStreamSynchronize(s));
+  c->h_state = c->h_ring[last & 1];
   const DevState& H = *c->h_state;
   std::memcpy(T, H.T, sizeof(T));  // LidarSlam.cpp:135-136
   st->n_iterations = H.n_iterations;
@@ -453,7 +512,8 @@ so_icp_ctx::~so_icp_ctx() {
     b->release();
   for (DevBuf& b : resident_scans) b.release();
   d_state_buf.release();
-  if (h_state) (void)hipHostFree(h_state);
+  for (DevState* h : h_ring) if (h) (void)hipHostFree(h);
+  for (hipEvent_t e : ev_outer) if (e) (void)hipEventDestroy(e);
   if (h_hist) (void)hipHostFree(h_hist);
   if (h_sums) (void)hipHostFree(h_sums);
   if (h_u32) (void)hipHostFree(h_u32);
@@ -532,11 +592,18 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if ((e = c->d_state_buf.reserve(sizeof(DevState))) != hipSuccess) return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
   if ((e = hipMemset(c->d_state_buf.p, 0, sizeof(DevState))) != hipSuccess) return bail(std::string("hipMemset: ") + hipGetErrorString(e));
   c->d_state = c->d_state_buf.as<DevState>();
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_state), sizeof(DevState))) != hipSuccess) return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
-  std::memset(c->h_state, 0, sizeof(DevState));
+  for (int i = 0; i < 2; ++i) {
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ring[i]), sizeof(DevState), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
+      return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    std::memset(c->h_ring[i], 0, sizeof(DevState));
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_ring[i]), c->h_ring[i], 0)) != hipSuccess) return bail(std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+    if ((e = hipEventCreateWithFlags(&c->ev_outer[i], hipEventDisableTiming)) != hipSuccess) return bail(std::string("hipEventCreate: ") + hipGetErrorString(e));
+  }
+  c->h_state = c->h_ring[0];
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_hist), (size_t)SO_ICP_MAX_OUTER * kHistReplicas * kHistStride * sizeof(int32_t))) != hipSuccess)
     return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if (const char* ev = std::getenv("SOICP_SYNC_PER_OUTER")) c->sync_per_outer = std::atoi(ev);
+  if (const char* ev = std::getenv("SOICP_READBACK")) c->direct_readback = std::string(ev) != "copy";
   const bool want_dmap = cfg->world_size == 1 && !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
   if (want_dmap) {
     c->dmap = std::make_unique<DeviceMap>(c->stream);

@@ -35,6 +35,11 @@ struct EvalParams {
   double a2;       // TukeyLoss a^2 with a = (double)sqrtf(3*planeRes)  (LidarSlam.cpp:271)
   int32_t variant; // 0: Ceres 2.0.0, 1: Ceres >= 2.1
   int32_t ablate;  // profiling only (env SOICP_ABLATE): bit5 skip the LM controller, bit6 skip the point loop
+  // Read-back without a copy engine round trip: when a solve ends, the controller's workgroup stores the whole state
+  // block into the pinned, host-coherent mirror hring[outer & 1] and then publishes seq_base | (outer + 1) in its seq
+  // word (system-scope release); the host polls that word.  hring[0] == nullptr disables it (host uses hipMemcpyAsync).
+  struct DevState* hring[2];
+  unsigned long long seq_base;
 };
 
 // per-correspondence record written by the k-NN + plane-fit kernel, read by the evaluation kernel
@@ -54,7 +59,7 @@ struct DevIterStats {
   double pose_after[7];
 };
 struct DevState {
-  // written by the host before each registration (one small H2D copy)
+  // the host's inputs (kernel arguments of reg_begin_kernel)
   double pose_in[7];
   int32_t max_outer, lm_max, pad0, pad1;
   // device-side control
@@ -66,8 +71,9 @@ struct DevState {
   double JtJ[36], Jtr[6];
   DevIterStats iters[16];
   unsigned long long dbg[16];  // profiling aid (SOICP_ABLATE bit 7): wall-clock stamps of the last evaluation's phases
+  unsigned long long seq;      // host mirror only: publication word (see EvalParams::hring), written last
 };
-constexpr int kDevStateHostBytes = 64;  // pose_in + max_outer/lm_max
+static_assert(sizeof(DevState) % 8 == 0, "DevState is copied in 8-byte words");
 
 constexpr int kHistReplicas = 16;    // histogram atomics are spread over replicas (contention), summed by eval_kernel
 constexpr int kHistStride = 32;      // ints per replica: reject[7] obs[9] stats[4]
@@ -88,7 +94,7 @@ inline int key_bits(uint32_t n_slots) { int b = 0; while ((1u << b) <= n_slots +
 
 size_t sort_temp_bytes(size_t n);
 
-void launch_reg_begin(DevState* st, hipStream_t s);
+void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* d_hist, hipStream_t s);
 void launch_scan_keys(const float* d_scan_xyz, uint32_t n, const DevState* st, const DevMapView& map,
                       int max_surface_features, int rank, int world, uint32_t* d_keys, uint32_t* d_vals, DevState* st_rw,
                       hipStream_t s);
@@ -106,7 +112,7 @@ void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, con
                  DevState* st, const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist,
                  LmSums* d_sums, const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper,
                  hipStream_t s);
-void launch_lm_step(int slot, DevState* st, const LmSums* d_sums, hipStream_t s);
+void launch_lm_step(int slot, DevState* st, const LmSums* d_sums, int32_t* d_hist, const EvalParams& ep, hipStream_t s);
 // Seam B
 void launch_knn_only(const float* d_q_xyz, uint32_t nq, int k, const DevMapView& map, float gate_d2, float* d_nbr,
                      float* d_d2, int32_t* d_idx, uint8_t* d_found, uint32_t* d_fallback_list,

@@ -15,6 +15,7 @@
 // Paths in citations are relative to /root/reference/super_odometry/{src,include/super_odometry}.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstring>  // rocprim/iterator/texture_cache_iterator.hpp calls ::memset on the host path
 
 #include <rocprim/rocprim.hpp>
@@ -76,12 +77,18 @@ __device__ __forceinline__ CellRef locate(const DevMapView& m, float qx, float q
 // ------------------------------------------------------------------------------------------------
 // scan preparation
 // ------------------------------------------------------------------------------------------------
-// registration prologue: pose <- host-provided guess, counters cleared (single thread)
-__global__ void reg_begin_kernel(DevState* st) {
-  for (int i = 0; i < 7; ++i) { st->T[i] = st->pose_in[i]; st->eval_pose[i] = st->pose_in[i]; }
-  st->outer_iter = 0; st->reg_done = 0; st->lm_more = 0; st->n_iterations = 0;
-  st->n_kept = 0; st->n_chunks = 0;
+// registration prologue: pose <- host-provided guess (kernel arguments: no H2D copy), counters and histograms cleared
+struct RegBeginArgs { double pose[7]; int32_t max_outer, lm_max; };
+__global__ __launch_bounds__(512) void reg_begin_kernel(DevState* st, RegBeginArgs a, int32_t* __restrict__ hist) {
+  hist[threadIdx.x] = 0;  // kHistReplicas * kHistStride ints
+  if (threadIdx.x < 7) { st->pose_in[threadIdx.x] = a.pose[threadIdx.x]; st->T[threadIdx.x] = a.pose[threadIdx.x]; st->eval_pose[threadIdx.x] = a.pose[threadIdx.x]; }
+  if (threadIdx.x == 0) {
+    st->max_outer = a.max_outer; st->lm_max = a.lm_max;
+    st->outer_iter = 0; st->reg_done = 0; st->lm_more = 0; st->n_iterations = 0;
+    st->n_kept = 0; st->n_chunks = 0;
+  }
 }
+static_assert(kHistReplicas * kHistStride == 512, "reg_begin_kernel clears one histogram word per thread");
 
 __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict__ scan, uint32_t n,
                                                         const DevState* __restrict__ st, DevMapView map,
@@ -859,12 +866,12 @@ struct LmCtl {       // LDS copy of the DevState fields the controller reads (pr
   int32_t lm_max, outer_iter, max_outer, pad;
 };
 
-__device__ __attribute__((noinline)) void lm_control(int slot, DevState* st, LmState& S, const LmSums& sums, const LmCtl& ctl) {
+__device__ __attribute__((noinline)) int lm_control(int slot, DevState* st, LmState& S, const LmSums& sums, const LmCtl& ctl) {
   int more;
   if (slot == 0) more = lm_begin(S, ctl.T, sums, ctl.lm_max, st->eval_pose);
   else more = lm_feed(S, sums, st->eval_pose);
   st->lm_more = more;
-  if (more) return;
+  if (more) return 1;
   // solve finished: T_w_lidar <- optimised pose, iteration statistics, termination rule
   for (int i = 0; i < 7; ++i) st->T[i] = S.x[i];
   const int o = ctl.outer_iter;
@@ -883,6 +890,7 @@ __device__ __attribute__((noinline)) void lm_control(int slot, DevState* st, LmS
     for (int i = 0; i < 36; ++i) st->JtJ[i] = have ? S.H[i] : 0.0;
     for (int i = 0; i < 6; ++i) st->Jtr[i] = have ? S.g[i] : 0.0;
   }
+  return 0;
 }
 
 // threads [first, first+10) fetch the controller's inputs
@@ -892,6 +900,22 @@ __device__ __forceinline__ void load_ctl(LmCtl& ctl, const DevState* st, int tid
   else if (k == 7) ctl.lm_max = st->lm_max;
   else if (k == 8) ctl.outer_iter = st->outer_iter;
   else if (k == 9) ctl.max_outer = st->max_outer;
+}
+
+// End of a solve: publish the state block to the host mirror (see EvalParams::hring).  Called by every thread of the
+// controller's workgroup after the controller's global stores; `outer` = index of the outer iteration that just ended.
+__device__ __forceinline__ void publish_state(const DevState* st, const EvalParams& ep, int outer, int tid, int nthreads) {
+  DevState* dst = ep.hring[outer & 1];
+  if (!dst) return;
+  __threadfence_block();  // the controller thread's stores to *st are visible to the workgroup
+  __syncthreads();
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(st);
+  unsigned long long* out = reinterpret_cast<unsigned long long*>(dst);
+  constexpr int kWords = (int)(offsetof(DevState, seq) / 8);
+  for (int i = tid; i < kWords; i += nthreads) out[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&dst->seq, ep.seq_base | (unsigned long long)(outer + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // cooperative copy of the controller state between global memory and LDS (sizeof(LmState) is a multiple of 8)
@@ -941,6 +965,7 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
   __shared__ LmSums sh_sums;
   __shared__ LmState sh_S;
   __shared__ LmCtl sh_ctl;
+  __shared__ int sh_more;
   __shared__ int32_t lh[16];
   __shared__ bool is_last;
   if (!eval_slot_active(st, slot)) return;
@@ -1089,9 +1114,12 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
   copy_words(reinterpret_cast<double*>(out), o, (int)(sizeof(LmSums) / 8), tid, 256);
   if (stamp) t_sums = wall_clock64();
   if (!fuse_lm) return;  // sharded map: the sums are all-reduced first, lm_step_kernel runs the controller
-  if (tid == 0 && !(ep.ablate & 32)) lm_control(slot, st, sh_S, sh_sums, sh_ctl);  // sh_S / sh_ctl arrived with the partials
+  if (tid == 0) sh_more = (ep.ablate & 32) ? 1 : lm_control(slot, st, sh_S, sh_sums, sh_ctl);  // sh_S / sh_ctl arrived with the partials
   __syncthreads();
+  // the solve is over: clear the histogram replicas for the next outer iteration (ResetDistanceParameters, LidarSlam.cpp:847-852)
+  if (!sh_more) { hist[tid] = 0; hist[256 + tid] = 0; }
   copy_words(reinterpret_cast<double*>(&st->S), reinterpret_cast<const double*>(&sh_S), (int)(sizeof(LmState) / 8), tid, 256);
+  if (!sh_more) publish_state(st, ep, sh_ctl.outer_iter, tid, 256);
   if (stamp && tid == 0) {
     t_lm = wall_clock64();
     unsigned long long* d = st->dbg + (FIT ? 0 : 8);
@@ -1101,19 +1129,24 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
 }
 
 // controller as its own launch (used when the sums pass through the RCCL all-reduce between eval and control)
-__global__ __launch_bounds__(64) void lm_step_kernel(int slot, DevState* st, const LmSums* __restrict__ sums_in) {
+__global__ __launch_bounds__(64) void lm_step_kernel(int slot, DevState* st, const LmSums* __restrict__ sums_in, int32_t* __restrict__ hist, EvalParams ep) {
   __shared__ LmSums sh_sums;
   __shared__ LmState sh_S;
   __shared__ LmCtl sh_ctl;
+  __shared__ int sh_more;
   if (!eval_slot_active(st, slot)) return;
   const int tid = threadIdx.x;
   copy_words(reinterpret_cast<double*>(&sh_sums), reinterpret_cast<const double*>(sums_in), (int)(sizeof(LmSums) / 8), tid, 64);
   copy_words(reinterpret_cast<double*>(&sh_S), reinterpret_cast<const double*>(&st->S), (int)(sizeof(LmState) / 8), tid, 64);
   load_ctl(sh_ctl, st, tid, 32);
   __syncthreads();
-  if (tid == 0) lm_control(slot, st, sh_S, sh_sums, sh_ctl);
+  if (tid == 0) sh_more = lm_control(slot, st, sh_S, sh_sums, sh_ctl);
   __syncthreads();
   copy_words(reinterpret_cast<double*>(&st->S), reinterpret_cast<const double*>(&sh_S), (int)(sizeof(LmState) / 8), tid, 64);
+  if (!sh_more) {
+    for (int i = tid; i < kHistReplicas * kHistStride; i += 64) hist[i] = 0;
+    publish_state(st, ep, sh_ctl.outer_iter, tid, 64);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1214,7 +1247,12 @@ size_t sort_temp_bytes(size_t n) {
   return bytes;
 }
 
-void launch_reg_begin(DevState* st, hipStream_t s) { hipLaunchKernelGGL(reg_begin_kernel, dim3(1), dim3(1), 0, s, st); }
+void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist, hipStream_t s) {
+  RegBeginArgs a;
+  for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
+  a.max_outer = max_outer; a.lm_max = lm_max;
+  hipLaunchKernelGGL(reg_begin_kernel, dim3(1), dim3(512), 0, s, st, a, hist);
+}
 void launch_scan_keys(const float* d_scan, uint32_t n, const DevState* st, const DevMapView& map, int max_sf, int rank,
                       int world, uint32_t* keys, uint32_t* vals, DevState* st_rw, hipStream_t s) {
   if (!n) return;
@@ -1255,8 +1293,8 @@ void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, con
                        partials, ticket, hist, sums, map.pts, nbr5, mp);
   }
 }
-void launch_lm_step(int slot, DevState* st, const LmSums* sums, hipStream_t s) {
-  hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, s, slot, st, sums);
+void launch_lm_step(int slot, DevState* st, const LmSums* sums, int32_t* hist, const EvalParams& ep, hipStream_t s) {
+  hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, s, slot, st, sums, hist, ep);
 }
 void launch_knn_only(const float* q, uint32_t nq, int k, const DevMapView& map, float gate_d2, float* nbr, float* d2,
                      int32_t* idx, uint8_t* found, uint32_t* fb_list, uint32_t* fb_count, hipStream_t s) {
