@@ -316,19 +316,18 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   const int lm_max = std::min(c->cfg.lm_max_iterations > 0 ? c->cfg.lm_max_iterations : 4, 16);
   DevState* ds = c->d_state;
   hipStream_t s = c->stream;
-  // ---- the guess and the loop bounds travel as kernel arguments of the device-side prologue (no H2D copy)
-  launch_reg_begin(ds, pose_in, max_outer, lm_max, c->d_hist, s);
-  // ---- once per registration: sampling rule, spatial sort (locality survives the small pose updates), chunk list
+  // ---- once per registration: prologue (the guess and the loop bounds travel as kernel arguments, no H2D copy),
+  //      sampling rule, spatial sort (locality survives the small pose updates), chunk list + gather
+  span_begin(c, 2, (uint32_t)n);
+  launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
+                   c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), s);
   if (n) {
-    span_begin(c, 2, (uint32_t)n);
-    launch_scan_keys(d_scan, (uint32_t)n, ds, c->view, c->cfg.max_surface_features, c->cfg.rank, c->cfg.world_size,
-                     c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), ds, s);
     launch_sort_pairs(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->d_keys0.as<uint32_t>(), c->d_keys1.as<uint32_t>(),
                       c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, key_bits(c->view.n_slots), s);
-    launch_chunk_heads(c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_chunks.as<uint32_t>(), ds, s);
-    launch_gather_scan(d_scan, c->d_vals1.as<uint32_t>(), c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
-    span_end(c);
+    launch_chunk_heads(c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_chunks.as<uint32_t>(), ds, d_scan,
+                       c->d_vals1.as<uint32_t>(), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
   }
+  span_end(c);
   MatchParams mp = match_params(map_plane_res(c));
   if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
     HIP_TRY(c, c->d_kdbg.reserve((size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long)));

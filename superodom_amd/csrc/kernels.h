@@ -95,15 +95,15 @@ inline int key_bits(uint32_t n_slots) { int b = 0; while ((1u << b) <= n_slots +
 size_t sort_temp_bytes(size_t n);
 
 void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* d_hist, hipStream_t s);
-void launch_scan_keys(const float* d_scan_xyz, uint32_t n, const DevState* st, const DevMapView& map,
-                      int max_surface_features, int rank, int world, uint32_t* d_keys, uint32_t* d_vals, DevState* st_rw,
-                      hipStream_t s);
+// scan_keys also runs the registration prologue (reg_begin) in its first workgroup; n == 0 launches the prologue alone
+void launch_scan_keys(const float* d_scan_xyz, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max,
+                      int32_t* d_hist, const DevMapView& map, int max_surface_features, int rank, int world, uint32_t* d_keys,
+                      uint32_t* d_vals, hipStream_t s);
 void launch_sort_pairs(void* d_temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                        const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, int end_bit, hipStream_t s);
+// chunk work list + gather of the scan into sorted SoA order
 void launch_chunk_heads(const uint32_t* d_keys_sorted, uint32_t n, uint32_t dropped_key, uint32_t* d_chunk_start, DevState* st,
-                        hipStream_t s);
-void launch_gather_scan(const float* d_scan_xyz, const uint32_t* d_perm, const uint32_t* d_keys_sorted, uint32_t n,
-                        uint32_t dropped_key, float* spx, float* spy, float* spz, hipStream_t s);
+                        const float* d_scan_xyz, const uint32_t* d_perm, float* spx, float* spy, float* spz, hipStream_t s);
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* d_keys_sorted,
                       const uint32_t* d_chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
                       CorrBuffers corr, uint32_t* d_nbr5 /*5 canonical indices per query*/,

@@ -79,24 +79,34 @@ __device__ __forceinline__ CellRef locate(const DevMapView& m, float qx, float q
 // ------------------------------------------------------------------------------------------------
 // registration prologue: pose <- host-provided guess (kernel arguments: no H2D copy), counters and histograms cleared
 struct RegBeginArgs { double pose[7]; int32_t max_outer, lm_max; };
-__global__ __launch_bounds__(512) void reg_begin_kernel(DevState* st, RegBeginArgs a, int32_t* __restrict__ hist) {
-  hist[threadIdx.x] = 0;  // kHistReplicas * kHistStride ints
-  if (threadIdx.x < 7) { st->pose_in[threadIdx.x] = a.pose[threadIdx.x]; st->T[threadIdx.x] = a.pose[threadIdx.x]; st->eval_pose[threadIdx.x] = a.pose[threadIdx.x]; }
-  if (threadIdx.x == 0) {
+__device__ __forceinline__ void reg_begin_state(DevState* st, const RegBeginArgs& a, int tid) {
+  if (tid < 7) { st->pose_in[tid] = a.pose[tid]; st->T[tid] = a.pose[tid]; st->eval_pose[tid] = a.pose[tid]; }
+  if (tid == 0) {
     st->max_outer = a.max_outer; st->lm_max = a.lm_max;
     st->outer_iter = 0; st->reg_done = 0; st->lm_more = 0; st->n_iterations = 0;
     st->n_kept = 0; st->n_chunks = 0;
   }
 }
+// stand-alone prologue (empty scan: scan_keys_kernel, which normally carries it, is not launched)
+__global__ __launch_bounds__(512) void reg_begin_kernel(DevState* st, RegBeginArgs a, int32_t* __restrict__ hist) {
+  hist[threadIdx.x] = 0;  // kHistReplicas * kHistStride ints
+  reg_begin_state(st, a, threadIdx.x);
+}
 static_assert(kHistReplicas * kHistStride == 512, "reg_begin_kernel clears one histogram word per thread");
 
+// (workgroup 0 also runs the registration prologue: one launch less per registration)
 __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict__ scan, uint32_t n,
-                                                        const DevState* __restrict__ st, DevMapView map,
+                                                        DevState* __restrict__ st, RegBeginArgs a, int32_t* __restrict__ hist,
+                                                        DevMapView map,
                                                         int max_surface_features, int rank, int world,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  if (blockIdx.x == 0) {
+    hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
+    reg_begin_state(st, a, threadIdx.x);
+  }
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Pose pose = pose_from_array(st->pose_in);
+  const Pose pose = pose_from_array(a.pose);
   const int cell_bits = (map.n_slots + 2u <= 2048u) ? 21 : 18;  // == key_cell_bits()
   const uint32_t kDropped = (map.n_slots + 1u) << cell_bits, kNoCube = map.n_slots << cell_bits;
   uint32_t key = kDropped;
@@ -136,30 +146,24 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   vals[i] = i;
 }
 
-__global__ __launch_bounds__(256) void gather_scan_kernel(const float* __restrict__ scan, const uint32_t* __restrict__ perm,
-                                                          const uint32_t* __restrict__ keys_sorted, uint32_t n,
-                                                          uint32_t dropped_key, float* __restrict__ spx,
-                                                          float* __restrict__ spy, float* __restrict__ spz) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n || keys_sorted[j] == dropped_key) return;
-  const uint32_t i = perm[j];
-  spx[j] = scan[3 * i]; spy[j] = scan[3 * i + 1]; spz[j] = scan[3 * i + 2];
-}
-
 // Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries with the same key (one half-cell octant
 // of the map grid), handled by one wavefront.  Runs longer than 64 are cut every 64 queries counted from the START OF
 // THE RUN (not at 64-aligned positions of the array: alignment would cut almost every run once more and cost ~25%
 // more chunks).  A chunk's lanes therefore share one small union block of map cells and the cost of a wave is ~ one
 // candidate set whatever the query density.  Descriptor = start | (count-1) << 26.
 // (Measured before: merging several cells into one chunk halves the wave count and DOUBLES the kernel time.)
+// The same launch gathers the scan into sorted SoA order (spx/spy/spz), which the k-NN and evaluation kernels read.
 __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t kKeyDropped,
-                                                           uint32_t* __restrict__ chunk_start, DevState* __restrict__ st) {
+                                                           uint32_t* __restrict__ chunk_start, DevState* __restrict__ st,
+                                                           const float* __restrict__ scan, const uint32_t* __restrict__ perm,
+                                                           float* __restrict__ spx, float* __restrict__ spy, float* __restrict__ spz) {
   __shared__ uint32_t wave_cnt[16];
   __shared__ uint32_t block_base;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t key = i < n ? keys[i] : kKeyDropped;
   const bool kept = key != kKeyDropped;
+  if (kept) { const uint32_t o = perm[i]; spx[i] = scan[3 * o]; spy[i] = scan[3 * o + 1]; spz[i] = scan[3 * o + 2]; }
   // keys are sorted and the dropped key is the largest value: the kept queries are the prefix [0, n_kept)
   if (kept && (i + 1 == n || keys[i + 1] == kKeyDropped)) st->n_kept = i + 1;
   bool head = false;
@@ -1253,11 +1257,13 @@ void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_
   a.max_outer = max_outer; a.lm_max = lm_max;
   hipLaunchKernelGGL(reg_begin_kernel, dim3(1), dim3(512), 0, s, st, a, hist);
 }
-void launch_scan_keys(const float* d_scan, uint32_t n, const DevState* st, const DevMapView& map, int max_sf, int rank,
-                      int world, uint32_t* keys, uint32_t* vals, DevState* st_rw, hipStream_t s) {
-  if (!n) return;
-  (void)st_rw;
-  hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, map, max_sf, rank, world, keys, vals);
+void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist,
+                      const DevMapView& map, int max_sf, int rank, int world, uint32_t* keys, uint32_t* vals, hipStream_t s) {
+  if (!n) { launch_reg_begin(st, pose, max_outer, lm_max, hist, s); return; }
+  RegBeginArgs a;
+  for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
+  a.max_outer = max_outer; a.lm_max = lm_max;
+  hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals);
 }
 void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo,
                        uint32_t n, int end_bit, hipStream_t s) {
@@ -1265,14 +1271,10 @@ void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t
   (void)rocprim::radix_sort_pairs<SortConfig>(tmp, tmp_bytes, ki, ko, vi, vo, (size_t)n, 0, (unsigned)end_bit, s);
 }
 void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n, uint32_t dropped_key, uint32_t* chunk_start, DevState* st,
-                        hipStream_t s) {
+                        const float* d_scan, const uint32_t* perm, float* spx, float* spy, float* spz, hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(chunk_heads_kernel, grid_for(n, 1024), dim3(1024), 0, s, keys_sorted, n, dropped_key, chunk_start, st);
-}
-void launch_gather_scan(const float* d_scan, const uint32_t* perm, const uint32_t* keys_sorted, uint32_t n, uint32_t dropped_key,
-                        float* spx, float* spy, float* spz, hipStream_t s) {
-  if (!n) return;
-  hipLaunchKernelGGL(gather_scan_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, perm, keys_sorted, n, dropped_key, spx, spy, spz);
+  hipLaunchKernelGGL(chunk_heads_kernel, grid_for(n, 1024), dim3(1024), 0, s, keys_sorted, n, dropped_key, chunk_start, st, d_scan, perm,
+                     spx, spy, spz);
 }
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* keys_sorted,
                       const uint32_t* chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,

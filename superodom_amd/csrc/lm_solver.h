@@ -125,12 +125,13 @@ SO_HD int lm_propose(LmState& S, double next_pose[7]) {
       }
     }
     double A[36], Hs[36], gs[6], y[6], step[6];
+    const double inv_radius = 1.0 / S.radius;  // one division for the six diagonal terms (the controller is a serial fp64 chain)
     SO_UNROLL
     for (int i = 0; i < 6; ++i) {
       gs[i] = S.g[i] * S.scale[i];
       SO_UNROLL
       for (int j = 0; j < 6; ++j) { Hs[6 * i + j] = S.H[6 * i + j] * S.scale[i] * S.scale[j]; A[6 * i + j] = Hs[6 * i + j]; }
-      A[7 * i] += S.diag[i] / S.radius;  // lm_diagonal^2
+      A[7 * i] += S.diag[i] * inv_radius;  // lm_diagonal^2 = diag / radius
     }
     const bool ok = lm_chol6(A, gs, y);  // (Hs + D^2) y = gs ; step = -y
     S.reuse_diagonal = 1;
