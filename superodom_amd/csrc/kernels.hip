@@ -443,22 +443,23 @@ __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const d
 }
 
 // ------------------------------------------------------------------------------------------------
-// knn_plane_kernel -- wave-cooperative, cell-grouped exact 5-NN (the plane fit follows in plane_eval_kernel).
+// knn_plane_kernel -- wave-cooperative exact 5-NN (the plane fit follows in eval_kernel<true>).
 //
-// A wavefront owns 64 consecutive queries of the spatially sorted scan.  Queries that fall into the
-// same map cell share the same 27-cell candidate set, so the wave walks its lanes cell-group by
-// cell-group (ballot / readlane) and, for one group at a time, streams the group's candidates as
-// WAVE-UNIFORM operands: the candidate index is uniform, hence every candidate is fetched once per wave
-// through the scalar cache (s_load_dwordx4) and broadcast to the 64 lanes for free; the VALU only
-// touches per-lane query data.  Selection is branch-free: a 32-bit key = (approximate fp32 d2 with its
-// low 10 mantissa bits replaced by the candidate's position in the group) runs through a sorted
-// 8-register network built from v_min_u32 / v_med3_u32 (no divergence, no 64-bit compares).
-// After all groups are done each lane re-ranks its 8 survivors with the reference's exact arithmetic
-// (octree.h:93-102, fp64 squares narrowed to float; ties by canonical index) and CERTIFIES the result:
-// every candidate outside the 8 has approximate d2 >= L (the 8th key with its index bits cleared), so if
-// the exact 5th distance is below L*(1-1e-6) no outsider can belong to the exact 5-NN.  A lane that
-// cannot be certified (8 near-equidistant candidates, or a group with more than 1024 candidates) falls
-// back to the per-lane exact scan knn27().  Result: bit-identical neighbour lists to the oracle.
+// A wavefront owns one CHUNK of the spatially sorted scan: <= 64 queries that shared one half-cell octant of the map
+// grid when the scan was sorted.  The wave forms the union of its lanes' search-ball cell ranges (ballot / readlane,
+// wave-uniform), stages that block's points once in an LDS tile (coalesced 16-byte loads, block-local coordinates,
+// canonical index alongside) and streams them back as WAVE-UNIFORM broadcast operands: four ds_read_b128 feed four
+// candidates to all 64 lanes; the VALU only touches per-lane query data.  Selection is branch-free: a 32-bit key =
+// (approximate fp32 d2 with its low 11 mantissa bits replaced by the candidate's position) runs through a sorted
+// 8-register network of v_med3_i32 (no divergence, no 64-bit compares).
+// Each lane then re-ranks its 8 survivors with the reference's exact arithmetic (octree.h:93-102, fp64 squares narrowed
+// to float; ties by canonical index) and CERTIFIES the result: every point that was not re-ranked has exact d2 >= R2,
+// R2 = min(squared distance to the faces of the scanned block, 8th key with its index bits cleared minus the fp32 error
+// bound); exact 5th distance below R2 => the list is the exact 5-NN.
+// Two passes: NEAR (radius = half a cell => 2x2x2 cells for an octant chunk, a third of the candidates) and, only for
+// lanes it could not certify, FULL (the reference's gate radius sqrt(3*planeRes), where "not inside the gate ball" is a
+// certain TOO_FAR).  What is still uncertified (8 near-equidistant candidates, or a block with more than 2048
+// candidates) falls back to the per-lane exact scan knn27().  Result: bit-identical neighbour lists to the oracle.
 // ------------------------------------------------------------------------------------------------
 constexpr int kKeyIdxBits = 11;                                  // a key addresses up to 2048 candidates of one group
 constexpr uint32_t kKeyIdxMask = (1u << kKeyIdxBits) - 1u;
@@ -523,7 +524,7 @@ __device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz
   return (int32_t)((__float_as_uint(v) & keep_mask) | (jloc & ~keep_mask));
 }
 
-__global__ __launch_bounds__(256, 5) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
+__global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
                                                         const float* __restrict__ spz,
                                                         const uint32_t* __restrict__ skeys,
                                                         const uint32_t* __restrict__ chunk_start,
