@@ -106,6 +106,7 @@ struct so_icp_ctx {
   DevState* h_ring[2] = {nullptr, nullptr}; hipEvent_t ev_outer[2] = {nullptr, nullptr};  // per-outer-iteration read-backs (double-buffered)
   DevState* d_ring[2] = {nullptr, nullptr};  // device-side addresses of the pinned mirrors
   bool direct_readback = true; unsigned long long reg_counter = 0;
+  bool persistent_solve = true;  // SOICP_PERSISTENT=0: one launch per evaluation
   int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
   int sync_per_outer = 1;  // 1: read back reg_done after every outer iteration and stop enqueuing (eager mode)
   std::vector<DevBuf> resident_scans;  // so_icp_upload_scan
@@ -346,6 +347,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   // (The histogram replicas are cleared by reg_begin and again by the controller when a solve ends:
   //  ResetDistanceParameters, LidarSlam.cpp:847-852.)
   // part A: correspondences + plane fit + first evaluation; part B: the remaining evaluations + read-back
+  const bool persistent = c->persistent_solve && c->comm == nullptr;
   auto enqueue_eval = [&](int slot) -> int {
     span_begin(c, 1, (uint32_t)n);
     const bool fuse_lm = (c->comm == nullptr);  // single device: the last workgroup of eval runs the LM controller itself
@@ -375,10 +377,18 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
                                 kHistReplicas * kHistStride * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     // setupOptimizationProblem + solveOptimizationProblem (LidarSlam.cpp:213-240): 1 + lm_max fused evaluations
     eval_span_first.push_back(c->spans.size());
+    if (persistent) {  // the whole solve in one launch (workgroups hand the next pose to each other on the device)
+      span_begin(c, 1, (uint32_t)n);
+      launch_solve(lm_max, c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), corr, ds, ep, c->d_partials, c->d_ticket,
+                   c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, s);
+      span_end(c);
+      return SO_ICP_OK;
+    }
     return enqueue_eval(0);
   };
   auto enqueue_outer_b = [&](int it) -> int {
-    for (int slot = 1; slot <= lm_max; ++slot) { const int r = enqueue_eval(slot); if (r) return r; }
+    if (!persistent)
+      for (int slot = 1; slot <= lm_max; ++slot) { const int r = enqueue_eval(slot); if (r) return r; }
     // the whole state block (pose, per-iteration statistics, final normal equations) into this iteration's pinned mirror
     if (!direct_rb) HIP_TRY(c, hipMemcpyAsync(c->h_ring[it & 1], ds, sizeof(DevState), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));
@@ -576,16 +586,17 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   c->map.set_resolution(cfg->line_res, cfg->plane_res);
   auto bail = [&](const std::string& m) { g_create_error = m; delete c; return (so_icp_ctx*)nullptr; };
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(std::string("hipStreamCreate: ") + hipGetErrorString(e));
-  const size_t small_bytes = 4096 + sizeof(LmSums) + 256 + (size_t)kFitBlocksMax * kSumsStride * sizeof(double);
+  const size_t partial_bytes = (size_t)kFitBlocksMax * kSumsStride * sizeof(double);
+  const size_t small_bytes = 4096 + sizeof(LmSums) + 256 + partial_bytes + 256 + kSyncBytes;
   if ((e = c->d_small.reserve(small_bytes)) != hipSuccess) return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
   if ((e = hipMemset(c->d_small.p, 0, c->d_small.cap)) != hipSuccess) return bail(std::string("hipMemset: ") + hipGetErrorString(e));
   char* base = c->d_small.as<char>();
   c->d_hist = reinterpret_cast<int32_t*>(base);            // kHistReplicas x kHistStride ints (2 KB)
-  c->d_ticket = reinterpret_cast<uint32_t*>(base + 2048);
   c->d_nkept = reinterpret_cast<uint32_t*>(base + 2112);   // Seam B scratch counters
   c->d_fbcount = reinterpret_cast<uint32_t*>(base + 2176);
   c->d_sums = reinterpret_cast<LmSums*>(base + 4096);
   c->d_partials = reinterpret_cast<double*>(base + 4096 + ((sizeof(LmSums) + 255) / 256) * 256);
+  c->d_ticket = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->d_partials) + ((partial_bytes + 255) / 256) * 256);  // arrival counters + hand-off record (kSyncBytes)
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), sizeof(LmSums))) != hipSuccess) return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_u32), 64)) != hipSuccess) return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if ((e = c->d_state_buf.reserve(sizeof(DevState))) != hipSuccess) return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -603,6 +614,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
     return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if (const char* ev = std::getenv("SOICP_SYNC_PER_OUTER")) c->sync_per_outer = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_READBACK")) c->direct_readback = std::string(ev) != "copy";
+  if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   const bool want_dmap = cfg->world_size == 1 && !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
   if (want_dmap) {
     c->dmap = std::make_unique<DeviceMap>(c->stream);

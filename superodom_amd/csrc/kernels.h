@@ -80,6 +80,10 @@ constexpr int kHistStride = 32;      // ints per replica: reject[7] obs[9] stats
 constexpr int kKnnBlocks = 2048;     // 8192 wavefronts, one per chunk (grid-stride beyond that); surplus wavefronts exit at once
 constexpr int kEvalBlocks = 256;     // one workgroup per CU
 constexpr int kFitBlocksMax = 256;   // plane-fit + first evaluation: one query per thread up to 131072 queries
+// cross-workgroup synchronisation block of the evaluation kernels: 16 arrival counters on their own 128-byte lines,
+// then the 8 x 16-byte hand-off record {value, epoch} of solve_kernel
+constexpr int kArriveCounters = 16, kArriveStrideWords = 32, kHandoffWordOffset = kArriveCounters * kArriveStrideWords;
+constexpr int kSyncBytes = kHandoffWordOffset * 4 + 8 * 16;
 constexpr int kSumsStride = 48;      // doubles per partial record (45 used)
 // sort key = (cube slot << 21) | Morton(half-cell: 7 bits per axis, low 3 bits = octant inside the map cell).  Two
 // special "slots" sort behind every real cube:
@@ -112,6 +116,10 @@ void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, con
                  DevState* st, const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist,
                  LmSums* d_sums, const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper,
                  hipStream_t s);
+// the whole solve (slot 0 .. lm_max) of one outer iteration in one launch (single device only)
+void launch_solve(int lm_max, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, DevState* st,
+                  const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist, LmSums* d_sums,
+                  const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper, hipStream_t s);
 void launch_lm_step(int slot, DevState* st, const LmSums* d_sums, int32_t* d_hist, const EvalParams& ep, hipStream_t s);
 // Seam B
 void launch_knn_only(const float* d_q_xyz, uint32_t nq, int k, const DevMapView& map, float gate_d2, float* d_nbr,

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>  // rocprim/iterator/texture_cache_iterator.hpp calls ::memset on the host path
 
 #include <rocprim/rocprim.hpp>
@@ -952,28 +953,49 @@ __device__ __forceinline__ double reduce_records(double (*red)[kRedStride], doub
   return tot;
 }
 
-// FIT = true : the slot-0 launch of an outer iteration.  Dense over the queries (full lane occupancy for the heavy
-//              fp64 work): plane fit from the five neighbour indices left by knn_plane_kernel (PCA gate, 5x3 LS
-//              plane, inlier gate, coefficient, observability labels -> correspondence record + histograms), then
-//              the first evaluation at the outer pose.
-// FIT = false: evaluations at the poses requested by the LM controller.
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+// 16-byte agent-scope (sc1) store / load: one access, bypassing the non-coherent per-XCD L2 state [MI355X guide, G16]
+__device__ __forceinline__ void store16_sc1(u4v* p, u4v v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u4v load16_sc1(const u4v* p) {
+  u4v v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+struct EvalShared {
+  double red[256][kRedStride];  // 60 KB: per-thread accumulators, later the workgroup records
+  double part[8][32];
+  LmSums sums;
+  LmState S;
+  LmCtl ctl;
+  double pose[7];
+  unsigned long long epoch;
+  int more;
+  int32_t lh[16];
+  bool is_last;
+};
+enum { kPassNotLast = 0, kPassMore = 1, kPassDone = 2, kPassSums = 3 };
+
+// One evaluation pass of this workgroup at `pose`: accumulate, reduce, hand off.  Returns kPassNotLast in every
+// workgroup but the one that arrives last; that one reduces the partial records and (fuse_lm) runs the LM controller:
+// kPassMore = another evaluation is requested at sh.S.cand, kPassDone = the solve ended (state published),
+// kPassSums = !fuse_lm, the sums are in `out` for the all-reduce.
 template <bool FIT>
-__global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const float* __restrict__ spx,
-                                                   const float* __restrict__ spy, const float* __restrict__ spz,
-                                                   CorrBuffers corr, DevState* __restrict__ st, EvalParams ep,
-                                                   double* __restrict__ partials, uint32_t* __restrict__ ticket,
-                                                   int32_t* __restrict__ hist, LmSums* __restrict__ out,
-                                                   const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
-                                                   MatchParams mp) {
-  __shared__ double red[256][kRedStride];  // 60 KB: per-thread accumulators, later the workgroup records
-  __shared__ double part[8][32];
-  __shared__ LmSums sh_sums;
-  __shared__ LmState sh_S;
-  __shared__ LmCtl sh_ctl;
-  __shared__ int sh_more;
-  __shared__ int32_t lh[16];
-  __shared__ bool is_last;
-  if (!eval_slot_active(st, slot)) return;
+__device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose, const float* __restrict__ spx,
+                                         const float* __restrict__ spy, const float* __restrict__ spz,
+                                         const CorrBuffers& corr, DevState* __restrict__ st, const EvalParams& ep,
+                                         double* __restrict__ partials, uint32_t* __restrict__ ticket,
+                                         int32_t* __restrict__ hist, LmSums* __restrict__ out,
+                                         const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
+                                         const MatchParams& mp, EvalShared& sh) {
+  double (*red)[kRedStride] = sh.red;
+  double (*part)[32] = sh.part;
+  LmSums& sh_sums = sh.sums;
+  LmState& sh_S = sh.S;
+  LmCtl& sh_ctl = sh.ctl;
+  int& sh_more = sh.more;
+  int32_t* lh = sh.lh;
+  bool& is_last = sh.is_last;
   const int tid = threadIdx.x;
   const bool stamp = (ep.ablate & 128) != 0;
   unsigned long long t_begin = 0, t_loop = 0, t_red = 0, t_ticket = 0, t_loaded = 0, t_sums = 0, t_lm = 0;
@@ -983,7 +1005,6 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
     __syncthreads();
   }
   const uint32_t n_kept = (ep.ablate & 64) ? 0u : st->n_kept;
-  const Pose pose = pose_from_array(slot == 0 ? st->T : st->eval_pose);
   double acc[kNAcc];
 #pragma unroll
   for (int a = 0; a < kNAcc; ++a) acc[a] = 0;
@@ -1071,12 +1092,26 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (stamp) t_red = wall_clock64();
-  if (tid == 0) {
-    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (t == gridDim.x - 1);
+  // Arrival: one fire-and-forget add per workgroup, spread over 16 counters on separate lines (256 adds on ONE word
+  // serialise for ~2 us); workgroup 0 is the designated finisher and polls the 16 counters with one 16-lane load.
+  if (tid == 0) __hip_atomic_fetch_add(&ticket[(blockIdx.x & (kArriveCounters - 1)) * kArriveStrideWords], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (blockIdx.x != 0) return kPassNotLast;
+  if (tid < 64) {
+    const uint32_t lanes = kArriveCounters;
+    const uint32_t expect = (tid < (int)lanes) ? (gridDim.x + lanes - 1u - (uint32_t)tid) / lanes : 0u;  // workgroups b with b % 16 == tid
+    const unsigned long long t0 = wall_clock64();
+    bool ok = false;
+    for (;;) {
+      uint32_t v = 0;
+      if (tid < (int)lanes) v = __hip_atomic_load(&ticket[tid * kArriveStrideWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__ballot(v != expect) == 0ull) { ok = true; break; }
+      if (wall_clock64() - t0 > 5000000ull) break;  // 50 ms: give up instead of hanging the device
+    }
+    if (tid < (int)lanes) __hip_atomic_store(&ticket[tid * kArriveStrideWords], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+    if (tid == 0) is_last = ok;
   }
   __syncthreads();
-  if (!is_last) return;
+  if (!is_last) return kPassNotLast;  // timeout: the solve is abandoned, the host reports the missing publication
   if (stamp) t_ticket = wall_clock64();
   // thread b fetches workgroup b's record from the transposed table partials[a][b] (coalesced: 4 lines per wave
   // load).  The compiler serialises agent-scope atomic loads with a vmcnt(0) after each (6 us measured), so the 29
@@ -1088,8 +1123,9 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
 #pragma unroll
     for (int a = 0; a < kNAcc; ++a)
       asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r[a]) : "v"(rec + a * kPartStride) : "memory");
-    if (fuse_lm) {
-      copy_words(reinterpret_cast<double*>(&sh_S), reinterpret_cast<const double*>(&st->S), (int)(sizeof(LmState) / 8), tid, 256);
+    if (fuse_lm) {  // the controller state may have been written by another workgroup of this very launch: coherent loads
+      if (tid < (int)(sizeof(LmState) / 8))
+        reinterpret_cast<double*>(&sh_S)[tid] = __hip_atomic_load(reinterpret_cast<const double*>(&st->S) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       load_ctl(sh_ctl, st, tid, 128);
     }
     asm volatile("s_waitcnt vmcnt(0)"
@@ -1114,22 +1150,108 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
       h += __hip_atomic_load(&hist[r * kHistStride + (tid - 32)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     o[kNAcc + (tid - 32)] = (double)h;
   }
-  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
   __syncthreads();
   copy_words(reinterpret_cast<double*>(out), o, (int)(sizeof(LmSums) / 8), tid, 256);
   if (stamp) t_sums = wall_clock64();
-  if (!fuse_lm) return;  // sharded map: the sums are all-reduced first, lm_step_kernel runs the controller
+  if (!fuse_lm) return kPassSums;  // sharded map: the sums are all-reduced first, lm_step_kernel runs the controller
   if (tid == 0) sh_more = (ep.ablate & 32) ? 1 : lm_control(slot, st, sh_S, sh_sums, sh_ctl);  // sh_S / sh_ctl arrived with the partials
   __syncthreads();
   // the solve is over: clear the histogram replicas for the next outer iteration (ResetDistanceParameters, LidarSlam.cpp:847-852)
   if (!sh_more) { hist[tid] = 0; hist[256 + tid] = 0; }
-  copy_words(reinterpret_cast<double*>(&st->S), reinterpret_cast<const double*>(&sh_S), (int)(sizeof(LmState) / 8), tid, 256);
+  if (tid < (int)(sizeof(LmState) / 8))
+    __hip_atomic_store(reinterpret_cast<double*>(&st->S) + tid, reinterpret_cast<const double*>(&sh_S)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!sh_more) publish_state(st, ep, sh_ctl.outer_iter, tid, 256);
   if (stamp && tid == 0) {
     t_lm = wall_clock64();
     unsigned long long* d = st->dbg + (FIT ? 0 : 8);
     d[0] = t_loop - t_begin; d[1] = t_red - t_loop; d[2] = t_ticket - t_red; d[3] = t_loaded - t_ticket; d[4] = t_sums - t_loaded;
     d[5] = t_lm - t_sums; d[6] = t_lm - t_begin;
+  }
+  return sh_more ? kPassMore : kPassDone;
+}
+
+static_assert(sizeof(LmState) / 8 <= 256, "controller state is moved one word per thread");
+// FIT = true : the slot-0 launch of an outer iteration.  Dense over the queries (full lane occupancy for the heavy
+//              fp64 work): plane fit from the five neighbour indices left by knn_plane_kernel (PCA gate, 5x3 LS
+//              plane, inlier gate, coefficient, observability labels -> correspondence record + histograms), then
+//              the first evaluation at the outer pose.
+// FIT = false: evaluations at the poses requested by the LM controller.
+template <bool FIT>
+__global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const float* __restrict__ spx,
+                                                   const float* __restrict__ spy, const float* __restrict__ spz,
+                                                   CorrBuffers corr, DevState* __restrict__ st, EvalParams ep,
+                                                   double* __restrict__ partials, uint32_t* __restrict__ ticket,
+                                                   int32_t* __restrict__ hist, LmSums* __restrict__ out,
+                                                   const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
+                                                   MatchParams mp) {
+  __shared__ EvalShared sh;
+  if (!eval_slot_active(st, slot)) return;
+  const Pose pose = pose_from_array(slot == 0 ? st->T : st->eval_pose);
+  (void)eval_pass<FIT>(slot, fuse_lm, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh);
+}
+
+// The whole solve of one outer iteration in ONE launch (single device): slot 0 = plane fit + first evaluation, then up
+// to lm_max evaluations at the poses the controller requests.  Between two evaluations the workgroups wait for the
+// controller's workgroup to publish {next pose, more?} and then an epoch word, all with agent-scope (sc1) stores / loads
+// -- the XCDs' L2s are not coherent with each other, so nothing that crosses workgroups inside this launch goes
+// through plain loads.  Requires every workgroup to be resident (<= 256 workgroups of 256 threads, 60 KB LDS each: two
+// fit on a CU); a wait that exceeds 50 ms gives up (the host then reports the missing publication).
+__global__ __launch_bounds__(256) void solve_kernel(int lm_max, const float* __restrict__ spx, const float* __restrict__ spy,
+                                                    const float* __restrict__ spz, CorrBuffers corr, DevState* __restrict__ st,
+                                                    EvalParams ep, double* __restrict__ partials, uint32_t* __restrict__ ticket,
+                                                    int32_t* __restrict__ hist, LmSums* __restrict__ out,
+                                                    const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
+                                                    MatchParams mp) {
+  __shared__ EvalShared sh;
+  if (st->reg_done) return;
+  const int tid = threadIdx.x;
+  // hand-off record: 8 chunks of 16 bytes {value, epoch}, each written / read with ONE sc1 dwordx4 access (atomic as a
+  // unit), so a reader that sees the expected epoch in a chunk has that chunk's value: no second round trip, no
+  // publisher-side wait between data and flag.  Chunks 0..6 = next pose, chunk 7 = "another evaluation follows".
+  u4v* hand = reinterpret_cast<u4v*>(ticket + kHandoffWordOffset);
+  // epoch before this launch: read before this workgroup adds its first arrival, i.e. before the controller of this
+  // launch can have advanced it
+  if (tid == 0) { const u4v v = load16_sc1(hand + 7); sh.epoch = ((unsigned long long)v.w << 32) | v.z; }
+  __syncthreads();
+  const unsigned long long e0 = sh.epoch;
+  Pose pose = pose_from_array(st->T);
+  int code = eval_pass<true>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh);
+  for (int slot = 1; slot <= lm_max; ++slot) {
+    __syncthreads();
+    const unsigned long long want = e0 + (unsigned long long)slot;
+    if (code == kPassMore || code == kPassDone) {  // this workgroup ran the controller: publish {request, more?}
+      const int more = (code == kPassMore) ? 1 : 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // counters re-armed, controller state stored
+      if (tid < 8) {
+        const unsigned long long val = (tid < 7) ? (unsigned long long)__double_as_longlong(sh.S.cand[tid]) : (unsigned long long)more;
+        const u4v v = {(unsigned int)val, (unsigned int)(val >> 32), (unsigned int)want, (unsigned int)(want >> 32)};
+        store16_sc1(hand + tid, v);
+      }
+      if (tid < 7) sh.pose[tid] = sh.S.cand[tid];
+      if (tid == 0) sh.more = more;
+    } else if (tid < 64) {  // wait for the controller's workgroup: lanes 0..7 poll one chunk each
+      bool done = tid >= 8;
+      unsigned long long val = 0;
+      const unsigned long long t0 = wall_clock64();
+      bool ok = true;
+      for (;;) {
+        if (!done) {
+          const u4v v = load16_sc1(hand + tid);
+          const unsigned long long tag = ((unsigned long long)v.w << 32) | v.z;
+          if (tag - e0 >= (unsigned long long)slot && tag - e0 <= 64ull) { done = true; val = ((unsigned long long)v.y << 32) | v.x; }
+        }
+        if (__ballot(!done) == 0ull) break;
+        if (wall_clock64() - t0 > 5000000ull) { ok = false; break; }  // 50 ms at 100 MHz: give up instead of hanging the device
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (tid < 7) sh.pose[tid] = __longlong_as_double((long long)val);
+      if (tid == 7) sh.more = ok ? (int)val : -1;
+    }
+    __syncthreads();
+    if (sh.more != 1) return;  // solve ended (or timeout)
+    pose = pose_from_array(sh.pose);
+    __syncthreads();
+    code = eval_pass<false>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh);
   }
 }
 
@@ -1242,13 +1364,36 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
-// rocPRIM picks block sort + merge passes for ~131 k pairs (measured 65 us per registration); forcing Onesweep
-// (merge_sort_limit = 0) was measured SLOWER (120 us: look-back state memsets + 8-bit passes), so the default stays.
+// rocPRIM picks block sort + merge passes for ~131 k pairs (measured 58 us per registration); forcing Onesweep
+// (merge_sort_limit = 0) was measured SLOWER (120 us: look-back state memsets + 8-bit passes).
+// SOICP_SORT_CFG selects a merge-sort tuning (experiment switch).
 using SortConfig = rocprim::default_config;
+using MergeCfg1 = rocprim::merge_sort_config<512, 256, 16, 128, 128, 4, 0>;
+using MergeCfg2 = rocprim::merge_sort_config<512, 512, 8, 128, 256, 8, 0>;
+using MergeCfg3 = rocprim::merge_sort_config<256, 256, 8, 128, 128, 8, 0>;
+using MergeCfg4 = rocprim::merge_sort_config<512, 256, 16, 128, 128, 4, (1u << 30)>;
+using MergeCfg5 = rocprim::merge_sort_config<512, 256, 8, 128, 128, 4, (1u << 30)>;
+static int sort_cfg() { static const int v = std::getenv("SOICP_SORT_CFG") ? std::atoi(std::getenv("SOICP_SORT_CFG")) : 0; return v; }
+template <class Cfg>
+static hipError_t merge_pairs(void* tmp, size_t& bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo, size_t n,
+                              hipStream_t s) {
+  return rocprim::merge_sort<Cfg>(tmp, bytes, ki, ko, vi, vo, n, rocprim::less<uint32_t>(), s);
+}
+static hipError_t sort_dispatch(void* tmp, size_t& bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo, size_t n,
+                                unsigned end_bit, hipStream_t s) {
+  switch (sort_cfg()) {
+    case 1: return merge_pairs<MergeCfg1>(tmp, bytes, ki, ko, vi, vo, n, s);
+    case 2: return merge_pairs<MergeCfg2>(tmp, bytes, ki, ko, vi, vo, n, s);
+    case 3: return merge_pairs<MergeCfg3>(tmp, bytes, ki, ko, vi, vo, n, s);
+    case 4: return merge_pairs<MergeCfg4>(tmp, bytes, ki, ko, vi, vo, n, s);
+    case 5: return merge_pairs<MergeCfg5>(tmp, bytes, ki, ko, vi, vo, n, s);
+    default: return rocprim::radix_sort_pairs<SortConfig>(tmp, bytes, ki, ko, vi, vo, n, 0, end_bit, s);
+  }
+}
 size_t sort_temp_bytes(size_t n) {
   size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                              (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
+  (void)sort_dispatch(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 32,
+                      (hipStream_t)0);
   return bytes;
 }
 
@@ -1269,7 +1414,7 @@ void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const doubl
 void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo,
                        uint32_t n, int end_bit, hipStream_t s) {
   if (!n) return;
-  (void)rocprim::radix_sort_pairs<SortConfig>(tmp, tmp_bytes, ki, ko, vi, vo, (size_t)n, 0, (unsigned)end_bit, s);
+  (void)sort_dispatch(tmp, tmp_bytes, ki, ko, vi, vo, (size_t)n, (unsigned)end_bit, s);
 }
 void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n, uint32_t dropped_key, uint32_t* chunk_start, DevState* st,
                         const float* d_scan, const uint32_t* perm, float* spx, float* spy, float* spz, hipStream_t s) {
@@ -1295,6 +1440,14 @@ void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, con
     hipLaunchKernelGGL(eval_kernel<false>, dim3(kEvalBlocks), dim3(256), 0, s, slot, fuse_lm ? 1 : 0, spx, spy, spz, corr, st, ep,
                        partials, ticket, hist, sums, map.pts, nbr5, mp);
   }
+}
+void launch_solve(int lm_max, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, DevState* st,
+                  const EvalParams& ep, double* partials, uint32_t* ticket, int32_t* hist, LmSums* sums, const DevMapView& map,
+                  const uint32_t* nbr5, const MatchParams& mp, uint32_t n_upper, hipStream_t s) {
+  uint32_t blocks = (n_upper + 255u) / 256u;
+  blocks = blocks < 1 ? 1 : (blocks > (uint32_t)kFitBlocksMax ? (uint32_t)kFitBlocksMax : blocks);
+  hipLaunchKernelGGL(solve_kernel, dim3(blocks), dim3(256), 0, s, lm_max, spx, spy, spz, corr, st, ep, partials, ticket, hist, sums,
+                     map.pts, nbr5, mp);
 }
 void launch_lm_step(int slot, DevState* st, const LmSums* sums, int32_t* hist, const EvalParams& ep, hipStream_t s) {
   hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, s, slot, st, sums, hist, ep);
