@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--max-outer", type=int, default=5, help="LocalizationICPMaxIter (5 = config of record)")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every kernel (adds bubbles)")
     ap.add_argument("--cpu-sample", type=int, default=1, help="registrations timed for the CPU baseline")
+    ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the k-NN launches (no roofline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,7 +64,7 @@ def main():
     max_outer, lm_iters = args.max_outer, 4
     slam = binding.LidarSlamGpu(device_id=local_rank, rank=rank, world_size=world, plane_res=sc.plane_res,
                                 line_res=sc.plane_res / 2, max_iterations=max_outer, lm_max_iterations=lm_iters,
-                                max_surface_features=-1, time_kernels=2 if args.time_all_kernels else 1)
+                                max_surface_features=-1, time_kernels=2 if args.time_all_kernels else (0 if args.no_kernel_events else 1))
     if world > 1:
         uid = [binding.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -164,9 +165,13 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "knn_plane_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": b_knn, "avg_launch_ms": knn_ms, "launches": int(tm.knn_launches),
+                     "timing": "HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL) on the context's stream, inside the timed region, "
+                               "on every 4th registration (every launch with --time-all-kernels); no-op launches after convergence excluded",
                      "queries_per_launch": q_per_launch, "map_points_in_touched_cubes": m_per_launch,
                      "note": "B = 36*Q + 12*M_t (SURVEY 8d); with M_t = whole map (BASELINE.md table) B would be %.0f and frac %.4f"
                              % (b_knn_whole_map, (b_knn_whole_map / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if knn_ms > 0 else 0.0)},
+        "host": {"c_abi_ms_per_step": tm.host_ms_total / max(tm.registrations, 1),
+                 "note": "wall time inside so_icp_register_dev (enqueue + wait + post-processing); ms_per_step - this = Python/ctypes overhead of the bench loop"},
         "kernels": {"knn_plane_ms_per_step": tm.knn_ms_total / args.steps, "eval_ms_per_step": tm.eval_ms_total / args.steps,
                     "prep_sort_ms_per_step": tm.prep_ms_total / args.steps,
                     "eval_avg_launch_ms": eval_ms, "eval_launches_per_step": tm.eval_launches / args.steps,

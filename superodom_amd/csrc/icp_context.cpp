@@ -346,6 +346,9 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   // One outer iteration = knn_plane -> [ eval(slot) -> (all-reduce -> lm_step) ] x (1 + lm_max) -> state read-back.
   // (The histogram replicas are cleared by reg_begin and again by the controller when a solve ends:
   //  ResetDistanceParameters, LidarSlam.cpp:847-852.)
+  // time_kernels == 1 samples every 4th registration: even dispatch-attached events cost ~5 us of stream time per
+  // timed launch (completion-signal handling), which would otherwise sit inside every step of a throughput run
+  const bool timed = c->cfg.time_kernels >= 2 || (c->cfg.time_kernels == 1 && (c->timing.registrations & 3) == 0);
   // part A: correspondences + plane fit + first evaluation; part B: the remaining evaluations + read-back
   const bool persistent = c->persistent_solve && c->comm == nullptr;
   auto enqueue_eval = [&](int slot) -> int {
@@ -364,10 +367,13 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   auto enqueue_outer_a = [&](int it) -> int {
     // processPlannerFeatures: every kept query in parallel (LidarSlam.cpp:323-344)
     knn_span_of_outer.push_back(c->spans.size());
-    span_begin(c, 0, (uint32_t)n);
+    hipEvent_t ka = nullptr, kb = nullptr;
+    if (timed) {  // the events ride on the dispatch packet (hipExtLaunchKernelGGL), no marker packets
+      ka = next_event(c); kb = next_event(c);
+      if (ka && kb) c->spans.push_back(EventSpan{0, ka, kb, (uint32_t)n});
+    }
     launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->d_keys1.as<uint32_t>(),
-                     c->d_chunks.as<uint32_t>(), ds, c->view, mp, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s);
-    span_end(c);
+                     c->d_chunks.as<uint32_t>(), ds, c->view, mp, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s, ka, kb);
     static const int repeat_knn = std::getenv("SOICP_REPEAT_KNN") ? std::atoi(std::getenv("SOICP_REPEAT_KNN")) : 0;
     for (int rep = 0; rep < repeat_knn; ++rep)  // profiling aid: identical relaunch (results are idempotent)
       launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->d_keys1.as<uint32_t>(),
@@ -467,7 +473,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   relative_motion(T_last, T, st->translation_from_last, st->rotation_from_last);
   st->prediction_source = 0;
   std::memcpy(pose_out, T, sizeof(T));
-  if (c->cfg.time_kernels) {  // keep only the launches that did real work (no-op launches after convergence are excluded)
+  if (timed) {  // keep only the launches that did real work (no-op launches after convergence are excluded)
     std::vector<EventSpan> real;
     for (size_t i = 0; i < c->spans.size(); ++i) {
       const EventSpan& sp = c->spans[i];

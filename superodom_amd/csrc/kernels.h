@@ -111,7 +111,8 @@ void launch_chunk_heads(const uint32_t* d_keys_sorted, uint32_t n, uint32_t drop
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* d_keys_sorted,
                       const uint32_t* d_chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
                       CorrBuffers corr, uint32_t* d_nbr5 /*5 canonical indices per query*/,
-                      int32_t* d_hist /*kHistReplicas*kHistStride*/, hipStream_t s);
+                      int32_t* d_hist /*kHistReplicas*kHistStride*/, hipStream_t s, hipEvent_t ev_start = nullptr,
+                      hipEvent_t ev_stop = nullptr /* timing events attached to the dispatch itself */);
 void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr,
                  DevState* st, const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist,
                  LmSums* d_sums, const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper,

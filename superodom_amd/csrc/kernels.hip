@@ -14,6 +14,7 @@
 // kernels (64-wide wavefronts, fp64 VALU for the parts the reference computes in double).
 // Paths in citations are relative to /root/reference/super_odometry/{src,include/super_odometry}.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstddef>
 #include <cstdlib>
@@ -1424,9 +1425,15 @@ void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n, uint32_t droppe
 }
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* keys_sorted,
                       const uint32_t* chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
-                      CorrBuffers corr, uint32_t* nbr5, int32_t* hist, hipStream_t s) {
-  hipLaunchKernelGGL(knn_plane_kernel, dim3(kKnnBlocks), dim3(256), 0, s, spx, spy, spz, keys_sorted, chunk_start, st, map.pts,
-                     map.cell_start, map, mp, corr, nbr5, hist);
+                      CorrBuffers corr, uint32_t* nbr5, int32_t* hist, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  // timing events ride on the kernel's own dispatch packet (no marker packets: separate hipEventRecord calls cost
+  // ~3.7 us of stream time each, 8 % of a registration when every sweep is timed)
+  if (ev_start && ev_stop)
+    hipExtLaunchKernelGGL(knn_plane_kernel, dim3(kKnnBlocks), dim3(256), 0, s, ev_start, ev_stop, 0, spx, spy, spz, keys_sorted,
+                          chunk_start, st, map.pts, map.cell_start, map, mp, corr, nbr5, hist);
+  else
+    hipLaunchKernelGGL(knn_plane_kernel, dim3(kKnnBlocks), dim3(256), 0, s, spx, spy, spz, keys_sorted, chunk_start, st, map.pts,
+                       map.cell_start, map, mp, corr, nbr5, hist);
 }
 void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr,
                  DevState* st, const EvalParams& ep, double* partials, uint32_t* ticket, int32_t* hist, LmSums* sums,
