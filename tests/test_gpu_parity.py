@@ -150,6 +150,28 @@ def test_determinism_bitwise(gpu_slam_factory, oracle):
     assert np.array_equal(p1, p2), "fixed-order reductions: repeated registrations must agree bit for bit"
 
 
+@pytest.mark.parametrize("env", [{"SOICP_PERSISTENT": "0"}, {"SOICP_READBACK": "copy"}, {"SOICP_SYNC_PER_OUTER": "0"},
+                                 {"SOICP_PERSISTENT": "0", "SOICP_READBACK": "copy", "SOICP_SYNC_PER_OUTER": "0"}])
+def test_control_flow_variants_are_bit_identical(oracle, gpu_slam_factory, monkeypatch, env):
+    """The same kernels under every host-side schedule: persistent solve launch vs one launch per evaluation, state
+    published by the device vs hipMemcpyAsync read-back, speculative per-iteration enqueue vs everything up front."""
+    sc, ref, _ = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)  # read by so_icp_create
+    _, alt, _ = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
+    for i in (0, 7):
+        scan, guess = sc.scan(i), sc.guess(i)
+        rc1, p1, s1 = ref.register(scan, guess)
+        rc2, p2, s2 = alt.register(scan, guess)
+        assert rc1 == rc2 == 0 and s1.n_iterations == s2.n_iterations
+        assert np.array_equal(p1, p2), (env, p1 - p2)
+        for it in range(s1.n_iterations):
+            a, b = s1.iterations[it], s2.iterations[it]
+            assert (a.lm_iterations, a.num_surf_from_scan, a.termination) == (b.lm_iterations, b.num_surf_from_scan, b.termination)
+            assert a.final_cost == b.final_cost and list(a.reject_hist) == list(b.reject_hist) and list(a.obs_hist) == list(b.obs_hist)
+        assert np.array_equal(np.array(s1.JtJ), np.array(s2.JtJ))
+
+
 def test_rccl_path_world1_matches_oracle(oracle, gpu_slam_factory, soicp):
     """The N>1 code path (eval -> ncclAllReduce(45 fp64) -> lm_step_kernel) on a 1-rank RCCL communicator."""
     sc, slam, om = _setup("tiny", oracle, gpu_slam_factory, max_iterations=5)
