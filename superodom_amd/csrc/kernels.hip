@@ -300,6 +300,58 @@ __device__ __forceinline__ void eig3_sym(double a00, double a01, double a02, dou
   nrm[0] = n0; nrm[1] = n1; nrm[2] = n2;
 }
 
+// Same result without iterations (the cyclic Jacobi above costs ~1500 fp64 instructions per query, two thirds of the
+// plane-fit pass): the spectrum of a 5-point scatter matrix is lambda0 << lambda1 <= lambda2 for anything that can pass
+// the gates, so
+//   lambda0    = smallest root of the characteristic cubic by Newton from 0 (monotone from below for a polynomial with
+//                real roots; the matrix is first scaled to unit max-norm),
+//   lambda1,2  = roots of the deflated quadratic,
+//   n          = the largest of the three row cross products of (A - lambda0 I), normalised.
+// Eigenvalues agree with the Jacobi values to ~1e-14 relative, the normal to ~1e-15 when lambda0 is separated; only the
+// gates (LidarSlam.cpp:772) and the float observability labels consume them.
+__device__ __forceinline__ void eig3_sym_direct(double a00, double a01, double a02, double a11, double a12, double a22,
+                                                double ev[3], double nrm[3]) {
+  const double mx = fmax(fmax(fmax(fabs(a00), fabs(a11)), fabs(a22)), fmax(fmax(fabs(a01), fabs(a02)), fabs(a12)));
+  if (!(mx > 0.0)) { ev[0] = ev[1] = ev[2] = 0.0; nrm[0] = 1.0; nrm[1] = 0.0; nrm[2] = 0.0; return; }
+  const double is = 1.0 / mx;
+  a00 *= is; a01 *= is; a02 *= is; a11 *= is; a12 *= is; a22 *= is;
+  // p(l) = -l^3 + c2 l^2 - c1 l + c0
+  const double c2 = a00 + a11 + a22;
+  const double m00 = a11 * a22 - a12 * a12, m11 = a00 * a22 - a02 * a02, m22 = a00 * a11 - a01 * a01;
+  const double c1 = m00 + m11 + m22;
+  const double c0 = a00 * m00 - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
+  double l = 0.0;
+#pragma unroll 1
+  for (int it = 0; it < 60; ++it) {  // 2-3 iterations when lambda0 is separated; linear convergence only towards a double root
+    const double f = ((-l + c2) * l - c1) * l + c0;      // p(l)
+    const double df = (-3.0 * l + 2.0 * c2) * l - c1;    // p'(l) < 0 left of the smallest root
+    if (!(df < 0.0) || !(f > 0.0)) break;   // at (or, by rounding, just past) the root
+    const double step = f / df;              // < 0: the iterate moves right, never beyond the root (p is convex there)
+    l -= step;
+    if (!(-step > 4e-16)) break;             // the matrix has unit max-norm: below the noise of p(l)
+  }
+  if (!(l > 0.0)) l = fmax(l, 0.0);
+  // deflate: l1 + l2 = c2 - l, l1 l2 = c1 - l (c2 - l)
+  const double sm = c2 - l, pr = c1 - l * sm;
+  double disc = sm * sm - 4.0 * pr;
+  disc = disc > 0.0 ? sqrt(disc) : 0.0;
+  const double l2 = 0.5 * (sm + disc);
+  const double l1 = (l2 > 0.0) ? pr / l2 : 0.0;  // the smaller root from the product: no cancellation
+  ev[0] = l * mx; ev[1] = l1 * mx; ev[2] = l2 * mx;
+  // null vector of (A - l I): largest cross product of its rows
+  const double r00 = a00 - l, r11 = a11 - l, r22 = a22 - l;
+  const double x0 = a01 * a12 - a02 * r11, x1 = a02 * a01 - r00 * a12, x2 = r00 * r11 - a01 * a01;     // row0 x row1
+  const double y0 = a01 * r22 - a02 * a12, y1 = a02 * a02 - r00 * r22, y2 = r00 * a12 - a01 * a02;     // row0 x row2
+  const double z0 = r11 * r22 - a12 * a12, z1 = a12 * a02 - a01 * r22, z2 = a01 * a12 - r11 * a02;     // row1 x row2
+  const double nx = x0 * x0 + x1 * x1 + x2 * x2, ny = y0 * y0 + y1 * y1 + y2 * y2, nz = z0 * z0 + z1 * z1 + z2 * z2;
+  double v0 = x0, v1 = x1, v2 = x2, nn = nx;
+  if (ny > nn) { v0 = y0; v1 = y1; v2 = y2; nn = ny; }
+  if (nz > nn) { v0 = z0; v1 = z1; v2 = z2; nn = nz; }
+  if (!(nn > 0.0)) { nrm[0] = 1.0; nrm[1] = 0.0; nrm[2] = 0.0; return; }
+  const double inv = 1.0 / sqrt(nn);
+  nrm[0] = v0 * inv; nrm[1] = v1 * inv; nrm[2] = v2 * inv;
+}
+
 // least squares A x = -1 (A = 5x3 neighbour coordinates) by column-pivoted Householder QR
 // (restates matA0.colPivHouseholderQr().solve(matB0), LidarSlam.cpp:798-806).
 __device__ __forceinline__ bool plane_ls5(const float nb[15], double x[3]) {
@@ -420,7 +472,8 @@ __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const d
     s00 += a * a; s01 += a * b; s02 += a * c; s11 += b * b; s12 += b * c; s22 += c * c;
   }
   double ev[3], nrm[3];
-  eig3_sym(s00, s01, s02, s11, s12, s22, ev, nrm);
+  if (mp.ablate & 512) eig3_sym(s00, s01, s02, s11, s12, s22, ev, nrm);  // profiling switch: the iterative reference solver
+  else eig3_sym_direct(s00, s01, s02, s11, s12, s22, ev, nrm);
   if (ev[0] < 1e-6 || ev[1] / ev[2] < 0.1) return SO_MATCH_BAD_PCA;  // LidarSlam.cpp:772
   double x[3];
   if (!plane_ls5(nb, x)) return SO_MATCH_INVALID;                    // LidarSlam.cpp:809-812
@@ -1017,9 +1070,9 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   const double R00 = 1 - (tyy + tzz), R01 = txy - twz, R02 = txz + twy;
   const double R10 = txy + twz, R11 = 1 - (txx + tzz), R12 = tyz - twx;
   const double R20 = txz - twy, R21 = tyz + twx, R22 = 1 - (txx + tyy);
-  for (uint32_t j = blockIdx.x * blockDim.x + tid; j < n_kept; j += gridDim.x * blockDim.x) {
-    int status = corr.status[j];
-    if (!FIT && status != SO_MATCH_SUCCESS) continue;
+  // one query: (FIT) plane fit from the prefetched neighbour coordinates, then residual / Jacobian / sums
+  auto body = [&](const uint32_t j, int status, const float* nb) {
+    if (!FIT && status != SO_MATCH_SUCCESS) return;
     const double px = (double)spx[j], py = (double)spy[j], pz = (double)spz[j];
     double wx, wy, wz;
     quat_rotate<double>(pose.q, px, py, pz, wx, wy, wz);                   // lidarOptimization.cpp:59 == LidarSlam.cpp:397-398
@@ -1030,9 +1083,6 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       double fnd[4] = {0, 0, 0, 0}, fc = 0;
       int obs[3] = {0, 0, 0};
       if (status == SO_MATCH_PENDING) {
-        float nb[15];
-#pragma unroll
-        for (int t = 0; t < 5; ++t) { const float4 p = mpts[nbr5[(size_t)5 * j + t]]; nb[3 * t] = p.x; nb[3 * t + 1] = p.y; nb[3 * t + 2] = p.z; }
         const double pw[3] = {wx, wy, wz};
         status = plane_from_neighbours(nb, pw, pose, mp, fnd, fc, obs);
       }
@@ -1042,7 +1092,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       corr.nd[j] = nd; corr.coeff[j] = c; corr.status[j] = (uint8_t)status;
       atomicAdd(&lh[status], 1);                                          // MatchRejectionHistogramPlane, LidarSlam.cpp:341
       if (status == SO_MATCH_SUCCESS) { atomicAdd(&lh[7 + obs[0]], 1); atomicAdd(&lh[7 + obs[1]], 1); atomicAdd(&lh[7 + obs[2]], 1); }
-      if (status != SO_MATCH_SUCCESS) continue;
+      if (status != SO_MATCH_SUCCESS) return;
     } else {
       c = corr.coeff[j];
       nd = corr.nd[j];
@@ -1075,6 +1125,33 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
 #pragma unroll
       for (int b = a; b < 6; ++b) acc[k++] += wj * J[b];
     }
+  };
+  const uint32_t jstride = gridDim.x * blockDim.x;
+  if (FIT) {
+    // Two queries per trip with their gathers issued together: status + neighbour indices of both (one round trip),
+    // then the ten neighbour points (one round trip), then the two fits.  With one wavefront per SIMD nothing else
+    // hides the latency of the dependent index -> point loads (measured: 3 us of a 12 us pass).
+    for (uint32_t jA = blockIdx.x * blockDim.x + tid; jA < n_kept; jA += 2 * jstride) {
+      const uint32_t jB = jA + jstride;
+      const bool hasB = jB < n_kept;
+      const uint32_t jBs = hasB ? jB : jA;
+      const int stA = corr.status[jA];
+      const int stB = hasB ? (int)corr.status[jBs] : SO_MATCH_NOT_ENOUGH;
+      uint32_t iA[5], iB[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) { iA[t] = nbr5[(size_t)5 * jA + t]; iB[t] = nbr5[(size_t)5 * jBs + t]; }
+      float nbA[15], nbB[15];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {  // indices of a query that is not PENDING are stale: read point 0 instead
+        const float4 a = mpts[stA == SO_MATCH_PENDING ? iA[t] : 0u], b = mpts[stB == SO_MATCH_PENDING ? iB[t] : 0u];
+        nbA[3 * t] = a.x; nbA[3 * t + 1] = a.y; nbA[3 * t + 2] = a.z;
+        nbB[3 * t] = b.x; nbB[3 * t + 1] = b.y; nbB[3 * t + 2] = b.z;
+      }
+      body(jA, stA, nbA);
+      if (hasB) body(jB, stB, nbB);
+    }
+  } else {
+    for (uint32_t j = blockIdx.x * blockDim.x + tid; j < n_kept; j += jstride) body(j, corr.status[j], nullptr);
   }
   if (stamp) t_loop = wall_clock64();
   // workgroup reduction through LDS (transposed: no serial shuffle chains), fixed order
