@@ -21,7 +21,7 @@ static inline int cidx(int i, int j, int k) { return i + kMapW * j + kMapW * kMa
 
 DeviceMap::~DeviceMap() {
   for (void* p : {(void*)d_pool_, (void*)d_cell_start_, (void*)d_cube_slot_, (void*)d_wpts_, (void*)d_cent_, (void*)d_k0_, (void*)d_k1_,
-                  (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, d_temp_, (void*)d_cube_of_, (void*)d_touched_,
+                  (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, (void*)d_spts_, (void*)d_heads_, d_temp_, (void*)d_cube_of_, (void*)d_touched_,
                   (void*)d_touched_id_, (void*)d_small_, (void*)d_stage_})
     if (p) (void)hipFree(p);
   if (h_touched_) (void)hipHostFree(h_touched_);
@@ -122,11 +122,13 @@ int DeviceMap::ensure_work(size_t total, std::string& err) {
   }
   if (total <= work_cap_) return 0;
   const size_t cap = total + total / 4 + 1024;
-  for (void* p : {(void*)d_wpts_, (void*)d_cent_, (void*)d_k0_, (void*)d_k1_, (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, d_temp_})
+  for (void* p : {(void*)d_wpts_, (void*)d_cent_, (void*)d_spts_, (void*)d_heads_, (void*)d_k0_, (void*)d_k1_, (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, d_temp_})
     if (p) (void)hipFree(p);
-  d_wpts_ = d_cent_ = nullptr; d_k0_ = d_k1_ = d_v0_ = d_v1_ = d_flags_ = d_pos_ = nullptr; d_temp_ = nullptr; work_cap_ = 0;
+  d_wpts_ = d_cent_ = d_spts_ = nullptr; d_heads_ = nullptr; d_k0_ = d_k1_ = d_v0_ = d_v1_ = d_flags_ = d_pos_ = nullptr; d_temp_ = nullptr; work_cap_ = 0;
   DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_wpts_), cap * sizeof(float4)));
   DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cent_), cap * sizeof(float4)));
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_spts_), cap * sizeof(float4)));
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_heads_), (cap + 1) * sizeof(uint32_t)));
   for (uint32_t** p : {&d_k0_, &d_k1_, &d_v0_, &d_v1_, &d_flags_, &d_pos_}) DM_TRY(hipMalloc(reinterpret_cast<void**>(p), cap * sizeof(uint32_t)));
   temp_bytes_ = map_sort_temp_bytes(cap) + 256;
   DM_TRY(hipMalloc(&d_temp_, temp_bytes_));
@@ -252,7 +254,7 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     a.d_cube_of = d_cube_of_; a.d_touched_id = d_touched_id_; a.inv_leaf = inv_leaf;
     a.nc = nc_; a.ncell1 = ncell1_; a.inv_cell = 1.0 / cell_;
     a.pool = d_pool_; a.cap = kCapPerSlot; a.cell_start = d_cell_start_;
-    a.wpts = d_wpts_; a.cent = d_cent_;
+    a.wpts = d_wpts_; a.cent = d_cent_; a.spts = d_spts_; a.heads = d_heads_;
     a.keys0 = d_k0_; a.keys1 = d_k1_; a.vals0 = d_v0_; a.vals1 = d_v1_; a.flags = d_flags_; a.pos = d_pos_;
     a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
     a.temp = d_temp_; a.temp_bytes = temp_bytes_;

@@ -29,7 +29,7 @@ struct MapInsertArgs {
   float inv_leaf;
   int32_t nc; uint32_t ncell1; double inv_cell;
   float4* pool; uint32_t cap; uint32_t* cell_start;
-  float4* wpts; float4* cent;
+  float4* wpts; float4* cent; float4* spts /* working set in leaf-sorted order */; uint32_t* heads /* first index of leaf o; [n_leaves] = end */;
   uint32_t *keys0, *keys1, *vals0, *vals1, *flags, *pos;
   uint32_t* d_n_cent; uint32_t* d_counts;  // [1], [kMaxTouched]
   void* temp; size_t temp_bytes;

@@ -9,7 +9,8 @@
 //                         holds at most one old centroid, and PCL accumulates in input order)
 //   append_new_kernel     the new points follow in input order; key = (touched-cube id, leaf z, y, x)
 //   rocPRIM stable sort   by leaf key
-//   leaf_centroid_kernel  one thread per leaf head: float sums IN ORDER, centroid = sum / count  (VoxelGrid semantics)
+//   leaf_heads_kernel     working set gathered into leaf-sorted order, first index of every leaf
+//   leaf_centroid_kernel  one thread per leaf: float sums IN ORDER, centroid = sum / count  (VoxelGrid semantics)
 //   cell_key_kernel       key2 = (touched-cube id, cell z, y, x) of each centroid; rocPRIM stable sort
 //   scatter_kernel        centroids into the cube's region of the point pool (canonical order = cell, then leaf)
 //   table_kernel          per-cube prefix table by binary search (cell -> first canonical index)
@@ -32,22 +33,33 @@ __device__ __forceinline__ int cube_coord_f(float c, int origin) {  // == int((c
 }
 
 // LocalMap.h:596-610
-__global__ __launch_bounds__(256) void world_cube_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats,
-                                                         int o0, int o1, int o2, int32_t* __restrict__ cube_of,
-                                                         uint8_t* __restrict__ touched, uint32_t* __restrict__ n_inside) {
+__global__ __launch_bounds__(1024) void world_cube_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats,
+                                                          int o0, int o1, int o2, int32_t* __restrict__ cube_of,
+                                                          uint8_t* __restrict__ touched, uint32_t* __restrict__ n_inside) {
+  __shared__ uint32_t cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   int cube = -1;
   if (i < n) {
     const float* p = xyz + (size_t)i * stride_floats;
     const int ci = cube_coord_f(p[0], o0), cj = cube_coord_f(p[1], o1), ck = cube_coord_f(p[2], o2);
-    if (ci >= 0 && ci < 21 && cj >= 0 && cj < 21 && ck >= 0 && ck < 11) {
-      cube = ci + 21 * cj + 21 * 21 * ck;
-      touched[cube] = 1;
-    }
+    if (ci >= 0 && ci < 21 && cj >= 0 && cj < 21 && ck >= 0 && ck < 11) cube = ci + 21 * cj + 21 * 21 * ck;
     cube_of[i] = cube;
   }
-  const unsigned long long m = __ballot(cube >= 0);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_inside, (uint32_t)__popcll(m));  // off the ICP critical path
+  // one flag store per DISTINCT cube of the wavefront and one counter atomic per workgroup (every lane storing the same
+  // byte / every wavefront adding to the same word cost 50 us for 131 072 points)
+  unsigned long long todo = __ballot(cube >= 0);
+  const unsigned long long inside = todo;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int c = __builtin_amdgcn_readlane(cube, leader);
+    if ((threadIdx.x & 63) == leader) touched[c] = 1;
+    todo &= ~__ballot(cube == c);
+  }
+  if ((threadIdx.x & 63) == 0 && inside) atomicAdd(&cnt, (uint32_t)__popcll(inside));
+  __syncthreads();
+  if (threadIdx.x == 0 && cnt) atomicAdd(n_inside, cnt);
 }
 
 // scan + world transform in one pass (transformAndAddToMap, LidarSlam.cpp:60-80; TransformPoint, superodom_utils.h:119-123)
@@ -104,28 +116,14 @@ __global__ __launch_bounds__(256) void leaf_flags_kernel(const uint32_t* __restr
   flags[i] = (keys[i] != 0xFFFFFFFFu && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
 }
 
-// one thread per leaf: accumulate the leaf's points in (stable-sorted) input order in float, divide by float(count)
-// (pcl::CentroidPoint / AccumulatorXYZ semantics); emits the cell key of the centroid for the second sort
-__global__ __launch_bounds__(256) void leaf_centroid_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                            const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
-                                                            uint32_t n, const float4* __restrict__ wpts, MapTouched tt, int nc,
-                                                            double inv_cell, float4* __restrict__ cent, uint32_t* __restrict__ keys2,
-                                                            uint32_t* __restrict__ vals2, uint32_t* __restrict__ n_cent) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (i == n - 1) *n_cent = pos[i] + flags[i];
-  if (!flags[i]) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  uint32_t j = i;
-  const uint32_t key = keys[i];
-  do {
-    const float4 p = wpts[vals[j]];
-    s0 += p.x; s1 += p.y; s2 += p.z;
-    ++j;
-  } while (j < n && keys[j] == key);
-  const float cnt = (float)(j - i);
+constexpr uint32_t kLongLeaf = 64, kMaxLongLeaves = 4096;
+
+// centroid = float sum / float count, then its cell key for the second sort
+__device__ __forceinline__ void emit_centroid(uint32_t o, uint32_t key, float s0, float s1, float s2, uint32_t count, const MapTouched& tt,
+                                              int nc, double inv_cell, float4* __restrict__ cent, uint32_t* __restrict__ keys2,
+                                              uint32_t* __restrict__ vals2) {
+  const float cnt = (float)count;
   const float cx = s0 / cnt, cy = s1 / cnt, cz = s2 / cnt;
-  const uint32_t o = pos[i];
   cent[o] = make_float4(cx, cy, cz, 0.f);
   const int t = (int)(key >> 27);
   int g[3];
@@ -137,6 +135,94 @@ __global__ __launch_bounds__(256) void leaf_centroid_kernel(const uint32_t* __re
   }
   keys2[o] = ((uint32_t)t << 18) | (uint32_t)((g[2] * nc + g[1]) * nc + g[0]);  // linear cell index, as in the cube's table
   vals2[o] = o;
+}
+
+// leaf-sorted working set made contiguous (spts[i] = wpts[vals[i]]) + first index of every leaf (heads[ordinal]; the
+// entry behind the last leaf = number of valid elements) + number of leaves
+__global__ __launch_bounds__(256) void leaf_heads_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                         const uint32_t* __restrict__ flags, const uint32_t* __restrict__ pos,
+                                                         uint32_t n, const float4* __restrict__ wpts, float4* __restrict__ spts,
+                                                         uint32_t* __restrict__ heads, uint32_t* __restrict__ n_cent) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  spts[i] = wpts[vals[i]];
+  const uint32_t f = flags[i], o = pos[i];
+  if (f) heads[o] = i;
+  const bool valid = keys[i] != 0xFFFFFFFFu;
+  if (valid && (i + 1 == n || keys[i + 1] == 0xFFFFFFFFu)) { heads[o + f] = i + 1; *n_cent = o + f; }  // last valid element
+  if (i == 0 && !valid) *n_cent = 0;
+}
+
+// one thread per leaf: accumulate the leaf's points in (stable-sorted) input order in float, divide by float(count)
+// (pcl::CentroidPoint / AccumulatorXYZ semantics); emits the cell key of the centroid for the second sort.
+// The sums must run in order (float addition, PCL accumulates in input order), the LOADS need not: a leaf under the
+// sensor collects ~1000 scan points, and a dependent key -> index -> point chain per point made this kernel 380 us.
+// The points are contiguous now; sixteen are fetched per round trip, the next sixteen while these are added.
+__global__ __launch_bounds__(256) void leaf_centroid_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ heads,
+                                                            const uint32_t* __restrict__ n_cent, const float4* __restrict__ spts,
+                                                            MapTouched tt, int nc, double inv_cell, float4* __restrict__ cent,
+                                                            uint32_t* __restrict__ keys2, uint32_t* __restrict__ vals2,
+                                                            uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= *n_cent) return;
+  const uint32_t beg = heads[o], end = heads[o + 1];
+  const uint32_t key = keys[beg];
+  if (long_list && end - beg > kLongLeaf) {  // a whole wavefront takes this one (leaf_centroid_long_kernel)
+    const uint32_t at = atomicAdd(long_count, 1u);
+    if (at < kMaxLongLeaves) { long_list[at] = o; return; }
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  constexpr int B = 16;
+  float4 cur[B], nxt[B];
+#pragma unroll
+  for (int k = 0; k < B; ++k) cur[k] = spts[beg + k < end ? beg + k : end - 1];
+  for (uint32_t j = beg; j < end; j += B) {
+    const uint32_t jn = j + B;
+    if (jn < end) {
+#pragma unroll
+      for (int k = 0; k < B; ++k) nxt[k] = spts[jn + k < end ? jn + k : end - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < B; ++k)
+      if (j + k < end) { s0 += cur[k].x; s1 += cur[k].y; s2 += cur[k].z; }
+#pragma unroll
+    for (int k = 0; k < B; ++k) cur[k] = nxt[k];
+  }
+  emit_centroid(o, key, s0, s1, s2, end - beg, tt, nc, inv_cell, cent, keys2, vals2);
+}
+
+// leaves with more than kLongLeaf points (the ground right under the sensor: ~1000 scan points in one 0.2 m leaf): one
+// WAVEFRONT per leaf loads 64 points per instruction (next 64 in flight) and adds them in order out of its lanes
+__global__ __launch_bounds__(256) void leaf_centroid_long_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ heads,
+                                                                 const float4* __restrict__ spts, MapTouched tt, int nc, double inv_cell,
+                                                                 float4* __restrict__ cent, uint32_t* __restrict__ keys2,
+                                                                 uint32_t* __restrict__ vals2, const uint32_t* __restrict__ long_list,
+                                                                 const uint32_t* __restrict__ long_count) {
+  const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_long = *long_count < kMaxLongLeaves ? *long_count : kMaxLongLeaves;
+  if (w >= n_long) return;
+  const uint32_t o = long_list[w];
+  const uint32_t beg = heads[o], end = heads[o + 1];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  float4 cur = spts[beg + lane < end ? beg + lane : end - 1];
+  for (uint32_t j = beg; j < end; j += 64) {
+    const uint32_t jn = j + 64;
+    float4 nxt = cur;
+    if (jn < end) nxt = spts[jn + lane < end ? jn + lane : end - 1];
+    // lanes behind the end contribute +0.0f (s + 0.0f == s exactly), so the in-order sum is a fixed, fully unrolled
+    // sequence of 64 lane reads -- the same in every lane
+    const bool live = j + (uint32_t)lane < end;
+    const float x = live ? cur.x : 0.f, y = live ? cur.y : 0.f, z = live ? cur.z : 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      s0 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), k));
+      s1 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), k));
+      s2 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), k));
+    }
+    cur = nxt;
+  }
+  if (lane == 0) emit_centroid(o, keys[beg], s0, s1, s2, end - beg, tt, nc, inv_cell, cent, keys2, vals2);
 }
 
 __global__ __launch_bounds__(256) void pad_keys_kernel(uint32_t* __restrict__ keys2, uint32_t* __restrict__ vals2,
@@ -203,7 +289,7 @@ size_t map_sort_temp_bytes(size_t n) {
 void launch_world_cube(const float* d_xyz, uint32_t n, uint32_t stride_floats, const int origin[3], int32_t* d_cube_of, uint8_t* d_touched,
                        uint32_t* d_n_inside, hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(world_cube_kernel, grid_for(n, 256), dim3(256), 0, s, d_xyz, n, stride_floats, origin[0], origin[1], origin[2], d_cube_of,
+  hipLaunchKernelGGL(world_cube_kernel, grid_for(n, 1024), dim3(1024), 0, s, d_xyz, n, stride_floats, origin[0], origin[1], origin[2], d_cube_of,
                      d_touched, d_n_inside);
 }
 void launch_transform_scan(const float* d_scan, uint32_t n, const Pose& pose, float* d_out, hipStream_t s) {
@@ -223,8 +309,13 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(leaf_flags_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, total, a.flags);
   tb = a.temp_bytes;
   (void)rocprim::exclusive_scan(a.temp, tb, a.flags, a.pos, 0u, (size_t)total, rocprim::plus<uint32_t>(), s);
-  hipLaunchKernelGGL(leaf_centroid_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.flags, a.pos, total, a.wpts, a.tt, a.nc,
-                     a.inv_cell, a.cent, a.keys0, a.vals0, a.d_n_cent);
+  hipLaunchKernelGGL(leaf_heads_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.flags, a.pos, total, a.wpts, a.spts, a.heads,
+                     a.d_n_cent);
+  // d_n_cent + 1 = number of long leaves (cleared with d_small_), list = the flags array (free after the scan)
+  hipLaunchKernelGGL(leaf_centroid_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.heads, a.d_n_cent, a.spts, a.tt, a.nc, a.inv_cell,
+                     a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
+  hipLaunchKernelGGL(leaf_centroid_long_kernel, dim3(kMaxLongLeaves / 4), dim3(256), 0, s, a.keys1, a.heads, a.spts, a.tt, a.nc, a.inv_cell,
+                     a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
   hipLaunchKernelGGL(pad_keys_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals0, a.d_n_cent, total);
   tb = a.temp_bytes;
   (void)rocprim::radix_sort_pairs(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 0, 32, s);  // stable: leaf order inside a cell
