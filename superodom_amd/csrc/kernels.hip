@@ -211,6 +211,14 @@ __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __res
 struct Top5 {
   unsigned long long b0, b1, b2, b3, b4;
   __device__ __forceinline__ void init() { b0 = b1 = b2 = b3 = b4 = ~0ull; }
+  // five keys at once: 9-comparator sorting network (a third of the instructions of five insertions)
+  __device__ __forceinline__ void set5(unsigned long long e0, unsigned long long e1, unsigned long long e2, unsigned long long e3,
+                                       unsigned long long e4) {
+#define SO_CX(a, b) { const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; }
+    SO_CX(e0, e1) SO_CX(e3, e4) SO_CX(e2, e4) SO_CX(e2, e3) SO_CX(e1, e4) SO_CX(e0, e3) SO_CX(e0, e2) SO_CX(e1, e3) SO_CX(e1, e2)
+#undef SO_CX
+    b0 = e0; b1 = e1; b2 = e2; b3 = e3; b4 = e4;
+  }
   __device__ __forceinline__ void insert(unsigned long long k) {
     if (k < b4) {
       b4 = k;
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   const int lo_y = max(0, (int)floorf((uy - r_cover) * inv_cellf)), hi_y = min(nc - 1, (int)floorf((uy + r_cover) * inv_cellf));
   const int lo_z = max(0, (int)floorf((uz - r_cover) * inv_cellf)), hi_z = min(nc - 1, (int)floorf((uz + r_cover) * inv_cellf));
   uint32_t g0 = 0xFFFFFFFFu, g1 = g0, g2 = g0, g3 = g0, g4 = g0, g5 = g0, g6 = g0, g7 = g0;  // canonical indices of the 8 survivors
-  int32_t k8 = kKeyEmpty;      // 8th key of the lane's group pass
+  int32_t k6 = kKeyEmpty, k8 = kKeyEmpty;  // 6th and 8th key of the lane's group pass
   float cov2 = 0.f;            // squared distance from the query to the boundary of the scanned block
   bool scanned = false;
   while (todo) {
@@ -706,13 +714,21 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
       if (nrows <= 32) {  // row table: lane r fetches the bounds of x-run r, prefix sums by shuffles
         vb = 0; vl = 0;
         if (lane < nrows) {
-          const int z = bz0 + lane / nyr, y = by0 + lane % nyr;
+          // lane / nyr without the ~30-instruction integer division: (lane + 0.5) / nyr is never within 0.5 / 32 of an
+          // integer, far more than the error of the float reciprocal (lane < 32, nyr <= 32)
+          const int zq = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)nyr));
+          const int z = bz0 + zq, y = by0 + (lane - zq * nyr);
           const uint32_t* row = mcell_start + (size_t)gslot * map.ncell1 + ((size_t)z * nc + y) * nc;
           vb = row[bx0]; vl = row[bx1 + 1] - vb;
         }
-        uint32_t inc = vl;  // inclusive scan over lanes 0..31
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        // inclusive scan over lanes 0..31 on the DPP network (row_shr 1,2,4,8 inside the rows of 16, row_bcast:15 carries
+        // row 0's total into row 1): no LDS round trips
+        uint32_t inc = vl;
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xA, 0xF, false);
         total = __builtin_amdgcn_readlane(inc, 31);
         if (lane < 32) { rowoff[lane] = inc - vl; rowbeg[lane] = vb; }
         if (lane == 0) rowoff[32] = total;
@@ -813,7 +829,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
     }
     if (mine) {
       g0 = gi[0]; g1 = gi[1]; g2 = gi[2]; g3 = gi[3]; g4 = gi[4]; g5 = gi[5]; g6 = gi[6]; g7 = gi[7];
-      k8 = net.a7;
+      k6 = net.a5; k8 = net.a7;
       scanned = true;
       if (pass == 1) {
         cov2 = 1e30f;  // the block contains the lane's whole gate ball by construction
@@ -834,25 +850,48 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   }
   // exact re-rank of the survivors + certification
   if (scanned && !need_exact && !(mp.ablate & 4)) {
-    top.init();
+    // First the five best approximate keys only.  Every candidate that is NOT re-ranked has exact d2 >= R2:
+    //   in-block outsiders: approximate d2 >= L (the first key left out, index bits cleared), exact >= L - kApproxAbsErr;
+    //   points of the cube outside the block: farther than the block boundary (cov2).
     const uint32_t gs[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
+    unsigned long long e[5];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < 5; ++t) {
+      e[t] = ~0ull;
       if (gs[t] != 0xFFFFFFFFu) {
         const float4 p = mpts[gs[t]];
-        top.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, p.x, p.y, p.z)) << 32) | gs[t]);
+        e[t] = ((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, p.x, p.y, p.z)) << 32) | gs[t];
       }
     }
-    // Every candidate that was NOT re-ranked has exact d2 >= R2:
-    //   in-block outsiders: approximate d2 >= L (8th key, index bits cleared), exact >= L - kApproxAbsErr;
-    //   points of the cube outside the block: farther than the block boundary (cov2).
-    double R2 = (double)cov2 * (1.0 - 1e-6);
-    if (k8 != kKeyEmpty) R2 = fmin(R2, (double)__uint_as_float((uint32_t)k8 & ~kKeyIdxMask) * (1.0 - 1e-6) - (double)kApproxAbsErr);
-    const bool have5 = top.b4 != ~0ull;
-    const double d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
-    if (have5 && d5 < R2) {
+    top.set5(e[0], e[1], e[2], e[3], e[4]);
+    const double cov = (double)cov2 * (1.0 - 1e-6);
+    double R2 = cov;
+    if (k6 != kKeyEmpty) R2 = fmin(R2, (double)__uint_as_float((uint32_t)k6 & ~kKeyIdxMask) * (1.0 - 1e-6) - (double)kApproxAbsErr);
+    bool have5 = top.b4 != ~0ull;
+    double d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
+    bool exact = have5 && d5 < R2;
+    bool far = !exact && R2 > (double)mp.sq_max_dist_f;
+    // a 5th and a 6th candidate too close to call on approximate keys (a few lanes in a thousand): re-rank all eight
+    if (__ballot(!exact && !far && g5 != 0xFFFFFFFFu)) {
+      if (!exact && !far) {
+#pragma unroll
+        for (int t = 5; t < 8; ++t) {
+          if (gs[t] != 0xFFFFFFFFu) {
+            const float4 p = mpts[gs[t]];
+            top.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, p.x, p.y, p.z)) << 32) | gs[t]);
+          }
+        }
+        R2 = cov;
+        if (k8 != kKeyEmpty) R2 = fmin(R2, (double)__uint_as_float((uint32_t)k8 & ~kKeyIdxMask) * (1.0 - 1e-6) - (double)kApproxAbsErr);
+        have5 = top.b4 != ~0ull;
+        d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
+        exact = have5 && d5 < R2;
+        far = !exact && R2 > (double)mp.sq_max_dist_f;
+      }
+    }
+    if (exact) {
       resolved = true;  // exact 5-NN
-    } else if (R2 > (double)mp.sq_max_dist_f) {
+    } else if (far) {
       too_far_certain = true;  // the true 5th neighbour is >= R2 > gate (LidarSlam.cpp:741)
       resolved = true;
     } else if (pass == 1) {

@@ -16,6 +16,7 @@
 //   table_kernel          per-cube prefix table by binary search (cell -> first canonical index)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -278,10 +279,22 @@ __global__ __launch_bounds__(256) void gather_export_kernel(const float4* __rest
 // ------------------------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
+// Stable (key, index) sort of the working set.  rocPRIM's default switches from merge sort to Onesweep at 1 M items;
+// SOICP_MAP_SORT=onesweep lowers the switch to 200 k (experiment switch).
+using OnesweepEarly = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 200000>;
+static bool map_sort_onesweep() {
+  static const bool v = [] { const char* e = std::getenv("SOICP_MAP_SORT"); return e && std::strcmp(e, "onesweep") == 0; }();
+  return v;
+}
+static hipError_t map_sort(void* tmp, size_t& bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo, size_t n,
+                           unsigned end_bit, hipStream_t s) {
+  if (map_sort_onesweep()) return rocprim::radix_sort_pairs<OnesweepEarly>(tmp, bytes, ki, ko, vi, vo, n, 0, end_bit, s);
+  return rocprim::radix_sort_pairs(tmp, bytes, ki, ko, vi, vo, n, 0, end_bit, s);
+}
+
 size_t map_sort_temp_bytes(size_t n) {
   size_t a = 0, b = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, n, 0, 32, (hipStream_t)0);
+  (void)map_sort(nullptr, a, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 32, (hipStream_t)0);
   (void)rocprim::exclusive_scan(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u, n, rocprim::plus<uint32_t>(), (hipStream_t)0);
   return a > b ? a : b;
 }
@@ -305,7 +318,7 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(append_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of, a.d_touched_id,
                        a.tt, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0);
   size_t tb = a.temp_bytes;
-  (void)rocprim::radix_sort_pairs(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 0, 32, s);  // stable
+  (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable
   hipLaunchKernelGGL(leaf_flags_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, total, a.flags);
   tb = a.temp_bytes;
   (void)rocprim::exclusive_scan(a.temp, tb, a.flags, a.pos, 0u, (size_t)total, rocprim::plus<uint32_t>(), s);
@@ -318,7 +331,7 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
                      a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
   hipLaunchKernelGGL(pad_keys_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals0, a.d_n_cent, total);
   tb = a.temp_bytes;
-  (void)rocprim::radix_sort_pairs(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 0, 32, s);  // stable: leaf order inside a cell
+  (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable: leaf order inside a cell
   hipLaunchKernelGGL(scatter_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.d_n_cent, a.cent, a.tt, a.cap, a.pool, a.d_counts);
   hipLaunchKernelGGL(table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.keys1, a.d_n_cent, a.tt, a.cap, a.ncell1, a.cell_start);
 }
