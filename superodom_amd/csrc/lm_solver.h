@@ -76,9 +76,11 @@ SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
     SO_UNROLL
     for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
     if (!(d > 0.0)) return false;
-    d = sqrt(d);
-    A[6 * j + j] = d;
-    inv[j] = 1.0 / d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    inv[j] = rsqrt(d);  // only 1/L_jj is used below; one long fp64 operation per column instead of sqrt + division
+#else
+    inv[j] = 1.0 / sqrt(d);
+#endif
     SO_UNROLL
     for (int i = j + 1; i < 6; ++i) {
       double s = A[6 * i + j];
