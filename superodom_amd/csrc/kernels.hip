@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
 __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t kKeyDropped,
                                                            uint32_t* __restrict__ chunk_start, DevState* __restrict__ st,
                                                            const float* __restrict__ scan, const uint32_t* __restrict__ perm,
-                                                           float* __restrict__ spx, float* __restrict__ spy, float* __restrict__ spz) {
+                                                           float* __restrict__ spx, float* __restrict__ spy, float* __restrict__ spz,
+                                                           int chunk_mode) {
   __shared__ uint32_t wave_cnt[16];
   __shared__ uint32_t block_base;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,7 +170,33 @@ __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __res
   // keys are sorted and the dropped key is the largest value: the kept queries are the prefix [0, n_kept)
   if (kept && (i + 1 == n || keys[i + 1] == kKeyDropped)) st->n_kept = i + 1;
   bool head = false;
-  if (kept) {
+  uint32_t count = 0;
+  if (chunk_mode >= 2) {
+    // 64-aligned block = ONE chunk when it spans at most chunk_mode different keys (adjacent octants / cells: one union
+    // block, full lanes, the per-chunk overhead paid once); a block that scatters over more keys (sparse far-range
+    // returns, one cell group per query) is cut at every key change so that no wavefront serialises many groups.
+    const bool key_head = kept && (lane == 0 || keys[i - 1] != key);
+    const unsigned long long km = __ballot(key_head);
+    const bool merge = __popcll(km) <= chunk_mode;
+    head = merge ? (kept && lane == 0) : key_head;
+    const unsigned long long kept_mask = __ballot(kept);
+    const unsigned long long hm = __ballot(head);
+    if (head) {
+      const unsigned long long later = (lane == 63) ? 0ull : (hm >> (lane + 1));
+      const int end = later ? lane + 1 + (__ffsll((long long)later) - 1) : (int)__popcll(kept_mask);
+      count = (uint32_t)(end - lane);
+    }
+  } else if (chunk_mode == 1) {  // experiment: 64-aligned blocks whatever the keys (full lanes, several cell groups per wavefront)
+    head = kept && (i & 63u) == 0;
+    if (head) {
+      if (i + 63 < n && keys[i + 63] != kKeyDropped) count = 64;
+      else {
+        uint32_t lo = i + 1, hi = (i + 63 < n) ? i + 63 : n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] != kKeyDropped) lo = mid + 1; else hi = mid; }
+        count = lo - i;
+      }
+    }
+  } else if (kept) {
     if (i == 0 || keys[i - 1] != key) {
       head = true;  // first query of a run
     } else if (i >= 64 && keys[i - 64] == key) {  // inside a long run: every 64th query counted from the run's start
@@ -178,8 +205,7 @@ __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __res
       head = ((i - lo) & 63u) == 0;
     }
   }
-  uint32_t count = 0;
-  if (head) {  // end of the chunk: 64 queries or the end of the run
+  if (head && chunk_mode == 0) {  // end of the chunk: 64 queries or the end of the run
     if (i + 63 < n && keys[i + 63] == key) {
       count = 64;
     } else {
@@ -1490,7 +1516,12 @@ using MergeCfg2 = rocprim::merge_sort_config<512, 512, 8, 128, 256, 8, 0>;
 using MergeCfg3 = rocprim::merge_sort_config<256, 256, 8, 128, 128, 8, 0>;
 using MergeCfg4 = rocprim::merge_sort_config<512, 256, 16, 128, 128, 4, (1u << 30)>;
 using MergeCfg5 = rocprim::merge_sort_config<512, 256, 8, 128, 128, 4, (1u << 30)>;
-static int sort_cfg() { static const int v = std::getenv("SOICP_SORT_CFG") ? std::atoi(std::getenv("SOICP_SORT_CFG")) : 0; return v; }
+using MergeCfg6 = rocprim::merge_sort_config<512, 512, 4, 128, 128, 4, (1u << 30)>;
+using MergeCfg7 = rocprim::merge_sort_config<1024, 512, 4, 128, 128, 4, (1u << 30)>;
+using MergeCfg8 = rocprim::merge_sort_config<256, 256, 8, 128, 128, 4, (1u << 30)>;
+using MergeCfg9 = rocprim::merge_sort_config<1024, 256, 8, 128, 128, 4, (1u << 30)>;
+// default 6: stable merge sort, 2048-item block sort + odd-even merges (61 us against 68 us for rocPRIM's own choice)
+static int sort_cfg() { static const int v = std::getenv("SOICP_SORT_CFG") ? std::atoi(std::getenv("SOICP_SORT_CFG")) : 6; return v; }
 template <class Cfg>
 static hipError_t merge_pairs(void* tmp, size_t& bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo, size_t n,
                               hipStream_t s) {
@@ -1504,6 +1535,10 @@ static hipError_t sort_dispatch(void* tmp, size_t& bytes, const uint32_t* ki, ui
     case 3: return merge_pairs<MergeCfg3>(tmp, bytes, ki, ko, vi, vo, n, s);
     case 4: return merge_pairs<MergeCfg4>(tmp, bytes, ki, ko, vi, vo, n, s);
     case 5: return merge_pairs<MergeCfg5>(tmp, bytes, ki, ko, vi, vo, n, s);
+    case 6: return merge_pairs<MergeCfg6>(tmp, bytes, ki, ko, vi, vo, n, s);
+    case 7: return merge_pairs<MergeCfg7>(tmp, bytes, ki, ko, vi, vo, n, s);
+    case 8: return merge_pairs<MergeCfg8>(tmp, bytes, ki, ko, vi, vo, n, s);
+    case 9: return merge_pairs<MergeCfg9>(tmp, bytes, ki, ko, vi, vo, n, s);
     default: return rocprim::radix_sort_pairs<SortConfig>(tmp, bytes, ki, ko, vi, vo, n, 0, end_bit, s);
   }
 }
@@ -1536,8 +1571,9 @@ void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t
 void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n, uint32_t dropped_key, uint32_t* chunk_start, DevState* st,
                         const float* d_scan, const uint32_t* perm, float* spx, float* spy, float* spz, hipStream_t s) {
   if (!n) return;
+  static const int chunk_mode = std::getenv("SOICP_CHUNK_MODE") ? std::atoi(std::getenv("SOICP_CHUNK_MODE")) : 0;
   hipLaunchKernelGGL(chunk_heads_kernel, grid_for(n, 1024), dim3(1024), 0, s, keys_sorted, n, dropped_key, chunk_start, st, d_scan, perm,
-                     spx, spy, spz);
+                     spx, spy, spz, chunk_mode);
 }
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* keys_sorted,
                       const uint32_t* chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
