@@ -17,6 +17,7 @@ HEADERS = ["kernels.h", "map_kernels.h", "device_map.h", "lm_solver.h", "local_m
 ARCH = "gfx950"
 # -ffp-contract=off: the fp64 plane fit / evaluation follow the reference's unfused arithmetic
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+COMMON += os.environ.get("SOICP_EXTRA_CXXFLAGS", "").split()  # experiments, e.g. -DSO_SOLVE_BLOCKS=512
 
 
 def _stale():

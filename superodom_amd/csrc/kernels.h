@@ -78,8 +78,11 @@ static_assert(sizeof(DevState) % 8 == 0, "DevState is copied in 8-byte words");
 constexpr int kHistReplicas = 16;    // histogram atomics are spread over replicas (contention), summed by eval_kernel
 constexpr int kHistStride = 32;      // ints per replica: reject[7] obs[9] stats[4]
 constexpr int kKnnBlocks = 2048;     // 8192 wavefronts, one per chunk (grid-stride beyond that); surplus wavefronts exit at once
-constexpr int kEvalBlocks = 256;     // one workgroup per CU
-constexpr int kFitBlocksMax = 256;   // plane-fit + first evaluation: one query per thread up to 131072 queries
+#ifndef SO_SOLVE_BLOCKS
+#define SO_SOLVE_BLOCKS 256
+#endif
+constexpr int kEvalBlocks = SO_SOLVE_BLOCKS;     // workgroups of the evaluation / solve launches (256 = one per CU, 512 = two)
+constexpr int kFitBlocksMax = SO_SOLVE_BLOCKS;
 // cross-workgroup synchronisation block of the evaluation kernels: 16 arrival counters on their own 128-byte lines,
 // then the 8 x 16-byte hand-off record {value, epoch} of solve_kernel
 constexpr int kArriveCounters = 16, kArriveStrideWords = 32, kHandoffWordOffset = kArriveCounters * kArriveStrideWords;

@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void copy_words(double* dst, const double* src, int n
 }
 static_assert(sizeof(LmState) % 8 == 0 && sizeof(LmSums) % 8 == 0, "controller state must be double-aligned");
 
-constexpr int kPartStride = 256;      // partials[a][workgroup]: transposed so that the last workgroup reads it coalesced
+constexpr int kPartStride = SO_SOLVE_BLOCKS;  // partials[a][workgroup]: transposed so that the last workgroup reads it coalesced
 static_assert(kEvalBlocks <= kPartStride && kFitBlocksMax <= kPartStride && kNAcc <= kSumsStride, "partials table");
 constexpr int kRedStride = kNAcc + 1;  // 30 doubles per record in LDS
 
@@ -1260,25 +1260,37 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   // load).  The compiler serialises agent-scope atomic loads with a vmcnt(0) after each (6 us measured), so the 29
   // sc1 loads are issued back to back, the controller state is fetched behind them, and ONE wait covers all.
   {
-    double r[kNAcc];
-    const bool have = tid < gridDim.x;  // no divergence around the asm: a register copy before the wait would read garbage
-    const double* rec = partials + (have ? tid : 0);
+    constexpr int kRec = (SO_SOLVE_BLOCKS + 255) / 256;  // records per thread
+    double r[kRec][kNAcc];
+    bool have[kRec];
 #pragma unroll
-    for (int a = 0; a < kNAcc; ++a)
-      asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r[a]) : "v"(rec + a * kPartStride) : "memory");
+    for (int q = 0; q < kRec; ++q) {
+      have[q] = (uint32_t)(tid + 256 * q) < gridDim.x;  // no divergence around the asm: a register copy before the wait would read garbage
+      const double* rec = partials + (have[q] ? tid + 256 * q : 0);
+#pragma unroll
+      for (int a = 0; a < kNAcc; ++a)
+        asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r[q][a]) : "v"(rec + a * kPartStride) : "memory");
+    }
     if (fuse_lm) {  // the controller state may have been written by another workgroup of this very launch: coherent loads
       if (tid < (int)(sizeof(LmState) / 8))
         reinterpret_cast<double*>(&sh_S)[tid] = __hip_atomic_load(reinterpret_cast<const double*>(&st->S) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       load_ctl(sh_ctl, st, tid, 128);
     }
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
-                   "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]),
-                   "+v"(r[17]), "+v"(r[18]), "+v"(r[19]), "+v"(r[20]), "+v"(r[21]), "+v"(r[22]), "+v"(r[23]), "+v"(r[24]),
-                   "+v"(r[25]), "+v"(r[26]), "+v"(r[27]), "+v"(r[28])
-                 :: "memory");
 #pragma unroll
-    for (int a = 0; a < kNAcc; ++a) red[tid][a] = have ? r[a] : 0.0;
+    for (int q = 0; q < kRec; ++q)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(r[q][0]), "+v"(r[q][1]), "+v"(r[q][2]), "+v"(r[q][3]), "+v"(r[q][4]), "+v"(r[q][5]), "+v"(r[q][6]), "+v"(r[q][7]),
+                     "+v"(r[q][8]), "+v"(r[q][9]), "+v"(r[q][10]), "+v"(r[q][11]), "+v"(r[q][12]), "+v"(r[q][13]), "+v"(r[q][14]),
+                     "+v"(r[q][15]), "+v"(r[q][16]), "+v"(r[q][17]), "+v"(r[q][18]), "+v"(r[q][19]), "+v"(r[q][20]), "+v"(r[q][21]),
+                     "+v"(r[q][22]), "+v"(r[q][23]), "+v"(r[q][24]), "+v"(r[q][25]), "+v"(r[q][26]), "+v"(r[q][27]), "+v"(r[q][28])
+                   :: "memory");
+#pragma unroll
+    for (int a = 0; a < kNAcc; ++a) {
+      double v = have[0] ? r[0][a] : 0.0;
+#pragma unroll
+      for (int q = 1; q < kRec; ++q) v += have[q] ? r[q][a] : 0.0;  // fixed order: record tid, tid + 256, ...
+      red[tid][a] = v;
+    }
   }
   __syncthreads();
   if (stamp) t_loaded = wall_clock64();
@@ -1320,7 +1332,7 @@ static_assert(sizeof(LmState) / 8 <= 256, "controller state is moved one word pe
 //              the first evaluation at the outer pose.
 // FIT = false: evaluations at the poses requested by the LM controller.
 template <bool FIT>
-__global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const float* __restrict__ spx,
+__global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void eval_kernel(int slot, int fuse_lm, const float* __restrict__ spx,
                                                    const float* __restrict__ spy, const float* __restrict__ spz,
                                                    CorrBuffers corr, DevState* __restrict__ st, EvalParams ep,
                                                    double* __restrict__ partials, uint32_t* __restrict__ ticket,
@@ -1339,7 +1351,7 @@ __global__ __launch_bounds__(256) void eval_kernel(int slot, int fuse_lm, const 
 // -- the XCDs' L2s are not coherent with each other, so nothing that crosses workgroups inside this launch goes
 // through plain loads.  Requires every workgroup to be resident (<= 256 workgroups of 256 threads, 60 KB LDS each: two
 // fit on a CU); a wait that exceeds 50 ms gives up (the host then reports the missing publication).
-__global__ __launch_bounds__(256) void solve_kernel(int lm_max, const float* __restrict__ spx, const float* __restrict__ spy,
+__global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int lm_max, const float* __restrict__ spx, const float* __restrict__ spy,
                                                     const float* __restrict__ spz, CorrBuffers corr, DevState* __restrict__ st,
                                                     EvalParams ep, double* __restrict__ partials, uint32_t* __restrict__ ticket,
                                                     int32_t* __restrict__ hist, LmSums* __restrict__ out,
