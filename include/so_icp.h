@@ -174,6 +174,31 @@ int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t str
 /* same, scan already resident in HBM as packed float xyz (n*3 floats, device pointer) */
 int so_icp_register_dev(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n,
                         const double pose_in[7], double pose_out[7], so_icp_stats *stats);
+/* Batched hypotheses (BASELINE.json configs[4], the "degeneracy / alignment-risk" use): the SAME scan registered from
+ * n_hyp initial poses (poses_in = n_hyp x 7).  Every hypothesis is an independent so_icp_register (own sort, own
+ * correspondences, own LM solves); the map window is shifted once, for hypothesis 0 (LS.cpp:363), and the context's
+ * scan-to-scan state (previous observability histogram, startup counter) is left as it was.  d_scan_xyz != NULL
+ * takes a scan already resident in HBM (so_icp_upload_scan), else scan_xyz is uploaded once.  Returns the number of
+ * hypotheses that returned SO_ICP_OK (>= 0), or a negative error; rc_out[h] (nullable) = status of hypothesis h. */
+int so_icp_register_batch(so_icp_ctx *ctx, const float *scan_xyz, const void *d_scan_xyz, size_t n, size_t stride_bytes,
+                          const double *poses_in, int n_hyp, double *poses_out, so_icp_stats *stats /* n_hyp, nullable */,
+                          int32_t *rc_out /* n_hyp, nullable */);
+
+/* LidarSLAM::EstimateRegistrationError (LS.cpp:854-889) from the final normal equations in so_icp_stats, without the
+ * A x 6 SVD: covariance in the tangent space = (J^T J)^-1 with the loss applied (ceres::Covariance,
+ * apply_loss_function = true, GetCovarianceBlockInTangentSpace), then the eigen-analysis of its position and
+ * orientation blocks (LS.h:127-151).  Host arithmetic only; returns SO_ICP_E_INVALID when J^T J is singular. */
+typedef struct {
+  double covariance[36];               /* row-major, DoF order X Y Z rX rY rZ */
+  double position_error;               /* sqrt(largest eigenvalue of the position block) */
+  double position_error_direction[3];
+  double pos_inverse_condition_num;    /* sqrt(lambda_min) / sqrt(lambda_max) */
+  double orientation_error_deg;        /* Rad2Deg(sqrt(largest eigenvalue of the orientation block)) */
+  double orientation_error_direction[3];
+  double ori_inverse_condition_num;
+} so_icp_registration_error_t;
+int so_icp_registration_error(const so_icp_stats *stats, so_icp_registration_error_t *out);
+
 /* upload a scan once and keep it resident in HBM (device pointer owned by the context until
  * so_icp_free_scan / so_icp_destroy) */
 int so_icp_upload_scan(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes, void **d_scan_out);

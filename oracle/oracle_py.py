@@ -261,3 +261,21 @@ class RefOctree:
         q = _f32(q).reshape(-1, 3); idx = np.zeros((len(q), k), np.int64); d2 = np.zeros((len(q), k), np.float32)
         self.R.ref_octree_knn(self.h, _p(q, C.c_float), len(q), k, _p(idx, C.c_int64), _p(d2, C.c_float))
         return idx, d2
+
+
+def registration_error(JtJ):
+    """Oracle for LidarSLAM::EstimateRegistrationError (LidarSlam.cpp:854-889; TEST INFRASTRUCTURE like the rest of oracle/).
+    ceres::Covariance with apply_loss_function=true in the tangent space = inverse of the loss-corrected J^T J
+    [UPSTREAM ceres 2.0.0 covariance_impl.cc]; then Eigen::SelfAdjointEigenSolver on the position / orientation blocks
+    (ascending eigenvalues, LS.cpp:874-886).  numpy restatement; parity unpinned upstream (the reference never consumes
+    the result)."""
+    import numpy as _np
+    H = _np.asarray(JtJ, dtype=_np.float64).reshape(6, 6)
+    cov = _np.linalg.inv(H)
+    cov = 0.5 * (cov + cov.T)
+    wp, vp = _np.linalg.eigh(cov[:3, :3])
+    wo, vo = _np.linalg.eigh(cov[3:, 3:])
+    return {"covariance": cov, "position_error": float(_np.sqrt(wp[2])), "position_error_direction": vp[:, 2],
+            "pos_inverse_condition_num": float(_np.sqrt(wp[0]) / _np.sqrt(wp[2])),
+            "orientation_error_deg": float(_np.degrees(_np.sqrt(wo[2]))), "orientation_error_direction": vo[:, 2],
+            "ori_inverse_condition_num": float(_np.sqrt(wo[0]) / _np.sqrt(wo[2]))}

@@ -40,6 +40,13 @@ class Stats(C.Structure):
                 ("iterations", IterStats * MAX_OUTER)]
 
 
+class RegistrationError(C.Structure):
+    """so_icp_registration_error_t (LidarSLAM::RegistrationError, LS.h:127-151)"""
+    _fields_ = [("covariance", C.c_double * 36), ("position_error", C.c_double), ("position_error_direction", C.c_double * 3),
+                ("pos_inverse_condition_num", C.c_double), ("orientation_error_deg", C.c_double),
+                ("orientation_error_direction", C.c_double * 3), ("ori_inverse_condition_num", C.c_double)]
+
+
 class Timing(C.Structure):
     _fields_ = [("knn_ms_total", C.c_double), ("knn_launches", C.c_int64), ("knn_queries", C.c_int64), ("knn_map_points", C.c_int64),
                 ("eval_ms_total", C.c_double), ("eval_launches", C.c_int64), ("eval_points", C.c_int64),
@@ -62,7 +69,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_map_size", "so_icp_map_clear", "so_icp_map_get_origin", "so_icp_knn_surf", "so_icp_register",
             "so_icp_register_dev", "so_icp_upload_scan", "so_icp_free_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
-            "so_icp_get_timing", "so_icp_reset_timing", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps"]
+            "so_icp_get_timing", "so_icp_reset_timing", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error"]
 
 _lib = None
 
@@ -110,6 +117,8 @@ def load():
     L.so_icp_reset_timing.argtypes = [vp]
     L.so_icp_synchronize.argtypes = [vp]
     L.so_icp_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.so_icp_register_batch.argtypes = [vp, f32p, vp, C.c_size_t, C.c_size_t, f64p, C.c_int, f64p, C.POINTER(Stats), i32p]
+    L.so_icp_registration_error.argtypes = [C.POINTER(Stats), C.POINTER(RegistrationError)]
     L.so_icp_debug_knn_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = L
     return L
@@ -240,6 +249,21 @@ class LidarSlamGpu:
         rc = self._check(self.L.so_icp_register_dev(self.h, d_scan, n, _p(pose_in, C.c_double), _p(out, C.c_double), C.byref(st)))
         return rc, out, st
 
+    def register_batch(self, scan, poses_in, d_scan=None, n=None):
+        """Same scan, many initial poses (so_icp_register_batch).  scan: host array, or None with (d_scan, n) from upload_scan.
+        Returns (number of hypotheses that converged normally, rc[B], poses_out[B,7], stats list)."""
+        poses_in = np.ascontiguousarray(poses_in, dtype=np.float64).reshape(-1, 7)
+        B = len(poses_in)
+        out = np.zeros((B, 7)); rcs = np.zeros(B, np.int32); st = (Stats * B)()
+        if d_scan is None:
+            scan = _f32(scan).reshape(-1, 3)
+            ok = self._check(self.L.so_icp_register_batch(self.h, _p(scan, C.c_float), None, len(scan), 12, _p(poses_in, C.c_double), B,
+                                                          _p(out, C.c_double), st, _p(rcs, C.c_int32)))
+        else:
+            ok = self._check(self.L.so_icp_register_batch(self.h, None, d_scan, n, 12, _p(poses_in, C.c_double), B,
+                                                          _p(out, C.c_double), st, _p(rcs, C.c_int32)))
+        return ok, rcs, out, list(st)
+
     def localization(self, initialization, T_w_lidar, planar_points, time_laser_odometry):
         scan = _f32(planar_points).reshape(-1, 3); T = np.ascontiguousarray(T_w_lidar, dtype=np.float64)
         out = np.zeros(7); st = Stats()
@@ -276,6 +300,13 @@ class LidarSlamGpu:
 
     def synchronize(self):
         self._check(self.L.so_icp_synchronize(self.h))
+
+
+def registration_error(stats):
+    """EstimateRegistrationError (LS.cpp:854-889) from the final normal equations; None when J^T J is singular."""
+    out = RegistrationError()
+    rc = load().so_icp_registration_error(C.byref(stats), C.byref(out))
+    return out if rc == 0 else None
 
 
 def comm_unique_id():

@@ -115,6 +115,8 @@ struct so_icp_ctx {
   // persistent LidarSLAM state
   int32_t prev_obs_hist[SO_ICP_N_OBS]{};
   bool have_hist = false;
+  int last_pos[3] = {0, 0, 0};
+  bool no_map_shift = false;  // so_icp_register_batch: hypotheses after the first keep the window of the first
   int startup_count = 0;
   double last_time = 0;
   // timing
@@ -301,7 +303,8 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   std::memcpy(pose_out, pose_in, sizeof(T));
   if (c->have_hist) uncertainty_from_hist(c->prev_obs_hist, st->uncertainty);  // LidarSlam.cpp:47
   int pos[3];
-  map_shift(c, T, pos);                                                       // LidarSlam.cpp:363
+  if (!c->no_map_shift) { map_shift(c, T, pos); std::memcpy(c->last_pos, pos, sizeof(pos)); }  // LidarSlam.cpp:363
+  else std::memcpy(pos, c->last_pos, sizeof(pos));
   st->pos_in_localmap[0] = pos[0]; st->pos_in_localmap[1] = pos[1]; st->pos_in_localmap[2] = pos[2];
   st->laser_cloud_surf_from_map_num = map_count_5x5(c, pos);                  // LidarSlam.cpp:367
   st->laser_cloud_surf_stack_num = (int32_t)n;
@@ -769,6 +772,112 @@ int so_icp_register(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_byt
   const int rc = upload_scan_impl(c, xyz, n, stride_bytes, c->d_scan_own);
   if (rc) return rc;
   return register_core(c, c->d_scan_own.as<float>(), n, pose_in, pose_out, st);
+}
+
+int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, size_t n, size_t stride_bytes, const double* poses_in,
+                          int n_hyp, double* poses_out, so_icp_stats* stats, int32_t* rc_out) {
+  if (!c || !poses_in || !poses_out || n_hyp < 0 || (!xyz && !d_scan && n)) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  const float* scan = static_cast<const float*>(d_scan);
+  if (!scan) {
+    const int rc = upload_scan_impl(c, xyz, n, stride_bytes, c->d_scan_own);
+    if (rc) return rc;
+    scan = c->d_scan_own.as<float>();
+  }
+  // scan-to-scan state of the tracker is not advanced by hypothesis testing
+  int32_t saved_hist[SO_ICP_N_OBS];
+  std::memcpy(saved_hist, c->prev_obs_hist, sizeof(saved_hist));
+  const bool saved_have = c->have_hist;
+  const int saved_startup = c->startup_count;
+  int ok = 0, err = 0;
+  for (int h = 0; h < n_hyp; ++h) {
+    c->no_map_shift = h > 0;  // the window is placed by hypothesis 0 (all hypotheses must see the same map)
+    so_icp_stats local;
+    const int rc = register_core(c, scan, n, poses_in + 7 * (size_t)h, poses_out + 7 * (size_t)h, stats ? stats + h : &local);
+    std::memcpy(c->prev_obs_hist, saved_hist, sizeof(saved_hist));
+    c->have_hist = saved_have; c->startup_count = saved_startup;
+    if (rc_out) rc_out[h] = rc;
+    if (rc == SO_ICP_OK) ++ok;
+    if (rc < 0) { err = rc; break; }
+  }
+  c->no_map_shift = false;
+  return err ? err : ok;
+}
+
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi), ascending eigenvalues, eigenvectors in the columns of V
+static void eig3_host(const double A[9], double ev[3], double V[9]) {
+  double a[9]; std::memcpy(a, A, sizeof(a));
+  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 32; ++sweep) {
+    const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+    if (off <= 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        const double apq = a[3 * p + q];
+        if (apq == 0.0) continue;
+        const double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < 3; ++k) {  // A <- A G
+          const double akp = a[3 * k + p], akq = a[3 * k + q];
+          a[3 * k + p] = cs * akp - sn * akq; a[3 * k + q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < 3; ++k) {  // A <- G^T A
+          const double apk = a[3 * p + k], aqk = a[3 * q + k];
+          a[3 * p + k] = cs * apk - sn * aqk; a[3 * q + k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < 3; ++k) {
+          const double vkp = V[3 * k + p], vkq = V[3 * k + q];
+          V[3 * k + p] = cs * vkp - sn * vkq; V[3 * k + q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  int idx[3] = {0, 1, 2};
+  for (int i = 0; i < 3; ++i) ev[i] = a[4 * i];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2 - i; ++j)
+      if (ev[idx[j]] > ev[idx[j + 1]]) std::swap(idx[j], idx[j + 1]);
+  double e2[3], V2[9];
+  for (int c2 = 0; c2 < 3; ++c2) { e2[c2] = ev[idx[c2]]; for (int r = 0; r < 3; ++r) V2[3 * r + c2] = V[3 * r + idx[c2]]; }
+  std::memcpy(ev, e2, sizeof(e2)); std::memcpy(V, V2, sizeof(V2));
+}
+
+int so_icp_registration_error(const so_icp_stats* st, so_icp_registration_error_t* out) {
+  if (!st || !out) return SO_ICP_E_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  // (J^T J)^-1 by Cholesky: L L^T = H, then solve for the six unit vectors
+  double L[36];
+  for (int j = 0; j < 6; ++j) {
+    double d = st->JtJ[6 * j + j];
+    for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
+    if (!(d > 0.0) || !std::isfinite(d)) return SO_ICP_E_INVALID;
+    L[6 * j + j] = std::sqrt(d);
+    for (int i = j + 1; i < 6; ++i) {
+      double s = st->JtJ[6 * i + j];
+      for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
+      L[6 * i + j] = s / L[6 * j + j];
+    }
+  }
+  for (int c2 = 0; c2 < 6; ++c2) {
+    double z[6], x[6];
+    for (int i = 0; i < 6; ++i) { double s = (i == c2) ? 1.0 : 0.0; for (int k = 0; k < i; ++k) s -= L[6 * i + k] * z[k]; z[i] = s / L[6 * i + i]; }
+    for (int i = 5; i >= 0; --i) { double s = z[i]; for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k]; x[i] = s / L[6 * i + i]; }
+    for (int r = 0; r < 6; ++r) out->covariance[6 * r + c2] = x[r];
+  }
+  for (int r = 0; r < 6; ++r)  // symmetrise the rounding
+    for (int c2 = r + 1; c2 < 6; ++c2) { const double m = 0.5 * (out->covariance[6 * r + c2] + out->covariance[6 * c2 + r]); out->covariance[6 * r + c2] = out->covariance[6 * c2 + r] = m; }
+  double P[9], O[9], ev[3], V[9];
+  for (int r = 0; r < 3; ++r) for (int c2 = 0; c2 < 3; ++c2) { P[3 * r + c2] = out->covariance[6 * r + c2]; O[3 * r + c2] = out->covariance[6 * (r + 3) + c2 + 3]; }
+  eig3_host(P, ev, V);
+  out->position_error = std::sqrt(ev[2]);
+  for (int r = 0; r < 3; ++r) out->position_error_direction[r] = V[3 * r + 2];
+  out->pos_inverse_condition_num = std::sqrt(ev[0]) / std::sqrt(ev[2]);
+  eig3_host(O, ev, V);
+  out->orientation_error_deg = std::sqrt(ev[2]) * 180.0 / M_PI;
+  for (int r = 0; r < 3; ++r) out->orientation_error_direction[r] = V[3 * r + 2];
+  out->ori_inverse_condition_num = std::sqrt(ev[0]) / std::sqrt(ev[2]);
+  return SO_ICP_OK;
 }
 
 int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7], const float* xyz, size_t n, size_t stride_bytes,

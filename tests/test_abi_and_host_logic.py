@@ -148,3 +148,29 @@ def test_lm_controller_no_residuals(soicp):
     more, nxt = drv.begin(x0, soicp.LmDriver.sums(0.0, 0.0, np.zeros(6), np.zeros((6, 6))), 4)
     pose, st = drv.result()
     assert more == 0 and st.termination == 4 and np.array_equal(pose, x0)
+
+
+def test_registration_error_matches_numpy_oracle(soicp, oracle):
+    """so_icp_registration_error (EstimateRegistrationError, LS.cpp:854-889) is host arithmetic: covariance = inverse of
+    the loss-corrected J^T J, eigen-analysis of its 3x3 blocks -- against the numpy oracle."""
+    rng = np.random.default_rng(7)
+    for trial in range(20):
+        J = rng.normal(size=(200, 6)) * np.array([1, 1, 0.3, 5, 5, 2.0]) * (0.05 if trial == 19 else 1.0)
+        H = J.T @ J
+        st = soicp.Stats()
+        for i in range(36):
+            st.JtJ[i] = H.flat[i]
+        e = soicp.registration_error(st)
+        o = oracle.registration_error(H)
+        assert e is not None
+        cov = np.array(e.covariance).reshape(6, 6)
+        assert np.allclose(cov, o["covariance"], rtol=1e-10, atol=1e-14)
+        assert np.isclose(e.position_error, o["position_error"], rtol=1e-10)
+        assert np.isclose(e.orientation_error_deg, o["orientation_error_deg"], rtol=1e-10)
+        assert np.isclose(e.pos_inverse_condition_num, o["pos_inverse_condition_num"], rtol=1e-9)
+        assert np.isclose(e.ori_inverse_condition_num, o["ori_inverse_condition_num"], rtol=1e-9)
+        # eigenvector signs are free
+        assert abs(abs(np.dot(np.array(e.position_error_direction), o["position_error_direction"])) - 1) < 1e-8
+        assert abs(abs(np.dot(np.array(e.orientation_error_direction), o["orientation_error_direction"])) - 1) < 1e-8
+    sing = soicp.Stats()  # all-zero J^T J: singular
+    assert soicp.registration_error(sing) is None

@@ -172,6 +172,33 @@ def test_control_flow_variants_are_bit_identical(oracle, gpu_slam_factory, monke
         assert np.array_equal(np.array(s1.JtJ), np.array(s2.JtJ))
 
 
+def test_register_batch_hypotheses_match_single_registrations_and_oracle(oracle, gpu_slam_factory, soicp):
+    """so_icp_register_batch (BASELINE configs[4]): B initial poses for one scan = B independent registrations; the
+    tracker state (previous observability histogram) is not advanced; covariance of each result from its J^T J."""
+    sc, slam, om = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
+    scan = sc.scan(2)
+    rng = np.random.default_rng(5)
+    poses = np.stack([synth.perturb_pose(sc.gt_pose(2), 5000 + h, 0.25, 2.5) for h in range(6)])
+    _, p_before, s_before = slam.register(scan, sc.guess(2))
+    ok, rcs, out, sts = slam.register_batch(scan, poses)
+    assert ok == int(np.sum(rcs == 0)) and len(out) == 6
+    for h in range(6):
+        orc, opose, ost, _ = om.register(scan, poses[h], oracle.default_config(max_iterations=5))
+        assert rcs[h] == orc and sts[h].n_iterations == ost.n_iterations
+        good, dt, dr = pose_close(out[h], opose, 1e-8, 1e-8)
+        assert good, (h, dt, dr)
+        e = soicp.registration_error(sts[h])
+        o = oracle.registration_error(np.array(sts[h].JtJ))
+        assert e is not None and np.isclose(e.position_error, o["position_error"], rtol=1e-9)
+    # the batch left the scan-to-scan state alone: the same registration gives the same uncertainty inputs again
+    _, p_after, s_after = slam.register(scan, sc.guess(2))
+    assert np.array_equal(p_before, p_after) and list(s_after.uncertainty) == list(slam.register(scan, sc.guess(2))[2].uncertainty)
+    # resident-scan variant
+    d, n = slam.upload_scan(scan)
+    ok2, rcs2, out2, _ = slam.register_batch(None, poses, d_scan=d, n=n)
+    assert ok2 == ok and np.array_equal(out2, out)
+
+
 def test_rccl_path_world1_matches_oracle(oracle, gpu_slam_factory, soicp):
     """The N>1 code path (eval -> ncclAllReduce(45 fp64) -> lm_step_kernel) on a 1-rank RCCL communicator."""
     sc, slam, om = _setup("tiny", oracle, gpu_slam_factory, max_iterations=5)
