@@ -211,6 +211,27 @@ int so_icp_localization(so_icp_ctx *ctx, int initialization, const double T_w_li
                         const float *planar_xyz, size_t n, size_t stride_bytes, double time_laser_odometry,
                         double pose_out[7], so_icp_stats *stats);
 
+/* same, scan already resident in HBM as packed float xyz (e.g. the output of so_icp_prefilter_scan) */
+int so_icp_localization_dev(so_icp_ctx *ctx, int initialization, const double T_w_lidar[7], const void *d_scan_xyz, size_t n,
+                            double time_laser_odometry, double pose_out[7], so_icp_stats *stats);
+/* copy a resident scan (packed float xyz) back to the host */
+int so_icp_download_scan(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n, float *out_xyz);
+
+/* -------- the step before Seam A: laserMapping::adjustVoxelSize (lmap.cpp:598-651) on the device ----------------
+ * auto_voxel_size != 0: average_distance = mean|x| * mean|y| * mean|z| of the surf cloud chooses the resolutions
+ * (< 25: 0.1 / 0.2, > 65: 0.4 / 0.8, else unchanged), count_far_points (> 3 m) > 3000 raises increase_blind_radius.
+ * Then pcl::VoxelGrid (leaf = planeRes: float leaf coordinates, centroids accumulated in float in input order, output in
+ * ascending leaf index; "leaf size too small" passes the cloud through) and localMap.lineRes_/planeRes_ = the result
+ * (lmap.cpp:648-649).  *d_filtered_out (packed float xyz, owned by the context, valid until the next call) feeds
+ * so_icp_register_dev / so_icp_localization_dev without a host round trip. */
+typedef struct {
+  double average_distance;
+  int32_t count_far_points, increase_blind_radius;
+  float line_res, plane_res;  /* resolutions in effect after the call */
+} so_icp_prefilter_info;
+int so_icp_prefilter_scan(so_icp_ctx *ctx, const float *surf_xyz, size_t n, size_t stride_bytes, int auto_voxel_size,
+                          float line_res, float plane_res, void **d_filtered_out, size_t *n_out, so_icp_prefilter_info *info);
+
 /* -------- multi-GPU: one process per GPU, one collective (sum of 45 fp64) per evaluation ------- */
 #define SO_ICP_UNIQUE_ID_BYTES 128
 int so_icp_comm_unique_id(uint8_t id[SO_ICP_UNIQUE_ID_BYTES]);                 /* rank 0: ncclGetUniqueId */

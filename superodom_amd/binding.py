@@ -47,6 +47,11 @@ class RegistrationError(C.Structure):
                 ("orientation_error_direction", C.c_double * 3), ("ori_inverse_condition_num", C.c_double)]
 
 
+class PrefilterInfo(C.Structure):
+    _fields_ = [("average_distance", C.c_double), ("count_far_points", C.c_int32), ("increase_blind_radius", C.c_int32),
+                ("line_res", C.c_float), ("plane_res", C.c_float)]
+
+
 class Timing(C.Structure):
     _fields_ = [("knn_ms_total", C.c_double), ("knn_launches", C.c_int64), ("knn_queries", C.c_int64), ("knn_map_points", C.c_int64),
                 ("eval_ms_total", C.c_double), ("eval_launches", C.c_int64), ("eval_points", C.c_int64),
@@ -69,7 +74,8 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_map_size", "so_icp_map_clear", "so_icp_map_get_origin", "so_icp_knn_surf", "so_icp_register",
             "so_icp_register_dev", "so_icp_upload_scan", "so_icp_free_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
-            "so_icp_get_timing", "so_icp_reset_timing", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error"]
+            "so_icp_get_timing", "so_icp_reset_timing", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
+            "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan"]
 
 _lib = None
 
@@ -119,6 +125,10 @@ def load():
     L.so_icp_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.so_icp_register_batch.argtypes = [vp, f32p, vp, C.c_size_t, C.c_size_t, f64p, C.c_int, f64p, C.POINTER(Stats), i32p]
     L.so_icp_registration_error.argtypes = [C.POINTER(Stats), C.POINTER(RegistrationError)]
+    L.so_icp_localization_dev.argtypes = [vp, C.c_int, f64p, vp, C.c_size_t, C.c_double, f64p, C.POINTER(Stats)]
+    L.so_icp_download_scan.argtypes = [vp, vp, C.c_size_t, f32p]
+    L.so_icp_prefilter_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_float, C.c_float, C.POINTER(vp),
+                                        C.POINTER(C.c_size_t), C.POINTER(PrefilterInfo)]
     L.so_icp_debug_knn_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = L
     return L
@@ -270,6 +280,24 @@ class LidarSlamGpu:
         rc = self._check(self.L.so_icp_localization(self.h, int(bool(initialization)), _p(T, C.c_double), _p(scan, C.c_float),
                                                     len(scan), 12, float(time_laser_odometry), _p(out, C.c_double), C.byref(st)))
         return rc, out, st
+
+    def localization_dev(self, initialization, T_w_lidar, d_scan, n, time_laser_odometry):
+        T = np.ascontiguousarray(T_w_lidar, dtype=np.float64); out = np.zeros(7); st = Stats()
+        rc = self._check(self.L.so_icp_localization_dev(self.h, int(bool(initialization)), _p(T, C.c_double), d_scan, n,
+                                                        float(time_laser_odometry), _p(out, C.c_double), C.byref(st)))
+        return rc, out, st
+
+    def download_scan(self, d_scan, n):
+        out = np.zeros((n, 3), np.float32)
+        self._check(self.L.so_icp_download_scan(self.h, d_scan, n, _p(out, C.c_float)))
+        return out
+
+    def prefilter_scan(self, surf_points, auto_voxel_size, line_res, plane_res):
+        """laserMapping::adjustVoxelSize on the device; returns (d_scan, n, PrefilterInfo)."""
+        pts = _f32(surf_points).reshape(-1, 3); d = C.c_void_p(); n = C.c_size_t(0); info = PrefilterInfo()
+        self._check(self.L.so_icp_prefilter_scan(self.h, _p(pts, C.c_float), len(pts), 12, int(bool(auto_voxel_size)), float(line_res),
+                                                 float(plane_res), C.byref(d), C.byref(n), C.byref(info)))
+        return d.value, n.value, info
 
     # ---- multi-GPU ----
     def comm_init(self, uid_bytes):

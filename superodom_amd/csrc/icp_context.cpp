@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -110,6 +111,7 @@ struct so_icp_ctx {
   int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
   int sync_per_outer = 1;  // 1: read back reg_done after every outer iteration and stop enqueuing (eager mode)
   std::vector<DevBuf> resident_scans;  // so_icp_upload_scan
+  DevBuf pf_in, pf_out, pf_small, pf_w, pf_s, pf_k0, pf_k1, pf_v0, pf_v1, pf_flags, pf_pos, pf_heads, pf_temp;  // so_icp_prefilter_scan
   // Seam B scratch
   DevBuf d_q, d_nbr, d_d2, d_idx, d_found, d_fblist;
   // persistent LidarSLAM state
@@ -526,7 +528,8 @@ so_icp_ctx::~so_icp_ctx() {
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1, &d_chunks,
                     &d_sort_tmp, &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
-                    &d_found, &d_fblist, &d_kdbg})
+                    &d_found, &d_fblist, &d_kdbg, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
+                    &pf_heads, &pf_temp})
     b->release();
   for (DevBuf& b : resident_scans) b.release();
   d_state_buf.release();
@@ -919,6 +922,135 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   if (c->dmap) { const int r = transform_and_add_dev(pose_out); if (r) return r; }  // LidarSlam.cpp:163-167
   else transform_and_add(pose_out);
   c->last_time = time_laser_odometry;
+  return SO_ICP_OK;
+}
+
+int so_icp_download_scan(so_icp_ctx* c, const void* d_scan, size_t n, float* out_xyz) {
+  if (!c || (!d_scan && n) || (!out_xyz && n)) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  if (!n) return SO_ICP_OK;
+  HIP_TRY(c, hipMemcpyAsync(out_xyz, d_scan, n * 12, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SO_ICP_OK;
+}
+
+int so_icp_localization_dev(so_icp_ctx* c, int initialization, const double T_in[7], const void* d_scan, size_t n,
+                            double time_laser_odometry, double pose_out[7], so_icp_stats* st) {
+  if (!c || !T_in || !pose_out || (!d_scan && n)) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  if (!c->dmap) {  // host-side LocalMap (sharded ranks): the insert needs the points on the host
+    std::vector<float> h(n * 3);
+    const int rc = so_icp_download_scan(c, d_scan, n, h.data());
+    if (rc) return rc;
+    return so_icp_localization(c, initialization, T_in, h.data(), n, 12, time_laser_odometry, pose_out, st);
+  }
+  auto transform_and_add_dev = [&](const double T[7]) -> int {  // transformAndAddToMap (LidarSlam.cpp:60-80) on the device
+    HIP_TRY(c, c->d_world.reserve((n + 64) * 12));
+    launch_transform_scan(static_cast<const float*>(d_scan), (uint32_t)n, pose_from_array(T), c->d_world.as<float>(), c->stream);
+    return c->dmap->add_surf_dev(c->d_world.as<float>(), n, 3, c->err) < 0 ? SO_ICP_E_HIP : SO_ICP_OK;
+  };
+  if (!initialization) {  // initializeMapping, LidarSlam.cpp:83-94
+    std::memcpy(pose_out, T_in, 7 * sizeof(double));
+    if (st) std::memset(st, 0, sizeof(*st));
+    c->dmap->set_origin(T_in);
+    const int r = transform_and_add_dev(T_in);
+    if (r) return r;
+    c->last_time = time_laser_odometry;
+    return SO_ICP_MAP_SEEDED;
+  }
+  so_icp_stats local;
+  if (!st) st = &local;
+  const int rc = register_core(c, static_cast<const float*>(d_scan), n, T_in, pose_out, st);
+  if (rc != SO_ICP_OK) return rc;
+  const double dt = time_laser_odometry - c->last_time;  // checkMotionThresholds, LidarSlam.cpp:173-195
+  if (st->translation_from_last / dt > c->cfg.velocity_failure_threshold) c->startup_count = 5;
+  st->startup_count = c->startup_count;
+  const int r = transform_and_add_dev(pose_out);  // LidarSlam.cpp:163-167
+  if (r) return r;
+  c->last_time = time_laser_odometry;
+  return SO_ICP_OK;
+}
+
+// laserMapping::adjustVoxelSize (laserMapping.cpp:598-651) on the device: cloud statistics -> resolution choice ->
+// pcl::VoxelGrid of the surf cloud at planeRes; the resolutions are pushed into the context like the node does.
+int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, int auto_voxel_size, float line_res,
+                          float plane_res, void** d_out, size_t* n_out, so_icp_prefilter_info* info) {
+  if (!c || (!xyz && n) || !d_out || !n_out) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  if (stride_bytes == 0) stride_bytes = 12;
+  if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
+  const uint32_t sf = (uint32_t)(stride_bytes / 4);
+  hipStream_t s = c->stream;
+  so_icp_prefilter_info li;
+  std::memset(&li, 0, sizeof(li));
+  li.line_res = line_res; li.plane_res = plane_res;
+  *d_out = nullptr; *n_out = 0;
+  if (!n) { if (info) *info = li; return so_icp_set_resolution(c, line_res, plane_res); }
+  // raw cloud -> device (with its stride)
+  HIP_TRY(c, c->pf_in.reserve(n * stride_bytes + 64));
+  HIP_TRY(c, hipMemcpyAsync(c->pf_in.p, xyz, n * stride_bytes, hipMemcpyHostToDevice, s));
+  // statistics + bounding box (fp64 tree sums; the reference accumulates |x|,|y|,|z| in float in input order --
+  // the statistic only feeds the 25 / 65 thresholds and the 3000-far-points flag)
+  constexpr int kStatBlocks = 256;
+  HIP_TRY(c, c->pf_small.reserve(kStatBlocks * 10 * sizeof(double) + 64));
+  launch_vg_stats(c->pf_in.as<float>(), (uint32_t)n, sf, c->pf_small.as<double>(), kStatBlocks, s);
+  std::vector<double> part((size_t)kStatBlocks * 10);
+  HIP_TRY(c, hipMemcpyAsync(part.data(), c->pf_small.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  double acc[10] = {0, 0, 0, 0, 3.0e38, 3.0e38, 3.0e38, -3.0e38, -3.0e38, -3.0e38};
+  for (int b = 0; b < kStatBlocks; ++b)
+    for (int k = 0; k < 10; ++k) {
+      const double v = part[(size_t)b * 10 + k];
+      acc[k] = k < 4 ? acc[k] + v : (k < 7 ? std::min(acc[k], v) : std::max(acc[k], v));
+    }
+  if (auto_voxel_size) {
+    const float ax = (float)(acc[0] / (double)n), ay = (float)(acc[1] / (double)n), az = (float)(acc[2] / (double)n);
+    li.average_distance = (double)(ax * ay * az);       // laserMapping.cpp:620-621 (float product)
+    li.count_far_points = (int32_t)acc[3];
+    li.increase_blind_radius = li.count_far_points > 3000;
+    if (li.average_distance < 25) { li.line_res = 0.1f; li.plane_res = 0.2f; }
+    else if (li.average_distance > 65) { li.line_res = 0.4f; li.plane_res = 0.8f; }
+  }
+  int rc = so_icp_set_resolution(c, li.line_res, li.plane_res);  // lmap.cpp:648-649
+  if (rc) return rc;
+  // pcl::VoxelGrid::applyFilter: bounding box -> min_b / div_b; "leaf size too small" passes the cloud through
+  const float leaf = li.plane_res, inv = 1.0f / leaf;
+  const float mn[3] = {(float)acc[4], (float)acc[5], (float)acc[6]}, mx[3] = {(float)acc[7], (float)acc[8], (float)acc[9]};
+  const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+  HIP_TRY(c, c->pf_out.reserve((n + 64) * 12));
+  if (dx * dy * dz > (int64_t)INT32_MAX) {
+    if (sf == 3) HIP_TRY(c, hipMemcpyAsync(c->pf_out.p, c->pf_in.p, n * 12, hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(c, hipMemcpy2DAsync(c->pf_out.p, 12, c->pf_in.p, stride_bytes, 12, n, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *d_out = c->pf_out.p; *n_out = n;
+    if (info) *info = li;
+    return SO_ICP_OK;
+  }
+  VoxelFilterArgs a{};
+  for (int k = 0; k < 3; ++k) {
+    a.min_b[k] = (int)std::floor(mn[k] * inv);
+    a.div_b[k] = (int)std::floor(mx[k] * inv) - a.min_b[k] + 1;
+  }
+  const size_t cap = n + 1024;
+  HIP_TRY(c, c->pf_w.reserve(cap * 16)); HIP_TRY(c, c->pf_s.reserve(cap * 16));
+  for (DevBuf* b : {&c->pf_k0, &c->pf_k1, &c->pf_v0, &c->pf_v1, &c->pf_flags, &c->pf_pos, &c->pf_heads}) HIP_TRY(c, b->reserve((cap + 1) * 4));
+  const size_t tb = map_sort_temp_bytes(cap) + 256;
+  HIP_TRY(c, c->pf_temp.reserve(tb));
+  HIP_TRY(c, hipMemsetAsync(c->pf_small.p, 0, 64, s));
+  a.d_xyz = c->pf_in.as<float>(); a.n = (uint32_t)n; a.stride_floats = sf; a.inv_leaf = inv;
+  a.wpts = c->pf_w.as<float4>(); a.spts = c->pf_s.as<float4>();
+  a.keys0 = c->pf_k0.as<uint32_t>(); a.keys1 = c->pf_k1.as<uint32_t>(); a.vals0 = c->pf_v0.as<uint32_t>(); a.vals1 = c->pf_v1.as<uint32_t>();
+  a.flags = c->pf_flags.as<uint32_t>(); a.pos = c->pf_pos.as<uint32_t>(); a.heads = c->pf_heads.as<uint32_t>();
+  a.d_n_cent = c->pf_small.as<uint32_t>(); a.d_out = c->pf_out.as<float>();
+  a.temp = c->pf_temp.p; a.temp_bytes = c->pf_temp.cap;
+  launch_voxel_filter(a, s);
+  uint32_t n_leaves = 0;
+  HIP_TRY(c, hipMemcpyAsync(&n_leaves, c->pf_small.p, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  *d_out = c->pf_out.p; *n_out = n_leaves;
+  if (info) *info = li;
   return SO_ICP_OK;
 }
 

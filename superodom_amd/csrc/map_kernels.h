@@ -35,6 +35,19 @@ struct MapInsertArgs {
   void* temp; size_t temp_bytes;
 };
 
+// scan pre-filter (adjustVoxelSize): statistics + VoxelGrid of one cloud
+struct VoxelFilterArgs {
+  const float* d_xyz; uint32_t n, stride_floats;
+  float inv_leaf; int min_b[3], div_b[3];
+  float4 *wpts, *spts;
+  uint32_t *keys0, *keys1, *vals0, *vals1, *flags, *pos, *heads;
+  uint32_t* d_n_cent;  // [0] number of leaves, [1] long-leaf counter (both zeroed by the caller)
+  float* d_out;        // packed xyz centroids in ascending leaf index
+  void* temp; size_t temp_bytes;
+};
+void launch_vg_stats(const float* d_xyz, uint32_t n, uint32_t stride_floats, double* d_part /* blocks x 10 */, int blocks, hipStream_t s);
+void launch_voxel_filter(const VoxelFilterArgs& a, hipStream_t s);
+
 size_t map_sort_temp_bytes(size_t n);
 void launch_world_cube(const float* d_xyz, uint32_t n, uint32_t stride_floats, const int origin[3], int32_t* d_cube_of,
                        uint8_t* d_touched, uint32_t* d_n_inside, hipStream_t s);

@@ -279,6 +279,106 @@ __global__ __launch_bounds__(256) void gather_export_kernel(const float4* __rest
 // ------------------------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
+// ------------------------------------------------------------------------------------------------
+// Scan pre-filter (laserMapping::adjustVoxelSize, laserMapping.cpp:598-651): cloud statistics + pcl::VoxelGrid of the
+// surf cloud at planeRes, on the device.
+// ------------------------------------------------------------------------------------------------
+// per-workgroup partial sums of |x|, |y|, |z| (fp64), count of points farther than 3 m, min / max of the coordinates
+__global__ __launch_bounds__(256) void vg_stats_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats,
+                                                       double* __restrict__ part /* [blocks][10] */) {
+  __shared__ double sh[256][10];
+  double a[10] = {0, 0, 0, 0, 3.0e38, 3.0e38, 3.0e38, -3.0e38, -3.0e38, -3.0e38};
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float* p = xyz + (size_t)i * stride_floats;
+    const float x = p[0], y = p[1], z = p[2];
+    a[0] += (double)fabsf(x); a[1] += (double)fabsf(y); a[2] += (double)fabsf(z);
+    if (x * x + y * y + z * z > 9.f) a[3] += 1.0;  // laserMapping.cpp:611 (float arithmetic)
+    a[4] = fmin(a[4], (double)x); a[5] = fmin(a[5], (double)y); a[6] = fmin(a[6], (double)z);
+    a[7] = fmax(a[7], (double)x); a[8] = fmax(a[8], (double)y); a[9] = fmax(a[9], (double)z);
+  }
+  for (int k = 0; k < 10; ++k) sh[threadIdx.x][k] = a[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int k = 0; k < 10; ++k) {
+        const double o = sh[threadIdx.x + s][k];
+        double& m = sh[threadIdx.x][k];
+        m = k < 4 ? m + o : (k < 7 ? fmin(m, o) : fmax(m, o));
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x < 10) part[(size_t)blockIdx.x * 10 + threadIdx.x] = sh[0][threadIdx.x];
+}
+
+// pcl::VoxelGrid leaf index: ijk = floor(p * inv_leaf) - min_b in float arithmetic, idx = i0 + i1*d0 + i2*d0*d1
+__global__ __launch_bounds__(256) void vg_keys_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats, float inv_leaf,
+                                                      int mb0, int mb1, int mb2, int d0, int d01, float4* __restrict__ wpts,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = xyz + (size_t)i * stride_floats;
+  const float x = p[0], y = p[1], z = p[2];
+  wpts[i] = make_float4(x, y, z, 0.f);
+  vals[i] = i;
+  const int i0 = (int)(floorf(x * inv_leaf) - (float)mb0), i1 = (int)(floorf(y * inv_leaf) - (float)mb1), i2 = (int)(floorf(z * inv_leaf) - (float)mb2);
+  keys[i] = (uint32_t)(i0 + i1 * d0 + i2 * d01);
+}
+
+// centroid of every leaf (float sums in the stable-sorted input order), packed xyz out; long leaves go to the wavefront kernel
+__global__ __launch_bounds__(256) void vg_centroid_kernel(const uint32_t* __restrict__ heads, const uint32_t* __restrict__ n_cent,
+                                                          const float4* __restrict__ spts, float* __restrict__ out,
+                                                          uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= *n_cent) return;
+  const uint32_t beg = heads[o], end = heads[o + 1];
+  if (end - beg > kLongLeaf) {
+    const uint32_t at = atomicAdd(long_count, 1u);
+    if (at < kMaxLongLeaves) { long_list[at] = o; return; }
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  constexpr int B = 16;
+  for (uint32_t j = beg; j < end; j += B) {
+    float4 cur[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) cur[k] = spts[j + k < end ? j + k : end - 1];
+#pragma unroll
+    for (int k = 0; k < B; ++k)
+      if (j + k < end) { s0 += cur[k].x; s1 += cur[k].y; s2 += cur[k].z; }
+  }
+  const float cnt = (float)(end - beg);
+  out[3 * (size_t)o] = s0 / cnt; out[3 * (size_t)o + 1] = s1 / cnt; out[3 * (size_t)o + 2] = s2 / cnt;
+}
+__global__ __launch_bounds__(256) void vg_centroid_long_kernel(const uint32_t* __restrict__ heads, const float4* __restrict__ spts,
+                                                               float* __restrict__ out, const uint32_t* __restrict__ long_list,
+                                                               const uint32_t* __restrict__ long_count) {
+  const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_long = *long_count < kMaxLongLeaves ? *long_count : kMaxLongLeaves;
+  if (w >= n_long) return;
+  const uint32_t o = long_list[w];
+  const uint32_t beg = heads[o], end = heads[o + 1];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  float4 cur = spts[beg + lane < end ? beg + lane : end - 1];
+  for (uint32_t j = beg; j < end; j += 64) {
+    const uint32_t jn = j + 64;
+    float4 nxt = cur;
+    if (jn < end) nxt = spts[jn + lane < end ? jn + lane : end - 1];
+    const bool live = j + (uint32_t)lane < end;
+    const float x = live ? cur.x : 0.f, y = live ? cur.y : 0.f, z = live ? cur.z : 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      s0 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), k));
+      s1 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), k));
+      s2 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), k));
+    }
+    cur = nxt;
+  }
+  if (lane == 0) {
+    const float cnt = (float)(end - beg);
+    out[3 * (size_t)o] = s0 / cnt; out[3 * (size_t)o + 1] = s1 / cnt; out[3 * (size_t)o + 2] = s2 / cnt;
+  }
+}
+
 // Stable (key, index) sort of the working set.  rocPRIM's default switches from merge sort to Onesweep at 1 M items;
 // SOICP_MAP_SORT=onesweep lowers the switch to 200 k (experiment switch).
 using OnesweepEarly = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 200000>;
@@ -334,6 +434,23 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
   (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable: leaf order inside a cell
   hipLaunchKernelGGL(scatter_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.d_n_cent, a.cent, a.tt, a.cap, a.pool, a.d_counts);
   hipLaunchKernelGGL(table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.keys1, a.d_n_cent, a.tt, a.cap, a.ncell1, a.cell_start);
+}
+void launch_vg_stats(const float* d_xyz, uint32_t n, uint32_t stride_floats, double* d_part, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(vg_stats_kernel, dim3(blocks), dim3(256), 0, s, d_xyz, n, stride_floats, d_part);
+}
+void launch_voxel_filter(const VoxelFilterArgs& a, hipStream_t s) {
+  const uint32_t n = a.n;
+  hipLaunchKernelGGL(vg_keys_kernel, grid_for(n, 256), dim3(256), 0, s, a.d_xyz, n, a.stride_floats, a.inv_leaf, a.min_b[0], a.min_b[1],
+                     a.min_b[2], a.div_b[0], a.div_b[0] * a.div_b[1], a.wpts, a.keys0, a.vals0);
+  size_t tb = a.temp_bytes;
+  (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)n, 32, s);  // stable: input order inside a leaf
+  hipLaunchKernelGGL(leaf_flags_kernel, grid_for(n, 256), dim3(256), 0, s, a.keys1, n, a.flags);
+  tb = a.temp_bytes;
+  (void)rocprim::exclusive_scan(a.temp, tb, a.flags, a.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), s);
+  hipLaunchKernelGGL(leaf_heads_kernel, grid_for(n, 256), dim3(256), 0, s, a.keys1, a.vals1, a.flags, a.pos, n, a.wpts, a.spts, a.heads,
+                     a.d_n_cent);
+  hipLaunchKernelGGL(vg_centroid_kernel, grid_for(n, 256), dim3(256), 0, s, a.heads, a.d_n_cent, a.spts, a.d_out, a.flags, a.d_n_cent + 1);
+  hipLaunchKernelGGL(vg_centroid_long_kernel, dim3(kMaxLongLeaves / 4), dim3(256), 0, s, a.heads, a.spts, a.d_out, a.flags, a.d_n_cent + 1);
 }
 void launch_gather_export(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, float* d_out, hipStream_t s) {
   if (!count) return;

@@ -101,3 +101,44 @@ def test_full_size_localization_rate(gpu_slam_factory):
     assert slam.map_size() > n0  # the scans added new voxels
     assert min(times) < 0.05, f"Localization() should take milliseconds, got {times}"
     print("localization wall times (s):", [round(t, 5) for t in times])
+
+
+def test_scan_prefilter_matches_pcl_voxelgrid_restatement(oracle, gpu_slam_factory):
+    """so_icp_prefilter_scan = laserMapping::adjustVoxelSize (lmap.cpp:598-651): statistics, resolution choice and the
+    VoxelGrid of the raw surf cloud, point for point against the oracle's pcl::VoxelGrid restatement; the filtered cloud
+    stays on the device and feeds Localization."""
+    sc = synth.Scene("os1_128_2m")
+    slam = gpu_slam_factory(plane_res=0.4, line_res=0.2, max_surface_features=-1, max_iterations=5)
+    assert slam.add_surf_point_cloud(sc.map_points) > 0
+    raw = sc.scan(1)  # 131 072 raw returns: up to ~1000 points per 0.2 m leaf under the sensor
+    # reference statistic: float accumulation in input order (lmap.cpp:605-621)
+    a = np.abs(raw).astype(np.float32)
+    avg = [np.add.accumulate(a[:, k], dtype=np.float32)[-1] / np.float32(len(raw)) for k in range(3)]
+    avg_dist = float(np.float32(avg[0]) * np.float32(avg[1]) * np.float32(avg[2]))
+    far = int(np.sum((raw[:, 0] * raw[:, 0] + raw[:, 1] * raw[:, 1] + raw[:, 2] * raw[:, 2]) > np.float32(9)))
+    d, n, info = slam.prefilter_scan(raw, True, 0.2, 0.4)
+    assert abs(info.average_distance - avg_dist) <= 1e-3 * avg_dist and info.count_far_points == far
+    assert info.increase_blind_radius == int(far > 3000)
+    want_plane = 0.2 if avg_dist < 25 else (0.8 if avg_dist > 65 else 0.4)
+    assert abs(info.plane_res - want_plane) < 1e-7
+    got = slam.download_scan(d, n)
+    ref = oracle.voxel_grid(raw, info.plane_res)
+    assert got.shape == ref.shape and np.array_equal(got, ref), "VoxelGrid centroids differ from the restatement"
+    # fixed resolution path + the device-resident hand-over to Localization
+    d2, n2, info2 = slam.prefilter_scan(raw, False, 0.1, sc.plane_res)
+    assert abs(info2.plane_res - sc.plane_res) < 1e-7 and np.array_equal(slam.download_scan(d2, n2), oracle.voxel_grid(raw, sc.plane_res))
+    slam2 = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5)
+    slam2.add_surf_point_cloud(sc.map_points)
+    slam2.shift_map(sc.gt_pose(0)[:3])
+    d3, n3, _ = slam2.prefilter_scan(raw, False, sc.plane_res / 2, sc.plane_res)
+    host = slam2.download_scan(d3, n3)
+    rc, pose, st = slam2.localization_dev(True, sc.guess(1), d3, n3, 0.1)
+    assert rc == 0
+    e = synth.pose_error(pose, sc.gt_pose(1))
+    assert e[0] < 0.02 and e[1] < 0.004
+    # same call through the host-buffer entry point on a second context gives the same pose
+    slam3 = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5)
+    slam3.add_surf_point_cloud(sc.map_points)
+    slam3.shift_map(sc.gt_pose(0)[:3])
+    rc3, pose3, _ = slam3.localization(True, sc.guess(1), host, 0.1)
+    assert rc3 == 0 and np.array_equal(pose, pose3) and slam2.map_size() == slam3.map_size()
