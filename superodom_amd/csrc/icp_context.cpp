@@ -18,6 +18,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/so_icp.h"
@@ -118,6 +119,10 @@ struct so_icp_ctx {
   int32_t prev_obs_hist[SO_ICP_N_OBS]{};
   bool have_hist = false;
   int last_pos[3] = {0, 0, 0};
+  // so_icp_register_batch: worker contexts register hypotheses concurrently against the PARENT's resident map
+  struct Borrow { bool on = false; DevMapView view{}; float plane_res = 0; int pos[3] = {0, 0, 0}; int count_5x5 = 0; } borrow;
+  std::vector<so_icp_ctx*> workers;
+  bool batch_mode = false;    // no kernel timing, tracker state read-only
   bool no_map_shift = false;  // so_icp_register_batch: hypotheses after the first keep the window of the first
   int startup_count = 0;
   double last_time = 0;
@@ -161,7 +166,7 @@ hipEvent_t next_event(so_icp_ctx* c) {
 // time_kernels: 1 = bracket only the dominant (k-NN) kernel -- cheap enough to stay on inside a timed region;
 //               2 = bracket every kernel (events cost a few microseconds of pipeline bubble each)
 void span_begin(so_icp_ctx* c, int kind, uint32_t units) {
-  if (!c->cfg.time_kernels || (c->cfg.time_kernels == 1 && kind != 0)) return;
+  if (c->batch_mode || !c->cfg.time_kernels || (c->cfg.time_kernels == 1 && kind != 0)) return;
   EventSpan s{kind, next_event(c), next_event(c), units};
   if (!s.a || !s.b) return;
   (void)hipEventRecord(s.a, c->stream);
@@ -305,14 +310,16 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   std::memcpy(pose_out, pose_in, sizeof(T));
   if (c->have_hist) uncertainty_from_hist(c->prev_obs_hist, st->uncertainty);  // LidarSlam.cpp:47
   int pos[3];
-  if (!c->no_map_shift) { map_shift(c, T, pos); std::memcpy(c->last_pos, pos, sizeof(pos)); }  // LidarSlam.cpp:363
+  if (c->borrow.on) std::memcpy(pos, c->borrow.pos, sizeof(pos));  // window, count and map view were fixed by the batch driver
+  else if (!c->no_map_shift) { map_shift(c, T, pos); std::memcpy(c->last_pos, pos, sizeof(pos)); }  // LidarSlam.cpp:363
   else std::memcpy(pos, c->last_pos, sizeof(pos));
   st->pos_in_localmap[0] = pos[0]; st->pos_in_localmap[1] = pos[1]; st->pos_in_localmap[2] = pos[2];
-  st->laser_cloud_surf_from_map_num = map_count_5x5(c, pos);                  // LidarSlam.cpp:367
+  st->laser_cloud_surf_from_map_num = c->borrow.on ? c->borrow.count_5x5 : map_count_5x5(c, pos);  // LidarSlam.cpp:367
   st->laser_cloud_surf_stack_num = (int32_t)n;
   st->startup_count = c->startup_count;
   if (!(st->laser_cloud_surf_from_map_num > 50)) return SO_ICP_NOT_ENOUGH_MAP_FEATURES;  // LidarSlam.cpp:113-116
-  int rc = upload_map(c);
+  int rc = SO_ICP_OK;
+  if (c->borrow.on) c->view = c->borrow.view; else rc = upload_map(c);
   if (rc) return rc;
   rc = reserve_scan_buffers(c, n);
   if (rc) return rc;
@@ -334,13 +341,14 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
                        c->d_vals1.as<uint32_t>(), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
   }
   span_end(c);
-  MatchParams mp = match_params(map_plane_res(c));
+  const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
+  MatchParams mp = match_params(plane_res_now);
   if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
     HIP_TRY(c, c->d_kdbg.reserve((size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemsetAsync(c->d_kdbg.p, 0, (size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long), s));
     mp.kdbg = c->d_kdbg.as<unsigned long long>();
   }
-  EvalParams ep = eval_params(map_plane_res(c), c->cfg.tukey_variant);
+  EvalParams ep = eval_params(plane_res_now, c->cfg.tukey_variant);
   // read-back: the controller's workgroup publishes the state block straight into the pinned mirrors (polled below);
   // SOICP_READBACK=copy (or the controller ablated away) falls back to hipMemcpyAsync + event
   const bool direct_rb = c->direct_readback && !(ep.ablate & 32);
@@ -353,9 +361,11 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   //  ResetDistanceParameters, LidarSlam.cpp:847-852.)
   // time_kernels == 1 samples every 4th registration: even dispatch-attached events cost ~5 us of stream time per
   // timed launch (completion-signal handling), which would otherwise sit inside every step of a throughput run
-  const bool timed = c->cfg.time_kernels >= 2 || (c->cfg.time_kernels == 1 && (c->timing.registrations & 3) == 0);
+  const bool timed = !c->batch_mode && (c->cfg.time_kernels >= 2 || (c->cfg.time_kernels == 1 && (c->timing.registrations & 3) == 0));
   // part A: correspondences + plane fit + first evaluation; part B: the remaining evaluations + read-back
-  const bool persistent = c->persistent_solve && c->comm == nullptr;
+  // (concurrent hypotheses: two persistent launches could each hold part of the CUs and wait for the rest -- one launch per
+  //  evaluation there; only workgroup 0 of a launch ever waits, for workgroups that finish unconditionally)
+  const bool persistent = c->persistent_solve && c->comm == nullptr && !c->batch_mode;
   auto enqueue_eval = [&](int slot) -> int {
     span_begin(c, 1, (uint32_t)n);
     const bool fuse_lm = (c->comm == nullptr);  // single device: the last workgroup of eval runs the LM controller itself
@@ -466,7 +476,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     std::memcpy(is.obs_hist, d.obs_hist, sizeof(is.obs_hist));
     std::memcpy(is.pose_after, d.pose_after, sizeof(is.pose_after));
   }
-  if (H.n_iterations > 0) {
+  if (H.n_iterations > 0 && !c->batch_mode) {
     std::memcpy(c->prev_obs_hist, H.iters[H.n_iterations - 1].obs_hist, sizeof(c->prev_obs_hist));
     c->have_hist = true;
   }
@@ -525,6 +535,7 @@ int upload_scan_impl(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_by
 }  // namespace
 
 so_icp_ctx::~so_icp_ctx() {
+  for (so_icp_ctx* w : workers) delete w;
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1, &d_chunks,
                     &d_sort_tmp, &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
@@ -782,29 +793,65 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
   if (!c || !poses_in || !poses_out || n_hyp < 0 || (!xyz && !d_scan && n)) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);
   HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  if (n_hyp == 0) return 0;
   const float* scan = static_cast<const float*>(d_scan);
   if (!scan) {
     const int rc = upload_scan_impl(c, xyz, n, stride_bytes, c->d_scan_own);
     if (rc) return rc;
     scan = c->d_scan_own.as<float>();
   }
-  // scan-to-scan state of the tracker is not advanced by hypothesis testing
-  int32_t saved_hist[SO_ICP_N_OBS];
-  std::memcpy(saved_hist, c->prev_obs_hist, sizeof(saved_hist));
-  const bool saved_have = c->have_hist;
-  const int saved_startup = c->startup_count;
-  int ok = 0, err = 0;
-  for (int h = 0; h < n_hyp; ++h) {
-    c->no_map_shift = h > 0;  // the window is placed by hypothesis 0 (all hypotheses must see the same map)
-    so_icp_stats local;
-    const int rc = register_core(c, scan, n, poses_in + 7 * (size_t)h, poses_out + 7 * (size_t)h, stats ? stats + h : &local);
-    std::memcpy(c->prev_obs_hist, saved_hist, sizeof(saved_hist));
-    c->have_hist = saved_have; c->startup_count = saved_startup;
-    if (rc_out) rc_out[h] = rc;
-    if (rc == SO_ICP_OK) ++ok;
-    if (rc < 0) { err = rc; break; }
+  // the map window is placed once, for hypothesis 0 (LidarSlam.cpp:363); every hypothesis sees that map
+  int pos[3];
+  map_shift(c, poses_in, pos);
+  std::memcpy(c->last_pos, pos, sizeof(pos));
+  int rc = upload_map(c);
+  if (rc) return rc;
+  static const int want_lanes = std::getenv("SOICP_BATCH_LANES") ? std::atoi(std::getenv("SOICP_BATCH_LANES")) : 8;
+  const int lanes = std::max(1, std::min({want_lanes, n_hyp, 8}));
+  // worker contexts: own stream / buffers / device state, no map of their own (they borrow this context's resident map)
+  while ((int)c->workers.size() < lanes - 1) {
+    so_icp_config wc = c->cfg;
+    wc.time_kernels = 0;
+    so_icp_ctx* w = so_icp_create(&wc);
+    if (!w) return fail(c, SO_ICP_E_HIP, "so_icp_register_batch: worker context: " + g_create_error);
+    w->dmap.reset();
+    c->workers.push_back(w);
   }
-  c->no_map_shift = false;
+  so_icp_ctx::Borrow bw;
+  bw.on = true; bw.view = c->view; bw.plane_res = map_plane_res(c);
+  std::memcpy(bw.pos, pos, sizeof(pos));
+  bw.count_5x5 = map_count_5x5(c, pos);
+  std::vector<so_icp_ctx*> lane_ctx(1, c);
+  for (int l = 1; l < lanes; ++l) lane_ctx.push_back(c->workers[l - 1]);
+  for (so_icp_ctx* w : lane_ctx) {
+    w->borrow = bw; w->batch_mode = true;
+    std::memcpy(w->prev_obs_hist, c->prev_obs_hist, sizeof(c->prev_obs_hist));
+    w->have_hist = c->have_hist; w->startup_count = c->startup_count;
+    w->cfg.max_iterations = c->cfg.max_iterations; w->cfg.lm_max_iterations = c->cfg.lm_max_iterations;
+    w->cfg.max_surface_features = c->cfg.max_surface_features;
+  }
+  std::vector<int> lane_rc(lanes, 0);
+  std::vector<int> hyp_rc((size_t)n_hyp, 0);
+  auto run_lane = [&](int l) {
+    so_icp_ctx* w = lane_ctx[l];
+    if (hipSetDevice(c->cfg.device_id) != hipSuccess) { lane_rc[l] = SO_ICP_E_HIP; return; }
+    for (int h = l; h < n_hyp; h += lanes) {
+      so_icp_stats local;
+      const int r = register_core(w, scan, n, poses_in + 7 * (size_t)h, poses_out + 7 * (size_t)h, stats ? stats + h : &local);
+      hyp_rc[h] = r;
+      if (r < 0) { lane_rc[l] = r; return; }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int l = 1; l < lanes; ++l) th.emplace_back(run_lane, l);
+  run_lane(0);
+  for (std::thread& t : th) t.join();
+  int ok = 0, err = 0;
+  for (int l = 0; l < lanes; ++l) {
+    lane_ctx[l]->borrow.on = false; lane_ctx[l]->batch_mode = false;
+    if (lane_rc[l] < 0 && !err) { err = lane_rc[l]; if (l > 0) c->err = "worker: " + lane_ctx[l]->err; }
+  }
+  for (int h = 0; h < n_hyp; ++h) { if (rc_out) rc_out[h] = hyp_rc[h]; if (hyp_rc[h] == SO_ICP_OK) ++ok; }
   return err ? err : ok;
 }
 
