@@ -603,6 +603,12 @@ __device__ __forceinline__ int32_t make_key(float d2a, uint32_t jloc_uniform, ui
   asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(keep_mask), "v"(d2a), "s"(jloc_uniform));
   return r;
 }
+// same with a per-lane position (VGPR operand)
+__device__ __forceinline__ int32_t make_key_v(float d2a, uint32_t jloc, uint32_t keep_mask) {
+  int32_t r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(keep_mask), "v"(d2a), "v"(jloc));
+  return r;
+}
 __device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz, float qq, float cx, float cy, float cz,
                                               float cc, uint32_t jloc, uint32_t keep_mask) {
   float v = cc + qq;
@@ -623,8 +629,8 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
                                                         MatchParams mp, CorrBuffers corr, uint32_t* __restrict__ nbr5,
                                                         int32_t* __restrict__ hist) {
   __shared__ int32_t lh[20];
-  __shared__ __attribute__((aligned(16))) float tiles[4][4][kTileCand + 4];  // per wavefront: x[], y[], z[], |c|^2 (block-local)
-  __shared__ uint32_t tcanon[4][kTileCand + 4];  // per wavefront: canonical map index of the staged candidate
+  __shared__ __attribute__((aligned(16))) float tiles[4][4][kTileCand + 16];  // per wavefront: x[], y[], z[], |c|^2 (block-local)
+  __shared__ uint32_t tcanon[4][kTileCand + 16];  // per wavefront: canonical map index of the staged candidate
   __shared__ uint32_t rowtab[4][2][36];  // per wavefront: exclusive candidate offsets [33] and first canonical index [32] of the block's x-runs
   if (st->reg_done) return;  // the registration already converged: this launch is a no-op
   const uint32_t n_kept = st->n_kept, n_chunks = st->n_chunks;
@@ -660,12 +666,21 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   if (stamp) ts[0] = wall_clock64();
   uint32_t j = 0;
   bool valid_q = false;
+  // A chunk of at most 32 queries is served by BOTH halves of the wavefront: lanes l and l + 32 hold the same query and
+  // scan alternate candidate quads, then exchange their eight survivors (the average chunk has 27 queries).
+  bool split = false, split4 = false;  // <= 16 queries: four parts of 16 lanes
   {
     const uint32_t desc = __builtin_amdgcn_readfirstlane(chunk_start[chunk]);
     const uint32_t start = desc & 0x03FFFFFFu, count = (desc >> 26) + 1u;
-    j = start + lane;
-    valid_q = (lane < (int)count) && (j < n_kept);
+    split = count <= 32u && !(mp.ablate & 1024);
+    split4 = count <= 16u && split && !(mp.ablate & 2048);
+    const int ql = split4 ? (lane & 15) : (split ? (lane & 31) : lane);
+    j = start + (uint32_t)ql;
+    valid_q = (ql < (int)count) && (j < n_kept);
   }
+  // quad offset of this part of the wavefront, and candidates consumed per trip by all parts together
+  const uint32_t hoff = split4 ? (uint32_t)(lane >> 4) << 2 : (split ? (uint32_t)(lane >> 5) << 2 : 0u);
+  const uint32_t sstep = split4 ? 16u : 8u;
   double pw[3] = {0, 0, 0};
   float qx = 0, qy = 0, qz = 0;
   float ux = 0, uy = 0, uz = 0;  // cube-local coordinates of the query (for the coverage test)
@@ -795,7 +810,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (!(mp.ablate & 16))
-      for (uint32_t t = lane; t < cnt + 4; t += 64) {
+      for (uint32_t t = lane; t < cnt + 16; t += 64) {
         float lx = 0.f, ly = 0.f, lz = 0.f, lc = 3.0e38f;  // padding entries lose against every real candidate
         uint32_t canon = 0xFFFFFFFFu;
         if (t < cnt) {
@@ -812,7 +827,21 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (!(mp.ablate & 8)) {
+      if (!(mp.ablate & 8) && split) {
+        // two quads per trip, one per half of the wavefront (two LDS addresses per read)
+        for (uint32_t jl = 0; jl < cnt; jl += sstep) {
+          const uint32_t a = jl + hoff;
+          const float4 X = *reinterpret_cast<const float4*>(tx + a), Y = *reinterpret_cast<const float4*>(ty + a);
+          const float4 Z = *reinterpret_cast<const float4*>(tz + a), C = *reinterpret_cast<const float4*>(tc + a);
+          const float2v d01 = approx_d2_pair(pqx, pqy, pqz, pqq, float2v{X.x, X.y}, float2v{Y.x, Y.y}, float2v{Z.x, Z.y}, float2v{C.x, C.y});
+          const float2v d23 = approx_d2_pair(pqx, pqy, pqz, pqq, float2v{X.z, X.w}, float2v{Y.z, Y.w}, float2v{Z.z, Z.w}, float2v{C.z, C.w});
+          const uint32_t e = base + a;  // per lane
+          net.push(make_key_v(d01.x, e, keep));
+          net.push(make_key_v(d01.y, e + 1, keep));
+          net.push(make_key_v(d23.x, e + 2, keep));
+          net.push(make_key_v(d23.y, e + 3, keep));
+        }
+      } else if (!(mp.ablate & 8)) {
         // uniform addresses: four broadcast ds_read_b128 feed four candidates; the next quad is fetched while this one
         // runs through the selection network (software pipeline, no wait between LDS issue and use)
         float4 X = *reinterpret_cast<const float4*>(tx), Y = *reinterpret_cast<const float4*>(ty);
@@ -830,6 +859,16 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
           net.push(make_key(d23.y, e + 3, keep));
           X = Xn; Y = Yn; Z = Zn; C = Cn;
         }
+      }
+    }
+    if (split) {  // the other half's eight survivors: both halves end up with the same merged set
+      const int32_t o0 = __shfl_xor(net.a0, 32, 64), o1 = __shfl_xor(net.a1, 32, 64), o2 = __shfl_xor(net.a2, 32, 64), o3 = __shfl_xor(net.a3, 32, 64);
+      const int32_t o4 = __shfl_xor(net.a4, 32, 64), o5 = __shfl_xor(net.a5, 32, 64), o6 = __shfl_xor(net.a6, 32, 64), o7 = __shfl_xor(net.a7, 32, 64);
+      net.push(o0); net.push(o1); net.push(o2); net.push(o3); net.push(o4); net.push(o5); net.push(o6); net.push(o7);
+      if (split4) {
+        const int32_t p0 = __shfl_xor(net.a0, 16, 64), p1 = __shfl_xor(net.a1, 16, 64), p2 = __shfl_xor(net.a2, 16, 64), p3 = __shfl_xor(net.a3, 16, 64);
+        const int32_t p4 = __shfl_xor(net.a4, 16, 64), p5 = __shfl_xor(net.a5, 16, 64), p6 = __shfl_xor(net.a6, 16, 64), p7 = __shfl_xor(net.a7, 16, 64);
+        net.push(p0); net.push(p1); net.push(p2); net.push(p3); net.push(p4); net.push(p5); net.push(p6); net.push(p7);
       }
     }
     if (stamp) { ts[3] = wall_clock64(); acc[2] += ts[3] - ts[2]; }
@@ -931,7 +970,7 @@ __global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict_
   __builtin_amdgcn_s_setprio(0);
   if (lane == 0) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
 
-  if (valid_q) {
+  if (valid_q && (!split || lane < (split4 ? 16 : 32))) {
     int status;
     if (c.slot < 0) {
       status = SO_MATCH_NOT_ENOUGH;  // LidarSlam.cpp:736-739
