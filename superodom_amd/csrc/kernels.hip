@@ -619,7 +619,7 @@ __device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz
   return (int32_t)((__float_as_uint(v) & keep_mask) | (jloc & ~keep_mask));
 }
 
-__global__ __launch_bounds__(256) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
+__global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
                                                         const float* __restrict__ spz,
                                                         const uint32_t* __restrict__ skeys,
                                                         const uint32_t* __restrict__ chunk_start,

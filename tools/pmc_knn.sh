@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "knn_plane" not in k and "eval_kernel" not in k:
+        if "knn_plane" not in k and "eval_kernel" not in k and "solve_kernel" not in k:
             continue
         key = (k.split("(")[0][:40], row["Counter_Name"])
         acc[key][0] += float(row["Counter_Value"]); acc[key][1] += 1
