@@ -1,6 +1,8 @@
 """-m gpu parity tests: the HIP path (through the C ABI of include/so_icp.h) against the CPU oracle on
 identical seeded inputs.  Bit-exact for index/distance work, <= 1e-4 m / 1e-4 rad for poses (the
 tolerance BASELINE.json's north_star states), identical iteration counts and histograms."""
+import os
+
 import numpy as np
 import pytest
 
@@ -268,6 +270,39 @@ def test_full_size_properties():
     orc, opose, ost, _ = om.register(scan, guess, oracle_py.default_config(max_iterations=5))
     ok, dt, dr = pose_close(poses[0], opose, TOL_T, TOL_R)
     assert ok and dt < 1e-8 and dr < 1e-8, (dt, dr)
+
+
+def test_million_point_scan_grid_stride_paths():
+    """Eight times the BASELINE scan in one registration (1 048 576 queries, ~38 000 chunks): every kernel runs its
+    grid-stride / multi-trip path (k-NN work list beyond one wavefront per slot, four fit trips per thread, 1 M-pair sort).
+    Same histograms, iteration counts and pose as the oracle."""
+    import oracle_py
+    from superodom_amd import binding
+    sc = synth.Scene("os1_128_2m")
+    slam = binding.LidarSlamGpu(plane_res=sc.plane_res, max_surface_features=-1, max_iterations=5)
+    slam.add_surf_point_cloud(sc.map_points)
+    base = sc.scan(2)
+    rng = np.random.default_rng(11)
+    scan = np.concatenate([base + rng.normal(0, 0.004, base.shape).astype(np.float32) for _ in range(8)]).astype(np.float32)
+    assert len(scan) == 8 * 131072
+    guess = sc.guess(2)
+    rc, pose, st = slam.register(scan, guess)
+    assert rc == 0
+    om = oracle_py.OracleMap(plane_res=sc.plane_res)
+    om.add_surf(slam.export_map(), raw=True)
+    oracle_py.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    try:
+        orc, opose, ost, _ = om.register(scan, guess, oracle_py.default_config(max_iterations=5))
+    finally:
+        oracle_py.set_num_threads(1)
+    assert orc == 0 and st.n_iterations == ost.n_iterations
+    for it in range(st.n_iterations):
+        assert st.iterations[it].lm_iterations == ost.iters[it].lm_iterations
+        assert st.iterations[it].num_surf_from_scan == ost.iters[it].num_surf
+        assert list(st.iterations[it].reject_hist) == list(ost.iters[it].reject_hist)
+        assert list(st.iterations[it].obs_hist) == list(ost.iters[it].obs_hist)
+    ok, dt, dr = pose_close(pose, opose, 1e-8, 1e-8)
+    assert ok, (dt, dr)
 
 
 def test_sharded_map_covers_every_query_exactly_once(oracle, gpu_slam_factory):
