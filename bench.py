@@ -166,7 +166,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": b_knn, "avg_launch_ms": knn_ms, "launches": int(tm.knn_launches),
                      "timing": "HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL) on the context's stream, inside the timed region, "
-                               "on every 4th registration (every launch with --time-all-kernels); no-op launches after convergence excluded",
+                               "on every 3rd registration (every launch with --time-all-kernels); no-op launches after convergence excluded",
                      "queries_per_launch": q_per_launch, "map_points_in_touched_cubes": m_per_launch,
                      "note": "B = 36*Q + 12*M_t (SURVEY 8d); with M_t = whole map (BASELINE.md table) B would be %.0f and frac %.4f"
                              % (b_knn_whole_map, (b_knn_whole_map / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if knn_ms > 0 else 0.0)},

@@ -76,7 +76,7 @@ typedef struct {
   int32_t k;                    /* LocalizationPlaneDistanceNbrNeighbors = 5 (LS.h:277); only 5 supported */
   int32_t tukey_variant;        /* 0 = Ceres 2.0.0 TukeyLoss (rho' = 0.5 (1-s/a^2)^2); 1 = Ceres >= 2.1 */
   int32_t time_kernels;         /* HIP-event timing on the context's stream (so_icp_get_timing): 1 = the k-NN kernel only, on every
-                                   4th registration (events attached to the dispatch; cheap enough for a timed region),
+                                   3rd registration (events attached to the dispatch; cheap enough for a timed region),
                                    2 = every kernel of every registration (adds pipeline bubbles; profiling only) */
   float line_res, plane_res;    /* localMap.lineRes_/planeRes_ (LM.h:760-761; pushed every frame, lmap.cpp:648-649) */
   double yaw_ratio;             /* OptSet.yaw_ratio (LS.cpp:906) */

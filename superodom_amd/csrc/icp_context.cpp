@@ -359,9 +359,10 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   // One outer iteration = knn_plane -> [ eval(slot) -> (all-reduce -> lm_step) ] x (1 + lm_max) -> state read-back.
   // (The histogram replicas are cleared by reg_begin and again by the controller when a solve ends:
   //  ResetDistanceParameters, LidarSlam.cpp:847-852.)
-  // time_kernels == 1 samples every 4th registration: even dispatch-attached events cost ~5 us of stream time per
+  // time_kernels == 1 samples every 3rd registration (a period coprime to the scan rotation of typical benchmarks, so
+  // that every scan of the rotation gets timed): even dispatch-attached events cost ~5 us of stream time per
   // timed launch (completion-signal handling), which would otherwise sit inside every step of a throughput run
-  const bool timed = !c->batch_mode && (c->cfg.time_kernels >= 2 || (c->cfg.time_kernels == 1 && (c->timing.registrations & 3) == 0));
+  const bool timed = !c->batch_mode && (c->cfg.time_kernels >= 2 || (c->cfg.time_kernels == 1 && (c->timing.registrations % 3) == 0));
   // part A: correspondences + plane fit + first evaluation; part B: the remaining evaluations + read-back
   // (concurrent hypotheses: two persistent launches could each hold part of the CUs and wait for the rest -- one launch per
   //  evaluation there; only workgroup 0 of a launch ever waits, for workgroups that finish unconditionally)
