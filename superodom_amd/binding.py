@@ -134,6 +134,9 @@ def load():
     return L
 
 
+_F64P = C.POINTER(C.c_double)
+
+
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
@@ -253,10 +256,15 @@ class LidarSlamGpu:
     def free_scan(self, d_scan):
         self._check(self.L.so_icp_free_scan(self.h, d_scan))
 
-    def register_dev(self, d_scan, n, pose_in, stats=None):
-        pose_in = np.ascontiguousarray(pose_in, dtype=np.float64); out = np.zeros(7)
+    def register_dev(self, d_scan, n, pose_in, stats=None, pose_out=None):
+        """pose_in / pose_out may be preallocated contiguous float64 arrays (no per-call allocation in a timed loop)."""
+        if not (isinstance(pose_in, np.ndarray) and pose_in.dtype == np.float64 and pose_in.flags.c_contiguous):
+            pose_in = np.ascontiguousarray(pose_in, dtype=np.float64)
+        out = pose_out if pose_out is not None else np.zeros(7)
         st = stats if stats is not None else Stats()
-        rc = self._check(self.L.so_icp_register_dev(self.h, d_scan, n, _p(pose_in, C.c_double), _p(out, C.c_double), C.byref(st)))
+        rc = self.L.so_icp_register_dev(self.h, d_scan, n, pose_in.ctypes.data_as(_F64P), out.ctypes.data_as(_F64P), C.byref(st))
+        if rc < 0:
+            self._check(rc)
         return rc, out, st
 
     def register_batch(self, scan, poses_in, d_scan=None, n=None):
