@@ -252,6 +252,7 @@ EvalParams eval_params(float plane_res, int variant) {
   ep.ablate = ablate;
   ep.hring[0] = ep.hring[1] = nullptr;
   ep.seq_base = 0;
+  ep.n_queries = 0; ep.q_stride = 1;
   return ep;
 }
 
@@ -333,7 +334,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   //      sampling rule, spatial sort (locality survives the small pose updates), chunk list + gather
   span_begin(c, 2, (uint32_t)n);
   launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
-                   c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), s);
+                   c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), s);
   if (n) {
     launch_sort_pairs(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->d_keys0.as<uint32_t>(), c->d_keys1.as<uint32_t>(),
                       c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, key_bits(c->view.n_slots), s);
@@ -354,6 +355,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   const bool direct_rb = c->direct_readback && !(ep.ablate & 32);
   const unsigned long long seq_base = (++c->reg_counter) << 8;
   if (direct_rb) { ep.hring[0] = c->d_ring[0]; ep.hring[1] = c->d_ring[1]; ep.seq_base = seq_base; }
+  ep.n_queries = (uint32_t)n; ep.q_stride = 3;  // evaluation kernels read the scan itself, in its own order
   CorrBuffers corr{c->d_nd.as<double4>(), c->d_coeff.as<double>(), c->d_status.as<uint8_t>()};
   std::vector<size_t> knn_span_of_outer, eval_span_first;
   // One outer iteration = knn_plane -> [ eval(slot) -> (all-reduce -> lm_step) ] x (1 + lm_max) -> state read-back.
@@ -370,7 +372,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   auto enqueue_eval = [&](int slot) -> int {
     span_begin(c, 1, (uint32_t)n);
     const bool fuse_lm = (c->comm == nullptr);  // single device: the last workgroup of eval runs the LM controller itself
-    launch_eval(slot, fuse_lm, c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), corr, ds, ep, c->d_partials,
+    launch_eval(slot, fuse_lm, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep, c->d_partials,
                 c->d_ticket, c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, s);
     span_end(c);
     if (!fuse_lm) {  // per-evaluation collective: 45 fp64 summed over the shards (xGMI, latency-bound), then the controller
@@ -388,11 +390,11 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
       ka = next_event(c); kb = next_event(c);
       if (ka && kb) c->spans.push_back(EventSpan{0, ka, kb, (uint32_t)n});
     }
-    launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->d_keys1.as<uint32_t>(),
+    launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->d_vals1.as<uint32_t>(),
                      c->d_chunks.as<uint32_t>(), ds, c->view, mp, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s, ka, kb);
     static const int repeat_knn = std::getenv("SOICP_REPEAT_KNN") ? std::atoi(std::getenv("SOICP_REPEAT_KNN")) : 0;
     for (int rep = 0; rep < repeat_knn; ++rep)  // profiling aid: identical relaunch (results are idempotent)
-      launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->d_keys1.as<uint32_t>(),
+      launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->d_vals1.as<uint32_t>(),
                        c->d_chunks.as<uint32_t>(), ds, c->view, mp, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s);
     if (c->cfg.time_kernels >= 2)  // kernel statistics of this sweep (profiling mode only)
       HIP_TRY(c, hipMemcpyAsync(c->h_hist + (size_t)it * kHistReplicas * kHistStride, c->d_hist,
@@ -401,7 +403,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     eval_span_first.push_back(c->spans.size());
     if (persistent) {  // the whole solve in one launch (workgroups hand the next pose to each other on the device)
       span_begin(c, 1, (uint32_t)n);
-      launch_solve(lm_max, c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), corr, ds, ep, c->d_partials, c->d_ticket,
+      launch_solve(lm_max, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep, c->d_partials, c->d_ticket,
                    c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, s);
       span_end(c);
       return SO_ICP_OK;

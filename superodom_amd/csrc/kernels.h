@@ -35,6 +35,9 @@ struct EvalParams {
   double a2;       // TukeyLoss a^2 with a = (double)sqrtf(3*planeRes)  (LidarSlam.cpp:271)
   int32_t variant; // 0: Ceres 2.0.0, 1: Ceres >= 2.1
   int32_t ablate;  // profiling only (env SOICP_ABLATE): bit5 skip the LM controller, bit6 skip the point loop
+  // the evaluation kernels walk the queries in ORIGINAL scan order (deterministic sums whatever the spatial binning did):
+  // spx/spy/spz = scan, scan+1, scan+2 with q_stride 3; correspondence records are indexed by the original query index
+  uint32_t n_queries, q_stride;
   // Read-back without a copy engine round trip: when a solve ends, the controller's workgroup stores the whole state
   // block into the pinned, host-coherent mirror hring[outer & 1] and then publishes seq_base | (outer + 1) in its seq
   // word (system-scope release); the host polls that word.  hring[0] == nullptr disables it (host uses hipMemcpyAsync).
@@ -105,7 +108,7 @@ void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_
 // scan_keys also runs the registration prologue (reg_begin) in its first workgroup; n == 0 launches the prologue alone
 void launch_scan_keys(const float* d_scan_xyz, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max,
                       int32_t* d_hist, const DevMapView& map, int max_surface_features, int rank, int world, uint32_t* d_keys,
-                      uint32_t* d_vals, hipStream_t s);
+                      uint32_t* d_vals, uint8_t* d_status /* SO_MATCH_DROPPED for queries that are not processed */, hipStream_t s);
 void launch_sort_pairs(void* d_temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                        const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, int end_bit, hipStream_t s);
 // chunk work list + gather of the scan into sorted SoA order

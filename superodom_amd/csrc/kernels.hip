@@ -32,6 +32,7 @@ namespace soicp {
 #define SO_MATCH_BAD_PCA 3
 #define SO_MATCH_INVALID 4
 #define SO_MATCH_MSE 5
+#define SO_MATCH_DROPPED 254  // not sampled / not owned by this rank: never counted, never evaluated
 #define SO_MATCH_PENDING 255  // k-NN done, plane fit not yet (internal hand-off between the two kernels)
 
 // ------------------------------------------------------------------------------------------------
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
                                                         DevState* __restrict__ st, RegBeginArgs a, int32_t* __restrict__ hist,
                                                         DevMapView map,
                                                         int max_surface_features, int rank, int world,
-                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                        uint8_t* __restrict__ status) {
   if (blockIdx.x == 0) {
     hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
     reg_begin_state(st, a, threadIdx.x);
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   }
   keys[i] = key;
   vals[i] = i;
+  if (key == kDropped) status[i] = SO_MATCH_DROPPED;  // every other query gets its status from the k-NN sweep
 }
 
 // Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries with the same key (one half-cell octant
@@ -621,7 +624,7 @@ __device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz
 
 __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
                                                         const float* __restrict__ spz,
-                                                        const uint32_t* __restrict__ skeys,
+                                                        const uint32_t* __restrict__ perm /* binned position -> query index */,
                                                         const uint32_t* __restrict__ chunk_start,
                                                         const DevState* __restrict__ st,
                                                         const float4* __restrict__ mpts,
@@ -971,6 +974,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   if (lane == 0) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
 
   if (valid_q && (!split || lane < (split4 ? 16 : 32))) {
+    const uint32_t oi = perm[j];  // results are filed under the query's index in the scan
     int status;
     if (c.slot < 0) {
       status = SO_MATCH_NOT_ENOUGH;  // LidarSlam.cpp:736-739
@@ -986,11 +990,11 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
         status = SO_MATCH_TOO_FAR;   // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
       } else {
         status = SO_MATCH_PENDING;   // five neighbours inside the gate: the plane fit runs in plane_eval_kernel
-        uint32_t* o = nbr5 + (size_t)5 * j;
+        uint32_t* o = nbr5 + (size_t)5 * oi;
         o[0] = (uint32_t)top.b0; o[1] = (uint32_t)top.b1; o[2] = (uint32_t)top.b2; o[3] = (uint32_t)top.b3; o[4] = (uint32_t)top.b4;
       }
     }
-    corr.status[j] = (uint8_t)status;
+    corr.status[oi] = (uint8_t)status;
   }
   if (stamp) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1162,7 +1166,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     if (tid < 16) lh[tid] = 0;
     __syncthreads();
   }
-  const uint32_t n_kept = (ep.ablate & 64) ? 0u : st->n_kept;
+  const uint32_t n_kept = (ep.ablate & 64) ? 0u : ep.n_queries;  // every query of the scan, original order
+  const uint32_t qs = ep.q_stride;
   double acc[kNAcc];
 #pragma unroll
   for (int a = 0; a < kNAcc; ++a) acc[a] = 0;
@@ -1177,7 +1182,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   // one query: (FIT) plane fit from the prefetched neighbour coordinates, then residual / Jacobian / sums
   auto body = [&](const uint32_t j, int status, const float* nb) {
     if (!FIT && status != SO_MATCH_SUCCESS) return;
-    const double px = (double)spx[j], py = (double)spy[j], pz = (double)spz[j];
+    if (FIT && status == SO_MATCH_DROPPED) return;
+    const double px = (double)spx[(size_t)j * qs], py = (double)spy[(size_t)j * qs], pz = (double)spz[(size_t)j * qs];
     double wx, wy, wz;
     quat_rotate<double>(pose.q, px, py, pz, wx, wy, wz);                   // lidarOptimization.cpp:59 == LidarSlam.cpp:397-398
     wx += pose.t[0]; wy += pose.t[1]; wz += pose.t[2];
@@ -1607,12 +1613,12 @@ void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_
   hipLaunchKernelGGL(reg_begin_kernel, dim3(1), dim3(512), 0, s, st, a, hist);
 }
 void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist,
-                      const DevMapView& map, int max_sf, int rank, int world, uint32_t* keys, uint32_t* vals, hipStream_t s) {
+                      const DevMapView& map, int max_sf, int rank, int world, uint32_t* keys, uint32_t* vals, uint8_t* status, hipStream_t s) {
   if (!n) { launch_reg_begin(st, pose, max_outer, lm_max, hist, s); return; }
   RegBeginArgs a;
   for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
   a.max_outer = max_outer; a.lm_max = lm_max;
-  hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals);
+  hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals, status);
 }
 void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo,
                        uint32_t n, int end_bit, hipStream_t s) {
