@@ -109,6 +109,8 @@ struct so_icp_ctx {
   DevState* d_ring[2] = {nullptr, nullptr};  // device-side addresses of the pinned mirrors
   bool direct_readback = true; unsigned long long reg_counter = 0;
   bool persistent_solve = true;  // SOICP_PERSISTENT=0: one launch per evaluation
+  bool use_binning = true;       // SOICP_BINNING=sort: rocPRIM sort of (key, index) pairs + run-based chunk list
+  DevBuf d_bin_key, d_bin_cnt, d_bin_off; uint32_t bin_log2 = 0; bool bin_dirty = true;
   int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
   int sync_per_outer = 1;  // 1: read back reg_done after every outer iteration and stop enqueuing (eager mode)
   std::vector<DevBuf> resident_scans;  // so_icp_upload_scan
@@ -333,13 +335,35 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   // ---- once per registration: prologue (the guess and the loop bounds travel as kernel arguments, no H2D copy),
   //      sampling rule, spatial sort (locality survives the small pose updates), chunk list + gather
   span_begin(c, 2, (uint32_t)n);
-  launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
-                   c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), s);
-  if (n) {
-    launch_sort_pairs(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->d_keys0.as<uint32_t>(), c->d_keys1.as<uint32_t>(),
-                      c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, key_bits(c->view.n_slots), s);
-    launch_chunk_heads(c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_chunks.as<uint32_t>(), ds, d_scan,
-                       c->d_vals1.as<uint32_t>(), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
+  if (c->use_binning && n) {
+    // hash binning: keys + per-key counts (scan_keys), bucket offsets + chunk list (bin_offsets), placement (bin_place).
+    // The table has >= 2 slots per query; bin_offsets leaves it empty again.
+    uint32_t lg = 16;
+    while ((1ull << lg) < 2 * (unsigned long long)n) ++lg;
+    if (c->bin_log2 != lg || c->bin_dirty) {
+      const size_t T = (size_t)1 << lg;
+      HIP_TRY(c, c->d_bin_key.reserve(T * 4)); HIP_TRY(c, c->d_bin_cnt.reserve(T * 4)); HIP_TRY(c, c->d_bin_off.reserve(T * 4));
+      HIP_TRY(c, hipMemsetAsync(c->d_bin_key.p, 0xFF, T * 4, s));
+      HIP_TRY(c, hipMemsetAsync(c->d_bin_cnt.p, 0, T * 4, s));
+      c->bin_log2 = lg;
+    }
+    const BinTable bt{c->d_bin_key.as<uint32_t>(), c->d_bin_cnt.as<uint32_t>(), c->d_bin_off.as<uint32_t>(), lg};
+    c->bin_dirty = true;  // until bin_offsets has been enqueued behind scan_keys
+    launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
+                     c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), &bt, s);
+    launch_bin_offsets(bt, c->d_chunks.as<uint32_t>(), ds, s);
+    c->bin_dirty = false;
+    launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(),
+                     c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
+  } else {
+    launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
+                     c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), nullptr, s);
+    if (n) {
+      launch_sort_pairs(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->d_keys0.as<uint32_t>(), c->d_keys1.as<uint32_t>(),
+                        c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, key_bits(c->view.n_slots), s);
+      launch_chunk_heads(c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_chunks.as<uint32_t>(), ds, d_scan,
+                         c->d_vals1.as<uint32_t>(), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
+    }
   }
   span_end(c);
   const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
@@ -543,7 +567,7 @@ so_icp_ctx::~so_icp_ctx() {
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1, &d_chunks,
                     &d_sort_tmp, &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist, &d_kdbg, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
-                    &pf_heads, &pf_temp})
+                    &pf_heads, &pf_temp, &d_bin_key, &d_bin_cnt, &d_bin_off})
     b->release();
   for (DevBuf& b : resident_scans) b.release();
   d_state_buf.release();
@@ -641,6 +665,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_SYNC_PER_OUTER")) c->sync_per_outer = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_READBACK")) c->direct_readback = std::string(ev) != "copy";
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_BINNING")) c->use_binning = std::string(ev) != "sort";
   const bool want_dmap = cfg->world_size == 1 && !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
   if (want_dmap) {
     c->dmap = std::make_unique<DeviceMap>(c->stream);

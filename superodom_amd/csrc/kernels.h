@@ -105,10 +105,26 @@ inline int key_bits(uint32_t n_slots) { int b = 0; while ((1u << b) <= n_slots +
 size_t sort_temp_bytes(size_t n);
 
 void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* d_hist, hipStream_t s);
+// Spatial binning of the scan without a sort: an open-addressing table keyed by the sort key (cube slot | half-cell Morton
+// code) counts the queries of every key, a block scan over the table turns the counts into bucket offsets + the chunk
+// list, and a scatter places the queries.  The order INSIDE a bucket depends on the order of the atomics -- harmless: it
+// only decides which queries of one octant share a wavefront (results are exact per query, evaluation sums run in scan order).
+struct BinTable {
+  uint32_t* key;   // [size] 0xFFFFFFFF = empty (restored by launch_bin_offsets)
+  uint32_t* cnt;   // [size] queries per key (zeroed again by launch_bin_offsets)
+  uint32_t* off;   // [size] first binned position of the key
+  uint32_t log2_size;
+};
+// per query: table slot (0xFFFFFFFF = dropped) and rank inside its bucket
+void launch_bin_offsets(const BinTable& bt, uint32_t* d_chunk_start, DevState* st, hipStream_t s);
+void launch_bin_place(const BinTable& bt, const float* d_scan_xyz, uint32_t n, const uint32_t* d_qslot, const uint32_t* d_qrank,
+                      uint32_t* d_perm, float* spx, float* spy, float* spz, hipStream_t s);
+
 // scan_keys also runs the registration prologue (reg_begin) in its first workgroup; n == 0 launches the prologue alone
 void launch_scan_keys(const float* d_scan_xyz, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max,
                       int32_t* d_hist, const DevMapView& map, int max_surface_features, int rank, int world, uint32_t* d_keys,
-                      uint32_t* d_vals, uint8_t* d_status /* SO_MATCH_DROPPED for queries that are not processed */, hipStream_t s);
+                      uint32_t* d_vals, uint8_t* d_status /* SO_MATCH_DROPPED for queries that are not processed */,
+                      const BinTable* bin /* non-null: d_keys / d_vals receive table slot / rank instead of key / index */, hipStream_t s);
 void launch_sort_pairs(void* d_temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                        const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, int end_bit, hipStream_t s);
 // chunk work list + gather of the scan into sorted SoA order

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
                                                         DevMapView map,
                                                         int max_surface_features, int rank, int world,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint8_t* __restrict__ status) {
+                                                        uint8_t* __restrict__ status, BinTable bt) {
   if (blockIdx.x == 0) {
     hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
     reg_begin_state(st, a, threadIdx.x);
@@ -146,9 +146,95 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
       }
     }
   }
-  keys[i] = key;
-  vals[i] = i;
   if (key == kDropped) status[i] = SO_MATCH_DROPPED;  // every other query gets its status from the k-NN sweep
+  if (!bt.key) {  // sort path: (key, index) pairs for the radix / merge sort
+    keys[i] = key;
+    vals[i] = i;
+    return;
+  }
+  // ---- binning path: claim / find the key's table slot, then count the query in (one atomic per distinct key of the
+  //      wavefront: consecutive scan points are neighbours in space, a wavefront holds a handful of keys)
+  const bool kept = key != kDropped;
+  const int lane = threadIdx.x & 63;
+  // group the wavefront's queries by key first: only one lane per distinct key touches the table
+  uint32_t my_idx = 0, my_cnt = 0;
+  int lead = lane;
+  unsigned long long todo = __ballot(kept);
+  while (todo) {
+    const int L = __ffsll((long long)todo) - 1;
+    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
+    const unsigned long long m = __ballot(kept && key == kk);
+    if (kept && key == kk) { my_idx = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); my_cnt = (uint32_t)__popcll(m); lead = L; }
+    todo &= ~m;
+  }
+  uint32_t slot = 0xFFFFFFFFu, base = 0;
+  if (kept && lead == lane) {  // claim / find the key's slot (linear probing), then count the group in
+    const uint32_t mask = (1u << bt.log2_size) - 1u;
+    uint32_t h = (key * 2654435761u) >> (32 - bt.log2_size);
+    for (;;) {
+      uint32_t k = bt.key[h];  // a stale "empty" only costs the compare-and-swap below; a key, once written, stays
+      if (k == 0xFFFFFFFFu) k = atomicCAS(&bt.key[h], 0xFFFFFFFFu, key);
+      if (k == 0xFFFFFFFFu || k == key) break;
+      h = (h + 1) & mask;
+    }
+    slot = h;
+    base = atomicAdd(&bt.cnt[slot], my_cnt);
+  }
+  slot = (uint32_t)__shfl((int)slot, lead, 64);
+  base = (uint32_t)__shfl((int)base, lead, 64);
+  if (!kept) slot = 0xFFFFFFFFu;
+  keys[i] = slot;            // 0xFFFFFFFF for a dropped query
+  vals[i] = base + my_idx;   // rank inside the bucket
+}
+
+// bucket offsets + chunk list from the table counts; leaves the table empty for the next registration.
+// One thread per table slot, 1024 per workgroup: workgroup scan, one atomic pair per workgroup.
+__global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t* __restrict__ chunk_start, DevState* __restrict__ st) {
+  __shared__ uint32_t wq[16], wc[16], base_q, base_c;
+  const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t cnt = bt.cnt[sidx];
+  const uint32_t nch = (cnt + 63u) >> 6;
+  uint32_t iq = cnt, ic = nch;  // inclusive scans over the wavefront
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t a = (uint32_t)__shfl_up((int)iq, d, 64), b = (uint32_t)__shfl_up((int)ic, d, 64);
+    if (lane >= d) { iq += a; ic += b; }
+  }
+  if (lane == 63) { wq[wave] = iq; wc[wave] = ic; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tq = 0, tc = 0;
+    for (int w = 0; w < 16; ++w) { const uint32_t a = wq[w], b = wc[w]; wq[w] = tq; wc[w] = tc; tq += a; tc += b; }
+    base_q = tq ? atomicAdd(&st->n_kept, tq) : 0u;
+    base_c = tc ? atomicAdd(&st->n_chunks, tc) : 0u;
+  }
+  __syncthreads();
+  if (cnt) {
+    const uint32_t off = base_q + wq[wave] + (iq - cnt);
+    bt.off[sidx] = off;
+    uint32_t* o = chunk_start + base_c + wc[wave] + (ic - nch);
+    for (uint32_t c2 = 0; c2 < nch; ++c2) {
+      const uint32_t left = cnt - 64u * c2;
+      o[c2] = (off + 64u * c2) | (((left < 64u ? left : 64u) - 1u) << 26);
+    }
+    bt.cnt[sidx] = 0;
+    bt.key[sidx] = 0xFFFFFFFFu;
+  }
+}
+
+// queries into their binned positions (SoA) + the position -> query index map the k-NN kernel files its results with
+__global__ __launch_bounds__(256) void bin_place_kernel(BinTable bt, const float* __restrict__ scan, uint32_t n,
+                                                        const uint32_t* __restrict__ qslot, const uint32_t* __restrict__ qrank,
+                                                        uint32_t* __restrict__ perm, float* __restrict__ spx, float* __restrict__ spy,
+                                                        float* __restrict__ spz) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t sl = qslot[i];
+  if (sl == 0xFFFFFFFFu) return;
+  const uint32_t pos = bt.off[sl] + qrank[i];
+  perm[pos] = i;
+  spx[pos] = scan[3 * i]; spy[pos] = scan[3 * i + 1]; spz[pos] = scan[3 * i + 2];
 }
 
 // Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries with the same key (one half-cell octant
@@ -1613,12 +1699,22 @@ void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_
   hipLaunchKernelGGL(reg_begin_kernel, dim3(1), dim3(512), 0, s, st, a, hist);
 }
 void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist,
-                      const DevMapView& map, int max_sf, int rank, int world, uint32_t* keys, uint32_t* vals, uint8_t* status, hipStream_t s) {
+                      const DevMapView& map, int max_sf, int rank, int world, uint32_t* keys, uint32_t* vals, uint8_t* status,
+                      const BinTable* bin, hipStream_t s) {
   if (!n) { launch_reg_begin(st, pose, max_outer, lm_max, hist, s); return; }
   RegBeginArgs a;
   for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
   a.max_outer = max_outer; a.lm_max = lm_max;
-  hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals, status);
+  hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals, status,
+                     bin ? *bin : BinTable{nullptr, nullptr, nullptr, 0});
+}
+void launch_bin_offsets(const BinTable& bt, uint32_t* chunk_start, DevState* st, hipStream_t s) {
+  hipLaunchKernelGGL(bin_offsets_kernel, dim3((1u << bt.log2_size) / 1024u), dim3(1024), 0, s, bt, chunk_start, st);
+}
+void launch_bin_place(const BinTable& bt, const float* d_scan, uint32_t n, const uint32_t* qslot, const uint32_t* qrank, uint32_t* perm,
+                      float* spx, float* spy, float* spz, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(bin_place_kernel, grid_for(n, 256), dim3(256), 0, s, bt, d_scan, n, qslot, qrank, perm, spx, spy, spz);
 }
 void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo,
                        uint32_t n, int end_bit, hipStream_t s) {
