@@ -188,38 +188,49 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
 }
 
 // bucket offsets + chunk list from the table counts; leaves the table empty for the next registration.
-// One thread per table slot, 1024 per workgroup: workgroup scan, one atomic pair per workgroup.
+// Four table slots per thread (one 16-byte load), 1024 threads per workgroup: workgroup scan, one atomic pair per workgroup.
 __global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t* __restrict__ chunk_start, DevState* __restrict__ st) {
   __shared__ uint32_t wq[16], wc[16], base_q, base_c;
-  const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t4 = blockIdx.x * blockDim.x + threadIdx.x;  // slots 4*t4 .. 4*t4+3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t cnt = bt.cnt[sidx];
-  const uint32_t nch = (cnt + 63u) >> 6;
-  uint32_t iq = cnt, ic = nch;  // inclusive scans over the wavefront
+  const uint4 c4 = reinterpret_cast<const uint4*>(bt.cnt)[t4];
+  const uint32_t cnt[4] = {c4.x, c4.y, c4.z, c4.w};
+  uint32_t tq = 0, tc = 0;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t a = (uint32_t)__shfl_up((int)iq, d, 64), b = (uint32_t)__shfl_up((int)ic, d, 64);
-    if (lane >= d) { iq += a; ic += b; }
+  for (int k = 0; k < 4; ++k) { tq += cnt[k]; tc += (cnt[k] + 63u) >> 6; }
+  uint32_t iq = tq, ic = tc;  // inclusive scans over the wavefront
+  if (__ballot(tq != 0)) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t a = (uint32_t)__shfl_up((int)iq, d, 64), b = (uint32_t)__shfl_up((int)ic, d, 64);
+      if (lane >= d) { iq += a; ic += b; }
+    }
   }
   if (lane == 63) { wq[wave] = iq; wc[wave] = ic; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t tq = 0, tc = 0;
-    for (int w = 0; w < 16; ++w) { const uint32_t a = wq[w], b = wc[w]; wq[w] = tq; wc[w] = tc; tq += a; tc += b; }
-    base_q = tq ? atomicAdd(&st->n_kept, tq) : 0u;
-    base_c = tc ? atomicAdd(&st->n_chunks, tc) : 0u;
+    uint32_t sq = 0, sc = 0;
+    for (int w = 0; w < 16; ++w) { const uint32_t a = wq[w], b = wc[w]; wq[w] = sq; wc[w] = sc; sq += a; sc += b; }
+    base_q = sq ? atomicAdd(&st->n_kept, sq) : 0u;
+    base_c = sc ? atomicAdd(&st->n_chunks, sc) : 0u;
   }
   __syncthreads();
-  if (cnt) {
-    const uint32_t off = base_q + wq[wave] + (iq - cnt);
-    bt.off[sidx] = off;
-    uint32_t* o = chunk_start + base_c + wc[wave] + (ic - nch);
-    for (uint32_t c2 = 0; c2 < nch; ++c2) {
-      const uint32_t left = cnt - 64u * c2;
-      o[c2] = (off + 64u * c2) | (((left < 64u ? left : 64u) - 1u) << 26);
+  if (tq) {
+    uint32_t off = base_q + wq[wave] + (iq - tq);
+    uint32_t* o = chunk_start + base_c + wc[wave] + (ic - tc);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!cnt[k]) continue;
+      bt.off[4 * t4 + k] = off;
+      const uint32_t nch = (cnt[k] + 63u) >> 6;
+      for (uint32_t c2 = 0; c2 < nch; ++c2) {
+        const uint32_t left = cnt[k] - 64u * c2;
+        o[c2] = (off + 64u * c2) | (((left < 64u ? left : 64u) - 1u) << 26);
+      }
+      o += nch; off += cnt[k];
+      bt.key[4 * t4 + k] = 0xFFFFFFFFu;
     }
-    bt.cnt[sidx] = 0;
-    bt.key[sidx] = 0xFFFFFFFFu;
+    reinterpret_cast<uint4*>(bt.cnt)[t4] = make_uint4(0, 0, 0, 0);
   }
 }
 
@@ -1709,7 +1720,7 @@ void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const doubl
                      bin ? *bin : BinTable{nullptr, nullptr, nullptr, 0});
 }
 void launch_bin_offsets(const BinTable& bt, uint32_t* chunk_start, DevState* st, hipStream_t s) {
-  hipLaunchKernelGGL(bin_offsets_kernel, dim3((1u << bt.log2_size) / 1024u), dim3(1024), 0, s, bt, chunk_start, st);
+  hipLaunchKernelGGL(bin_offsets_kernel, dim3((1u << bt.log2_size) / 4096u), dim3(1024), 0, s, bt, chunk_start, st);
 }
 void launch_bin_place(const BinTable& bt, const float* d_scan, uint32_t n, const uint32_t* qslot, const uint32_t* qrank, uint32_t* perm,
                       float* spx, float* spy, float* spz, hipStream_t s) {
