@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--max-outer", type=int, default=5, help="LocalizationICPMaxIter (5 = config of record)")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every kernel (adds bubbles)")
     ap.add_argument("--cpu-sample", type=int, default=1, help="registrations timed for the CPU baseline")
+    ap.add_argument("--shuffle-scan", action="store_true", help="experiment: random point order inside every scan (worst case for the binning atomics)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the k-NN launches (no roofline)")
     args = ap.parse_args()
 
@@ -71,6 +72,8 @@ def main():
         slam.comm_init(uid[0])
     n_map = slam.add_surf_point_cloud(sc.map_points)
     scans = [sc.scan(i) for i in range(args.scans)]
+    if args.shuffle_scan:
+        scans = [s_[np.random.default_rng(77 + i).permutation(len(s_))] for i, s_ in enumerate(scans)]
     guesses = [sc.guess(i) for i in range(args.scans)]
     d_scans = [slam.upload_scan(s) for s in scans]  # inputs resident in HBM before the timed region
     Q = len(scans[0])

@@ -201,6 +201,28 @@ def test_register_batch_hypotheses_match_single_registrations_and_oracle(oracle,
     assert ok2 == ok and np.array_equal(out2, out)
 
 
+def test_point_order_inside_the_scan_does_not_matter(oracle, gpu_slam_factory, monkeypatch):
+    """A randomly permuted scan (worst case for the binning: every wavefront holds 64 different keys) registers to the
+    oracle's pose of the same permuted scan, and the rocPRIM sort path gives bit-identical results to the hash binning."""
+    sc, slam, om = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
+    scan = sc.scan(4)
+    perm = np.random.default_rng(3).permutation(len(scan))
+    shuffled = scan[perm]
+    guess = sc.guess(4)
+    rc, pose, st = slam.register(shuffled, guess)
+    orc, opose, ost, _ = om.register(shuffled, guess, oracle.default_config(max_iterations=5))
+    assert rc == orc == 0 and st.n_iterations == ost.n_iterations
+    for it in range(st.n_iterations):
+        assert list(st.iterations[it].reject_hist) == list(ost.iters[it].reject_hist)
+        assert list(st.iterations[it].obs_hist) == list(ost.iters[it].obs_hist)
+    ok, dt, dr = pose_close(pose, opose, 1e-8, 1e-8)
+    assert ok, (dt, dr)
+    monkeypatch.setenv("SOICP_BINNING", "sort")
+    _, alt, _ = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
+    rc2, pose2, st2 = alt.register(shuffled, guess)
+    assert rc2 == 0 and np.array_equal(pose, pose2) and np.array_equal(np.array(st.JtJ), np.array(st2.JtJ))
+
+
 def test_rccl_path_world1_matches_oracle(oracle, gpu_slam_factory, soicp):
     """The N>1 code path (eval -> ncclAllReduce(45 fp64) -> lm_step_kernel) on a 1-rank RCCL communicator."""
     sc, slam, om = _setup("tiny", oracle, gpu_slam_factory, max_iterations=5)
