@@ -1246,7 +1246,9 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
                                          double* __restrict__ partials, uint32_t* __restrict__ ticket,
                                          int32_t* __restrict__ hist, LmSums* __restrict__ out,
                                          const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
-                                         const MatchParams& mp, EvalShared& sh) {
+                                         const MatchParams& mp, EvalShared& sh, bool keep_state = false) {
+  // keep_state (solve_kernel): workgroup 0 is the finisher of every pass of the launch, so the controller state stays in
+  // its LDS from pass to pass and goes to memory only when the solve ends
   double (*red)[kRedStride] = sh.red;
   double (*part)[32] = sh.part;
   LmSums& sh_sums = sh.sums;
@@ -1413,8 +1415,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       for (int a = 0; a < kNAcc; ++a)
         asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r[q][a]) : "v"(rec + a * kPartStride) : "memory");
     }
-    if (fuse_lm) {  // the controller state may have been written by another workgroup of this very launch: coherent loads
-      if (tid < (int)(sizeof(LmState) / 8))
+    if (fuse_lm) {  // (coherent loads: cheap insurance, one word per thread)
+      if (!keep_state && tid < (int)(sizeof(LmState) / 8))
         reinterpret_cast<double*>(&sh_S)[tid] = __hip_atomic_load(reinterpret_cast<const double*>(&st->S) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       load_ctl(sh_ctl, st, tid, 128);
     }
@@ -1455,7 +1457,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   __syncthreads();
   // the solve is over: clear the histogram replicas for the next outer iteration (ResetDistanceParameters, LidarSlam.cpp:847-852)
   if (!sh_more) { hist[tid] = 0; hist[256 + tid] = 0; }
-  if (tid < (int)(sizeof(LmState) / 8))
+  if ((!keep_state || !sh_more) && tid < (int)(sizeof(LmState) / 8))
     __hip_atomic_store(reinterpret_cast<double*>(&st->S) + tid, reinterpret_cast<const double*>(&sh_S)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!sh_more) publish_state(st, ep, sh_ctl.outer_iter, tid, 256);
   if (stamp && tid == 0) {
@@ -1512,7 +1514,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
   __syncthreads();
   const unsigned long long e0 = sh.epoch;
   Pose pose = pose_from_array(st->T);
-  int code = eval_pass<true>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh);
+  int code = eval_pass<true>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, true);
   for (int slot = 1; slot <= lm_max; ++slot) {
     __syncthreads();
     const unsigned long long want = e0 + (unsigned long long)slot;
@@ -1548,7 +1550,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
     if (sh.more != 1) return;  // solve ended (or timeout)
     pose = pose_from_array(sh.pose);
     __syncthreads();
-    code = eval_pass<false>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh);
+    code = eval_pass<false>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, true);
   }
 }
 
