@@ -254,12 +254,12 @@ __global__ __launch_bounds__(256) void bin_place_kernel(BinTable bt, const float
 // more chunks).  A chunk's lanes therefore share one small union block of map cells and the cost of a wave is ~ one
 // candidate set whatever the query density.  Descriptor = start | (count-1) << 26.
 // (Measured before: merging several cells into one chunk halves the wave count and DOUBLES the kernel time.)
-// The same launch gathers the scan into sorted SoA order (spx/spy/spz), which the k-NN and evaluation kernels read.
+// The same launch gathers the scan into sorted SoA order (spx/spy/spz) for the k-NN kernel.  (SOICP_BINNING=sort path;
+// the default is the hash binning of scan_keys_kernel / bin_offsets_kernel / bin_place_kernel.)
 __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t kKeyDropped,
                                                            uint32_t* __restrict__ chunk_start, DevState* __restrict__ st,
                                                            const float* __restrict__ scan, const uint32_t* __restrict__ perm,
-                                                           float* __restrict__ spx, float* __restrict__ spy, float* __restrict__ spz,
-                                                           int chunk_mode) {
+                                                           float* __restrict__ spx, float* __restrict__ spy, float* __restrict__ spz) {
   __shared__ uint32_t wave_cnt[16];
   __shared__ uint32_t block_base;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,32 +271,7 @@ __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __res
   if (kept && (i + 1 == n || keys[i + 1] == kKeyDropped)) st->n_kept = i + 1;
   bool head = false;
   uint32_t count = 0;
-  if (chunk_mode >= 2) {
-    // 64-aligned block = ONE chunk when it spans at most chunk_mode different keys (adjacent octants / cells: one union
-    // block, full lanes, the per-chunk overhead paid once); a block that scatters over more keys (sparse far-range
-    // returns, one cell group per query) is cut at every key change so that no wavefront serialises many groups.
-    const bool key_head = kept && (lane == 0 || keys[i - 1] != key);
-    const unsigned long long km = __ballot(key_head);
-    const bool merge = __popcll(km) <= chunk_mode;
-    head = merge ? (kept && lane == 0) : key_head;
-    const unsigned long long kept_mask = __ballot(kept);
-    const unsigned long long hm = __ballot(head);
-    if (head) {
-      const unsigned long long later = (lane == 63) ? 0ull : (hm >> (lane + 1));
-      const int end = later ? lane + 1 + (__ffsll((long long)later) - 1) : (int)__popcll(kept_mask);
-      count = (uint32_t)(end - lane);
-    }
-  } else if (chunk_mode == 1) {  // experiment: 64-aligned blocks whatever the keys (full lanes, several cell groups per wavefront)
-    head = kept && (i & 63u) == 0;
-    if (head) {
-      if (i + 63 < n && keys[i + 63] != kKeyDropped) count = 64;
-      else {
-        uint32_t lo = i + 1, hi = (i + 63 < n) ? i + 63 : n;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] != kKeyDropped) lo = mid + 1; else hi = mid; }
-        count = lo - i;
-      }
-    }
-  } else if (kept) {
+  if (kept) {
     if (i == 0 || keys[i - 1] != key) {
       head = true;  // first query of a run
     } else if (i >= 64 && keys[i - 64] == key) {  // inside a long run: every 64th query counted from the run's start
@@ -305,7 +280,7 @@ __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __res
       head = ((i - lo) & 63u) == 0;
     }
   }
-  if (head && chunk_mode == 0) {  // end of the chunk: 64 queries or the end of the run
+  if (head) {  // end of the chunk: 64 queries or the end of the run
     if (i + 63 < n && keys[i + 63] == key) {
       count = 64;
     } else {
@@ -1748,9 +1723,8 @@ void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t
 void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n, uint32_t dropped_key, uint32_t* chunk_start, DevState* st,
                         const float* d_scan, const uint32_t* perm, float* spx, float* spy, float* spz, hipStream_t s) {
   if (!n) return;
-  static const int chunk_mode = std::getenv("SOICP_CHUNK_MODE") ? std::atoi(std::getenv("SOICP_CHUNK_MODE")) : 0;
   hipLaunchKernelGGL(chunk_heads_kernel, grid_for(n, 1024), dim3(1024), 0, s, keys_sorted, n, dropped_key, chunk_start, st, d_scan, perm,
-                     spx, spy, spz, chunk_mode);
+                     spx, spy, spz);
 }
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* keys_sorted,
                       const uint32_t* chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
