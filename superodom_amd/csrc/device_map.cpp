@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace soicp {
@@ -21,7 +22,7 @@ static inline int cidx(int i, int j, int k) { return i + kMapW * j + kMapW * kMa
 
 DeviceMap::~DeviceMap() {
   for (void* p : {(void*)d_pool_, (void*)d_cell_start_, (void*)d_cube_slot_, (void*)d_wpts_, (void*)d_cent_, (void*)d_k0_, (void*)d_k1_,
-                  (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, (void*)d_spts_, (void*)d_heads_, d_temp_, (void*)d_cube_of_, (void*)d_touched_,
+                  (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, (void*)d_spts_, (void*)d_heads_, (void*)d_grid_, (void*)d_grid_scan_, d_temp_, (void*)d_cube_of_, (void*)d_touched_,
                   (void*)d_touched_id_, (void*)d_small_, (void*)d_stage_})
     if (p) (void)hipFree(p);
   if (h_touched_) (void)hipHostFree(h_touched_);
@@ -257,6 +258,24 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     a.wpts = d_wpts_; a.cent = d_cent_; a.spts = d_spts_; a.heads = d_heads_;
     a.keys0 = d_k0_; a.keys1 = d_k1_; a.vals0 = d_v0_; a.vals1 = d_v1_; a.flags = d_flags_; a.pos = d_pos_;
     a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
+    static const bool use_grid = !(std::getenv("SOICP_MAP_STAGE2") && std::string(std::getenv("SOICP_MAP_STAGE2")) == "sort");
+    if (use_grid) {
+      const size_t gn = (size_t)tt.n * ncell1_ + 1024;
+      if (gn > grid_cap_) {
+        if (d_grid_) (void)hipFree(d_grid_);
+        if (d_grid_scan_) (void)hipFree(d_grid_scan_);
+        d_grid_ = d_grid_scan_ = nullptr; grid_cap_ = 0;
+        DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_grid_), gn * sizeof(uint32_t)));
+        DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_grid_scan_), gn * sizeof(uint32_t)));
+        grid_cap_ = gn;
+      }
+      if (temp_bytes_ < map_sort_temp_bytes(gn)) {  // the scan of the grids uses the sort's scratch buffer
+        (void)hipFree(d_temp_); d_temp_ = nullptr;
+        temp_bytes_ = map_sort_temp_bytes(gn) + 256;
+        DM_TRY(hipMalloc(&d_temp_, temp_bytes_));
+      }
+      a.grid = d_grid_; a.grid_scan = d_grid_scan_;
+    }
     a.temp = d_temp_; a.temp_bytes = temp_bytes_;
     launch_map_insert(a, stream_);
     DM_TRY(hipMemcpyAsync(h_small_, d_small_, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));

@@ -55,6 +55,7 @@ class DeviceMap {
   size_t work_cap_ = 0; size_t new_cap_ = 0;
   float4 *d_wpts_ = nullptr, *d_cent_ = nullptr, *d_spts_ = nullptr;
   uint32_t *d_k0_ = nullptr, *d_k1_ = nullptr, *d_v0_ = nullptr, *d_v1_ = nullptr, *d_flags_ = nullptr, *d_pos_ = nullptr, *d_heads_ = nullptr;
+  uint32_t *d_grid_ = nullptr, *d_grid_scan_ = nullptr; size_t grid_cap_ = 0;  // dense cell grids of the touched cubes (second stage)
   void* d_temp_ = nullptr; size_t temp_bytes_ = 0;
   int32_t* d_cube_of_ = nullptr; uint8_t* d_touched_ = nullptr; int8_t* d_touched_id_ = nullptr; uint32_t* d_small_ = nullptr;
   float* d_stage_ = nullptr; size_t stage_cap_ = 0;  // host->device staging of new points / export

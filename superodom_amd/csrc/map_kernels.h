@@ -32,6 +32,7 @@ struct MapInsertArgs {
   float4* wpts; float4* cent; float4* spts /* working set in leaf-sorted order */; uint32_t* heads /* first index of leaf o; [n_leaves] = end */;
   uint32_t *keys0, *keys1, *vals0, *vals1, *flags, *pos;
   uint32_t* d_n_cent; uint32_t* d_counts;  // [1], [kMaxTouched]
+  uint32_t *grid, *grid_scan;              // [tt.n * ncell1] each, or nullptr: second stage by sort + binary-search table
   void* temp; size_t temp_bytes;
 };
 

@@ -280,6 +280,61 @@ __global__ __launch_bounds__(256) void gather_export_kernel(const float4* __rest
 static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
 // ------------------------------------------------------------------------------------------------
+// Second stage without a sort: the centroids are counted into the dense cell grids of the touched cubes (atomic rank
+// inside a cell), an exclusive scan over the grids IS the cubes' new cell_start tables, the centroids are placed, and
+// every cell with more than one point is put into ascending leaf order (one centroid per leaf: the order is total, so the
+// result equals the stable sort by (cell, leaf) it replaces).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cell_count_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ n_cent,
+                                                         uint32_t ncell1, uint32_t* __restrict__ grid, uint32_t* __restrict__ rank) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= *n_cent) return;
+  const uint32_t k = keys2[o];
+  rank[o] = atomicAdd(&grid[(size_t)(k >> 18) * ncell1 + (k & 0x3FFFFu)], 1u);
+}
+// grid_scan = exclusive scan of grid over all touched cubes; per cube: table entry = slot*cap + (scan - scan at the cube's
+// first cell); the entry behind the last cell = the cube's new point count
+__global__ __launch_bounds__(256) void cell_table_kernel(const uint32_t* __restrict__ grid_scan, MapTouched tt, uint32_t cap, uint32_t ncell1,
+                                                         uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = blockIdx.y;
+  if (c >= ncell1) return;
+  const uint32_t local = grid_scan[(size_t)t * ncell1 + c] - grid_scan[(size_t)t * ncell1];
+  cell_start[(size_t)tt.slot[t] * ncell1 + c] = tt.slot[t] * cap + local;
+  if (c == ncell1 - 1) counts[t] = local;
+}
+// pass 1: every centroid into its cell's range of a scratch array, at the atomic rank, leaf key in .w
+__global__ __launch_bounds__(256) void cell_place_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ rank,
+                                                         const uint32_t* __restrict__ n_cent, const uint32_t* __restrict__ grid_scan,
+                                                         const float4* __restrict__ cent, MapTouched tt, uint32_t ncell1, float inv_leaf,
+                                                         float4* __restrict__ tmp) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= *n_cent) return;
+  const uint32_t k = keys2[o], t = k >> 18;
+  float4 v = cent[o];
+  v.w = __uint_as_float(leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t));
+  tmp[grid_scan[(size_t)t * ncell1 + (k & 0x3FFFFu)] + rank[o]] = v;  // global position over all touched cubes
+}
+// pass 2: final position inside the cell = number of the cell's centroids with a smaller leaf key (one centroid per leaf:
+// the keys are distinct), i.e. ascending leaf order -- what the stable sort by (cell, leaf) produced
+__global__ __launch_bounds__(256) void cell_rank_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ n_cent,
+                                                        const uint32_t* __restrict__ grid, const uint32_t* __restrict__ grid_scan,
+                                                        const float4* __restrict__ cent, const float4* __restrict__ tmp, MapTouched tt,
+                                                        uint32_t cap, uint32_t ncell1, float inv_leaf, float4* __restrict__ pool) {
+  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= *n_cent) return;
+  const uint32_t k = keys2[o], t = k >> 18;
+  const size_t gi = (size_t)t * ncell1 + (k & 0x3FFFFu);
+  const uint32_t beg = grid_scan[gi], cnt = grid[gi];
+  const float4 v = cent[o];
+  const uint32_t kv = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t);
+  uint32_t r = 0;
+  for (uint32_t j = 0; j < cnt; ++j) r += (__float_as_uint(tmp[beg + j].w) < kv) ? 1u : 0u;
+  const uint32_t local = beg - grid_scan[(size_t)t * ncell1] + r;
+  if (local < cap) pool[(size_t)tt.slot[t] * cap + local] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Scan pre-filter (laserMapping::adjustVoxelSize, laserMapping.cpp:598-651): cloud statistics + pcl::VoxelGrid of the
 // surf cloud at planeRes, on the device.
 // ------------------------------------------------------------------------------------------------
@@ -436,6 +491,20 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
                      a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
   hipLaunchKernelGGL(leaf_centroid_long_kernel, dim3(kMaxLongLeaves / 4), dim3(256), 0, s, a.keys1, a.heads, a.spts, a.tt, a.nc, a.inv_cell,
                      a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
+  if (a.grid) {  // second stage by counting into the cell grids (no sort)
+    const size_t gn = (size_t)a.tt.n * a.ncell1;
+    (void)hipMemsetAsync(a.grid, 0, gn * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.ncell1, a.grid, a.vals1);
+    tb = a.temp_bytes;
+    (void)rocprim::exclusive_scan(a.temp, tb, a.grid, a.grid_scan, 0u, gn, rocprim::plus<uint32_t>(), s);
+    hipLaunchKernelGGL(cell_table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.grid_scan, a.tt, a.cap, a.ncell1, a.cell_start,
+                       a.d_counts);
+    hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.tt, a.ncell1,
+                       a.inv_leaf, a.spts);  // spts (leaf-sorted working set) is free after the centroids
+    hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid, a.grid_scan, a.cent, a.spts, a.tt,
+                       a.cap, a.ncell1, a.inv_leaf, a.pool);
+    return;
+  }
   hipLaunchKernelGGL(pad_keys_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals0, a.d_n_cent, total);
   tb = a.temp_bytes;
   (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable: leaf order inside a cell
