@@ -11,9 +11,11 @@
 //   rocPRIM stable sort   by leaf key
 //   leaf_heads_kernel     working set gathered into leaf-sorted order, first index of every leaf
 //   leaf_centroid_kernel  one thread per leaf: float sums IN ORDER, centroid = sum / count  (VoxelGrid semantics)
-//   cell_key_kernel       key2 = (touched-cube id, cell z, y, x) of each centroid; rocPRIM stable sort
-//   scatter_kernel        centroids into the cube's region of the point pool (canonical order = cell, then leaf)
-//   table_kernel          per-cube prefix table by binary search (cell -> first canonical index)
+//   second stage (no sort): cell_count_kernel (centroids counted into the dense cell grids of the touched cubes, atomic rank),
+//                         exclusive scan of the grids = the cubes' new cell_start tables (cell_table_kernel), cell_place_kernel
+//                         (into a scratch array, leaf key alongside), cell_rank_kernel (final position inside the cell =
+//                         number of smaller leaf keys: canonical order = cell, then leaf).  SOICP_MAP_STAGE2=sort keeps the
+//                         earlier path (stable sort by cell key, scatter, table by binary search).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
