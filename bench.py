@@ -63,7 +63,7 @@ def main():
     # ---------------- synthetic workload (seeded) ----------------
     sc = synth.Scene(args.workload)
     max_outer, lm_iters = args.max_outer, 4
-    slam = binding.LidarSlamGpu(device_id=local_rank, rank=rank, world_size=world, plane_res=sc.plane_res,
+    slam = binding.LidarSlamGpu(device_id=int(os.environ.get("SOICP_BENCH_DEVICE", local_rank)), rank=rank, world_size=world, plane_res=sc.plane_res,
                                 line_res=sc.plane_res / 2, max_iterations=max_outer, lm_max_iterations=lm_iters,
                                 max_surface_features=-1, time_kernels=2 if args.time_all_kernels else (0 if args.no_kernel_events else 1))
     if world > 1:
