@@ -636,7 +636,8 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   c->map.set_resolution(cfg->line_res, cfg->plane_res);
   auto bail = [&](const std::string& m) { g_create_error = m; delete c; return (so_icp_ctx*)nullptr; };
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(std::string("hipStreamCreate: ") + hipGetErrorString(e));
-  const size_t partial_bytes = (size_t)kFitBlocksMax * kSumsStride * sizeof(double);
+  const size_t partial_bytes = std::max((size_t)kFitBlocksMax * kSumsStride * sizeof(double),
+                                        (size_t)kFitBlocksMax * kRecordChunksMax * 16);  // partial sums / tagged records of solve_kernel
   const size_t small_bytes = 4096 + sizeof(LmSums) + 256 + partial_bytes + 256 + kSyncBytes;
   if ((e = c->d_small.reserve(small_bytes)) != hipSuccess) return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
   if ((e = hipMemset(c->d_small.p, 0, c->d_small.cap)) != hipSuccess) return bail(std::string("hipMemset: ") + hipGetErrorString(e));

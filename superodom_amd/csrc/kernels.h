@@ -91,6 +91,7 @@ constexpr int kFitBlocksMax = SO_SOLVE_BLOCKS;
 constexpr int kArriveCounters = 16, kArriveStrideWords = 32, kHandoffWordOffset = kArriveCounters * kArriveStrideWords;
 constexpr int kSyncBytes = kHandoffWordOffset * 4 + 8 * 16;
 constexpr int kSumsStride = 48;      // doubles per partial record (45 used)
+constexpr int kRecordChunksMax = 40; // 16-byte chunks per workgroup record of the persistent solve (29 sums + 8 histogram pairs)
 // sort key = (cube slot << 21) | Morton(half-cell: 7 bits per axis, low 3 bits = octant inside the map cell).  Two
 // special "slots" sort behind every real cube:
 //   n_slots     : processed query whose cube is outside the window / has no tree (NOT_ENOUGH_NEIGHBORS)

@@ -1117,11 +1117,15 @@ struct LmCtl {       // LDS copy of the DevState fields the controller reads (pr
   int32_t lm_max, outer_iter, max_outer, pad;
 };
 
-__device__ __attribute__((noinline)) int lm_control(int slot, DevState* st, LmState& S, const LmSums& sums, const LmCtl& ctl) {
+__device__ __forceinline__ int lm_control_regs(int slot, DevState* st, LmState& S, const LmSums& sums, const LmCtl& ctl, bool persist) {
+  // persist (solve_kernel): the next pose travels in the hand-off record and nobody reads lm_more, so a pass that is
+  // followed by another one issues no global store at all (a store would have to drain before the next barrier)
   int more;
-  if (slot == 0) more = lm_begin(S, ctl.T, sums, ctl.lm_max, st->eval_pose);
-  else more = lm_feed(S, sums, st->eval_pose);
-  st->lm_more = more;
+  double unused_pose[7];
+  double* next_pose = persist ? unused_pose : st->eval_pose;
+  if (slot == 0) more = lm_begin(S, ctl.T, sums, ctl.lm_max, next_pose);
+  else more = lm_feed(S, sums, next_pose);
+  if (!persist || !more) st->lm_more = more;
   if (more) return 1;
   // solve finished: T_w_lidar <- optimised pose, iteration statistics, termination rule
   for (int i = 0; i < 7; ++i) st->T[i] = S.x[i];
@@ -1142,6 +1146,23 @@ __device__ __attribute__((noinline)) int lm_control(int slot, DevState* st, LmSt
     for (int i = 0; i < 6; ++i) st->Jtr[i] = have ? S.g[i] : 0.0;
   }
   return 0;
+}
+
+#ifndef SO_LM_INLINE
+#define SO_LM_INLINE __forceinline__
+#endif
+__device__ SO_LM_INLINE int lm_control(int slot, DevState* st, LmState& S_lds, const LmSums& sums_lds, const LmCtl& ctl, bool persist = false) {
+  // register copies: the controller is one thread's serial fp64 chain, and every LDS round trip inside it (~100 cycles,
+  // nothing to overlap with) would sit on the critical path of the whole device
+#ifdef SO_LM_LDS
+  return lm_control_regs(slot, st, S_lds, sums_lds, ctl, persist);
+#else
+  LmState S = S_lds;
+  const LmSums sums = sums_lds;
+  const int more_ = lm_control_regs(slot, st, S, sums, ctl, persist);
+  S_lds = S;
+  return more_;
+#endif
 }
 
 // threads [first, first+10) fetch the controller's inputs
@@ -1225,16 +1246,18 @@ enum { kPassNotLast = 0, kPassMore = 1, kPassDone = 2, kPassSums = 3 };
 // workgroup but the one that arrives last; that one reduces the partial records and (fuse_lm) runs the LM controller:
 // kPassMore = another evaluation is requested at sh.S.cand, kPassDone = the solve ended (state published),
 // kPassSums = !fuse_lm, the sums are in `out` for the all-reduce.
-template <bool FIT>
+template <bool FIT, bool PERSIST = false>
 __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose, const float* __restrict__ spx,
                                          const float* __restrict__ spy, const float* __restrict__ spz,
                                          const CorrBuffers& corr, DevState* __restrict__ st, const EvalParams& ep,
                                          double* __restrict__ partials, uint32_t* __restrict__ ticket,
                                          int32_t* __restrict__ hist, LmSums* __restrict__ out,
                                          const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
-                                         const MatchParams& mp, EvalShared& sh, bool keep_state = false) {
-  // keep_state (solve_kernel): workgroup 0 is the finisher of every pass of the launch, so the controller state stays in
-  // its LDS from pass to pass and goes to memory only when the solve ends
+                                         const MatchParams& mp, EvalShared& sh, unsigned long long pass_tag = 0) {
+  // PERSIST (solve_kernel): workgroup 0 is the finisher of every pass of the launch, so the controller state stays in
+  // its LDS from pass to pass and goes to memory only when the solve ends; the workgroup records are PUSHED (tagged
+  // 16-byte chunks, see below) instead of stored + counted
+  constexpr bool keep_state = PERSIST;
   double (*red)[kRedStride] = sh.red;
   double (*part)[32] = sh.part;
   LmSums& sh_sums = sh.sums;
@@ -1354,6 +1377,97 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   for (int a = 0; a < kNAcc; ++a) red[tid][a] = acc[a];
   __syncthreads();
   const double mine = reduce_records(red, part, tid);
+  if (PERSIST) {
+    // Push model: the record of this workgroup for this pass is kNAcc (+8 with the histograms of the fit pass) chunks of
+    // 16 bytes {value, pass tag}, each written with ONE sc1 dwordx4 store -- fire and forget: no drain, no arrival
+    // counter.  Workgroup 0 polls the table partials[chunk][workgroup] (thread b: the chunks of workgroup b, coalesced)
+    // until every chunk carries this pass's tag: one memory round trip from "last record written" to "all sums in
+    // hand" instead of two (arrival counter, then the records).  Tags grow monotonically over passes and launches.
+    static_assert(SO_SOLVE_BLOCKS <= 256, "one polling thread per workgroup record");
+    constexpr int kCh = kNAcc + (FIT ? 8 : 0);
+    static_assert(kCh <= kRecordChunksMax, "record table");
+    u4v* rec = reinterpret_cast<u4v*>(partials);
+    const unsigned int tlo = (unsigned int)pass_tag, thi = (unsigned int)(pass_tag >> 32);
+    // The correspondence stores of the fit loop are long on their way (the LDS reduction came in between); retiring
+    // them HERE, in the compiler's scoreboard too, keeps it from placing its own vmcnt waits between the hand-written
+    // polling loads below (which it cannot see), where each would cost a full memory round trip.
+    if (FIT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
+    if (tid < kNAcc) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(mine);
+      const u4v v = {(unsigned int)b, (unsigned int)(b >> 32), tlo, thi};
+      store16_sc1(rec + (size_t)tid * kPartStride + blockIdx.x, v);
+    } else if (FIT && tid >= 32 && tid < 40) {  // MatchRejectionHistogramPlane + observability histogram: two counters per chunk
+      const int k = tid - 32;
+      const u4v v = {(unsigned int)lh[2 * k], (unsigned int)lh[2 * k + 1], tlo, thi};
+      store16_sc1(rec + (size_t)(kNAcc + k) * kPartStride + blockIdx.x, v);
+    }
+    if (stamp) t_red = wall_clock64();
+    if (blockIdx.x != 0) return kPassNotLast;
+    u4v r[kCh];
+    const bool have = (uint32_t)tid < gridDim.x;
+    const u4v* base = rec + (have ? tid : 0);
+    const unsigned long long t0 = wall_clock64();
+    bool ok;
+    for (;;) {
+#pragma unroll
+      for (int a = 0; a < kCh; ++a)
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r[a]) : "v"(base + (size_t)a * kPartStride) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
+                     "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]), "+v"(r[17]), "+v"(r[18]),
+                     "+v"(r[19]), "+v"(r[20]), "+v"(r[21]), "+v"(r[22]), "+v"(r[23]), "+v"(r[24]), "+v"(r[25]), "+v"(r[26]), "+v"(r[27]),
+                     "+v"(r[28])
+                   :: "memory");
+      if (FIT)
+        asm volatile("" : "+v"(r[kCh - 8]), "+v"(r[kCh - 7]), "+v"(r[kCh - 6]), "+v"(r[kCh - 5]), "+v"(r[kCh - 4]), "+v"(r[kCh - 3]),
+                          "+v"(r[kCh - 2]), "+v"(r[kCh - 1]) :: "memory");
+      ok = true;
+#pragma unroll
+      for (int a = 0; a < kCh; ++a) ok = ok && r[a].z == tlo && r[a].w == thi;
+      ok = ok || !have;
+      if (__ballot(!ok) == 0ull) break;
+      if (wall_clock64() - t0 > 5000000ull) break;  // 50 ms: give up instead of hanging the device
+    }
+    if (!__syncthreads_and(ok ? 1 : 0)) return kPassNotLast;  // timeout: the solve is abandoned, the host reports the missing publication
+    if (stamp) t_ticket = t_loaded = wall_clock64();
+#pragma unroll
+    for (int a = 0; a < kNAcc; ++a)
+      red[tid][a] = have ? __longlong_as_double((long long)(((unsigned long long)r[a].y << 32) | r[a].x)) : 0.0;
+    __syncthreads();
+    const double total = reduce_records(red, part, tid);
+    double* o = reinterpret_cast<double*>(&sh_sums);
+    if (tid < kNAcc) o[tid] = total;  // cost, count, Jtr[6], JtJ[21]
+    if (FIT) {  // the 16 counters, summed the same way (exact in fp64); later passes of the solve keep them in LDS
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        red[tid][2 * k] = have ? (double)(int)r[kNAcc + k].x : 0.0;
+        red[tid][2 * k + 1] = have ? (double)(int)r[kNAcc + k].y : 0.0;
+      }
+      __syncthreads();
+      const double ht = reduce_records(red, part, tid);
+      if (tid < 16) o[kNAcc + tid] = ht;
+    }
+    __syncthreads();
+    if (stamp) t_sums = wall_clock64();
+    if (tid == 0) sh_more = (ep.ablate & 32) ? 1 : lm_control(slot, st, sh_S, sh_sums, sh_ctl, true);
+    __syncthreads();
+    unsigned long long t_ctl = 0;
+    if (stamp) t_ctl = wall_clock64();
+    if (!sh_more) {  // the solve is over: histogram replicas cleared for the next outer iteration, state to memory, publish
+      hist[tid] = 0; hist[256 + tid] = 0;
+      if (tid < (int)(sizeof(LmState) / 8))
+        __hip_atomic_store(reinterpret_cast<double*>(&st->S) + tid, reinterpret_cast<const double*>(&sh_S)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      publish_state(st, ep, sh_ctl.outer_iter, tid, 256);
+    }
+    if (stamp && tid == 0 && (FIT || slot == 1)) {
+      t_lm = wall_clock64();
+      unsigned long long* d = st->dbg + (FIT ? 0 : 8);
+      d[0] = t_loop - t_begin; d[1] = t_red - t_loop; d[2] = t_ticket - t_red; d[3] = t_loaded - t_ticket; d[4] = t_sums - t_loaded;
+      d[5] = t_lm - t_sums; d[6] = t_lm - t_begin; d[7] = t_ctl - t_sums;
+    }
+    return sh_more ? kPassMore : kPassDone;
+  }
   // Hand-off to the last workgroup WITHOUT release/acquire fences (each costs microseconds on gfx950): the 29
   // partial sums are 8-byte agent-scope relaxed atomic stores (write-through, sc1), drained with vmcnt(0) by the
   // storing wave before the arrival ticket; the consumer reads them with agent-scope relaxed atomic loads
@@ -1441,16 +1555,18 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   if (!fuse_lm) return kPassSums;  // sharded map: the sums are all-reduced first, lm_step_kernel runs the controller
   if (tid == 0) sh_more = (ep.ablate & 32) ? 1 : lm_control(slot, st, sh_S, sh_sums, sh_ctl);  // sh_S / sh_ctl arrived with the partials
   __syncthreads();
+  unsigned long long t_ctl = 0;
+  if (stamp) t_ctl = wall_clock64();
   // the solve is over: clear the histogram replicas for the next outer iteration (ResetDistanceParameters, LidarSlam.cpp:847-852)
   if (!sh_more) { hist[tid] = 0; hist[256 + tid] = 0; }
   if ((!keep_state || !sh_more) && tid < (int)(sizeof(LmState) / 8))
     __hip_atomic_store(reinterpret_cast<double*>(&st->S) + tid, reinterpret_cast<const double*>(&sh_S)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (!sh_more) publish_state(st, ep, sh_ctl.outer_iter, tid, 256);
-  if (stamp && tid == 0) {
+  if (stamp && tid == 0 && (FIT || slot == 1)) {  // (the plain-evaluation record is the one of slot 1: never the pass that publishes)
     t_lm = wall_clock64();
     unsigned long long* d = st->dbg + (FIT ? 0 : 8);
     d[0] = t_loop - t_begin; d[1] = t_red - t_loop; d[2] = t_ticket - t_red; d[3] = t_loaded - t_ticket; d[4] = t_sums - t_loaded;
-    d[5] = t_lm - t_sums; d[6] = t_lm - t_begin;
+    d[5] = t_lm - t_sums; d[6] = t_lm - t_begin; d[7] = t_ctl - t_sums;
   }
   return sh_more ? kPassMore : kPassDone;
 }
@@ -1500,13 +1616,18 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
   __syncthreads();
   const unsigned long long e0 = sh.epoch;
   Pose pose = pose_from_array(st->T);
-  int code = eval_pass<true>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, true);
+  if (tid == 0) {  // the controller's inputs are constant over the launch (read here, next to the pose: no fetch inside a pass)
+    for (int i = 0; i < 3; ++i) sh.ctl.T[i] = pose.t[i];
+    for (int i = 0; i < 4; ++i) sh.ctl.T[3 + i] = pose.q[i];
+    sh.ctl.lm_max = st->lm_max; sh.ctl.outer_iter = st->outer_iter; sh.ctl.max_outer = st->max_outer;
+  }
+  const unsigned long long tag0 = (e0 + 1ull) << 5;  // pass tags: unique over launches (every launch advances the epoch) and passes (slot <= 16)
+  int code = eval_pass<true, true>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0);
   for (int slot = 1; slot <= lm_max; ++slot) {
     __syncthreads();
     const unsigned long long want = e0 + (unsigned long long)slot;
     if (code == kPassMore || code == kPassDone) {  // this workgroup ran the controller: publish {request, more?}
       const int more = (code == kPassMore) ? 1 : 0;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // counters re-armed, controller state stored
       if (tid < 8) {
         const unsigned long long val = (tid < 7) ? (unsigned long long)__double_as_longlong(sh.S.cand[tid]) : (unsigned long long)more;
         const u4v v = {(unsigned int)val, (unsigned int)(val >> 32), (unsigned int)want, (unsigned int)(want >> 32)};
@@ -1536,7 +1657,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
     if (sh.more != 1) return;  // solve ended (or timeout)
     pose = pose_from_array(sh.pose);
     __syncthreads();
-    code = eval_pass<false>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, true);
+    code = eval_pass<false, true>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0 + (unsigned long long)slot);
   }
 }
 

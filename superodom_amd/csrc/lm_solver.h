@@ -67,6 +67,16 @@ SO_HD double lm_gradient_max_norm(const double x[7], const double g[6]) {
   return m;
 }
 
+// gradient_max_norm <= gradient_tolerance.  Fast exit: a translation component of the gradient above 1e-6 alone puts
+// |x - Plus(x, -g)|_inf far above the 1e-10 tolerance (for |x| < 1e5 the rounding of x - g stays below 3e-11), so the
+// quaternion update + normalisation (~100 serial fp64 operations of the single-thread controller) is skipped.
+SO_HD bool lm_gradient_converged(const double x[7], const double g[6]) {
+  SO_UNROLL
+  for (int i = 0; i < 3; ++i)
+    if (fabs(g[i]) > 1e-6 && fabs(x[i]) < 1e5) return false;
+  return lm_gradient_max_norm(x, g) <= LmConst::kGradientTolerance;
+}
+
 // Cholesky solve of a 6x6 SPD system; returns false when a pivot is not positive / result not finite.
 SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
   double inv[6];  // reciprocal pivots: one division per column instead of one per element
@@ -132,7 +142,10 @@ SO_HD int lm_propose(LmState& S, double next_pose[7]) {
     for (int i = 0; i < 6; ++i) {
       gs[i] = S.g[i] * S.scale[i];
       SO_UNROLL
-      for (int j = 0; j < 6; ++j) { Hs[6 * i + j] = S.H[6 * i + j] * S.scale[i] * S.scale[j]; A[6 * i + j] = Hs[6 * i + j]; }
+      for (int j = i; j < 6; ++j) {  // H is symmetric: 21 scaled entries, mirrored
+        Hs[6 * i + j] = S.H[6 * i + j] * S.scale[i] * S.scale[j]; Hs[6 * j + i] = Hs[6 * i + j];
+        A[6 * i + j] = Hs[6 * i + j]; A[6 * j + i] = Hs[6 * i + j];
+      }
       A[7 * i] += S.diag[i] * inv_radius;  // lm_diagonal^2 = diag / radius
     }
     const bool ok = lm_chol6(A, gs, y);  // (Hs + D^2) y = gs ; step = -y
@@ -146,11 +159,11 @@ SO_HD int lm_propose(LmState& S, double next_pose[7]) {
         sg += step[i] * gs[i];
       }
       SO_UNROLL
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < 6; ++i) {  // s^T Hs s over the upper triangle: diagonal once, off-diagonal terms twice
         double r = 0;
         SO_UNROLL
-        for (int j = 0; j < 6; ++j) r += Hs[6 * i + j] * step[j];
-        sHs += step[i] * r;
+        for (int j = i + 1; j < 6; ++j) r += Hs[6 * i + j] * step[j];
+        sHs += step[i] * (Hs[7 * i] * step[i] + 2.0 * r);
       }
       mcc = -sg - 0.5 * sHs;  // -(J s)^T (r + J s / 2)
     }
@@ -188,7 +201,7 @@ SO_HD int lm_begin(LmState& S, const double x0[7], const LmSums& sums, int max_i
   SO_UNROLL
   for (int i = 0; i < 7; ++i) n2 += S.x[i] * S.x[i];
   S.x_norm = sqrt(n2);
-  if (lm_gradient_max_norm(S.x, S.g) <= LmConst::kGradientTolerance) { S.termination = 3; S.done = 1; return 0; }
+  if (lm_gradient_converged(S.x, S.g)) { S.termination = 3; S.done = 1; return 0; }
   return lm_propose(S, next_pose);
 }
 
@@ -222,7 +235,7 @@ SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7]) {
     if (S.radius > LmConst::kMaxRadius) S.radius = LmConst::kMaxRadius;
     S.decrease_factor = 2.0;
     S.reuse_diagonal = 0;
-    if (lm_gradient_max_norm(S.x, S.g) <= LmConst::kGradientTolerance) { S.termination = 3; S.done = 1; return 0; }
+    if (lm_gradient_converged(S.x, S.g)) { S.termination = 3; S.done = 1; return 0; }
   } else {  // HandleUnsuccessfulStep / StepRejected
     S.radius = S.radius / S.decrease_factor;
     S.decrease_factor *= 2.0;

@@ -59,7 +59,11 @@ SO_HD void pose_plus(const double x[7], const double d[6], double o[7]) {
   quat_mul(x + 3, dq, q);
   // Eigen normalized() divides coefficient-wise; one reciprocal + four products differ from that by <= 1 ulp per
   // coefficient and cost a quarter of the serial fp64 latency inside the device-side controller
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double inv = rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);  // one long fp64 operation instead of sqrt + division
+#else
   const double inv = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#endif
   o[3] = q[0] * inv; o[4] = q[1] * inv; o[5] = q[2] * inv; o[6] = q[3] * inv;
 }
 

@@ -17,7 +17,7 @@ os.environ.setdefault("SOICP_ABLATE", "128")
 
 from superodom_amd import binding, synth  # noqa: E402
 
-NAMES = ["loop", "lds_reduce+store", "ticket", "load_partials", "reduce+sums", "lm", "total"]
+NAMES = ["loop", "lds_reduce+store", "ticket", "load_partials", "reduce+sums", "lm", "total", "controller"]
 
 
 def main():
@@ -31,13 +31,13 @@ def main():
     slam.add_surf_point_cloud(sc.map_points)
     d = slam.upload_scan(sc.scan(0))
     st = binding.Stats()
-    acc = np.zeros((2, 7))
+    acc = np.zeros((2, 8))
     for r in range(a.reps + 2):
         slam.register_dev(d[0], d[1], sc.guess(0), st)
         s = slam.debug_stamps().astype(np.float64) * 0.01  # 100 MHz -> us
         if r >= 2:
-            acc[0] += s[0:7]
-            acc[1] += s[8:15]
+            acc[0] += s[0:8]
+            acc[1] += s[8:16]
     acc /= a.reps
     rec = slam.debug_knn_stamps()
     if rec is not None:
