@@ -1240,6 +1240,11 @@ struct EvalShared {
   int32_t lh[16];
   bool is_last;
 };
+// the (at most) two accepted correspondences a thread of a persistent solve owns, kept in LDS between the passes
+struct CorrCache {
+  double nx[2][256], ny[2][256], nz[2][256], nw[2][256], c[2][256];
+  float px[2][256], py[2][256], pz[2][256];
+};
 enum { kPassNotLast = 0, kPassMore = 1, kPassDone = 2, kPassSums = 3 };
 
 // One evaluation pass of this workgroup at `pose`: accumulate, reduce, hand off.  Returns kPassNotLast in every
@@ -1253,7 +1258,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
                                          double* __restrict__ partials, uint32_t* __restrict__ ticket,
                                          int32_t* __restrict__ hist, LmSums* __restrict__ out,
                                          const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
-                                         const MatchParams& mp, EvalShared& sh, unsigned long long pass_tag = 0) {
+                                         const MatchParams& mp, EvalShared& sh, unsigned long long pass_tag = 0,
+                                         CorrCache* cc = nullptr) {
   // PERSIST (solve_kernel): workgroup 0 is the finisher of every pass of the launch, so the controller state stays in
   // its LDS from pass to pass and goes to memory only when the solve ends; the workgroup records are PUSHED (tagged
   // 16-byte chunks, see below) instead of stored + counted
@@ -1288,33 +1294,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   const double R10 = txy + twz, R11 = 1 - (txx + tzz), R12 = tyz - twx;
   const double R20 = txz - twy, R21 = tyz + twx, R22 = 1 - (txx + tyy);
   // one query: (FIT) plane fit from the prefetched neighbour coordinates, then residual / Jacobian / sums
-  auto body = [&](const uint32_t j, int status, const float* nb) {
-    if (!FIT && status != SO_MATCH_SUCCESS) return;
-    if (FIT && status == SO_MATCH_DROPPED) return;
-    const double px = (double)spx[(size_t)j * qs], py = (double)spy[(size_t)j * qs], pz = (double)spz[(size_t)j * qs];
-    double wx, wy, wz;
-    quat_rotate<double>(pose.q, px, py, pz, wx, wy, wz);                   // lidarOptimization.cpp:59 == LidarSlam.cpp:397-398
-    wx += pose.t[0]; wy += pose.t[1]; wz += pose.t[2];
-    double c;
-    double4 nd;
-    if (FIT) {
-      double fnd[4] = {0, 0, 0, 0}, fc = 0;
-      int obs[3] = {0, 0, 0};
-      if (status == SO_MATCH_PENDING) {
-        const double pw[3] = {wx, wy, wz};
-        status = plane_from_neighbours(nb, pw, pose, mp, fnd, fc, obs);
-      }
-      if (status != SO_MATCH_SUCCESS) { fc = 0; fnd[0] = fnd[1] = fnd[2] = fnd[3] = 0; }
-      nd = make_double4(fnd[0], fnd[1], fnd[2], fnd[3]);
-      c = fc;
-      corr.nd[j] = nd; corr.coeff[j] = c; corr.status[j] = (uint8_t)status;
-      atomicAdd(&lh[status], 1);                                          // MatchRejectionHistogramPlane, LidarSlam.cpp:341
-      if (status == SO_MATCH_SUCCESS) { atomicAdd(&lh[7 + obs[0]], 1); atomicAdd(&lh[7 + obs[1]], 1); atomicAdd(&lh[7 + obs[2]], 1); }
-      if (status != SO_MATCH_SUCCESS) return;
-    } else {
-      c = corr.coeff[j];
-      nd = corr.nd[j];
-    }
+  // residual, robust weight, Jacobian row and the 29 sums of one accepted correspondence (w* = R p + t)
+  auto tail = [&](double px, double py, double pz, double wx, double wy, double wz, const double4& nd, double c) {
     const double r = nd.x * wx + nd.y * wy + nd.z * wz + nd.w;             // lidarOptimization.cpp:61
     // ScaledLoss(TukeyLoss(a), c): rho, rho' [UPSTREAM ceres loss_function.cc]; corrector with rho''<=0
     const double s = r * r;
@@ -1344,11 +1325,51 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       for (int b = a; b < 6; ++b) acc[k++] += wj * J[b];
     }
   };
+  // one query: (FIT) plane fit from the prefetched neighbour coordinates, then residual / Jacobian / sums.
+  // trip = 0 / 1: the query is one of the two this thread owns in every pass of a persistent solve -- an accepted
+  // correspondence is then also left in the LDS cache, where the later passes of the launch find it.
+  auto body = [&](const uint32_t j, int status, const float* nb, int trip) {
+    if (!FIT && status != SO_MATCH_SUCCESS) return;
+    if (FIT && status == SO_MATCH_DROPPED) return;
+    const float fx = spx[(size_t)j * qs], fy = spy[(size_t)j * qs], fz = spz[(size_t)j * qs];
+    const double px = (double)fx, py = (double)fy, pz = (double)fz;
+    double wx, wy, wz;
+    quat_rotate<double>(pose.q, px, py, pz, wx, wy, wz);                   // lidarOptimization.cpp:59 == LidarSlam.cpp:397-398
+    wx += pose.t[0]; wy += pose.t[1]; wz += pose.t[2];
+    double c;
+    double4 nd;
+    if (FIT) {
+      double fnd[4] = {0, 0, 0, 0}, fc = 0;
+      int obs[3] = {0, 0, 0};
+      if (status == SO_MATCH_PENDING) {
+        const double pw[3] = {wx, wy, wz};
+        status = plane_from_neighbours(nb, pw, pose, mp, fnd, fc, obs);
+      }
+      if (status != SO_MATCH_SUCCESS) { fc = 0; fnd[0] = fnd[1] = fnd[2] = fnd[3] = 0; }
+      nd = make_double4(fnd[0], fnd[1], fnd[2], fnd[3]);
+      c = fc;
+      corr.nd[j] = nd; corr.coeff[j] = c; corr.status[j] = (uint8_t)status;
+      atomicAdd(&lh[status], 1);                                          // MatchRejectionHistogramPlane, LidarSlam.cpp:341
+      if (status == SO_MATCH_SUCCESS) { atomicAdd(&lh[7 + obs[0]], 1); atomicAdd(&lh[7 + obs[1]], 1); atomicAdd(&lh[7 + obs[2]], 1); }
+      if (status != SO_MATCH_SUCCESS) return;
+      if (PERSIST && trip >= 0) {
+        cc->nx[trip][tid] = nd.x; cc->ny[trip][tid] = nd.y; cc->nz[trip][tid] = nd.z; cc->nw[trip][tid] = nd.w;
+        cc->px[trip][tid] = fx; cc->py[trip][tid] = fy; cc->pz[trip][tid] = fz;
+        cc->c[trip][tid] = c;  // >= 0 marks the entry as an accepted correspondence
+      }
+    } else {
+      c = corr.coeff[j];
+      nd = corr.nd[j];
+    }
+    tail(px, py, pz, wx, wy, wz, nd, c);
+  };
   const uint32_t jstride = gridDim.x * blockDim.x;
   if (FIT) {
+    if (PERSIST) { cc->c[0][tid] = -1.0; cc->c[1][tid] = -1.0; }  // (each thread touches only its own column: no barrier)
     // Two queries per trip with their gathers issued together: status + neighbour indices of both (one round trip),
     // then the ten neighbour points (one round trip), then the two fits.  With one wavefront per SIMD nothing else
     // hides the latency of the dependent index -> point loads (measured: 3 us of a 12 us pass).
+    bool first = true;
     for (uint32_t jA = blockIdx.x * blockDim.x + tid; jA < n_kept; jA += 2 * jstride) {
       const uint32_t jB = jA + jstride;
       const bool hasB = jB < n_kept;
@@ -1365,11 +1386,27 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
         nbA[3 * t] = a.x; nbA[3 * t + 1] = a.y; nbA[3 * t + 2] = a.z;
         nbB[3 * t] = b.x; nbB[3 * t + 1] = b.y; nbB[3 * t + 2] = b.z;
       }
-      body(jA, stA, nbA);
-      if (hasB) body(jB, stB, nbB);
+      body(jA, stA, nbA, first ? 0 : -1);
+      if (hasB) body(jB, stB, nbB, first ? 1 : -1);
+      first = false;
     }
+  } else if (PERSIST) {
+    // the two queries this thread fitted first: out of the LDS cache (no memory round trip on the pass's critical path)
+#pragma unroll
+    for (int trip = 0; trip < 2; ++trip) {
+      const double c = cc->c[trip][tid];
+      const double4 nd = make_double4(cc->nx[trip][tid], cc->ny[trip][tid], cc->nz[trip][tid], cc->nw[trip][tid]);
+      const double px = (double)cc->px[trip][tid], py = (double)cc->py[trip][tid], pz = (double)cc->pz[trip][tid];
+      if (c >= 0.0) {
+        double wx, wy, wz;
+        quat_rotate<double>(pose.q, px, py, pz, wx, wy, wz);
+        wx += pose.t[0]; wy += pose.t[1]; wz += pose.t[2];
+        tail(px, py, pz, wx, wy, wz, nd, c);
+      }
+    }
+    for (uint32_t j = blockIdx.x * blockDim.x + tid + 2 * jstride; j < n_kept; j += jstride) body(j, corr.status[j], nullptr, -1);
   } else {
-    for (uint32_t j = blockIdx.x * blockDim.x + tid; j < n_kept; j += jstride) body(j, corr.status[j], nullptr);
+    for (uint32_t j = blockIdx.x * blockDim.x + tid; j < n_kept; j += jstride) body(j, corr.status[j], nullptr, -1);
   }
   if (stamp) t_loop = wall_clock64();
   // workgroup reduction through LDS (transposed: no serial shuffle chains), fixed order
@@ -1604,6 +1641,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
                                                     const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
                                                     MatchParams mp) {
   __shared__ EvalShared sh;
+  __shared__ CorrCache cache;  // 26 KB next to the 64 KB of EvalShared: gfx950 has 160 KB of LDS per CU, one workgroup each here
   if (st->reg_done) return;
   const int tid = threadIdx.x;
   // hand-off record: 8 chunks of 16 bytes {value, epoch}, each written / read with ONE sc1 dwordx4 access (atomic as a
@@ -1622,7 +1660,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
     sh.ctl.lm_max = st->lm_max; sh.ctl.outer_iter = st->outer_iter; sh.ctl.max_outer = st->max_outer;
   }
   const unsigned long long tag0 = (e0 + 1ull) << 5;  // pass tags: unique over launches (every launch advances the epoch) and passes (slot <= 16)
-  int code = eval_pass<true, true>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0);
+  int code = eval_pass<true, true>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0, &cache);
   for (int slot = 1; slot <= lm_max; ++slot) {
     __syncthreads();
     const unsigned long long want = e0 + (unsigned long long)slot;
@@ -1657,7 +1695,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
     if (sh.more != 1) return;  // solve ended (or timeout)
     pose = pose_from_array(sh.pose);
     __syncthreads();
-    code = eval_pass<false, true>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0 + (unsigned long long)slot);
+    code = eval_pass<false, true>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0 + (unsigned long long)slot, &cache);
   }
 }
 
