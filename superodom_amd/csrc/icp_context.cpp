@@ -392,7 +392,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   // part A: correspondences + plane fit + first evaluation; part B: the remaining evaluations + read-back
   // (concurrent hypotheses: two persistent launches could each hold part of the CUs and wait for the rest -- one launch per
   //  evaluation there; only workgroup 0 of a launch ever waits, for workgroups that finish unconditionally)
-  const bool persistent = c->persistent_solve && c->comm == nullptr && !c->batch_mode;
+  const bool persistent = c->persistent_solve && c->comm == nullptr && !c->batch_mode && !(ep.ablate & 32);  // (ablated controller: per-evaluation launches)
   auto enqueue_eval = [&](int slot) -> int {
     span_begin(c, 1, (uint32_t)n);
     const bool fuse_lm = (c->comm == nullptr);  // single device: the last workgroup of eval runs the LM controller itself

@@ -22,6 +22,9 @@
 
 #include <rocprim/rocprim.hpp>
 
+#ifdef SO_LM_STAMPS  // profiling build: device clock at the phases of the LM controller (tools/eval_stamps.py prints them)
+#define SO_LM_STAMP(dbg, i) do { if (dbg) (dbg)[i] = wall_clock64(); } while (0)
+#endif
 #include "kernels.h"
 
 namespace soicp {
@@ -1124,7 +1127,11 @@ __device__ __forceinline__ int lm_control_regs(int slot, DevState* st, LmState& 
   double unused_pose[7];
   double* next_pose = persist ? unused_pose : st->eval_pose;
   if (slot == 0) more = lm_begin(S, ctl.T, sums, ctl.lm_max, next_pose);
+#ifdef SO_LM_STAMPS
+  else more = lm_feed(S, sums, next_pose, slot == 1 ? st->dbg : nullptr);
+#else
   else more = lm_feed(S, sums, next_pose);
+#endif
   if (!persist || !more) st->lm_more = more;
   if (more) return 1;
   // solve finished: T_w_lidar <- optimised pose, iteration statistics, termination rule
@@ -1148,19 +1155,70 @@ __device__ __forceinline__ int lm_control_regs(int slot, DevState* st, LmState& 
   return 0;
 }
 
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+// 16-byte agent-scope (sc1) store / load: one access, bypassing the non-coherent per-XCD L2 state [MI355X guide, G16]
+__device__ __forceinline__ void store16_sc1(u4v* p, u4v v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u4v load16_sc1(const u4v* p) {
+  u4v v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 #ifndef SO_LM_INLINE
 #define SO_LM_INLINE __forceinline__
 #endif
-__device__ SO_LM_INLINE int lm_control(int slot, DevState* st, LmState& S_lds, const LmSums& sums_lds, const LmCtl& ctl, bool persist = false) {
+// hand / want / pose_out (persistent solve): the controller's thread publishes the hand-off record {next pose, more?}
+// straight from its registers, BEFORE the state goes back to LDS -- the other workgroups are already evaluating the
+// next pose while this thread is still tidying up.
+__device__ SO_LM_INLINE int lm_control(int slot, DevState* st, LmState& S_lds, const LmSums& sums_lds, const LmCtl& ctl, bool persist = false,
+                                       u4v* hand = nullptr, unsigned long long want = 0, double* pose_out = nullptr) {
   // register copies: the controller is one thread's serial fp64 chain, and every LDS round trip inside it (~100 cycles,
   // nothing to overlap with) would sit on the critical path of the whole device
 #ifdef SO_LM_LDS
   return lm_control_regs(slot, st, S_lds, sums_lds, ctl, persist);
 #else
-  LmState S = S_lds;
-  const LmSums sums = sums_lds;
-  const int more_ = lm_control_regs(slot, st, S, sums, ctl, persist);
-  S_lds = S;
+  // (the sums stay in LDS: they are read once, where a successful step adopts them; H is symmetric: only its upper
+  //  triangle lives in registers, the mirror image is rebuilt on the way out -- the full state plus the sums would not
+  //  fit the 256 architectural registers and the spill traffic would sit on the same critical path)
+  LmState S;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { S.x[i] = S_lds.x[i]; S.cand[i] = S_lds.cand[i]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    S.g[i] = S_lds.g[i]; S.scale[i] = S_lds.scale[i]; S.diag[i] = S_lds.diag[i];
+#pragma unroll
+    for (int j = i; j < 6; ++j) { S.H[6 * i + j] = S_lds.H[6 * i + j]; S.H[6 * j + i] = S.H[6 * i + j]; }
+  }
+  S.x_cost = S_lds.x_cost; S.x_norm = S_lds.x_norm; S.radius = S_lds.radius; S.decrease_factor = S_lds.decrease_factor;
+  S.model_cost_change = S_lds.model_cost_change; S.initial_cost = S_lds.initial_cost; S.count = S_lds.count;
+  S.iter = S_lds.iter; S.max_iter = S_lds.max_iter; S.reuse_diagonal = S_lds.reuse_diagonal; S.invalid_steps = S_lds.invalid_steps;
+  S.num_successful = S_lds.num_successful; S.termination = S_lds.termination; S.done = S_lds.done; S.lm_iterations = S_lds.lm_iterations;
+  const int more_ = lm_control_regs(slot, st, S, sums_lds, ctl, persist);
+  if (hand) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long val = (k < 7) ? (unsigned long long)__double_as_longlong(S.cand[k < 7 ? k : 0]) : (unsigned long long)more_;
+      const u4v v = {(unsigned int)val, (unsigned int)(val >> 32), (unsigned int)want, (unsigned int)(want >> 32)};
+      store16_sc1(hand + k, v);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pose_out[k] = S.cand[k];
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) { S_lds.x[i] = S.x[i]; S_lds.cand[i] = S.cand[i]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    S_lds.g[i] = S.g[i]; S_lds.scale[i] = S.scale[i]; S_lds.diag[i] = S.diag[i];
+#pragma unroll
+    for (int j = i; j < 6; ++j) { S_lds.H[6 * i + j] = S.H[6 * i + j]; S_lds.H[6 * j + i] = S.H[6 * i + j]; }
+  }
+  S_lds.x_cost = S.x_cost; S_lds.x_norm = S.x_norm; S_lds.radius = S.radius; S_lds.decrease_factor = S.decrease_factor;
+  S_lds.model_cost_change = S.model_cost_change; S_lds.initial_cost = S.initial_cost; S_lds.count = S.count;
+  S_lds.iter = S.iter; S_lds.max_iter = S.max_iter; S_lds.reuse_diagonal = S.reuse_diagonal; S_lds.invalid_steps = S.invalid_steps;
+  S_lds.num_successful = S.num_successful; S_lds.termination = S.termination; S_lds.done = S.done; S_lds.lm_iterations = S.lm_iterations;
+#ifdef SO_LM_STAMPS
+  if (slot == 1) st->dbg[7] = wall_clock64();
+#endif
   return more_;
 #endif
 }
@@ -1198,7 +1256,7 @@ static_assert(sizeof(LmState) % 8 == 0 && sizeof(LmSums) % 8 == 0, "controller s
 
 constexpr int kPartStride = SO_SOLVE_BLOCKS;  // partials[a][workgroup]: transposed so that the last workgroup reads it coalesced
 static_assert(kEvalBlocks <= kPartStride && kFitBlocksMax <= kPartStride && kNAcc <= kSumsStride, "partials table");
-constexpr int kRedStride = kNAcc + 1;  // 30 doubles per record in LDS
+constexpr int kRedStride = kNAcc + 2;  // 31 doubles per record in LDS: 62-dword rows, so 32 consecutive rows start in 32 different bank pairs
 
 // sum 256 records of kNAcc doubles held in red[256][kRedStride]: thread (a, c) adds rows 32c..32c+31 of value a in
 // order, then thread (a, 0) adds the 8 partial sums in order -- a fixed tree, identical on every launch.
@@ -1219,15 +1277,6 @@ __device__ __forceinline__ double reduce_records(double (*red)[kRedStride], doub
   return tot;
 }
 
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-// 16-byte agent-scope (sc1) store / load: one access, bypassing the non-coherent per-XCD L2 state [MI355X guide, G16]
-__device__ __forceinline__ void store16_sc1(u4v* p, u4v v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ u4v load16_sc1(const u4v* p) {
-  u4v v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
 struct EvalShared {
   double red[256][kRedStride];  // 60 KB: per-thread accumulators, later the workgroup records
   double part[8][32];
@@ -1238,6 +1287,7 @@ struct EvalShared {
   unsigned long long epoch;
   int more;
   int32_t lh[16];
+  int32_t hpart[8][16];
   bool is_last;
 };
 // the (at most) two accepted correspondences a thread of a persistent solve owns, kept in LDS between the passes
@@ -1259,7 +1309,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
                                          int32_t* __restrict__ hist, LmSums* __restrict__ out,
                                          const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
                                          const MatchParams& mp, EvalShared& sh, unsigned long long pass_tag = 0,
-                                         CorrCache* cc = nullptr) {
+                                         CorrCache* cc = nullptr, u4v* hand = nullptr, unsigned long long want = 0) {
   // PERSIST (solve_kernel): workgroup 0 is the finisher of every pass of the launch, so the controller state stays in
   // its LDS from pass to pass and goes to memory only when the solve ends; the workgroup records are PUSHED (tagged
   // 16-byte chunks, see below) instead of stored + counted
@@ -1296,7 +1346,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   // one query: (FIT) plane fit from the prefetched neighbour coordinates, then residual / Jacobian / sums
   // residual, robust weight, Jacobian row and the 29 sums of one accepted correspondence (w* = R p + t)
   auto tail = [&](double px, double py, double pz, double wx, double wy, double wz, const double4& nd, double c) {
-    const double r = nd.x * wx + nd.y * wy + nd.z * wz + nd.w;             // lidarOptimization.cpp:61
+    // (fused multiply-adds from here on: no thresholds downstream, see SO_FMA)
+    const double r = SO_FMA(nd.x, wx, SO_FMA(nd.y, wy, SO_FMA(nd.z, wz, nd.w)));  // lidarOptimization.cpp:61
     // ScaledLoss(TukeyLoss(a), c): rho, rho' [UPSTREAM ceres loss_function.cc]; corrector with rho''<=0
     const double s = r * r;
     double rho0, rho1;
@@ -1309,20 +1360,20 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     }
     const double w = c * rho1;
     // J = [n^T, -n^T R [p]x] = [n^T, (p x R^T n)^T]  (lidarOptimization.cpp:68-74)
-    const double m0 = R00 * nd.x + R10 * nd.y + R20 * nd.z;
-    const double m1 = R01 * nd.x + R11 * nd.y + R21 * nd.z;
-    const double m2 = R02 * nd.x + R12 * nd.y + R22 * nd.z;
-    const double J[6] = {nd.x, nd.y, nd.z, py * m2 - pz * m1, pz * m0 - px * m2, px * m1 - py * m0};
-    acc[0] += 0.5 * c * rho0;
+    const double m0 = SO_FMA(R00, nd.x, SO_FMA(R10, nd.y, R20 * nd.z));
+    const double m1 = SO_FMA(R01, nd.x, SO_FMA(R11, nd.y, R21 * nd.z));
+    const double m2 = SO_FMA(R02, nd.x, SO_FMA(R12, nd.y, R22 * nd.z));
+    const double J[6] = {nd.x, nd.y, nd.z, SO_FMA(py, m2, -(pz * m1)), SO_FMA(pz, m0, -(px * m2)), SO_FMA(px, m1, -(py * m0))};
+    acc[0] = SO_FMA(0.5 * c, rho0, acc[0]);
     acc[1] += 1.0;
     const double wr = w * r;
     int k = 8;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      acc[2 + a] += J[a] * wr;
+      acc[2 + a] = SO_FMA(J[a], wr, acc[2 + a]);
       const double wj = w * J[a];
 #pragma unroll
-      for (int b = a; b < 6; ++b) acc[k++] += wj * J[b];
+      for (int b = a; b < 6; ++b) { acc[k] = SO_FMA(wj, J[b], acc[k]); ++k; }
     }
   };
   // one query: (FIT) plane fit from the prefetched neighbour coordinates, then residual / Jacobian / sums.
@@ -1415,79 +1466,88 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   __syncthreads();
   const double mine = reduce_records(red, part, tid);
   if (PERSIST) {
-    // Push model: the record of this workgroup for this pass is kNAcc (+8 with the histograms of the fit pass) chunks of
-    // 16 bytes {value, pass tag}, each written with ONE sc1 dwordx4 store -- fire and forget: no drain, no arrival
-    // counter.  Workgroup 0 polls the table partials[chunk][workgroup] (thread b: the chunks of workgroup b, coalesced)
-    // until every chunk carries this pass's tag: one memory round trip from "last record written" to "all sums in
-    // hand" instead of two (arrival counter, then the records).  Tags grow monotonically over passes and launches.
-    static_assert(SO_SOLVE_BLOCKS <= 256, "one polling thread per workgroup record");
-    constexpr int kCh = kNAcc + (FIT ? 8 : 0);
-    static_assert(kCh <= kRecordChunksMax, "record table");
+    // Push model: the record of this workgroup for this pass is kNAcc chunks of 16 bytes {value (8), pass tag (4), one
+    // histogram counter of the fit pass (4)}, each written with ONE sc1 dwordx4 store -- fire and forget: no drain, no
+    // arrival counter.  Workgroup 0 polls the table until every chunk carries this pass's tag: one memory round trip
+    // from "last record written" to "all sums in hand" instead of two (arrival counter, then the records).
+    // Table layout [i][g][a] for workgroup w = 32 g + i: a writer's 29 chunks are contiguous, and polling thread
+    // t = 29 g + a reads chunk i at table[232 i + t] (coalesced over the workgroup); it owns value a of the 32 workgroups
+    // of group g and adds them IN REGISTERS, in the order of reduce_records (rows 32 g .. 32 g + 31, then the 8 groups).
+    // A stale chunk is always the previous pass's (every pass rewrites every chunk), so a 32-bit tag suffices.
+    static_assert(SO_SOLVE_BLOCKS == 256, "record table: 8 groups of 32 workgroups");
+    static_assert(kNAcc <= kRecordChunksMax, "record table");
     u4v* rec = reinterpret_cast<u4v*>(partials);
-    const unsigned int tlo = (unsigned int)pass_tag, thi = (unsigned int)(pass_tag >> 32);
+    const unsigned int tag = (unsigned int)pass_tag;
     // The correspondence stores of the fit loop are long on their way (the LDS reduction came in between); retiring
     // them HERE, in the compiler's scoreboard too, keeps it from placing its own vmcnt waits between the hand-written
     // polling loads below (which it cannot see), where each would cost a full memory round trip.
     if (FIT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
     if (tid < kNAcc) {
       const unsigned long long b = (unsigned long long)__double_as_longlong(mine);
-      const u4v v = {(unsigned int)b, (unsigned int)(b >> 32), tlo, thi};
-      store16_sc1(rec + (size_t)tid * kPartStride + blockIdx.x, v);
-    } else if (FIT && tid >= 32 && tid < 40) {  // MatchRejectionHistogramPlane + observability histogram: two counters per chunk
-      const int k = tid - 32;
-      const u4v v = {(unsigned int)lh[2 * k], (unsigned int)lh[2 * k + 1], tlo, thi};
-      store16_sc1(rec + (size_t)(kNAcc + k) * kPartStride + blockIdx.x, v);
+      const unsigned int extra = (FIT && tid < 16) ? (unsigned int)lh[tid] : 0u;  // MatchRejectionHistogramPlane + observability bins
+      const u4v v = {(unsigned int)b, (unsigned int)(b >> 32), tag, extra};
+      const uint32_t w = blockIdx.x;
+      store16_sc1(rec + ((w & 31u) * 8u + (w >> 5)) * kNAcc + tid, v);
     }
     if (stamp) t_red = wall_clock64();
     if (blockIdx.x != 0) return kPassNotLast;
-    u4v r[kCh];
-    const bool have = (uint32_t)tid < gridDim.x;
-    const u4v* base = rec + (have ? tid : 0);
+    constexpr int kPoll = 8 * kNAcc;  // 232 polling threads
+    const bool poller = tid < kPoll;
+    const int g = poller ? tid / kNAcc : 0, a = poller ? tid - g * kNAcc : 0;
+    const u4v* base = rec + (poller ? tid : 0);
+    u4v r[32];
     const unsigned long long t0 = wall_clock64();
     bool ok;
     for (;;) {
 #pragma unroll
-      for (int a = 0; a < kCh; ++a)
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r[a]) : "v"(base + (size_t)a * kPartStride) : "memory");
+      for (int i = 0; i < 32; ++i)
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r[i]) : "v"(base + (size_t)i * kPoll) : "memory");
       asm volatile("s_waitcnt vmcnt(0)"
                    : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]),
                      "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]), "+v"(r[17]), "+v"(r[18]),
                      "+v"(r[19]), "+v"(r[20]), "+v"(r[21]), "+v"(r[22]), "+v"(r[23]), "+v"(r[24]), "+v"(r[25]), "+v"(r[26]), "+v"(r[27]),
                      "+v"(r[28])
                    :: "memory");
-      if (FIT)
-        asm volatile("" : "+v"(r[kCh - 8]), "+v"(r[kCh - 7]), "+v"(r[kCh - 6]), "+v"(r[kCh - 5]), "+v"(r[kCh - 4]), "+v"(r[kCh - 3]),
-                          "+v"(r[kCh - 2]), "+v"(r[kCh - 1]) :: "memory");
+      asm volatile("" : "+v"(r[29]), "+v"(r[30]), "+v"(r[31]) :: "memory");
       ok = true;
 #pragma unroll
-      for (int a = 0; a < kCh; ++a) ok = ok && r[a].z == tlo && r[a].w == thi;
-      ok = ok || !have;
+      for (int i = 0; i < 32; ++i) ok = ok && (r[i].z == tag || (uint32_t)(32 * g + i) >= gridDim.x);
+      ok = ok || !poller;
       if (__ballot(!ok) == 0ull) break;
       if (wall_clock64() - t0 > 5000000ull) break;  // 50 ms: give up instead of hanging the device
     }
     if (!__syncthreads_and(ok ? 1 : 0)) return kPassNotLast;  // timeout: the solve is abandoned, the host reports the missing publication
     if (stamp) t_ticket = t_loaded = wall_clock64();
+    {
+      double sum = 0;
+      int hsum = 0;
 #pragma unroll
-    for (int a = 0; a < kNAcc; ++a)
-      red[tid][a] = have ? __longlong_as_double((long long)(((unsigned long long)r[a].y << 32) | r[a].x)) : 0.0;
-    __syncthreads();
-    const double total = reduce_records(red, part, tid);
-    double* o = reinterpret_cast<double*>(&sh_sums);
-    if (tid < kNAcc) o[tid] = total;  // cost, count, Jtr[6], JtJ[21]
-    if (FIT) {  // the 16 counters, summed the same way (exact in fp64); later passes of the solve keep them in LDS
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        red[tid][2 * k] = have ? (double)(int)r[kNAcc + k].x : 0.0;
-        red[tid][2 * k + 1] = have ? (double)(int)r[kNAcc + k].y : 0.0;
+      for (int i = 0; i < 32; ++i) {
+        const bool have = (uint32_t)(32 * g + i) < gridDim.x;
+        sum += have ? __longlong_as_double((long long)(((unsigned long long)r[i].y << 32) | r[i].x)) : 0.0;
+        if (FIT) hsum += have ? (int)r[i].w : 0;
       }
-      __syncthreads();
-      const double ht = reduce_records(red, part, tid);
-      if (tid < 16) o[kNAcc + tid] = ht;
+      if (poller) {
+        part[g][a] = sum;
+        if (FIT && a < 16) sh.hpart[g][a] = hsum;
+      }
+    }
+    __syncthreads();
+    double* o = reinterpret_cast<double*>(&sh_sums);
+    if (tid < kNAcc) {
+      double tot = 0;
+#pragma unroll
+      for (int cc8 = 0; cc8 < 8; ++cc8) tot += part[cc8][tid];
+      o[tid] = tot;  // cost, count, Jtr[6], JtJ[21]
+    } else if (FIT && tid >= 32 && tid < 48) {  // the 16 counters; later passes of the solve keep them in LDS
+      int h = 0;
+#pragma unroll
+      for (int cc8 = 0; cc8 < 8; ++cc8) h += sh.hpart[cc8][tid - 32];
+      o[kNAcc + (tid - 32)] = (double)h;
     }
     __syncthreads();
     if (stamp) t_sums = wall_clock64();
-    if (tid == 0) sh_more = (ep.ablate & 32) ? 1 : lm_control(slot, st, sh_S, sh_sums, sh_ctl, true);
+    if (tid == 0) sh_more = lm_control(slot, st, sh_S, sh_sums, sh_ctl, true, hand, want, sh.pose);  // (publishes the hand-off)
     __syncthreads();
     unsigned long long t_ctl = 0;
     if (stamp) t_ctl = wall_clock64();
@@ -1660,19 +1720,13 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
     sh.ctl.lm_max = st->lm_max; sh.ctl.outer_iter = st->outer_iter; sh.ctl.max_outer = st->max_outer;
   }
   const unsigned long long tag0 = (e0 + 1ull) << 5;  // pass tags: unique over launches (every launch advances the epoch) and passes (slot <= 16)
-  int code = eval_pass<true, true>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0, &cache);
+  int code = eval_pass<true, true>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0, &cache, hand, e0 + 1ull);
   for (int slot = 1; slot <= lm_max; ++slot) {
     __syncthreads();
     const unsigned long long want = e0 + (unsigned long long)slot;
-    if (code == kPassMore || code == kPassDone) {  // this workgroup ran the controller: publish {request, more?}
-      const int more = (code == kPassMore) ? 1 : 0;
-      if (tid < 8) {
-        const unsigned long long val = (tid < 7) ? (unsigned long long)__double_as_longlong(sh.S.cand[tid]) : (unsigned long long)more;
-        const u4v v = {(unsigned int)val, (unsigned int)(val >> 32), (unsigned int)want, (unsigned int)(want >> 32)};
-        store16_sc1(hand + tid, v);
-      }
-      if (tid < 7) sh.pose[tid] = sh.S.cand[tid];
-      if (tid == 0) sh.more = more;
+    if (code == kPassMore || code == kPassDone) {
+      // this workgroup ran the controller, whose thread has already published {request, more?} with epoch `want` and
+      // left them in sh.pose / sh.more
     } else if (tid < 64) {  // wait for the controller's workgroup: lanes 0..7 poll one chunk each
       bool done = tid >= 8;
       unsigned long long val = 0;
@@ -1695,7 +1749,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
     if (sh.more != 1) return;  // solve ended (or timeout)
     pose = pose_from_array(sh.pose);
     __syncthreads();
-    code = eval_pass<false, true>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0 + (unsigned long long)slot, &cache);
+    code = eval_pass<false, true>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0 + (unsigned long long)slot, &cache, hand, want + 1ull);
   }
 }
 

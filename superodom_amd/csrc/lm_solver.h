@@ -21,6 +21,10 @@
 #define SO_UNROLL
 #endif
 
+#ifndef SO_LM_STAMP
+#define SO_LM_STAMP(dbg, i)  // profiling builds (kernels.hip, -DSO_LM_STAMPS) record a device clock here
+#endif
+
 namespace soicp {
 
 struct LmSums {      // == so_icp_sums (include/so_icp.h), 45 doubles
@@ -80,12 +84,14 @@ SO_HD bool lm_gradient_converged(const double x[7], const double g[6]) {
 // Cholesky solve of a 6x6 SPD system; returns false when a pivot is not positive / result not finite.
 SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
   double inv[6];  // reciprocal pivots: one division per column instead of one per element
+  bool spd = true;  // no early exit: ONE basic block, so that the scheduler overlaps the columns' independent updates
+                    // with the serial pivot -> rsqrt -> next pivot chain (a failed pivot poisons y, which is discarded)
   SO_UNROLL
   for (int j = 0; j < 6; ++j) {
     double d = A[6 * j + j];
     SO_UNROLL
-    for (int k = 0; k < j; ++k) d -= A[6 * j + k] * A[6 * j + k];
-    if (!(d > 0.0)) return false;
+    for (int k = 0; k < j; ++k) d = SO_FMA(-A[6 * j + k], A[6 * j + k], d);
+    spd = spd && (d > 0.0);
 #if defined(__HIP_DEVICE_COMPILE__)
     inv[j] = rsqrt(d);  // only 1/L_jj is used below; one long fp64 operation per column instead of sqrt + division
 #else
@@ -95,7 +101,7 @@ SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
     for (int i = j + 1; i < 6; ++i) {
       double s = A[6 * i + j];
       SO_UNROLL
-      for (int k = 0; k < j; ++k) s -= A[6 * i + k] * A[6 * j + k];
+      for (int k = 0; k < j; ++k) s = SO_FMA(-A[6 * i + k], A[6 * j + k], s);
       A[6 * i + j] = s * inv[j];
     }
   }
@@ -104,24 +110,24 @@ SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
   for (int i = 0; i < 6; ++i) {
     double s = b[i];
     SO_UNROLL
-    for (int k = 0; k < i; ++k) s -= A[6 * i + k] * z[k];
+    for (int k = 0; k < i; ++k) s = SO_FMA(-A[6 * i + k], z[k], s);
     z[i] = s * inv[i];
   }
   SO_UNROLL
   for (int i = 5; i >= 0; --i) {
     double s = z[i];
     SO_UNROLL
-    for (int k = i + 1; k < 6; ++k) s -= A[6 * k + i] * y[k];
+    for (int k = i + 1; k < 6; ++k) s = SO_FMA(-A[6 * k + i], y[k], s);
     y[i] = s * inv[i];
   }
   SO_UNROLL
-  for (int i = 0; i < 6; ++i) if (!isfinite(y[i])) return false;
-  return true;
+  for (int i = 0; i < 6; ++i) spd = spd && isfinite(y[i]);
+  return spd;
 }
 
 // One pass of the while(FinalizeIterationAndCheckIfMinimizerCanContinue()) loop up to the point
 // where the candidate must be evaluated.  Returns 1 (evaluate S.cand) or 0 (solver finished).
-SO_HD int lm_propose(LmState& S, double next_pose[7]) {
+SO_HD int lm_propose(LmState& S, double next_pose[7], unsigned long long* dbg = nullptr) {
   for (;;) {
     if (S.iter >= S.max_iter) { S.termination = 0; S.done = 1; return 0; }           // MaxSolverIterationsReached
     if (S.radius <= LmConst::kMinRadius) { S.termination = 5; S.done = 1; return 0; } // MinTrustRegionRadiusReached
@@ -148,7 +154,9 @@ SO_HD int lm_propose(LmState& S, double next_pose[7]) {
       }
       A[7 * i] += S.diag[i] * inv_radius;  // lm_diagonal^2 = diag / radius
     }
+    SO_LM_STAMP(dbg, 3);
     const bool ok = lm_chol6(A, gs, y);  // (Hs + D^2) y = gs ; step = -y
+    SO_LM_STAMP(dbg, 4);
     S.reuse_diagonal = 1;
     double mcc = 0;
     if (ok) {
@@ -156,22 +164,23 @@ SO_HD int lm_propose(LmState& S, double next_pose[7]) {
       SO_UNROLL
       for (int i = 0; i < 6; ++i) {
         step[i] = -y[i];
-        sg += step[i] * gs[i];
+        sg = SO_FMA(step[i], gs[i], sg);
       }
       SO_UNROLL
       for (int i = 0; i < 6; ++i) {  // s^T Hs s over the upper triangle: diagonal once, off-diagonal terms twice
         double r = 0;
         SO_UNROLL
-        for (int j = i + 1; j < 6; ++j) r += Hs[6 * i + j] * step[j];
-        sHs += step[i] * (Hs[7 * i] * step[i] + 2.0 * r);
+        for (int j = i + 1; j < 6; ++j) r = SO_FMA(Hs[6 * i + j], step[j], r);
+        sHs = SO_FMA(step[i], SO_FMA(Hs[7 * i], step[i], 2.0 * r), sHs);
       }
-      mcc = -sg - 0.5 * sHs;  // -(J s)^T (r + J s / 2)
+      mcc = SO_FMA(-0.5, sHs, -sg);  // -(J s)^T (r + J s / 2)
     }
     if (!ok || !(mcc > 0.0)) {  // HandleInvalidStep
       if (++S.invalid_steps >= LmConst::kMaxConsecutiveInvalidSteps) { S.termination = 5; S.done = 1; return 0; }
       S.radius *= 0.5;
       continue;
     }
+    SO_LM_STAMP(dbg, 5);
     S.invalid_steps = 0;
     S.model_cost_change = mcc;
     double delta[6];
@@ -180,6 +189,7 @@ SO_HD int lm_propose(LmState& S, double next_pose[7]) {
     pose_plus(S.x, delta, S.cand);
     SO_UNROLL
     for (int i = 0; i < 7; ++i) next_pose[i] = S.cand[i];
+    SO_LM_STAMP(dbg, 6);
     return 1;
   }
 }
@@ -199,31 +209,33 @@ SO_HD int lm_begin(LmState& S, const double x0[7], const LmSums& sums, int max_i
   for (int j = 0; j < 6; ++j) S.scale[j] = 1.0 / (1.0 + sqrt(S.H[7 * j]));  // jacobi_scaling, fixed at iteration 0
   double n2 = 0;
   SO_UNROLL
-  for (int i = 0; i < 7; ++i) n2 += S.x[i] * S.x[i];
+  for (int i = 0; i < 7; ++i) n2 = SO_FMA(S.x[i], S.x[i], n2);
   S.x_norm = sqrt(n2);
   if (lm_gradient_converged(S.x, S.g)) { S.termination = 3; S.done = 1; return 0; }
   return lm_propose(S, next_pose);
 }
 
-SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7]) {
+SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7], unsigned long long* dbg = nullptr) {
   if (S.done) return 0;
+  SO_LM_STAMP(dbg, 0);
   const double cand_cost = sums.cost;
   // ParameterToleranceReached
   double sn = 0;
   SO_UNROLL
-  for (int i = 0; i < 7; ++i) sn += (S.x[i] - S.cand[i]) * (S.x[i] - S.cand[i]);
+  for (int i = 0; i < 7; ++i) sn = SO_FMA(S.x[i] - S.cand[i], S.x[i] - S.cand[i], sn);
   sn = sqrt(sn);
   if (sn <= LmConst::kParameterTolerance * (S.x_norm + LmConst::kParameterTolerance)) { S.termination = 2; S.done = 1; return 0; }
   // FunctionToleranceReached
   const double cost_change = S.x_cost - cand_cost;
   if (fabs(cost_change) <= LmConst::kFunctionTolerance * S.x_cost) { S.termination = 1; S.done = 1; return 0; }
   const double rel = cost_change / S.model_cost_change;  // TrustRegionStepEvaluator::StepQuality, monotonic
+  SO_LM_STAMP(dbg, 1);
   if (rel > LmConst::kMinRelativeDecrease) {             // HandleSuccessfulStep
     SO_UNROLL
     for (int i = 0; i < 7; ++i) S.x[i] = S.cand[i];
     double n2 = 0;
     SO_UNROLL
-    for (int i = 0; i < 7; ++i) n2 += S.x[i] * S.x[i];
+    for (int i = 0; i < 7; ++i) n2 = SO_FMA(S.x[i], S.x[i], n2);
     S.x_norm = sqrt(n2);
     S.x_cost = cand_cost;
     lm_unpack(sums, S.H, S.g);
@@ -241,7 +253,8 @@ SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7]) {
     S.decrease_factor *= 2.0;
     S.reuse_diagonal = 1;
   }
-  return lm_propose(S, next_pose);
+  SO_LM_STAMP(dbg, 2);
+  return lm_propose(S, next_pose, dbg);
 }
 
 }  // namespace soicp

@@ -43,6 +43,11 @@ SO_HD void quat_rotate(const T q[4], T vx, T vy, T vz, T& ox, T& oy, T& oz) {
   oz = vz + q[3] * uz + (q[0] * uy - q[1] * ux);
 }
 
+// a * b + c with one rounding.  Used where the restated arithmetic has no thresholds downstream (the LM controller's
+// linear algebra and the normal-equation sums): half the serial fp64 operations of the unfused form; the plane fit and
+// its gates keep the reference's unfused arithmetic (-ffp-contract=off).
+#define SO_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
 SO_HD void quat_mul(const double a[4], const double b[4], double o[4]) {
   o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
   o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
@@ -55,14 +60,18 @@ SO_HD void quat_mul(const double a[4], const double b[4], double o[4]) {
 SO_HD void pose_plus(const double x[7], const double d[6], double o[7]) {
   o[0] = x[0] + d[0]; o[1] = x[1] + d[1]; o[2] = x[2] + d[2];
   const double dq[4] = {d[3] / 2.0, d[4] / 2.0, d[5] / 2.0, 1.0};
-  double q[4];
-  quat_mul(x + 3, dq, q);
+  double q[4];  // x.q (x) [dq, 1]
+  const double* a = x + 3;
+  q[3] = SO_FMA(-a[2], dq[2], SO_FMA(-a[1], dq[1], SO_FMA(-a[0], dq[0], a[3])));
+  q[0] = SO_FMA(-a[2], dq[1], SO_FMA(a[1], dq[2], SO_FMA(a[3], dq[0], a[0])));
+  q[1] = SO_FMA(-a[0], dq[2], SO_FMA(a[2], dq[0], SO_FMA(a[3], dq[1], a[1])));
+  q[2] = SO_FMA(-a[1], dq[0], SO_FMA(a[0], dq[1], SO_FMA(a[3], dq[2], a[2])));
   // Eigen normalized() divides coefficient-wise; one reciprocal + four products differ from that by <= 1 ulp per
   // coefficient and cost a quarter of the serial fp64 latency inside the device-side controller
 #if defined(__HIP_DEVICE_COMPILE__)
-  const double inv = rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);  // one long fp64 operation instead of sqrt + division
+  const double inv = rsqrt(SO_FMA(q[3], q[3], SO_FMA(q[2], q[2], SO_FMA(q[1], q[1], q[0] * q[0]))));  // one long fp64 operation instead of sqrt + division
 #else
-  const double inv = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double inv = 1.0 / sqrt(SO_FMA(q[3], q[3], SO_FMA(q[2], q[2], SO_FMA(q[1], q[1], q[0] * q[0]))));
 #endif
   o[3] = q[0] * inv; o[4] = q[1] * inv; o[5] = q[2] * inv; o[6] = q[3] * inv;
 }

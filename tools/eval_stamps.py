@@ -32,13 +32,20 @@ def main():
     d = slam.upload_scan(sc.scan(0))
     st = binding.Stats()
     acc = np.zeros((2, 8))
+    lm_stamps = os.environ.get("SOICP_LM_STAMPS")  # library built with -DSO_LM_STAMPS: dbg[0..7] = clocks inside the controller (slot 1)
+    lm_acc = np.zeros(7)
     for r in range(a.reps + 2):
         slam.register_dev(d[0], d[1], sc.guess(0), st)
         s = slam.debug_stamps().astype(np.float64) * 0.01  # 100 MHz -> us
+        if r >= 2 and lm_stamps:
+            lm_acc += np.diff(slam.debug_stamps().astype(np.float64)[0:8]) * 0.01
         if r >= 2:
             acc[0] += s[0:8]
             acc[1] += s[8:16]
     acc /= a.reps
+    if lm_stamps:
+        print("controller phases (us):", dict(zip(["feed:tolerances+rel", "feed:accept+unpack+gradient", "propose:scale+Hs", "cholesky+solve", "model change",
+                                                    "pose_plus", "store back"], np.round(lm_acc / a.reps, 2))))
     rec = slam.debug_knn_stamps()
     if rec is not None:
         rec = rec.astype(np.float64)
