@@ -776,7 +776,9 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   int wcube0 = 0, wcube1 = 0, wcube2 = 0;  // world id of the query's cube
   CellRef c;
   c.slot = -1; c.cx = c.cy = c.cz = 0;
+  uint32_t oi = 0;  // the query's index in the scan (results are filed under it): fetched with the coordinates, used at the very end
   if (valid_q) {
+    oi = perm[j];
     quat_rotate<double>(pose.q, (double)spx[j], (double)spy[j], (double)spz[j], pw[0], pw[1], pw[2]);  // LidarSlam.cpp:397-398
     pw[0] += pose.t[0]; pw[1] += pose.t[1]; pw[2] += pose.t[2];
     qx = (float)pw[0]; qy = (float)pw[1]; qz = (float)pw[2];                                            // LidarSlam.cpp:728-731
@@ -1060,7 +1062,6 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   if (lane == 0) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
 
   if (valid_q && (!split || lane < (split4 ? 16 : 32))) {
-    const uint32_t oi = perm[j];  // results are filed under the query's index in the scan
     int status;
     if (c.slot < 0) {
       status = SO_MATCH_NOT_ENOUGH;  // LidarSlam.cpp:736-739
