@@ -125,6 +125,7 @@ struct so_icp_ctx {
   struct Borrow { bool on = false; DevMapView view{}; float plane_res = 0; int pos[3] = {0, 0, 0}; int count_5x5 = 0; } borrow;
   std::vector<so_icp_ctx*> workers;
   bool batch_mode = false;    // no kernel timing, tracker state read-only
+  bool batch_single = false;  // batch on ONE lane: nothing runs next to it, the persistent solve launch is safe
   bool no_map_shift = false;  // so_icp_register_batch: hypotheses after the first keep the window of the first
   int startup_count = 0;
   double last_time = 0;
@@ -392,7 +393,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   // part A: correspondences + plane fit + first evaluation; part B: the remaining evaluations + read-back
   // (concurrent hypotheses: two persistent launches could each hold part of the CUs and wait for the rest -- one launch per
   //  evaluation there; only workgroup 0 of a launch ever waits, for workgroups that finish unconditionally)
-  const bool persistent = c->persistent_solve && c->comm == nullptr && !c->batch_mode && !(ep.ablate & 32);  // (ablated controller: per-evaluation launches)
+  const bool persistent = c->persistent_solve && c->comm == nullptr && (!c->batch_mode || c->batch_single) && !(ep.ablate & 32);  // (ablated controller: per-evaluation launches)
   auto enqueue_eval = [&](int slot) -> int {
     span_begin(c, 1, (uint32_t)n);
     const bool fuse_lm = (c->comm == nullptr);  // single device: the last workgroup of eval runs the LM controller itself
@@ -853,7 +854,7 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
   std::vector<so_icp_ctx*> lane_ctx(1, c);
   for (int l = 1; l < lanes; ++l) lane_ctx.push_back(c->workers[l - 1]);
   for (so_icp_ctx* w : lane_ctx) {
-    w->borrow = bw; w->batch_mode = true;
+    w->borrow = bw; w->batch_mode = true; w->batch_single = (lanes == 1);
     std::memcpy(w->prev_obs_hist, c->prev_obs_hist, sizeof(c->prev_obs_hist));
     w->have_hist = c->have_hist; w->startup_count = c->startup_count;
     w->cfg.max_iterations = c->cfg.max_iterations; w->cfg.lm_max_iterations = c->cfg.lm_max_iterations;
