@@ -738,7 +738,8 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   const bool stamp = (mp.ablate & 128) != 0 && mp.kdbg != nullptr;
   unsigned long long ts[4] = {0, 0, 0, 0}, acc[5] = {0, 0, 0, 0, 0}, t_first = 0, n_mine = 0, t_maxchunk = 0;
   unsigned long long n_cand_total = 0, n_q_total = 0, n_groups_total = 0, n_pass2 = 0, max_info = 0, n_fb_total = 0;
-  if (stamp) t_first = wall_clock64();
+  unsigned long long c_first = 0;
+  if (stamp) { t_first = wall_clock64(); c_first = clock64(); }
   const int nc = map.nc;
   const float cell = (float)(1.0 / map.inv_cell);
   const float inv_cellf = (float)map.inv_cell;
@@ -1096,6 +1097,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
     unsigned long long* d = mp.kdbg + ((size_t)(st->outer_iter & 1) * gridDim.x * 4 + blockIdx.x * 4 + wv) * 16;
     d[0] = t_first; d[1] = wall_clock64();
     for (int i = 0; i < 5; ++i) d[2 + i] = acc[i];
+    d[15] = clock64() - c_first;  // shader-clock ticks over the wavefront's life (d[1] - d[0] = the same span at 100 MHz)
     d[7] = n_mine; d[8] = t_maxchunk; d[9] = n_cand_total; d[10] = n_q_total; d[11] = n_groups_total; d[12] = n_pass2; d[13] = max_info; d[14] = n_fb_total;
   }
   __syncthreads();

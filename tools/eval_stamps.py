@@ -62,6 +62,8 @@ def main():
                   f"queries {int(busy[:, 10].sum())}, candidates/chunk {busy[:, 9].sum() / nch:.0f}, groups/chunk {busy[:, 11].sum() / nch:.2f}, "
                   f"chunks with a full pass {int(busy[:, 12].sum())}")
             print("   per chunk (us): prologue %.2f  group_setup %.2f  stage+scan %.2f  merge+survivors %.2f  epilogue %.2f" % tuple(ph))
+            span = busy[:, 1] - busy[:, 0]
+            print("   shader clock over the wavefronts' lives: median %.0f MHz" % (np.median(busy[:, 15] / np.maximum(span, 1)) * 100.0))
             start = (busy[:, 0] - t0) * 0.01
             life = (busy[:, 1] - busy[:, 0]) * 0.01
             print("   workgroup start offset us: p50 %.1f p90 %.1f max %.1f | life us: p50 %.1f p90 %.1f max %.1f | max chunk %.1f us" % (
