@@ -352,7 +352,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     c->bin_dirty = true;  // until bin_offsets has been enqueued behind scan_keys
     launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
                      c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), &bt, s);
-    launch_bin_offsets(bt, c->d_chunks.as<uint32_t>(), ds, s);
+    launch_bin_offsets(bt, c->d_chunks.as<uint32_t>(), (uint32_t)(c->d_chunks.cap / 4), ds, s);
     c->bin_dirty = false;
     launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(),
                      c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
@@ -369,6 +369,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   span_end(c);
   const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
   MatchParams mp = match_params(plane_res_now);
+  mp.chunk_cap = (uint32_t)(c->d_chunks.cap / 4);
   if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
     HIP_TRY(c, c->d_kdbg.reserve((size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemsetAsync(c->d_kdbg.p, 0, (size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long), s));

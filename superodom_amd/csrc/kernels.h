@@ -29,6 +29,7 @@ struct MatchParams {
   double max_point_dist;  // planeRes / 2.0 (LidarSlam.cpp:820)
   int32_t ablate;         // profiling only (env SOICP_ABLATE): bit0 skip plane fit, bit1 skip scan, bit2 skip re-rank
   unsigned long long* kdbg;  // profiling only (SOICP_ABLATE bit 7): 2 sweeps x 4*kKnnBlocks wavefront records of 16 stamps, else nullptr
+  uint32_t chunk_cap;     // entries of the chunk list buffer: LIGHT chunks (<= 16 queries) are listed from its top downwards
 };
 
 struct EvalParams {
@@ -67,7 +68,7 @@ struct DevState {
   int32_t max_outer, lm_max, pad0, pad1;
   // device-side control
   int32_t outer_iter, reg_done, lm_more, n_iterations;
-  uint32_t n_kept, n_chunks, pad2, pad3;
+  uint32_t n_kept, n_chunks /* normal chunks */, n_light /* chunks of <= 16 queries, listed separately */, pad3;
   double T[7];          // pose of the current outer iteration (T_w_lidar)
   double eval_pose[7];  // pose the next LM evaluation is requested at
   LmState S;
@@ -80,7 +81,8 @@ static_assert(sizeof(DevState) % 8 == 0, "DevState is copied in 8-byte words");
 
 constexpr int kHistReplicas = 16;    // histogram atomics are spread over replicas (contention), summed by eval_kernel
 constexpr int kHistStride = 32;      // ints per replica: reject[7] obs[9] stats[4]
-constexpr int kKnnBlocks = 2048;     // 8192 wavefronts, one per chunk (grid-stride beyond that); surplus wavefronts exit at once
+constexpr int kKnnBlocks = 1024;     // 4096 wavefronts = what the chip holds at 4 per SIMD; one chunk each, and a second one for the
+                                     // wavefronts whose first chunk is a light one (see knn_plane_kernel: everything in ONE round)
 #ifndef SO_SOLVE_BLOCKS
 #define SO_SOLVE_BLOCKS 256
 #endif
@@ -117,7 +119,7 @@ struct BinTable {
   uint32_t log2_size;
 };
 // per query: table slot (0xFFFFFFFF = dropped) and rank inside its bucket
-void launch_bin_offsets(const BinTable& bt, uint32_t* d_chunk_start, DevState* st, hipStream_t s);
+void launch_bin_offsets(const BinTable& bt, uint32_t* d_chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s);
 void launch_bin_place(const BinTable& bt, const float* d_scan_xyz, uint32_t n, const uint32_t* d_qslot, const uint32_t* d_qrank,
                       uint32_t* d_perm, float* spx, float* spy, float* spz, hipStream_t s);
 

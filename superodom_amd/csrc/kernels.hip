@@ -90,7 +90,7 @@ __device__ __forceinline__ void reg_begin_state(DevState* st, const RegBeginArgs
   if (tid == 0) {
     st->max_outer = a.max_outer; st->lm_max = a.lm_max;
     st->outer_iter = 0; st->reg_done = 0; st->lm_more = 0; st->n_iterations = 0;
-    st->n_kept = 0; st->n_chunks = 0;
+    st->n_kept = 0; st->n_chunks = 0; st->n_light = 0;
   }
 }
 // stand-alone prologue (empty scan: scan_keys_kernel, which normally carries it, is not launched)
@@ -190,47 +190,59 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   vals[i] = base + my_idx;   // rank inside the bucket
 }
 
-// bucket offsets + chunk list from the table counts; leaves the table empty for the next registration.
-// Four table slots per thread (one 16-byte load), 1024 threads per workgroup: workgroup scan, one atomic pair per workgroup.
-__global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t* __restrict__ chunk_start, DevState* __restrict__ st) {
-  __shared__ uint32_t wq[16], wc[16], base_q, base_c;
+// bucket offsets + chunk lists from the table counts; leaves the table empty for the next registration.
+// Four table slots per thread (one 16-byte load), 1024 threads per workgroup: workgroup scan, one atomic triple per workgroup.
+// A bucket is cut every 64 queries; a last piece of <= 16 queries is a LIGHT chunk (the k-NN wavefront scans its
+// candidates with four parts of its lanes: about half the time of a full chunk) and goes to the second list, which
+// grows from the top of the buffer downwards -- the k-NN kernel pairs light chunks so that all chunks run in one round.
+__global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t* __restrict__ chunk_start, uint32_t chunk_cap,
+                                                           DevState* __restrict__ st) {
+  __shared__ uint32_t wq[16], wc[16], wl[16], base_q, base_c, base_l;
   const uint32_t t4 = blockIdx.x * blockDim.x + threadIdx.x;  // slots 4*t4 .. 4*t4+3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint4 c4 = reinterpret_cast<const uint4*>(bt.cnt)[t4];
   const uint32_t cnt[4] = {c4.x, c4.y, c4.z, c4.w};
-  uint32_t tq = 0, tc = 0;
+  uint32_t tq = 0, tc = 0, tl = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { tq += cnt[k]; tc += (cnt[k] + 63u) >> 6; }
-  uint32_t iq = tq, ic = tc;  // inclusive scans over the wavefront
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t r = cnt[k] & 63u;
+    tq += cnt[k]; tc += (cnt[k] >> 6) + (r > 16u ? 1u : 0u); tl += (r > 0u && r <= 16u) ? 1u : 0u;
+  }
+  uint32_t iq = tq, ic = tc, il = tl;  // inclusive scans over the wavefront
   if (__ballot(tq != 0)) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t a = (uint32_t)__shfl_up((int)iq, d, 64), b = (uint32_t)__shfl_up((int)ic, d, 64);
-      if (lane >= d) { iq += a; ic += b; }
+      const uint32_t a = (uint32_t)__shfl_up((int)iq, d, 64), b = (uint32_t)__shfl_up((int)ic, d, 64), c = (uint32_t)__shfl_up((int)il, d, 64);
+      if (lane >= d) { iq += a; ic += b; il += c; }
     }
   }
-  if (lane == 63) { wq[wave] = iq; wc[wave] = ic; }
+  if (lane == 63) { wq[wave] = iq; wc[wave] = ic; wl[wave] = il; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t sq = 0, sc = 0;
-    for (int w = 0; w < 16; ++w) { const uint32_t a = wq[w], b = wc[w]; wq[w] = sq; wc[w] = sc; sq += a; sc += b; }
+    uint32_t sq = 0, sc = 0, sl = 0;
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t a = wq[w], b = wc[w], c = wl[w];
+      wq[w] = sq; wc[w] = sc; wl[w] = sl; sq += a; sc += b; sl += c;
+    }
     base_q = sq ? atomicAdd(&st->n_kept, sq) : 0u;
     base_c = sc ? atomicAdd(&st->n_chunks, sc) : 0u;
+    base_l = sl ? atomicAdd(&st->n_light, sl) : 0u;
   }
   __syncthreads();
   if (tq) {
     uint32_t off = base_q + wq[wave] + (iq - tq);
     uint32_t* o = chunk_start + base_c + wc[wave] + (ic - tc);
+    uint32_t li = base_l + wl[wave] + (il - tl);  // index in the light list: entry chunk_cap - 1 - li
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (!cnt[k]) continue;
       bt.off[4 * t4 + k] = off;
-      const uint32_t nch = (cnt[k] + 63u) >> 6;
-      for (uint32_t c2 = 0; c2 < nch; ++c2) {
-        const uint32_t left = cnt[k] - 64u * c2;
-        o[c2] = (off + 64u * c2) | (((left < 64u ? left : 64u) - 1u) << 26);
-      }
-      o += nch; off += cnt[k];
+      const uint32_t full = cnt[k] >> 6, r = cnt[k] & 63u;
+      for (uint32_t c2 = 0; c2 < full; ++c2) o[c2] = (off + 64u * c2) | (63u << 26);
+      o += full;
+      if (r > 16u) *o++ = (off + 64u * full) | ((r - 1u) << 26);
+      else if (r > 0u) chunk_start[chunk_cap - 1u - li++] = (off + 64u * full) | ((r - 1u) << 26);
+      off += cnt[k];
       bt.key[4 * t4 + k] = 0xFFFFFFFFu;
     }
     reinterpret_cast<uint4*>(bt.cnt)[t4] = make_uint4(0, 0, 0, 0);
@@ -722,7 +734,12 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   __shared__ uint32_t tcanon[4][kTileCand + 16];  // per wavefront: canonical map index of the staged candidate
   __shared__ uint32_t rowtab[4][2][36];  // per wavefront: exclusive candidate offsets [33] and first canonical index [32] of the block's x-runs
   if (st->reg_done) return;  // the registration already converged: this launch is a no-op
-  const uint32_t n_kept = st->n_kept, n_chunks = st->n_chunks;
+  const uint32_t n_kept = st->n_kept, n_normal = st->n_chunks, n_light = st->n_light;
+  // Logical order of the work list: [first half of the light chunks][normal chunks][second half of the light chunks].
+  // Wavefront w takes positions w, w + 4096, ...: with up to 8 192 chunks the wavefronts that get a second chunk are the
+  // ones whose first chunk is light, and their second chunk is light too -- two light chunks cost about as much as one
+  // full chunk, so the whole sweep runs in ONE round of resident wavefronts (a second round ran on a mostly empty chip).
+  const uint32_t n_chunks = n_normal + n_light, n_light1 = (n_light + 1u) >> 1;
   const Pose pose = pose_from_array(st->T);
   if (threadIdx.x < 20) lh[threadIdx.x] = 0;
   __syncthreads();
@@ -751,7 +768,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   const float r_gate = sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f;
   const float r_near = 0.5f * cell;
   const int first_pass = (r_near < 0.8f * r_gate && !(mp.ablate & 256)) ? 0 : 1;
-  // one wavefront per chunk of the work list (grid-stride when the list is longer than the grid)
+  // one wavefront per chunk of the work list (a second / further chunk when the list is longer than the grid)
   for (uint32_t chunk = blockIdx.x * 4 + wv; chunk < n_chunks; chunk += gridDim.x * 4) {
   if (stamp) ts[0] = wall_clock64();
   uint32_t j = 0;
@@ -760,7 +777,9 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   // scan alternate candidate quads, then exchange their eight survivors (the average chunk has 27 queries).
   bool split = false, split4 = false;  // <= 16 queries: four parts of 16 lanes
   {
-    const uint32_t desc = __builtin_amdgcn_readfirstlane(chunk_start[chunk]);
+    const uint32_t entry = chunk < n_light1 ? mp.chunk_cap - 1u - chunk
+                         : (chunk < n_light1 + n_normal ? chunk - n_light1 : mp.chunk_cap - 1u - (chunk - n_normal));
+    const uint32_t desc = __builtin_amdgcn_readfirstlane(chunk_start[entry]);
     const uint32_t start = desc & 0x03FFFFFFu, count = (desc >> 26) + 1u;
     split = count <= 32u && !(mp.ablate & 1024);
     split4 = count <= 16u && split && !(mp.ablate & 2048);
@@ -1923,8 +1942,8 @@ void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const doubl
   hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals, status,
                      bin ? *bin : BinTable{nullptr, nullptr, nullptr, 0});
 }
-void launch_bin_offsets(const BinTable& bt, uint32_t* chunk_start, DevState* st, hipStream_t s) {
-  hipLaunchKernelGGL(bin_offsets_kernel, dim3((1u << bt.log2_size) / 4096u), dim3(1024), 0, s, bt, chunk_start, st);
+void launch_bin_offsets(const BinTable& bt, uint32_t* chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s) {
+  hipLaunchKernelGGL(bin_offsets_kernel, dim3((1u << bt.log2_size) / 4096u), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st);
 }
 void launch_bin_place(const BinTable& bt, const float* d_scan, uint32_t n, const uint32_t* qslot, const uint32_t* qrank, uint32_t* perm,
                       float* spx, float* spy, float* spz, hipStream_t s) {

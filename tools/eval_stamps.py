@@ -72,9 +72,28 @@ def main():
             k = int(np.argmax(busy[:, 8]))
             mi = int(busy[k, 13])
             print("   slowest chunk: %.1f us, candidates scanned %d, groups(all passes) %d, fallback lanes %d | fallback lanes total %d" % (
-                busy[k, 8] * 0.01, mi >> 32, mi & 0xFFFF, (mi >> 16) & 0xFFFF, int(busy[:, 14].sum())))
+                busy[k, 8] * 0.01, mi >> 32, mi & 0xFFFF, (mi >> 16) & 0xFFFF, int((busy[:, 14].astype(np.uint64) & np.uint64(0xFFFFFFFF)).sum())))
             order = np.argsort(-busy[:, 8])[:8]
             print("   top chunks (us, cand, fb):", [(round(busy[q, 8] * 0.01, 1), int(busy[q, 13]) >> 32, (int(busy[q, 13]) >> 16) & 0xFFFF) for q in order])
+            if os.environ.get("SOICP_HWID"):  # where the wavefronts ran: (xcc, se, cu, simd) from HW_ID / XCC_ID in d[14]
+                hw = (r[:, 14].astype(np.uint64) >> np.uint64(32))
+                xcc = (hw >> np.uint64(16)) & np.uint64(0xF); simd = (hw >> np.uint64(4)) & np.uint64(3); cu = (hw >> np.uint64(8)) & np.uint64(0xF)
+                se = (hw >> np.uint64(13)) & np.uint64(7)
+                for w in list(range(0, 12)) + [1024, 1025, 2048, 2049, 3072, 3073, 4092, 4093]:
+                    if w < len(r):
+                        print("      wave %4d (wg %4d): xcc %d se %d cu %2d simd %d" % (w, w // 4, xcc[w], se[w], cu[w], simd[w]))
+                place = (xcc * np.uint64(4096) + se * np.uint64(256) + cu * np.uint64(4) + simd).astype(np.int64)
+                cost = r[:, 8] * 0.01
+                u, inv = np.unique(place, return_inverse=True)
+                loads = np.bincount(inv, weights=cost); cnts = np.bincount(inv)
+                print("      distinct SIMDs %d; wavefronts per SIMD min %d max %d; chunk-time per SIMD: mean %.1f max %.1f us" % (len(u), cnts.min(), cnts.max(), loads.mean(), loads.max()))
+            single = busy[busy[:, 7] == 1]
+            if len(single):  # phase breakdown of the slowest single-chunk wavefronts: (total | prologue, set-up, stage+scan, merge, epilogue | queries, candidates, start)
+                so = np.argsort(-single[:, 8])[:6]
+                print("   slowest single-chunk wavefronts:")
+                for q in so:
+                    w = single[q]
+                    print("      %.1f us | %s | queries %d cand %d start %.1f" % (w[8] * 0.01, " ".join("%.1f" % (x * 0.01) for x in w[2:7]), int(w[10]), int(w[9]), (w[0] - t0) * 0.01))
             idle = r[r[:, 7] == 0]
             if len(idle):
                 print("   idle workgroups: start offset p50 %.1f max %.1f us" % (np.percentile((idle[:, 0] - t0) * 0.01, 50), ((idle[:, 0] - t0) * 0.01).max()))
