@@ -1117,7 +1117,8 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
     d[0] = t_first; d[1] = wall_clock64();
     for (int i = 0; i < 5; ++i) d[2 + i] = acc[i];
     d[15] = clock64() - c_first;  // shader-clock ticks over the wavefront's life (d[1] - d[0] = the same span at 100 MHz)
-    d[7] = n_mine; d[8] = t_maxchunk; d[9] = n_cand_total; d[10] = n_q_total; d[11] = n_groups_total; d[12] = n_pass2; d[13] = max_info; d[14] = n_fb_total;
+    d[7] = n_mine; d[8] = t_maxchunk; d[9] = n_cand_total; d[10] = n_q_total; d[11] = n_groups_total; d[12] = n_pass2; d[13] = max_info;
+    d[14] = n_fb_total | ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 48);  // + HW_ID[15:0] (wave, simd, cu, se), XCC_ID: where the wavefront ran
   }
   __syncthreads();
   if (threadIdx.x >= 16 && threadIdx.x < 20 && lh[threadIdx.x])  // kernel statistics only; the histograms are built by plane_eval_kernel
