@@ -174,6 +174,29 @@ def test_control_flow_variants_are_bit_identical(oracle, gpu_slam_factory, monke
         assert np.array_equal(np.array(s1.JtJ), np.array(s2.JtJ))
 
 
+@pytest.mark.parametrize("max_outer,lm_max", [(1, 1), (1, 4), (2, 2), (3, 1), (5, 3), (4, 8)])
+def test_loop_bounds_follow_the_oracle(oracle, gpu_slam_factory, max_outer, lm_max):
+    """Outer-iteration and LM-iteration limits (LocalizationICPMaxIter, max_num_iterations): the persistent solve launch runs
+    1 + (LM iterations) passes per outer iteration, publishes one hand-off per pass and ends on whichever limit comes first.
+    Iteration counts, termination codes, histograms and pose follow the oracle for every combination; a second
+    registration on the same context checks that the pass tags / hand-off epochs carry over between launches."""
+    sc, slam, om = _setup("small", oracle, gpu_slam_factory, max_iterations=max_outer, lm_max_iterations=lm_max)
+    cfg = oracle.default_config(max_iterations=max_outer, lm_max_iterations=lm_max)
+    for i in (1, 2):
+        scan, guess = sc.scan(i), sc.guess(i)
+        rc, pose, st = slam.register(scan, guess)
+        orc, opose, ost, _ = om.register(scan, guess, cfg)
+        assert rc == orc == 0 and st.n_iterations == ost.n_iterations <= max_outer
+        for it in range(st.n_iterations):
+            assert st.iterations[it].lm_iterations == ost.iters[it].lm_iterations <= lm_max
+            assert st.iterations[it].num_successful_steps == ost.iters[it].num_successful_steps
+            assert st.iterations[it].termination == ost.iters[it].termination
+            assert list(st.iterations[it].reject_hist) == list(ost.iters[it].reject_hist)
+            assert list(st.iterations[it].obs_hist) == list(ost.iters[it].obs_hist)
+        ok, dt, dr = pose_close(pose, opose, 1e-8, 1e-8)
+        assert ok, (dt, dr)
+
+
 def test_register_batch_hypotheses_match_single_registrations_and_oracle(oracle, gpu_slam_factory, soicp):
     """so_icp_register_batch (BASELINE configs[4]): B initial poses for one scan = B independent registrations; the
     tracker state (previous observability histogram) is not advanced; covariance of each result from its J^T J."""
