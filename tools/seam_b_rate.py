@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[1] on one GPU: Seam B (LocalMap::nearestKSearchSurf, k = 5) for a 16 x 1800 scan (28 800
+world-frame queries) against a 200 000-point map through so_icp_knn_surf -- host buffers in, host buffers out (the
+residuals stay on the CPU in this configuration, so the PCIe copies are part of the call).  Compared with the CPU
+restatement (exact grid k-NN, 1 thread) and, when oracle/_ref is built, the reference's own octree.
+usage (GPU box): python tools/seam_b_rate.py [--reps 20]"""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from superodom_amd import binding, synth  # noqa: E402
+
+ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=20)
+a = ap.parse_args()
+sc = synth.Scene("vlp16_200k")
+slam = binding.LidarSlamGpu(device_id=0, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_iterations=5, max_surface_features=-1)
+slam.add_surf_point_cloud(sc.map_points)
+scan, gt = sc.scan(1), sc.gt_pose(1)
+R = synth.quat_to_R(gt[3:])
+q = (scan @ R.T + gt[:3]).astype(np.float32)
+found, nbr, d2, idx = slam.nearest_k_search_surf(q, 5)  # warm-up
+t = time.perf_counter()
+for _ in range(a.reps):
+    found, nbr, d2, idx = slam.nearest_k_search_surf(q, 5)
+dt = (time.perf_counter() - t) / a.reps
+print("Seam B, %d queries vs %d map points: %.3f ms per call = %.1f M queries/s (host buffers, copies included); found %d" % (
+    len(q), slam.map_size(), 1e3 * dt, len(q) / dt / 1e6, int(found.sum())))
+try:
+    import oracle_py
+    mp = slam.export_map()
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_octree.so")):  # the reference's own octree (oct.h + nanoflann compiled as they are), one tree, 1 thread
+        t = time.perf_counter(); ro = oracle_py.RefOctree(mp); tb = time.perf_counter() - t
+        t = time.perf_counter(); ridx, rd2 = ro.knn(q, 5); dc = time.perf_counter() - t
+        print("reference octree on the host (1 thread): build %.1f ms, %d queries in %.1f ms = %.2f M queries/s; GPU call / CPU = %.0fx" % (
+            1e3 * tb, len(q), 1e3 * dc, len(q) / dc / 1e6, dc / dt))
+    om = oracle_py.OracleMap(plane_res=sc.plane_res)
+    om.add_surf(mp, raw=True)
+    sub = q[::8]
+    t = time.perf_counter(); of, on, od = om.knn(sub, 5)[:3]; dc = time.perf_counter() - t
+    f8 = found[::8].astype(bool)
+    same = np.array_equal(np.asarray(of).astype(bool), f8) and np.array_equal(np.asarray(od)[f8].view(np.uint32), d2[::8][f8].view(np.uint32))
+    print("CPU restatement (cube-restricted exact grid k-NN, one ctypes call per query, every 8th query): found flags and d2 bit-identical to the GPU: %s" % same)
+except Exception as e:  # the oracle is optional here
+    print("oracle not available:", e)
