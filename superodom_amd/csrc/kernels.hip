@@ -1,13 +1,19 @@
 // kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the scan-to-map ICP hot path.
 //
-//   scan_keys_kernel    sampling rule + world transform + spatial sort key        (LidarSlam.cpp:346-359, 397-398)
-//   gather_scan_kernel  AoS scan -> spatially sorted SoA (once per registration)
-//   knn_plane_kernel    per query: cube-restricted exact 5-NN over the hashed-voxel cell grid, then in
-//                       registers the PCA gate, the 5x3 LS plane, inlier gate, fit coefficient and the
-//                       observability labels                                       (LidarSlam.cpp:514-572)
-//   eval_kernel         per LM evaluation: residual, Tukey*coeff weight, 6-DoF Jacobian and the fp64
-//                       21+6+1+1 normal-equation sums, wavefront-shuffle reduced, deterministic
-//                       two-stage finish by the last workgroup                     (lidarOptimization.cpp:55-80)
+//   scan_keys_kernel    registration prologue, sampling rule, world transform, spatial key (cube | half-cell octant) and
+//                       the hash-binning count of every query                     (LidarSlam.cpp:346-359, 397-398)
+//   bin_offsets_kernel  bucket offsets + the k-NN work lists (normal / light chunks); bin_place_kernel: binned SoA scan
+//                       (SOICP_BINNING=sort: rocPRIM sort + chunk_heads_kernel instead)
+//   knn_plane_kernel    one wavefront per chunk: cube-restricted exact 5-NN over the hashed-voxel cell grid (LDS-staged
+//                       candidate tiles, selection network, exact re-rank + certification), distance gate
+//                                                                                  (LocalMap.h:481-525, LidarSlam.cpp:720-747)
+//   solve_kernel        ONE persistent launch per outer iteration: plane fit (PCA gate, 5x3 LS plane, inlier gate,
+//                       coefficient, observability labels; LidarSlam.cpp:514-693) + every LM evaluation (residual,
+//                       Tukey x coefficient weight, 6-DoF Jacobian, the 21+6+1+1 fp64 normal-equation sums;
+//                       lidarOptimization.cpp:55-80) + the Ceres-equivalent LM controller (lm_solver.h), with
+//                       device-side hand-offs between the passes
+//   eval_kernel / lm_step_kernel   the same passes as one launch per evaluation (sharded map: the sums pass through the
+//                       RCCL all-reduce; concurrent hypotheses of so_icp_register_batch)
 //   knn_only / knn_fallback   Seam B (LocalMap::nearestKSearchSurf, LocalMap.h:481-525)
 //
 // Nothing here is a dense contraction, so no MFMA: these are HBM/latency-bound gather-scan-reduce
