@@ -197,6 +197,38 @@ def test_loop_bounds_follow_the_oracle(oracle, gpu_slam_factory, max_outer, lm_m
         assert ok, (dt, dr)
 
 
+@pytest.mark.parametrize("plane_res,map_points", [(0.1, 30_000), (0.4, 6_000)])
+def test_other_map_resolutions(oracle, gpu_slam_factory, plane_res, map_points):
+    """mapping_plane_resolution other than 0.2 (indoor 0.1, coarse 0.4): the cell size of the k-NN grid, the gates
+    (3 planeRes, planeRes / 2), the Tukey scale and the VoxelGrid leaf all follow planeRes.  Same checks as at 0.2."""
+    sc = synth.Scene("tiny", plane_res=plane_res, map_points=map_points)
+    slam = gpu_slam_factory(plane_res=plane_res, line_res=plane_res / 2, max_surface_features=-1, max_iterations=5)
+    assert slam.add_surf_point_cloud(sc.map_points) == slam.map_size()
+    om = oracle.OracleMap(plane_res=plane_res, line_res=plane_res / 2)
+    om.add_surf(slam.export_map(), raw=True)
+    cfg = oracle.default_config(max_iterations=5)
+    for i in (0, 3):
+        scan, guess = sc.scan(i), sc.guess(i)
+        rc, pose, st = slam.register(scan, guess)
+        orc, opose, ost, _ = om.register(scan, guess, cfg)
+        assert rc == orc == 0 and st.n_iterations == ost.n_iterations
+        for it in range(st.n_iterations):
+            assert st.iterations[it].lm_iterations == ost.iters[it].lm_iterations
+            assert st.iterations[it].num_surf_from_scan == ost.iters[it].num_surf
+            assert list(st.iterations[it].reject_hist) == list(ost.iters[it].reject_hist)
+            assert list(st.iterations[it].obs_hist) == list(ost.iters[it].obs_hist)
+        ok, dt, dr = pose_close(pose, opose, 1e-8, 1e-8)
+        assert ok, (dt, dr)
+    # Seam B at this resolution
+    gt = sc.gt_pose(0)
+    q = (sc.scan(0) @ synth.quat_to_R(gt[3:]).T + gt[:3]).astype(np.float32)[::7]
+    found, nbr, d2, idx = slam.nearest_k_search_surf(q, 5)
+    of, on, od = om.knn(q, 5)[:3]
+    assert np.array_equal(found.astype(bool), np.asarray(of).astype(bool))
+    f = found.astype(bool)
+    assert np.array_equal(d2[f].view(np.uint32), np.asarray(od)[f].view(np.uint32))
+
+
 def test_register_batch_hypotheses_match_single_registrations_and_oracle(oracle, gpu_slam_factory, soicp):
     """so_icp_register_batch (BASELINE configs[4]): B initial poses for one scan = B independent registrations; the
     tracker state (previous observability histogram) is not advanced; covariance of each result from its J^T J."""
