@@ -260,6 +260,8 @@ int so_icp_lm_result(const so_icp_lm_state *s, double pose[7], so_icp_iter_stats
 /* -------- measurement ------------------------------------------------------------------------ */
 int so_icp_get_timing(so_icp_ctx *ctx, so_icp_timing *t);
 int so_icp_reset_timing(so_icp_ctx *ctx);
+/* switch so_icp_config::time_kernels on a live context (e.g. 1 inside a timed region, 2 for a profiling pass after it) */
+int so_icp_set_time_kernels(so_icp_ctx *ctx, int mode);
 int so_icp_synchronize(so_icp_ctx *ctx);
 /* profiling aid: wall-clock stamps (100 MHz ticks) of the phases of the last fit / evaluation kernels (SOICP_ABLATE=128) */
 int so_icp_debug_stamps(so_icp_ctx *ctx, uint64_t out[16]);

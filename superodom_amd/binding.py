@@ -74,7 +74,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_map_size", "so_icp_map_clear", "so_icp_map_get_origin", "so_icp_knn_surf", "so_icp_register",
             "so_icp_register_dev", "so_icp_upload_scan", "so_icp_free_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
-            "so_icp_get_timing", "so_icp_reset_timing", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
+            "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan"]
 
 _lib = None
@@ -130,6 +130,7 @@ def load():
     L.so_icp_prefilter_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_float, C.c_float, C.POINTER(vp),
                                         C.POINTER(C.c_size_t), C.POINTER(PrefilterInfo)]
     L.so_icp_debug_knn_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.so_icp_set_time_kernels.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -318,6 +319,9 @@ class LidarSlamGpu:
 
     def reset_timing(self):
         self._check(self.L.so_icp_reset_timing(self.h))
+
+    def set_time_kernels(self, mode):
+        self._check(self.L.so_icp_set_time_kernels(self.h, int(mode)))
 
     def debug_stamps(self):
         out = np.zeros(16, np.uint64)

@@ -524,12 +524,17 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
       bool keep = (sp.kind == 2);
       for (int it = 0; it < H.n_iterations && !keep; ++it) {
         if (sp.kind == 0 && it < (int)knn_span_of_outer.size() && i == knn_span_of_outer[it]) keep = true;
+        // (a persistent solve launch is ONE span per outer iteration, the per-evaluation schedule 1 + #LM iterations)
         if (sp.kind == 1 && it < (int)eval_span_first.size() && i >= eval_span_first[it] &&
-            i < eval_span_first[it] + 1 + (size_t)std::max(H.iters[it].lm_iterations, 0)) keep = true;
+            i < eval_span_first[it] + (persistent ? 1 : 1 + (size_t)std::max(H.iters[it].lm_iterations, 0))) keep = true;
       }
       if (keep) { EventSpan r = sp; r.units = H.n_kept; real.push_back(r); }
     }
     c->spans.swap(real);
+    // profiling mode brackets the solve launches too: the last one has published its result but its stop event may not
+    // have signalled yet (hipEventElapsedTime would refuse it) -- wait for the stream there; the k-NN events of mode 1
+    // completed long ago
+    if (c->cfg.time_kernels >= 2) HIP_TRY(c, hipStreamSynchronize(s));
     spans_collect(c);
     for (int it = 0; it < H.n_iterations && c->cfg.time_kernels >= 2; ++it)
       for (int r = 0; r < kHistReplicas; ++r) {
@@ -1196,6 +1201,11 @@ int so_icp_lm_result(const so_icp_lm_state* s, double pose[7], so_icp_iter_stats
 
 int so_icp_get_timing(so_icp_ctx* c, so_icp_timing* t) { if (!c || !t) return SO_ICP_E_INVALID; *t = c->timing; return SO_ICP_OK; }
 int so_icp_reset_timing(so_icp_ctx* c) { if (!c) return SO_ICP_E_INVALID; std::memset(&c->timing, 0, sizeof(c->timing)); return SO_ICP_OK; }
+int so_icp_set_time_kernels(so_icp_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return SO_ICP_E_INVALID;
+  c->cfg.time_kernels = mode;
+  return SO_ICP_OK;
+}
 int so_icp_debug_stamps(so_icp_ctx* c, uint64_t out[16]) {
   if (!c || !out) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);
