@@ -1193,9 +1193,7 @@ __device__ __forceinline__ u4v load16_sc1(const u4v* p) {
   return v;
 }
 
-#ifndef SO_LM_INLINE
-#define SO_LM_INLINE __forceinline__
-#endif
+#define SO_LM_INLINE __forceinline__  // (out of line, the callee-saved registers go through scratch: +1 us per call)
 // hand / want / pose_out (persistent solve): the controller's thread publishes the hand-off record {next pose, more?}
 // straight from its registers, BEFORE the state goes back to LDS -- the other workgroups are already evaluating the
 // next pose while this thread is still tidying up.
@@ -1203,9 +1201,6 @@ __device__ SO_LM_INLINE int lm_control(int slot, DevState* st, LmState& S_lds, c
                                        u4v* hand = nullptr, unsigned long long want = 0, double* pose_out = nullptr) {
   // register copies: the controller is one thread's serial fp64 chain, and every LDS round trip inside it (~100 cycles,
   // nothing to overlap with) would sit on the critical path of the whole device
-#ifdef SO_LM_LDS
-  return lm_control_regs(slot, st, S_lds, sums_lds, ctl, persist);
-#else
   // (the sums stay in LDS: they are read once, where a successful step adopts them; H is symmetric: only its upper
   //  triangle lives in registers, the mirror image is rebuilt on the way out -- the full state plus the sums would not
   //  fit the 256 architectural registers and the spill traffic would sit on the same critical path)
@@ -1249,7 +1244,6 @@ __device__ SO_LM_INLINE int lm_control(int slot, DevState* st, LmState& S_lds, c
   if (slot == 1) st->dbg[7] = wall_clock64();
 #endif
   return more_;
-#endif
 }
 
 // threads [first, first+10) fetch the controller's inputs
