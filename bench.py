@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1, help="registrations timed for the CPU baseline")
     ap.add_argument("--shuffle-scan", action="store_true", help="experiment: random point order inside every scan (worst case for the binning atomics)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the k-NN launches (no roofline)")
+    ap.add_argument("--no-profile-pass", action="store_true", help="skip the kernel-split pass after the timed region (runs under rocprofv3 use it: one registration = one set of launches)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,7 +125,7 @@ def main():
     # ---- kernel split of a registration: a profiling pass AFTER the timed region (every launch bracketed by events,
     #      which would cost ~25 us per registration inside it); every rank runs it (the collectives need all of them)
     prof = None
-    if not args.no_kernel_events:
+    if not args.no_kernel_events and not args.no_profile_pass:
         slam.set_time_kernels(2)
         slam.reset_timing()
         n_prof = 2 * args.scans

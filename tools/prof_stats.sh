@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-run}
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline > /tmp/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-profile-pass > /tmp/prof_$TAG.log 2>&1
 mkdir -p $R/gpurun_out/prof_$TAG
 f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp $f $R/gpurun_out/prof_$TAG/kernel_stats.csv

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/tl
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > /tmp/tl.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-profile-pass > /tmp/tl.log 2>&1
 python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/tl/**/*kernel_trace.csv", recursive=True)[0]
