@@ -124,6 +124,7 @@ struct so_icp_ctx {
   // so_icp_register_batch: worker contexts register hypotheses concurrently against the PARENT's resident map
   struct Borrow { bool on = false; DevMapView view{}; float plane_res = 0; int pos[3] = {0, 0, 0}; int count_5x5 = 0; } borrow;
   std::vector<so_icp_ctx*> workers;
+  bool speculate = true;      // enqueue outer iteration i+1 before the report of i is in (SOICP_SPECULATE=0: wait first)
   bool batch_mode = false;    // no kernel timing, tracker state read-only
   bool batch_single = false;  // batch on ONE lane: nothing runs next to it, the persistent solve launch is safe
   bool no_map_shift = false;  // so_icp_register_batch: hypotheses after the first keep the window of the first
@@ -472,10 +473,11 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   if (c->sync_per_outer) {
     if ((rc = enqueue_outer_a(0)) || (rc = enqueue_outer_b(0))) return rc;
     for (int it = 0;; ++it) {
-      if (it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
+      if (c->speculate && it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
       if ((rc = await_outer(it))) return rc;
       last = it;
       if (c->h_ring[it & 1]->reg_done || it + 1 >= max_outer) break;
+      if (!c->speculate && (rc = enqueue_outer_a(it + 1))) return rc;  // SOICP_SPECULATE=0: no launch that could turn out a no-op
       if ((rc = enqueue_outer_b(it + 1))) return rc;
     }
   } else {
@@ -672,6 +674,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
     return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if (const char* ev = std::getenv("SOICP_SYNC_PER_OUTER")) c->sync_per_outer = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_READBACK")) c->direct_readback = std::string(ev) != "copy";
+  if (const char* ev = std::getenv("SOICP_SPECULATE")) c->speculate = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BINNING")) c->use_binning = std::string(ev) != "sort";
   const bool want_dmap = cfg->world_size == 1 && !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));

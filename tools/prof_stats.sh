@@ -8,7 +8,23 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python
 mkdir -p $R/gpurun_out/prof_$TAG
 f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp $f $R/gpurun_out/prof_$TAG/kernel_stats.csv
-tail -1 /tmp/prof_$TAG.log > $R/gpurun_out/prof_$TAG/bench_line.json
+grep "^{\"metric" /tmp/prof_$TAG.log | tail -1 > $R/gpurun_out/prof_$TAG/bench_line.json
+# second pass without speculative enqueue: every knn_plane_kernel / solve_kernel launch in it is a real one, so the
+# rocprofv3 averages can be compared directly with the HIP-event averages bench.py reports (which exclude no-op launches)
+rm -rf /tmp/prof_${TAG}_ns
+SOICP_SPECULATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_ns -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-profile-pass > /tmp/prof_${TAG}_ns.log 2>&1
+g=$(find /tmp/prof_${TAG}_ns -name "*kernel_stats.csv" | head -1)
+cp $g $R/gpurun_out/prof_$TAG/kernel_stats_no_speculation.csv
+grep "^{\"metric" /tmp/prof_${TAG}_ns.log | tail -1 > $R/gpurun_out/prof_$TAG/bench_line_no_speculation.json
+python - $g $R/gpurun_out/prof_$TAG/bench_line_no_speculation.json <<'PY'
+import csv, json, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+d = json.load(open(sys.argv[2]))
+for r in rows:
+    if "knn_plane_kernel" in r["Name"] or "solve_kernel" in r["Name"]:
+        print("no speculation:", r["Name"].split("(")[0], "calls", r["Calls"], "avg us %.2f" % (float(r["AverageNs"]) / 1e3))
+print("no speculation: bench.py HIP-event average of knn_plane_kernel in the same run: %.2f us; value %.0f registrations/s" % (1e3 * d["roofline"]["avg_launch_ms"], d["value"]))
+PY
 python - $f <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
