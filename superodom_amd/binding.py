@@ -317,6 +317,10 @@ class LidarSlamGpu:
     def timing(self):
         t = Timing(); self._check(self.L.so_icp_get_timing(self.h, C.byref(t))); return t
 
+    def last_error(self):
+        """Text of the context's last error or notice (so_icp_last_error)."""
+        return self.L.so_icp_last_error(self.h).decode()
+
     def reset_timing(self):
         self._check(self.L.so_icp_reset_timing(self.h))
 

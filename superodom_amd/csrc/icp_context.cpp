@@ -124,6 +124,8 @@ struct so_icp_ctx {
   // so_icp_register_batch: worker contexts register hypotheses concurrently against the PARENT's resident map
   struct Borrow { bool on = false; DevMapView view{}; float plane_res = 0; int pos[3] = {0, 0, 0}; int count_5x5 = 0; } borrow;
   std::vector<so_icp_ctx*> workers;
+  bool no_map_shift_once = false;  // retry of a registration: keep the window of the first attempt
+  int n_cus = 256;            // compute units of the device: upper bound of the persistent solve launch's workgroups
   bool speculate = true;      // enqueue outer iteration i+1 before the report of i is in (SOICP_SPECULATE=0: wait first)
   bool batch_mode = false;    // no kernel timing, tracker state read-only
   bool batch_single = false;  // batch on ONE lane: nothing runs next to it, the persistent solve launch is safe
@@ -242,7 +244,8 @@ MatchParams match_params(float plane_res) {
   mp.plane_res = plane_res;
   mp.sq_max_dist_f = 3 * plane_res;           // float product (LidarSlam.cpp:526)
   mp.max_point_dist = (double)plane_res / 2.0; // LidarSlam.cpp:820
-  static const int ablate = std::getenv("SOICP_ABLATE") ? std::atoi(std::getenv("SOICP_ABLATE")) : 0;
+  const char* ablate_env = std::getenv("SOICP_ABLATE");  // (read per registration: tests switch it inside one process)
+  const int ablate = ablate_env ? std::atoi(ablate_env) : 0;
   mp.ablate = ablate;
   mp.kdbg = nullptr;
   return mp;
@@ -252,7 +255,8 @@ EvalParams eval_params(float plane_res, int variant) {
   const double a = (double)sqrtf(3 * plane_res);  // std::sqrt(float) then TukeyLoss(double a) (LidarSlam.cpp:271)
   ep.a2 = a * a;
   ep.variant = variant;
-  static const int ablate = std::getenv("SOICP_ABLATE") ? std::atoi(std::getenv("SOICP_ABLATE")) : 0;
+  const char* ablate_env = std::getenv("SOICP_ABLATE");  // (read per registration: tests switch it inside one process)
+  const int ablate = ablate_env ? std::atoi(ablate_env) : 0;
   ep.ablate = ablate;
   ep.hring[0] = ep.hring[1] = nullptr;
   ep.seq_base = 0;
@@ -305,7 +309,8 @@ void yaw_correction(double T[7], const double last[7], double yaw_ratio) {
 // and every kernel consults DevState (reg_done / lm_more) to turn itself into a no-op once the controller has
 // finished -- no host round trip per evaluation.  One small read-back per outer iteration (or one per
 // registration with SOICP_SYNC_PER_OUTER=0) tells the host when to stop enqueuing.
-int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pose_in[7], double pose_out[7], so_icp_stats* st) {
+constexpr int kRetryWithoutPersistentSolve = -1000;  // internal: never leaves register_core
+int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const double pose_in[7], double pose_out[7], so_icp_stats* st) {
   const auto t_begin = std::chrono::steady_clock::now();
   so_icp_stats local;
   if (!st) st = &local;
@@ -316,8 +321,9 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   if (c->have_hist) uncertainty_from_hist(c->prev_obs_hist, st->uncertainty);  // LidarSlam.cpp:47
   int pos[3];
   if (c->borrow.on) std::memcpy(pos, c->borrow.pos, sizeof(pos));  // window, count and map view were fixed by the batch driver
-  else if (!c->no_map_shift) { map_shift(c, T, pos); std::memcpy(c->last_pos, pos, sizeof(pos)); }  // LidarSlam.cpp:363
+  else if (!c->no_map_shift && !c->no_map_shift_once) { map_shift(c, T, pos); std::memcpy(c->last_pos, pos, sizeof(pos)); }  // LidarSlam.cpp:363
   else std::memcpy(pos, c->last_pos, sizeof(pos));
+  c->no_map_shift_once = false;
   st->pos_in_localmap[0] = pos[0]; st->pos_in_localmap[1] = pos[1]; st->pos_in_localmap[2] = pos[2];
   st->laser_cloud_surf_from_map_num = c->borrow.on ? c->borrow.count_5x5 : map_count_5x5(c, pos);  // LidarSlam.cpp:367
   st->laser_cloud_surf_stack_num = (int32_t)n;
@@ -431,7 +437,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     if (persistent) {  // the whole solve in one launch (workgroups hand the next pose to each other on the device)
       span_begin(c, 1, (uint32_t)n);
       launch_solve(lm_max, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep, c->d_partials, c->d_ticket,
-                   c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, s);
+                   c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, (uint32_t)c->n_cus, s);
       span_end(c);
       return SO_ICP_OK;
     }
@@ -458,6 +464,14 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
         if (*seq == want) break;
         HIP_TRY(c, hipStreamSynchronize(s));
         if (*seq == want) break;
+        if (persistent) {
+          // The persistent solve launch needs all of its workgroups resident at once.  If the device could not provide that
+          // (compute units held by another process, a partitioned device, ...) its waits gave up after 50 ms: fall back to
+          // one launch per evaluation for the rest of this context's life and run the registration again.
+          c->persistent_solve = false;
+          c->err = "persistent solve launch did not complete (workgroups not co-resident?): using per-evaluation launches from now on";
+          return kRetryWithoutPersistentSolve;
+        }
         return fail(c, SO_ICP_E_HIP, "registration state was not published by the device");
       }
     }
@@ -548,6 +562,16 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   c->timing.registrations++;
   c->timing.host_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return SO_ICP_OK;
+}
+
+int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pose_in[7], double pose_out[7], so_icp_stats* st) {
+  int rc = register_core_once(c, d_scan, n, pose_in, pose_out, st);
+  if (rc == kRetryWithoutPersistentSolve) {
+    c->no_map_shift_once = true;  // the window was already placed for this scan
+    rc = register_core_once(c, d_scan, n, pose_in, pose_out, st);
+    if (rc == kRetryWithoutPersistentSolve) rc = fail(c, SO_ICP_E_HIP, "registration state was not published by the device");
+  }
+  return rc;
 }
 
 int upload_scan_impl(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, DevBuf& dst) {
@@ -645,6 +669,11 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   c->map.set_resolution(cfg->line_res, cfg->plane_res);
   auto bail = [&](const std::string& m) { g_create_error = m; delete c; return (so_icp_ctx*)nullptr; };
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  {  // the persistent solve launch holds one workgroup per compute unit: never ask for more than the device has
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && cus > 0) c->n_cus = cus;
+    if (const char* ev = std::getenv("SOICP_SOLVE_WORKGROUPS")) { const int w = std::atoi(ev); if (w >= 1 && w < c->n_cus) c->n_cus = w; }  // leave compute units to others
+  }
   const size_t partial_bytes = std::max((size_t)kFitBlocksMax * kSumsStride * sizeof(double),
                                         (size_t)kFitBlocksMax * kRecordChunksMax * 16);  // partial sums / tagged records of solve_kernel
   const size_t small_bytes = 4096 + sizeof(LmSums) + 256 + partial_bytes + 256 + kSyncBytes;

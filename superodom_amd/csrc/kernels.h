@@ -145,7 +145,7 @@ void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, con
 // the whole solve (slot 0 .. lm_max) of one outer iteration in one launch (single device only)
 void launch_solve(int lm_max, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, DevState* st,
                   const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist, LmSums* d_sums,
-                  const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper, hipStream_t s);
+                  const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper, uint32_t max_blocks, hipStream_t s);
 void launch_lm_step(int slot, DevState* st, const LmSums* d_sums, int32_t* d_hist, const EvalParams& ep, hipStream_t s);
 // Seam B
 void launch_knn_only(const float* d_q_xyz, uint32_t nq, int k, const DevMapView& map, float gate_d2, float* d_nbr,

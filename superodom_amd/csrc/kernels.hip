@@ -1536,6 +1536,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
 #pragma unroll
       for (int i = 0; i < 32; ++i) ok = ok && (r[i].z == tag || (uint32_t)(32 * g + i) >= gridDim.x);
       ok = ok || !poller;
+      if (ep.ablate & 8192) { ok = false; break; }  // test hook: behave as if the records never arrived (the launch is abandoned)
       if (__ballot(!ok) == 0ull) break;
       if (wall_clock64() - t0 > 5000000ull) break;  // 50 ms: give up instead of hanging the device
     }
@@ -1989,9 +1990,11 @@ void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, con
 }
 void launch_solve(int lm_max, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, DevState* st,
                   const EvalParams& ep, double* partials, uint32_t* ticket, int32_t* hist, LmSums* sums, const DevMapView& map,
-                  const uint32_t* nbr5, const MatchParams& mp, uint32_t n_upper, hipStream_t s) {
+                  const uint32_t* nbr5, const MatchParams& mp, uint32_t n_upper, uint32_t max_blocks, hipStream_t s) {
+  // every workgroup must be resident for the whole launch (94 KB of LDS: one per compute unit)
   uint32_t blocks = (n_upper + 255u) / 256u;
   blocks = blocks < 1 ? 1 : (blocks > (uint32_t)kFitBlocksMax ? (uint32_t)kFitBlocksMax : blocks);
+  if (max_blocks >= 1 && blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL(solve_kernel, dim3(blocks), dim3(256), 0, s, lm_max, spx, spy, spz, corr, st, ep, partials, ticket, hist, sums,
                      map.pts, nbr5, mp);
 }

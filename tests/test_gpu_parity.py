@@ -230,6 +230,37 @@ def test_other_map_resolutions(oracle, gpu_slam_factory, plane_res, map_points):
     assert np.array_equal(d2[f].view(np.uint32), np.asarray(od)[f].view(np.uint32))
 
 
+def test_persistent_solve_on_fewer_compute_units_and_fallback(oracle, gpu_slam_factory, monkeypatch):
+    """(1) SOICP_SOLVE_WORKGROUPS=48: the persistent solve launch with fewer workgroups than the scan has 256-query tiles
+    (threads walk more than the two queries the LDS cache holds).  (2) SOICP_ABLATE=8192 makes the first persistent launch
+    abandon its solve as if its workgroups had not been co-resident: the context must fall back to per-evaluation launches,
+    repeat the registration and keep working.  Both against the oracle."""
+    sc = synth.Scene("small")
+    cfg = oracle.default_config(max_iterations=5)
+    scan, guess = sc.scan(2), sc.guess(2)
+    for env in ({"SOICP_SOLVE_WORKGROUPS": "48"}, {"SOICP_ABLATE": "8192"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        slam = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5)
+        slam.add_surf_point_cloud(sc.map_points)
+        om = oracle.OracleMap(plane_res=sc.plane_res)
+        om.add_surf(slam.export_map(), raw=True)
+        for rep in range(2):
+            rc, pose, st = slam.register(scan, guess)
+            orc, opose, ost, _ = om.register(scan, guess, cfg)
+            assert rc == orc == 0 and st.n_iterations == ost.n_iterations, (env, rep, rc)
+            for it in range(st.n_iterations):
+                assert st.iterations[it].lm_iterations == ost.iters[it].lm_iterations
+                assert list(st.iterations[it].reject_hist) == list(ost.iters[it].reject_hist)
+                assert list(st.iterations[it].obs_hist) == list(ost.iters[it].obs_hist)
+            ok, dt, dr = pose_close(pose, opose, 1e-8, 1e-8)
+            assert ok, (env, dt, dr)
+        if "SOICP_ABLATE" in env:  # the notice the fall-back leaves behind proves that it was taken
+            assert "per-evaluation launches" in slam.last_error()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_register_batch_hypotheses_match_single_registrations_and_oracle(oracle, gpu_slam_factory, soicp):
     """so_icp_register_batch (BASELINE configs[4]): B initial poses for one scan = B independent registrations; the
     tracker state (previous observability histogram) is not advanced; covariance of each result from its J^T J."""
