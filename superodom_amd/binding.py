@@ -268,6 +268,14 @@ class LidarSlamGpu:
             self._check(rc)
         return rc, out, st
 
+    def prepare_register_dev(self, d_scan, n, pose_in, stats, pose_out):
+        """A zero-argument callable that performs exactly one so_icp_register_dev call with pre-built ctypes arguments
+        (timed loops: no per-call argument conversion in Python).  pose_in / pose_out: contiguous float64 arrays that
+        stay alive; returns the C return code."""
+        assert pose_in.dtype == np.float64 and pose_in.flags.c_contiguous and pose_out.dtype == np.float64 and pose_out.flags.c_contiguous
+        fn, args = self.L.so_icp_register_dev, (self.h, d_scan, n, pose_in.ctypes.data_as(_F64P), pose_out.ctypes.data_as(_F64P), C.byref(stats))
+        return lambda: fn(*args)
+
     def register_batch(self, scan, poses_in, d_scan=None, n=None):
         """Same scan, many initial poses (so_icp_register_batch).  scan: host array, or None with (d_scan, n) from upload_scan.
         Returns (number of hypotheses that converged normally, rc[B], poses_out[B,7], stats list)."""
