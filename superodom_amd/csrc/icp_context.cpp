@@ -434,18 +434,18 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
                                 kHistReplicas * kHistStride * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     // setupOptimizationProblem + solveOptimizationProblem (LidarSlam.cpp:213-240): 1 + lm_max fused evaluations
     eval_span_first.push_back(c->spans.size());
+    if (persistent) return SO_ICP_OK;  // the solve launch belongs to part B: only the k-NN sweep is speculated
+    return enqueue_eval(0);
+  };
+  auto enqueue_outer_b = [&](int it) -> int {
     if (persistent) {  // the whole solve in one launch (workgroups hand the next pose to each other on the device)
       span_begin(c, 1, (uint32_t)n);
       launch_solve(lm_max, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep, c->d_partials, c->d_ticket,
                    c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, (uint32_t)c->n_cus, s);
       span_end(c);
-      return SO_ICP_OK;
-    }
-    return enqueue_eval(0);
-  };
-  auto enqueue_outer_b = [&](int it) -> int {
-    if (!persistent)
+    } else {
       for (int slot = 1; slot <= lm_max; ++slot) { const int r = enqueue_eval(slot); if (r) return r; }
+    }
     // the whole state block (pose, per-iteration statistics, final normal equations) into this iteration's pinned mirror
     if (!direct_rb) HIP_TRY(c, hipMemcpyAsync(c->h_ring[it & 1], ds, sizeof(DevState), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));
@@ -478,11 +478,12 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     std::atomic_thread_fence(std::memory_order_acquire);
     return SO_ICP_OK;
   };
-  // The host stays ahead of what it knows: part A of iteration it+1 (the two heavy kernels) is enqueued before the
-  // report of iteration it is awaited, so the device never idles on a host round trip; part B follows as soon as the
-  // report says "not converged" (the device is then busy with part A for tens of microseconds).  If iteration it did
-  // converge, the two speculated launches are no-ops (every kernel consults DevState::reg_done) that drain while the
-  // host post-processes.  SOICP_SYNC_PER_OUTER=0 enqueues all max_outer iterations up front instead.
+  // The host stays ahead of what it knows: part A of iteration it+1 (the k-NN sweep; with a sharded map also the fit
+  // evaluation) is enqueued before the report of iteration it is awaited, so the device never idles on a host round trip;
+  // part B (the solve launch / the remaining evaluations) follows as soon as the report says "not converged" -- the device
+  // is then busy with part A for tens of microseconds.  If iteration it did converge, the speculated launch is a no-op
+  // (every kernel consults DevState::reg_done) that drains while the host post-processes.
+  // SOICP_SYNC_PER_OUTER=0 enqueues all max_outer iterations up front instead, SOICP_SPECULATE=0 nothing ahead.
   int last = 0;
   if (c->sync_per_outer) {
     if ((rc = enqueue_outer_a(0)) || (rc = enqueue_outer_b(0))) return rc;
