@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   slot = (uint32_t)__shfl((int)slot, lead, 64);
   base = (uint32_t)__shfl((int)base, lead, 64);
   if (!kept) slot = 0xFFFFFFFFu;
-  keys[i] = slot;            // 0xFFFFFFFF for a dropped query
-  vals[i] = base + my_idx;   // rank inside the bucket
+  __builtin_nontemporal_store(slot, &keys[i]);            // 0xFFFFFFFF for a dropped query
+  __builtin_nontemporal_store(base + my_idx, &vals[i]);   // rank inside the bucket
 }
 
 // bucket offsets + chunk lists from the table counts; leaves the table empty for the next registration.
@@ -265,8 +265,9 @@ __global__ __launch_bounds__(256) void bin_place_kernel(BinTable bt, const float
   const uint32_t sl = qslot[i];
   if (sl == 0xFFFFFFFFu) return;
   const uint32_t pos = bt.off[sl] + qrank[i];
-  perm[pos] = i;
-  spx[pos] = scan[3 * i]; spy[pos] = scan[3 * i + 1]; spz[pos] = scan[3 * i + 2];
+  __builtin_nontemporal_store(i, &perm[pos]);
+  __builtin_nontemporal_store(scan[3 * i], &spx[pos]); __builtin_nontemporal_store(scan[3 * i + 1], &spy[pos]);
+  __builtin_nontemporal_store(scan[3 * i + 2], &spz[pos]);
 }
 
 // Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries with the same key (one half-cell octant
@@ -1103,11 +1104,13 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
         status = SO_MATCH_TOO_FAR;   // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
       } else {
         status = SO_MATCH_PENDING;   // five neighbours inside the gate: the plane fit runs in plane_eval_kernel
-        uint32_t* o = nbr5 + (size_t)5 * oi;
-        o[0] = (uint32_t)top.b0; o[1] = (uint32_t)top.b1; o[2] = (uint32_t)top.b2; o[3] = (uint32_t)top.b3; o[4] = (uint32_t)top.b4;
+        uint32_t* o = nbr5 + (size_t)5 * oi;  // (streaming stores: read by the next launch only -- nothing to write back at kernel end)
+        __builtin_nontemporal_store((uint32_t)top.b0, o); __builtin_nontemporal_store((uint32_t)top.b1, o + 1);
+        __builtin_nontemporal_store((uint32_t)top.b2, o + 2); __builtin_nontemporal_store((uint32_t)top.b3, o + 3);
+        __builtin_nontemporal_store((uint32_t)top.b4, o + 4);
       }
     }
-    corr.status[oi] = (uint8_t)status;
+    __builtin_nontemporal_store((uint8_t)status, &corr.status[oi]);
   }
   if (stamp) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1422,7 +1425,11 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       if (status != SO_MATCH_SUCCESS) { fc = 0; fnd[0] = fnd[1] = fnd[2] = fnd[3] = 0; }
       nd = make_double4(fnd[0], fnd[1], fnd[2], fnd[3]);
       c = fc;
-      corr.nd[j] = nd; corr.coeff[j] = c; corr.status[j] = (uint8_t)status;
+      // streaming stores: the record is re-read at most by a later launch, and dirty L2 lines would have to be written
+      // back when this kernel ends (the next launch waits for that)
+      __builtin_nontemporal_store(nd.x, &corr.nd[j].x); __builtin_nontemporal_store(nd.y, &corr.nd[j].y);
+      __builtin_nontemporal_store(nd.z, &corr.nd[j].z); __builtin_nontemporal_store(nd.w, &corr.nd[j].w);
+      __builtin_nontemporal_store(c, &corr.coeff[j]); __builtin_nontemporal_store((uint8_t)status, &corr.status[j]);
       atomicAdd(&lh[status], 1);                                          // MatchRejectionHistogramPlane, LidarSlam.cpp:341
       if (status == SO_MATCH_SUCCESS) { atomicAdd(&lh[7 + obs[0]], 1); atomicAdd(&lh[7 + obs[1]], 1); atomicAdd(&lh[7 + obs[2]], 1); }
       if (status != SO_MATCH_SUCCESS) return;

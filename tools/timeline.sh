@@ -16,5 +16,6 @@ for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     print(f'{(s - t0) / 1e3:8.1f} us  dur {(e - s) / 1e3:7.1f}  gap {(s - prev_end) / 1e3:6.1f}  {r["Kernel_Name"].split("(")[0][:50]}')
     prev_end = e
+print("  next scan_keys starts %.1f us after the last launch above ended" % ((int(rows[b]["Start_Timestamp"]) - prev_end) / 1e3))
 print("registration period (scan_keys to scan_keys): %.1f us" % ((int(rows[b]["Start_Timestamp"]) - t0) / 1e3))
 PY
