@@ -23,7 +23,7 @@ d = json.load(open(sys.argv[2]))
 for r in rows:
     if "knn_plane_kernel" in r["Name"] or "solve_kernel" in r["Name"]:
         print("no speculation:", r["Name"].split("(")[0], "calls", r["Calls"], "avg us %.2f" % (float(r["AverageNs"]) / 1e3))
-print("no speculation: bench.py HIP-event average of knn_plane_kernel in the same run: %.2f us; value %.0f registrations/s" % (1e3 * d["roofline"]["avg_launch_ms"], d["value"]))
+print("no speculation: (compare with roofline.avg_launch_ms of the UNPROFILED bench line; under rocprofv3 the HIP events of this run read %.2f us)" % (1e3 * d["roofline"]["avg_launch_ms"]))
 PY
 python - $f <<'PY'
 import csv, sys
