@@ -1416,6 +1416,9 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     double c;
     double4 nd;
     if (FIT) {
+      if (PERSIST && trip >= 0) {  // (the coordinates go to the cache before the fit: three registers less to carry through it)
+        cc->px[trip][tid] = fx; cc->py[trip][tid] = fy; cc->pz[trip][tid] = fz;
+      }
       double fnd[4] = {0, 0, 0, 0}, fc = 0;
       int obs[3] = {0, 0, 0};
       if (status == SO_MATCH_PENDING) {
@@ -1435,7 +1438,6 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       if (status != SO_MATCH_SUCCESS) return;
       if (PERSIST && trip >= 0) {
         cc->nx[trip][tid] = nd.x; cc->ny[trip][tid] = nd.y; cc->nz[trip][tid] = nd.z; cc->nw[trip][tid] = nd.w;
-        cc->px[trip][tid] = fx; cc->py[trip][tid] = fy; cc->pz[trip][tid] = fz;
         cc->c[trip][tid] = c;  // >= 0 marks the entry as an accepted correspondence
       }
     } else {
