@@ -389,6 +389,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   const unsigned long long seq_base = (++c->reg_counter) << 8;
   if (direct_rb) { ep.hring[0] = c->d_ring[0]; ep.hring[1] = c->d_ring[1]; ep.seq_base = seq_base; }
   ep.n_queries = (uint32_t)n; ep.q_stride = 3;  // evaluation kernels read the scan itself, in its own order
+  ep.defer_publish = 0;
+  mp.hring[0] = ep.hring[0]; mp.hring[1] = ep.hring[1]; mp.seq_base = ep.seq_base; mp.publish_prev = 0;
   CorrBuffers corr{c->d_nd.as<double4>(), c->d_coeff.as<double>(), c->d_status.as<uint8_t>()};
   std::vector<size_t> knn_span_of_outer, eval_span_first;
   // One outer iteration = knn_plane -> [ eval(slot) -> (all-reduce -> lm_step) ] x (1 + lm_max) -> state read-back.
@@ -402,6 +404,10 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // (concurrent hypotheses: two persistent launches could each hold part of the CUs and wait for the rest -- one launch per
   //  evaluation there; only workgroup 0 of a launch ever waits, for workgroups that finish unconditionally)
   const bool persistent = c->persistent_solve && c->comm == nullptr && (!c->batch_mode || c->batch_single) && !(ep.ablate & 32);  // (ablated controller: per-evaluation launches)
+  // deferred report (see EvalParams::defer_publish): possible when the host always has the next k-NN launch in the queue
+  // before it waits for a report
+  const bool defer_reports = persistent && direct_rb && c->speculate && c->sync_per_outer && !std::getenv("SOICP_NO_DEFER");
+  mp.publish_prev = defer_reports ? 1 : 0;
   auto enqueue_eval = [&](int slot) -> int {
     span_begin(c, 1, (uint32_t)n);
     const bool fuse_lm = (c->comm == nullptr);  // single device: the last workgroup of eval runs the LM controller itself
@@ -438,9 +444,12 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     return enqueue_eval(0);
   };
   auto enqueue_outer_b = [&](int it) -> int {
+    const bool deferred = defer_reports && it + 1 < max_outer;  // the k-NN launch of it + 1 will be enqueued before the host waits
     if (persistent) {  // the whole solve in one launch (workgroups hand the next pose to each other on the device)
+      EvalParams ep_it = ep;
+      ep_it.defer_publish = deferred ? 1 : 0;
       span_begin(c, 1, (uint32_t)n);
-      launch_solve(lm_max, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep, c->d_partials, c->d_ticket,
+      launch_solve(lm_max, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep_it, c->d_partials, c->d_ticket,
                    c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, (uint32_t)c->n_cus, s);
       span_end(c);
     } else {
@@ -448,7 +457,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     }
     // the whole state block (pose, per-iteration statistics, final normal equations) into this iteration's pinned mirror
     if (!direct_rb) HIP_TRY(c, hipMemcpyAsync(c->h_ring[it & 1], ds, sizeof(DevState), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));
+    // (a deferred report is complete only after the NEXT k-NN launch: the event is recorded behind that one, see the loop)
+    if (!deferred) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));
     return SO_ICP_OK;
   };
   // wait until outer iteration `it` has been reported
@@ -489,6 +499,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     if ((rc = enqueue_outer_a(0)) || (rc = enqueue_outer_b(0))) return rc;
     for (int it = 0;; ++it) {
       if (c->speculate && it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
+      if (defer_reports && it + 1 < max_outer) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));  // behind the launch that reports it
       if ((rc = await_outer(it))) return rc;
       last = it;
       if (c->h_ring[it & 1]->reg_done || it + 1 >= max_outer) break;

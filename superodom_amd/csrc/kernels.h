@@ -30,6 +30,11 @@ struct MatchParams {
   int32_t ablate;         // profiling only (env SOICP_ABLATE): bit0 skip plane fit, bit1 skip scan, bit2 skip re-rank
   unsigned long long* kdbg;  // profiling only (SOICP_ABLATE bit 7): 2 sweeps x 4*kKnnBlocks wavefront records of 16 stamps, else nullptr
   uint32_t chunk_cap;     // entries of the chunk list buffer: LIGHT chunks (<= 16 queries) are listed from its top downwards
+  // deferred report: when the solve of outer iteration i-1 left the publication of its state block to the k-NN launch of
+  // iteration i (EvalParams::defer_publish), that launch's first workgroup writes it to hring[(i-1) & 1] (see EvalParams)
+  struct DevState* hring[2];
+  unsigned long long seq_base;
+  int32_t publish_prev;
 };
 
 struct EvalParams {
@@ -44,6 +49,9 @@ struct EvalParams {
   // word (system-scope release); the host polls that word.  hring[0] == nullptr disables it (host uses hipMemcpyAsync).
   struct DevState* hring[2];
   unsigned long long seq_base;
+  // 1: a solve that does NOT end the registration leaves the publication to the next k-NN launch (already enqueued by the
+  // host): the L2 write-back + system fence + PCIe stores (2.7 us) then overlap that sweep instead of delaying it
+  int32_t defer_publish;
 };
 
 // per-correspondence record written by the k-NN + plane-fit kernel, read by the evaluation kernel

@@ -727,6 +727,8 @@ __device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz
   return (int32_t)((__float_as_uint(v) & keep_mask) | (jloc & ~keep_mask));
 }
 
+__device__ __forceinline__ void publish_state_to(DevState* dst, const DevState* st, unsigned long long seq, int tid, int nthreads);  // below
+
 __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
                                                         const float* __restrict__ spz,
                                                         const uint32_t* __restrict__ perm /* binned position -> query index */,
@@ -741,6 +743,9 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   __shared__ uint32_t tcanon[4][kTileCand + 16];  // per wavefront: canonical map index of the staged candidate
   __shared__ uint32_t rowtab[4][2][36];  // per wavefront: exclusive candidate offsets [33] and first canonical index [32] of the block's x-runs
   if (st->reg_done) return;  // the registration already converged: this launch is a no-op
+  // the report of the previous outer iteration, left to this launch by its solve (MatchParams::publish_prev)
+  if (mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
+    publish_state_to(mp.hring[(st->outer_iter - 1) & 1], st, mp.seq_base | (unsigned long long)st->outer_iter, (int)threadIdx.x, 256);
   const uint32_t n_kept = st->n_kept, n_normal = st->n_chunks, n_light = st->n_light;
   // Logical order of the work list: [first half of the light chunks][normal chunks][second half of the light chunks].
   // Wavefront w takes positions w, w + 4096, ...: with up to 8 192 chunks the wavefronts that get a second chunk are the
@@ -1152,7 +1157,9 @@ struct LmCtl {       // LDS copy of the DevState fields the controller reads (pr
   int32_t lm_max, outer_iter, max_outer, pad;
 };
 
-__device__ __forceinline__ int lm_control_regs(int slot, DevState* st, LmState& S, const LmSums& sums, const LmCtl& ctl, bool persist) {
+__device__ __forceinline__ int lm_control_regs(int slot, DevState* st, LmState& S, const LmSums& sums, const LmCtl& ctl, bool persist,
+                                               int* reg_done_out = nullptr) {
+  if (reg_done_out) *reg_done_out = 0;
   // persist (solve_kernel): the next pose travels in the hand-off record and nobody reads lm_more, so a pass that is
   // followed by another one issues no global store at all (a store would have to drain before the next barrier)
   int more;
@@ -1180,6 +1187,7 @@ __device__ __forceinline__ int lm_control_regs(int slot, DevState* st, LmState& 
   st->n_iterations = o + 1;
   if (S.num_successful == 1 || o + 1 >= ctl.max_outer) {  // LidarSlam.cpp:141
     st->reg_done = 1;
+    if (reg_done_out) *reg_done_out = 1;
     const bool have = S.count > 0;
     for (int i = 0; i < 36; ++i) st->JtJ[i] = have ? S.H[i] : 0.0;
     for (int i = 0; i < 6; ++i) st->Jtr[i] = have ? S.g[i] : 0.0;
@@ -1201,7 +1209,7 @@ __device__ __forceinline__ u4v load16_sc1(const u4v* p) {
 // straight from its registers, BEFORE the state goes back to LDS -- the other workgroups are already evaluating the
 // next pose while this thread is still tidying up.
 __device__ SO_LM_INLINE int lm_control(int slot, DevState* st, LmState& S_lds, const LmSums& sums_lds, const LmCtl& ctl, bool persist = false,
-                                       u4v* hand = nullptr, unsigned long long want = 0, double* pose_out = nullptr) {
+                                       u4v* hand = nullptr, unsigned long long want = 0, double* pose_out = nullptr, int* reg_done_out = nullptr) {
   // register copies: the controller is one thread's serial fp64 chain, and every LDS round trip inside it (~100 cycles,
   // nothing to overlap with) would sit on the critical path of the whole device
   // (the sums stay in LDS: they are read once, where a successful step adopts them; H is symmetric: only its upper
@@ -1220,7 +1228,7 @@ __device__ SO_LM_INLINE int lm_control(int slot, DevState* st, LmState& S_lds, c
   S.model_cost_change = S_lds.model_cost_change; S.initial_cost = S_lds.initial_cost; S.count = S_lds.count;
   S.iter = S_lds.iter; S.max_iter = S_lds.max_iter; S.reuse_diagonal = S_lds.reuse_diagonal; S.invalid_steps = S_lds.invalid_steps;
   S.num_successful = S_lds.num_successful; S.termination = S_lds.termination; S.done = S_lds.done; S.lm_iterations = S_lds.lm_iterations;
-  const int more_ = lm_control_regs(slot, st, S, sums_lds, ctl, persist);
+  const int more_ = lm_control_regs(slot, st, S, sums_lds, ctl, persist, reg_done_out);
   if (hand) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -1261,7 +1269,9 @@ __device__ __forceinline__ void load_ctl(LmCtl& ctl, const DevState* st, int tid
 // End of a solve: publish the state block to the host mirror (see EvalParams::hring).  Called by every thread of the
 // controller's workgroup after the controller's global stores; `outer` = index of the outer iteration that just ended.
 __device__ __forceinline__ void publish_state(const DevState* st, const EvalParams& ep, int outer, int tid, int nthreads) {
-  DevState* dst = ep.hring[outer & 1];
+  publish_state_to(ep.hring[outer & 1], st, ep.seq_base | (unsigned long long)(outer + 1), tid, nthreads);
+}
+__device__ __forceinline__ void publish_state_to(DevState* dst, const DevState* st, unsigned long long seq, int tid, int nthreads) {
   if (!dst) return;
   __threadfence_block();  // the controller thread's stores to *st are visible to the workgroup
   __syncthreads();
@@ -1271,7 +1281,7 @@ __device__ __forceinline__ void publish_state(const DevState* st, const EvalPara
   for (int i = tid; i < kWords; i += nthreads) out[i] = src[i];
   __threadfence_system();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(&dst->seq, ep.seq_base | (unsigned long long)(outer + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid == 0) __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // cooperative copy of the controller state between global memory and LDS (sizeof(LmState) is a multiple of 8)
@@ -1314,6 +1324,7 @@ struct EvalShared {
   int more;
   int32_t lh[16];
   int32_t hpart[8][16];
+  int reg_done;  // set by the controller thread when the solve it just finished ends the registration
   bool is_last;
 };
 // the (at most) two accepted correspondences a thread of a persistent solve owns, kept in LDS between the passes
@@ -1580,7 +1591,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     }
     __syncthreads();
     if (stamp) t_sums = wall_clock64();
-    if (tid == 0) sh_more = lm_control(slot, st, sh_S, sh_sums, sh_ctl, true, hand, want, sh.pose);  // (publishes the hand-off)
+    if (tid == 0) sh_more = lm_control(slot, st, sh_S, sh_sums, sh_ctl, true, hand, want, sh.pose, &sh.reg_done);  // (publishes the hand-off)
     __syncthreads();
     unsigned long long t_ctl = 0;
     if (stamp) t_ctl = wall_clock64();
@@ -1588,7 +1599,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       hist[tid] = 0; hist[256 + tid] = 0;
       if (tid < (int)(sizeof(LmState) / 8))
         __hip_atomic_store(reinterpret_cast<double*>(&st->S) + tid, reinterpret_cast<const double*>(&sh_S)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      publish_state(st, ep, sh_ctl.outer_iter, tid, 256);
+      // (a solve that does not end the registration may leave the report to the next k-NN launch, see EvalParams)
+      if (!ep.defer_publish || sh.reg_done) publish_state(st, ep, sh_ctl.outer_iter, tid, 256);
     }
     if (stamp && tid == 0 && (FIT || slot == 1)) {
       t_lm = wall_clock64();

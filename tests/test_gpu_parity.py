@@ -153,7 +153,7 @@ def test_determinism_bitwise(gpu_slam_factory, oracle):
 
 
 @pytest.mark.parametrize("env", [{"SOICP_PERSISTENT": "0"}, {"SOICP_READBACK": "copy"}, {"SOICP_SYNC_PER_OUTER": "0"},
-                                 {"SOICP_SPECULATE": "0"}, {"SOICP_SPECULATE": "0", "SOICP_PERSISTENT": "0"},
+                                 {"SOICP_SPECULATE": "0"}, {"SOICP_SPECULATE": "0", "SOICP_PERSISTENT": "0"}, {"SOICP_NO_DEFER": "1"},
                                  {"SOICP_PERSISTENT": "0", "SOICP_READBACK": "copy", "SOICP_SYNC_PER_OUTER": "0"}])
 def test_control_flow_variants_are_bit_identical(oracle, gpu_slam_factory, monkeypatch, env):
     """The same kernels under every host-side schedule: persistent solve launch vs one launch per evaluation, state
