@@ -126,6 +126,8 @@ struct so_icp_ctx {
   std::vector<so_icp_ctx*> workers;
   bool no_map_shift_once = false;  // retry of a registration: keep the window of the first attempt
   int n_cus = 256;            // compute units of the device: upper bound of the persistent solve launch's workgroups
+  int ablate = 0;             // SOICP_ABLATE (profiling / test switches), read at creation
+  bool no_defer = false;      // SOICP_NO_DEFER=1
   bool speculate = true;      // enqueue outer iteration i+1 before the report of i is in (SOICP_SPECULATE=0: wait first)
   bool batch_mode = false;    // no kernel timing, tracker state read-only
   bool batch_single = false;  // batch on ONE lane: nothing runs next to it, the persistent solve launch is safe
@@ -239,24 +241,20 @@ int reserve_scan_buffers(so_icp_ctx* c, size_t n) {
   return SO_ICP_OK;
 }
 
-MatchParams match_params(float plane_res) {
+MatchParams match_params(float plane_res, int ablate) {
   MatchParams mp;
   mp.plane_res = plane_res;
   mp.sq_max_dist_f = 3 * plane_res;           // float product (LidarSlam.cpp:526)
   mp.max_point_dist = (double)plane_res / 2.0; // LidarSlam.cpp:820
-  const char* ablate_env = std::getenv("SOICP_ABLATE");  // (read per registration: tests switch it inside one process)
-  const int ablate = ablate_env ? std::atoi(ablate_env) : 0;
-  mp.ablate = ablate;
+  mp.ablate = ablate;  // SOICP_ABLATE, read when the context is created (a getenv per registration is a walk over environ)
   mp.kdbg = nullptr;
   return mp;
 }
-EvalParams eval_params(float plane_res, int variant) {
+EvalParams eval_params(float plane_res, int variant, int ablate) {
   EvalParams ep;
   const double a = (double)sqrtf(3 * plane_res);  // std::sqrt(float) then TukeyLoss(double a) (LidarSlam.cpp:271)
   ep.a2 = a * a;
   ep.variant = variant;
-  const char* ablate_env = std::getenv("SOICP_ABLATE");  // (read per registration: tests switch it inside one process)
-  const int ablate = ablate_env ? std::atoi(ablate_env) : 0;
   ep.ablate = ablate;
   ep.hring[0] = ep.hring[1] = nullptr;
   ep.seq_base = 0;
@@ -375,14 +373,14 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   }
   span_end(c);
   const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
-  MatchParams mp = match_params(plane_res_now);
+  MatchParams mp = match_params(plane_res_now, c->ablate);
   mp.chunk_cap = (uint32_t)(c->d_chunks.cap / 4);
   if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
     HIP_TRY(c, c->d_kdbg.reserve((size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemsetAsync(c->d_kdbg.p, 0, (size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long), s));
     mp.kdbg = c->d_kdbg.as<unsigned long long>();
   }
-  EvalParams ep = eval_params(plane_res_now, c->cfg.tukey_variant);
+  EvalParams ep = eval_params(plane_res_now, c->cfg.tukey_variant, c->ablate);
   // read-back: the controller's workgroup publishes the state block straight into the pinned mirrors (polled below);
   // SOICP_READBACK=copy (or the controller ablated away) falls back to hipMemcpyAsync + event
   const bool direct_rb = c->direct_readback && !(ep.ablate & 32);
@@ -406,7 +404,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   const bool persistent = c->persistent_solve && c->comm == nullptr && (!c->batch_mode || c->batch_single) && !(ep.ablate & 32);  // (ablated controller: per-evaluation launches)
   // deferred report (see EvalParams::defer_publish): possible when the host always has the next k-NN launch in the queue
   // before it waits for a report
-  const bool defer_reports = persistent && direct_rb && c->speculate && c->sync_per_outer && !std::getenv("SOICP_NO_DEFER");
+  const bool defer_reports = persistent && direct_rb && c->speculate && c->sync_per_outer && !c->no_defer;
   mp.publish_prev = defer_reports ? 1 : 0;
   auto enqueue_eval = [&](int slot) -> int {
     span_begin(c, 1, (uint32_t)n);
@@ -716,6 +714,8 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_SYNC_PER_OUTER")) c->sync_per_outer = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_READBACK")) c->direct_readback = std::string(ev) != "copy";
   if (const char* ev = std::getenv("SOICP_SPECULATE")) c->speculate = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_ABLATE")) c->ablate = std::atoi(ev);
+  if (const char* ev = std::getenv("SOICP_NO_DEFER")) c->no_defer = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BINNING")) c->use_binning = std::string(ev) != "sort";
   const bool want_dmap = cfg->world_size == 1 && !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
