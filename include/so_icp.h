@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SO_ICP_ABI_VERSION 1
+#define SO_ICP_ABI_VERSION 2
 
 /* LocalMap geometry, LM.h:131-138 */
 #define SO_ICP_MAP_W 21
@@ -72,7 +72,8 @@ typedef struct {
   int32_t rank, world_size;     /* map shard owned by this context (brick-hash of the voxel grid) */
   int32_t max_iterations;       /* LocalizationICPMaxIter (LS.h:273; YAML max_iterations: 5) */
   int32_t lm_max_iterations;    /* ceres max_num_iterations = 4 (LS.cpp:232) */
-  int32_t max_surface_features; /* OptSet.max_surface_features (LS.cpp:346-351); <=0: use all points */
+  int32_t max_surface_features; /* OptSet.max_surface_features (LS.cpp:346-359); < 0: use all points (the reference compares
+                                   size_t > int: a negative value never samples); 0 drops every point, like the reference */
   int32_t k;                    /* LocalizationPlaneDistanceNbrNeighbors = 5 (LS.h:277); only 5 supported */
   int32_t tukey_variant;        /* 0 = Ceres 2.0.0 TukeyLoss (rho' = 0.5 (1-s/a^2)^2); 1 = Ceres >= 2.1 */
   int32_t time_kernels;         /* HIP-event timing on the context's stream (so_icp_get_timing): 1 = the k-NN kernel only, on every
@@ -116,7 +117,21 @@ typedef struct {
   double uncertainty[6];                   /* x y z roll pitch yaw, LS.cpp:915-974 (histogram of the previous scan) */
   double JtJ[36], Jtr[6];                  /* loss-corrected normal equations at the returned pose */
   so_icp_iter_stats iterations[SO_ICP_MAX_OUTER];
+  uint32_t flags;                          /* SO_ICP_FLAG_*: degraded / non-default modes this registration ran in -- what the
+                                              reference would print as a warning (LS.cpp:113-116 style), for the node's log */
+  uint32_t reserved;
 } so_icp_stats;
+
+/* so_icp_stats::flags */
+#define SO_ICP_FLAG_PER_EVAL_LAUNCHES 0x1u   /* the persistent solve launch is not in use (disabled by a failed co-residency
+                                                 wait, SOICP_PERSISTENT=0, a sharded map or a concurrent batch): ~2x slower solve */
+#define SO_ICP_FLAG_RETRIED 0x2u             /* THIS registration was repeated after an abandoned persistent solve launch */
+#define SO_ICP_FLAG_HOST_MAP 0x4u            /* LocalMap lives on the host and is re-uploaded after every insert (planeRes < 0.1
+                                                 or SOICP_HOST_MAP=1) */
+#define SO_ICP_FLAG_SORT_BINNING 0x8u        /* scan binned by the rocPRIM sort path (SOICP_BINNING=sort) */
+#define SO_ICP_FLAG_SHARDED 0x10u            /* world_size > 1: map shard + collective per evaluation */
+#define SO_ICP_FLAG_STAGED_SCAN 0x20u        /* the scan came from so_icp_stage_scan (upload overlapped with earlier work) */
+#define SO_ICP_FLAG_COPY_READBACK 0x40u      /* state read back with hipMemcpyAsync (SOICP_READBACK=copy) */
 
 /* average kernel durations since the last so_icp_reset_timing (HIP events on the context's stream) */
 typedef struct {
@@ -171,6 +186,14 @@ int so_icp_knn_surf(so_icp_ctx *ctx, const float *q_xyz, size_t nq, int k,
  * the scan into the map (so_icp_localization does).  prev uncertainty comes from the previous call. */
 int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes,
                     const double pose_in[7], double pose_out[7], so_icp_stats *stats);
+/* Announce the NEXT scan: the host buffer is copied to a pinned staging slot and on to HBM by the context's copy thread +
+ * copy stream while the caller goes on (typically: while the previous so_icp_register is still running -- the node's
+ * feature callback, lmap.cpp:21-25, has the cloud long before process() reaches it).  A following so_icp_register /
+ * so_icp_localization with the SAME (scan_xyz, n, stride_bytes) consumes the staged copy instead of uploading again
+ * (so_icp_stats::flags carries SO_ICP_FLAG_STAGED_SCAN); any other call simply ignores it.  The caller's buffer must stay
+ * valid and unchanged until that call (or the next so_icp_stage_scan) returns.  Two slots: one scan may be staged while
+ * the previous one is being registered. */
+int so_icp_stage_scan(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes);
 /* same, scan already resident in HBM as packed float xyz (n*3 floats, device pointer) */
 int so_icp_register_dev(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n,
                         const double pose_in[7], double pose_out[7], so_icp_stats *stats);
@@ -263,6 +286,9 @@ int so_icp_reset_timing(so_icp_ctx *ctx);
 /* switch so_icp_config::time_kernels on a live context (e.g. 1 inside a timed region, 2 for a profiling pass after it) */
 int so_icp_set_time_kernels(so_icp_ctx *ctx, int mode);
 int so_icp_synchronize(so_icp_ctx *ctx);
+/* test aid: MatchingResult (LS.h:85-94) of every query of the last registration's LAST outer iteration, indexed like the scan
+ * (254 = not sampled / not owned by this rank) */
+int so_icp_debug_match_status(so_icp_ctx *ctx, uint8_t *out, size_t n);
 /* profiling aid: wall-clock stamps (100 MHz ticks) of the phases of the last fit / evaluation kernels (SOICP_ABLATE=128) */
 int so_icp_debug_stamps(so_icp_ctx *ctx, uint64_t out[16]);
 /* profiling aid: per-workgroup records (16 words each, 2 sweeps x workgroups) of the k-NN kernel's phases (SOICP_ABLATE=128);

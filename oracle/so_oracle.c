@@ -853,6 +853,10 @@ void orc_lm_solve(const orc_corr *c_all, size_t n_all, double pose[7], float pla
         gmax = 0;
         for (int j = 0; j < 7; ++j) { double v = fabs(x[j] - xp[j]); if (v > gmax) gmax = v; }
       }
+      /* FinalizeIterationAndCheckIfMinimizerCanContinue [UPSTREAM ceres 2.0.0 trust_region_minimizer.cc] tests
+       * MaxSolverIterationsReached BEFORE GradientToleranceReached: when both fire on the last iteration the summary
+       * says NO_CONVERGENCE (0), not CONVERGENCE by gradient (3) */
+      if (iter >= max_it) { st->termination = 0; break; }
       if (gmax <= g_tol) { st->termination = 3; break; }
     } else { /* HandleUnsuccessfulStep */
       radius = radius / decrease_factor;
@@ -876,7 +880,9 @@ void orc_uncertainty_from_hist(const int32_t H[ORC_N_OBS], double u[6]) {
 }
 /* LS:346-359 */
 int orc_should_process(size_t index, size_t n_points, int max_surface_features) {
-  if (max_surface_features <= 0 || n_points <= (size_t)max_surface_features) return 1;
+  /* `num_points > OptSet.max_surface_features` compares a size_t with an int (LS:347): a negative setting converts to a
+   * huge unsigned value (no sampling), 0 gives rate 0 and drops every point (0 + 0.001 > 0) */
+  if (max_surface_features < 0 || n_points <= (size_t)max_surface_features) return 1;
   double rate = 1.0 * max_surface_features / n_points;
   double rem = fmod(index * rate, 1.0);
   return !(rem + 0.001 > rate);

@@ -62,7 +62,7 @@ typedef struct orc_map orc_map;
 typedef struct {
   int max_iterations;        /* LocalizationICPMaxIter, LidarSlam.h:273; YAML max_iterations=5 */
   int lm_max_iterations;     /* options.max_num_iterations = 4, LidarSlam.cpp:232 */
-  int max_surface_features;  /* OptSet.max_surface_features; <=0 means "all" */
+  int max_surface_features;  /* OptSet.max_surface_features; <0 means "all", 0 drops every point (LS:346-359) */
   int k;                     /* LocalizationPlaneDistanceNbrNeighbors = 5, LidarSlam.h:277 */
   int tukey_variant;         /* 0: Ceres<=2.0 (rho'=0.5(1-s/a^2)^2), 1: Ceres>=2.1 (rho'=(1-s/a^2)^2) */
   int use_grid_knn;          /* 0: brute force inside the cube; 1: exact uniform-grid search */

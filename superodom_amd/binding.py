@@ -37,7 +37,11 @@ class Stats(C.Structure):
                 ("prediction_source", C.c_int32), ("total_translation", C.c_double), ("total_rotation", C.c_double),
                 ("translation_from_last", C.c_double), ("rotation_from_last", C.c_double), ("time_elapsed_ms", C.c_double),
                 ("uncertainty", C.c_double * 6), ("JtJ", C.c_double * 36), ("Jtr", C.c_double * 6),
-                ("iterations", IterStats * MAX_OUTER)]
+                ("iterations", IterStats * MAX_OUTER), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# so_icp_stats.flags
+FLAG_PER_EVAL_LAUNCHES, FLAG_RETRIED, FLAG_HOST_MAP, FLAG_SORT_BINNING, FLAG_SHARDED, FLAG_STAGED_SCAN, FLAG_COPY_READBACK = 1, 2, 4, 8, 16, 32, 64
 
 
 class RegistrationError(C.Structure):
@@ -75,7 +79,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_register_dev", "so_icp_upload_scan", "so_icp_free_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
-            "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan"]
+            "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status"]
 
 _lib = None
 
@@ -131,6 +135,8 @@ def load():
                                         C.POINTER(C.c_size_t), C.POINTER(PrefilterInfo)]
     L.so_icp_debug_knn_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
     L.so_icp_set_time_kernels.argtypes = [vp, C.c_int]
+    L.so_icp_stage_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
+    L.so_icp_debug_match_status.argtypes = [vp, u8p, C.c_size_t]
     _lib = L
     return L
 
@@ -248,6 +254,31 @@ class LidarSlamGpu:
         rc = self._check(self.L.so_icp_register(self.h, _p(scan, C.c_float), len(scan), 12, _p(pose_in, C.c_double),
                                                 _p(out, C.c_double), C.byref(st)))
         return rc, out, st
+
+    def stage_scan(self, scan):
+        """so_icp_stage_scan: announce the NEXT scan (contiguous float32 (n,3) array that stays alive and unchanged until
+        the register call that consumes it)."""
+        assert isinstance(scan, np.ndarray) and scan.dtype == np.float32 and scan.flags.c_contiguous
+        self._check(self.L.so_icp_stage_scan(self.h, _p(scan, C.c_float), len(scan), 12))
+
+    def prepare_stage_scan(self, scan):
+        assert isinstance(scan, np.ndarray) and scan.dtype == np.float32 and scan.flags.c_contiguous
+        fn, args = self.L.so_icp_stage_scan, (self.h, _p(scan, C.c_float), len(scan), 12)
+        return lambda: fn(*args)
+
+    def prepare_register(self, scan, pose_in, stats, pose_out):
+        """Zero-argument callable performing one so_icp_register (host scan buffer) with pre-built ctypes arguments."""
+        assert isinstance(scan, np.ndarray) and scan.dtype == np.float32 and scan.flags.c_contiguous
+        assert pose_in.dtype == np.float64 and pose_in.flags.c_contiguous and pose_out.dtype == np.float64 and pose_out.flags.c_contiguous
+        fn, args = self.L.so_icp_register, (self.h, _p(scan, C.c_float), len(scan), 12, pose_in.ctypes.data_as(_F64P),
+                                            pose_out.ctypes.data_as(_F64P), C.byref(stats))
+        return lambda: fn(*args)
+
+    def match_status(self, n):
+        """MatchingResult of every query of the last registration's last outer iteration (so_icp_debug_match_status)."""
+        out = np.zeros(n, np.uint8)
+        self._check(self.L.so_icp_debug_match_status(self.h, _p(out, C.c_uint8), n))
+        return out
 
     def upload_scan(self, scan):
         scan = _f32(scan).reshape(-1, 3); d = C.c_void_p()

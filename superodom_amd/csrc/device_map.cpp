@@ -152,36 +152,82 @@ bool DeviceMap::view(DevMapView& v, std::string& err) {
   return true;
 }
 
-int DeviceMap::set_resolution(float line_res, float plane_res) {
+// planeRes decides the leaf of the voxel filter and the cell of the index.  The resident points keep their positions:
+// the reference re-filters a block only when the next insert touches it (LocalMap.h:617-641), untouched blocks keep
+// their points.  Only the cell tables are rebuilt for the new cell size (launch_map_retable), on the device.
+int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err) {
   line_res_ = line_res;
   if (plane_res == plane_res_ && nc_ > 1) return 0;
-  // planeRes decides the leaf of the voxel filter and the cell of the index.  Existing points keep their positions
-  // (the reference re-filters a block only when it is touched again); the tables are rebuilt for the new cell size.
-  std::vector<float> keep;
-  std::string err;
-  const bool had = size() > 0;
-  if (had) {
-    keep.resize(size() * 3);
-    const int zero[3] = {0, 0, 0};
-    export_points(keep.data(), size(), false, zero, err);
-  }
+  const float old_res = plane_res_;
+  const bool had = size() > 0 && nc_ > 1;
   plane_res_ = plane_res;
+  finest_res_ = (had && finest_res_ > 0.f) ? std::min(finest_res_, std::min(old_res, plane_res)) : plane_res;
   double cell;
   nc_ = cells_per_cube(plane_res, &cell);
   cell_ = cell;
   const uint32_t new_ncell1 = (uint32_t)((size_t)nc_ * nc_ * nc_ + 1);
-  if (new_ncell1 != ncell1_ || !d_cell_start_) {  // table geometry changed: drop the device tables (pool is re-filled below)
-    if (d_pool_) (void)hipFree(d_pool_);
+  if (new_ncell1 != ncell1_ || !d_cell_start_) {  // table geometry changed: new tables, the point pool stays
     if (d_cell_start_) (void)hipFree(d_cell_start_);
-    d_pool_ = nullptr; d_cell_start_ = nullptr; slots_alloc_ = 0;
+    d_cell_start_ = nullptr;
     ncell1_ = new_ncell1;
+    if (slots_alloc_) DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cell_start_), (size_t)slots_alloc_ * ncell1_ * sizeof(uint32_t)));
   }
-  if (had) {
-    const std::vector<int32_t> cs = cube_slot_;
-    clear();
-    // re-insert: every leaf of the old grid holds one point; with a different leaf size the touched-block filter of the
-    // reference would merge them the same way on its next insert
-    add_surf_host(keep.data(), keep.size() / 3, 3, err);
+  if (!had) return 0;
+  std::vector<int> occupied;
+  size_t most = 0;
+  for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) occupied.push_back((int)s);
+  const float inv_leaf = 1.0f / finest_res_;  // the points' leaf keys are distinct on the finest grid they were filtered on
+  for (size_t r0 = 0; r0 < occupied.size(); r0 += kMaxTouched) {
+    MapInsertArgs a{};
+    MapTouched& tt = a.tt;
+    tt.n = (int)std::min<size_t>(kMaxTouched, occupied.size() - r0);
+    uint32_t n_old = 0;
+    for (int t = 0; t < tt.n; ++t) {
+      const int s = occupied[r0 + t], cube = slot_cube_[s];
+      tt.slot[t] = (uint32_t)s;
+      tt.old_prefix[t] = n_old;
+      n_old += slot_count_[s];
+      const int ci = cube % kMapW, cj = (cube / kMapW) % kMapH, ck = cube / (kMapW * kMapH);
+      const int w[3] = {ci - origin_[0], cj - origin_[1], ck - origin_[2]};
+      for (int ax = 0; ax < 3; ++ax) {
+        tt.cube_min[t][ax] = w[ax] * kCube - kHalfCube;
+        tt.leaf_lo[t][ax] = (int)std::floor((float)tt.cube_min[t][ax] * inv_leaf) - 2;
+      }
+    }
+    for (int t = tt.n; t <= kMaxTouched; ++t) tt.old_prefix[t] = n_old;
+    for (int t = tt.n; t < kMaxTouched; ++t) tt.slot[t] = 0;
+    most = std::max<size_t>(most, n_old);
+    if (ensure_work(n_old, err)) return -2;
+    if (ensure_grid((size_t)tt.n * ncell1_ + 1024, err)) return -2;
+    DM_TRY(hipMemsetAsync(d_small_, 0, 48 * sizeof(uint32_t), stream_));
+    a.n_old = n_old; a.inv_leaf = inv_leaf;
+    a.nc = nc_; a.ncell1 = ncell1_; a.inv_cell = 1.0 / cell_;
+    a.pool = d_pool_; a.cap = kCapPerSlot; a.cell_start = d_cell_start_;
+    a.wpts = d_wpts_; a.cent = d_cent_; a.spts = d_spts_; a.heads = d_heads_;
+    a.keys0 = d_k0_; a.keys1 = d_k1_; a.vals0 = d_v0_; a.vals1 = d_v1_; a.flags = d_flags_; a.pos = d_pos_;
+    a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
+    a.grid = d_grid_; a.grid_scan = d_grid_scan_;
+    a.temp = d_temp_; a.temp_bytes = temp_bytes_;
+    launch_map_retable(a, stream_);
+    DM_TRY(hipStreamSynchronize(stream_));  // `a` travels by value, but the next round reuses the work buffers
+  }
+  return 0;
+}
+
+int DeviceMap::ensure_grid(size_t gn, std::string& err) {
+  if (gn > grid_cap_) {
+    if (d_grid_) (void)hipFree(d_grid_);
+    if (d_grid_scan_) (void)hipFree(d_grid_scan_);
+    d_grid_ = d_grid_scan_ = nullptr; grid_cap_ = 0;
+    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_grid_), gn * sizeof(uint32_t)));
+    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_grid_scan_), gn * sizeof(uint32_t)));
+    grid_cap_ = gn;
+  }
+  if (temp_bytes_ < map_sort_temp_bytes(gn)) {  // the scan of the grids uses the sort's scratch buffer
+    if (d_temp_) (void)hipFree(d_temp_);
+    d_temp_ = nullptr;
+    temp_bytes_ = map_sort_temp_bytes(gn) + 256;
+    DM_TRY(hipMalloc(&d_temp_, temp_bytes_));
   }
   return 0;
 }
@@ -260,20 +306,7 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
     static const bool use_grid = !(std::getenv("SOICP_MAP_STAGE2") && std::string(std::getenv("SOICP_MAP_STAGE2")) == "sort");
     if (use_grid) {
-      const size_t gn = (size_t)tt.n * ncell1_ + 1024;
-      if (gn > grid_cap_) {
-        if (d_grid_) (void)hipFree(d_grid_);
-        if (d_grid_scan_) (void)hipFree(d_grid_scan_);
-        d_grid_ = d_grid_scan_ = nullptr; grid_cap_ = 0;
-        DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_grid_), gn * sizeof(uint32_t)));
-        DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_grid_scan_), gn * sizeof(uint32_t)));
-        grid_cap_ = gn;
-      }
-      if (temp_bytes_ < map_sort_temp_bytes(gn)) {  // the scan of the grids uses the sort's scratch buffer
-        (void)hipFree(d_temp_); d_temp_ = nullptr;
-        temp_bytes_ = map_sort_temp_bytes(gn) + 256;
-        DM_TRY(hipMalloc(&d_temp_, temp_bytes_));
-      }
+      if (ensure_grid((size_t)tt.n * ncell1_ + 1024, err)) return -2;
       a.grid = d_grid_; a.grid_scan = d_grid_scan_;
     }
     a.temp = d_temp_; a.temp_bytes = temp_bytes_;

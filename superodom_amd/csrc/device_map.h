@@ -22,7 +22,9 @@ class DeviceMap {
  public:
   explicit DeviceMap(hipStream_t s) : stream_(s) { origin_[0] = 10; origin_[1] = 10; origin_[2] = 5; cube_slot_.assign(kMapNum, -1); }
   ~DeviceMap();
-  int set_resolution(float line_res, float plane_res);  // changing planeRes re-bins the map (download, re-insert)
+  // changing planeRes rebuilds the cell tables over the resident points (they are re-filtered when an insert next touches
+  // their cube, like the reference); < 0: HIP error (text in err)
+  int set_resolution(float line_res, float plane_res, std::string& err);
   float plane_res() const { return plane_res_; }
   const int* origin() const { return origin_; }
   void set_origin(const double t[3]);
@@ -40,10 +42,11 @@ class DeviceMap {
  private:
   int ensure_pool(int slots_needed, std::string& err);
   int ensure_work(size_t total, std::string& err);
+  int ensure_grid(size_t gn, std::string& err);
   int alloc_slot(int cube);
   hipStream_t stream_;
   int origin_[3];
-  float line_res_ = 0.2f, plane_res_ = 0.4f;
+  float line_res_ = 0.2f, plane_res_ = 0.4f, finest_res_ = 0.f;
   int nc_ = 1; double cell_ = 50.0; uint32_t ncell1_ = 2;
   std::vector<int32_t> cube_slot_;   // kMapNum: slot or -1
   std::vector<int32_t> slot_cube_;   // slot -> cube or -1 (free)

@@ -6,16 +6,19 @@
 // HIP device so_icp_create() fails and says so.
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <climits>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -54,31 +57,33 @@ struct DevBuf {
   template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-// RCCL entry points, resolved lazily (one collective per evaluation; no link-time dependency)
-struct Uid { char internal[SO_ICP_UNIQUE_ID_BYTES]; };  // == ncclUniqueId (rccl.h: char internal[128])
+// RCCL entry points: prototypes and types come from <rccl/rccl.h>; the library itself is resolved lazily with dlopen
+// (a single-GPU process never loads librccl -- one collective per evaluation is the only use)
 struct Rccl {
   void* lib = nullptr;
-  int (*GetUniqueId)(void*) = nullptr;
-  int (*CommInitRank)(void**, int, Uid /*ncclUniqueId by value*/, int) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
+static_assert(sizeof(ncclUniqueId) == SO_ICP_UNIQUE_ID_BYTES, "SO_ICP_UNIQUE_ID_BYTES must equal sizeof(ncclUniqueId)");
 
 bool rccl_load(Rccl& r, std::string& err) {
   if (r.lib) return true;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
   if (!r.lib) { err = std::string("dlopen(librccl) failed: ") + dlerror(); return false; }
-  r.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(r.lib, "ncclGetUniqueId"));
-  r.CommInitRank = reinterpret_cast<int (*)(void**, int, Uid, int)>(dlsym(r.lib, "ncclCommInitRank"));
-  r.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(r.lib, "ncclAllReduce"));
-  r.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(r.lib, "ncclCommDestroy"));
-  r.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(r.lib, "ncclGetErrorString"));
-  if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) { err = "librccl lacks a required symbol"; return false; }
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+  if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.AllGather || !r.CommDestroy) { err = "librccl lacks a required symbol"; return false; }
   return true;
 }
-constexpr int kNcclDouble = 8, kNcclSum = 0;  // rccl.h: ncclFloat64 = 8, ncclSum = 0
 
 struct EventSpan { int kind; hipEvent_t a, b; uint32_t units; };  // kind 0 knn, 1 eval, 2 prep
 
@@ -140,7 +145,20 @@ struct so_icp_ctx {
   bool span_open = false;
   so_icp_timing timing{};
   // RCCL
-  Rccl rccl; void* comm = nullptr;
+  Rccl rccl; ncclComm_t comm = nullptr;
+  // so_icp_stage_scan: a copy thread + copy stream bring the NEXT scan to HBM while the current registration runs
+  struct StageSlot {
+    const float* src = nullptr; size_t n = 0, stride = 0;  // identity of the staged host buffer
+    DevBuf dev; float* pinned = nullptr; size_t pinned_cap = 0;
+    int state = 0;  // 0 empty, 1 queued, 2 ready, -1 failed
+    std::string err;
+  } stage[2];
+  int stage_next = 0;
+  bool stage_quit = false, stage_started = false;
+  std::thread stage_thread; std::mutex stage_mu; std::condition_variable stage_cv;
+  hipStream_t copy_stream = nullptr;
+  bool retried = false;       // the current registration is the repeat of an abandoned one
+  bool scan_staged = false;   // the scan of the current registration came from a stage slot
 
   ~so_icp_ctx();
 };
@@ -313,6 +331,11 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   so_icp_stats local;
   if (!st) st = &local;
   std::memset(st, 0, sizeof(*st));
+  // chunk descriptors keep a binned position in 26 bits (kernels.hip: bin_offsets_kernel / knn_plane_kernel)
+  if (n >= ((size_t)1 << 26)) return fail(c, SO_ICP_E_UNSUPPORTED, "scan of 2^26 points or more: chunk descriptors hold 26-bit positions");
+  st->flags = (c->retried ? SO_ICP_FLAG_RETRIED : 0u) | (!c->dmap && !c->borrow.on ? SO_ICP_FLAG_HOST_MAP : 0u) |
+              (c->use_binning ? 0u : SO_ICP_FLAG_SORT_BINNING) | (c->cfg.world_size > 1 ? SO_ICP_FLAG_SHARDED : 0u) |
+              (c->scan_staged ? SO_ICP_FLAG_STAGED_SCAN : 0u) | (c->direct_readback ? 0u : SO_ICP_FLAG_COPY_READBACK);
   double T[7], T_init[7], T_last[7];
   std::memcpy(T, pose_in, sizeof(T)); std::memcpy(T_init, pose_in, sizeof(T)); std::memcpy(T_last, pose_in, sizeof(T));  // LidarSlam.cpp:53-57
   std::memcpy(pose_out, pose_in, sizeof(T));
@@ -372,6 +395,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     }
   }
   span_end(c);
+  HIP_TRY(c, hipGetLastError());  // a refused launch would otherwise surface as a 50 ms wait or "state was not published"
   const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
   MatchParams mp = match_params(plane_res_now, c->ablate);
   mp.chunk_cap = (uint32_t)(c->d_chunks.cap / 4);
@@ -402,6 +426,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // (concurrent hypotheses: two persistent launches could each hold part of the CUs and wait for the rest -- one launch per
   //  evaluation there; only workgroup 0 of a launch ever waits, for workgroups that finish unconditionally)
   const bool persistent = c->persistent_solve && c->comm == nullptr && (!c->batch_mode || c->batch_single) && !(ep.ablate & 32);  // (ablated controller: per-evaluation launches)
+  if (!persistent) st->flags |= SO_ICP_FLAG_PER_EVAL_LAUNCHES;
   // deferred report (see EvalParams::defer_publish): possible when the host always has the next k-NN launch in the queue
   // before it waits for a report
   const bool defer_reports = persistent && direct_rb && c->speculate && c->sync_per_outer && !c->no_defer;
@@ -413,8 +438,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
                 c->d_ticket, c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, s);
     span_end(c);
     if (!fuse_lm) {  // per-evaluation collective: 45 fp64 summed over the shards (xGMI, latency-bound), then the controller
-      const int nrc = c->rccl.AllReduce(c->d_sums, c->d_sums, sizeof(LmSums) / sizeof(double), kNcclDouble, kNcclSum, c->comm, s);
-      if (nrc != 0) return fail(c, SO_ICP_E_RCCL, std::string("ncclAllReduce: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(nrc) : "?"));
+      const ncclResult_t nrc = c->rccl.AllReduce(c->d_sums, c->d_sums, sizeof(LmSums) / sizeof(double), ncclDouble, ncclSum, c->comm, s);
+      if (nrc != ncclSuccess) return fail(c, SO_ICP_E_RCCL, std::string("ncclAllReduce: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(nrc) : "?"));
       launch_lm_step(slot, ds, c->d_sums, c->d_hist, ep, s);
     }
     return SO_ICP_OK;
@@ -438,6 +463,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
                                 kHistReplicas * kHistStride * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     // setupOptimizationProblem + solveOptimizationProblem (LidarSlam.cpp:213-240): 1 + lm_max fused evaluations
     eval_span_first.push_back(c->spans.size());
+    HIP_TRY(c, hipGetLastError());
     if (persistent) return SO_ICP_OK;  // the solve launch belongs to part B: only the k-NN sweep is speculated
     return enqueue_eval(0);
   };
@@ -457,6 +483,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     if (!direct_rb) HIP_TRY(c, hipMemcpyAsync(c->h_ring[it & 1], ds, sizeof(DevState), hipMemcpyDeviceToHost, s));
     // (a deferred report is complete only after the NEXT k-NN launch: the event is recorded behind that one, see the loop)
     if (!deferred) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));
+    HIP_TRY(c, hipGetLastError());
     return SO_ICP_OK;
   };
   // wait until outer iteration `it` has been reported
@@ -578,7 +605,9 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   int rc = register_core_once(c, d_scan, n, pose_in, pose_out, st);
   if (rc == kRetryWithoutPersistentSolve) {
     c->no_map_shift_once = true;  // the window was already placed for this scan
+    c->retried = true;            // so_icp_stats::flags tells the caller (the context stays on per-evaluation launches)
     rc = register_core_once(c, d_scan, n, pose_in, pose_out, st);
+    c->retried = false;
     if (rc == kRetryWithoutPersistentSolve) rc = fail(c, SO_ICP_E_HIP, "registration state was not published by the device");
   }
   return rc;
@@ -602,9 +631,71 @@ int upload_scan_impl(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_by
   return SO_ICP_OK;
 }
 
+// ---- so_icp_stage_scan: copy thread -----------------------------------------------------------------------------
+// One thread per context, started on first use.  It owns the copy stream: pack (only for strided input) into a pinned
+// buffer, hipMemcpyAsync to the slot's HBM buffer, wait, mark the slot ready.  The registration thread never touches
+// the copy stream; it only waits (on the condition variable) for the slot it is about to consume.
+void stage_worker(so_icp_ctx* c) {
+  (void)hipSetDevice(c->cfg.device_id);
+  std::unique_lock<std::mutex> lk(c->stage_mu);
+  for (;;) {
+    c->stage_cv.wait(lk, [&] { return c->stage_quit || c->stage[0].state == 1 || c->stage[1].state == 1; });
+    if (c->stage_quit) return;
+    so_icp_ctx::StageSlot& sl = c->stage[c->stage[0].state == 1 ? 0 : 1];
+    const float* src = sl.src; const size_t n = sl.n, stride = sl.stride;
+    lk.unlock();
+    std::string err;
+    hipError_t e = sl.dev.reserve((n + 64) * 12);
+    if (e == hipSuccess && n) {
+      const float* from = src;
+      if (stride != 12) {  // strided input (e.g. 32-byte pcl::PointXYZI): pack through a pinned buffer
+        if (sl.pinned_cap < n * 12) {
+          if (sl.pinned) (void)hipHostFree(sl.pinned);
+          sl.pinned = nullptr; sl.pinned_cap = 0;
+          e = hipHostMalloc(reinterpret_cast<void**>(&sl.pinned), n * 12 + 4096);
+          if (e == hipSuccess) sl.pinned_cap = n * 12 + 4096;
+        }
+        if (e == hipSuccess) {
+          const size_t sf = stride / 4;
+          for (size_t i = 0; i < n; ++i) { sl.pinned[3 * i] = src[i * sf]; sl.pinned[3 * i + 1] = src[i * sf + 1]; sl.pinned[3 * i + 2] = src[i * sf + 2]; }
+          from = sl.pinned;
+        }
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(sl.dev.p, from, n * 12, hipMemcpyHostToDevice, c->copy_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+    }
+    if (e != hipSuccess) err = std::string("so_icp_stage_scan: ") + hipGetErrorString(e);
+    lk.lock();
+    if (sl.src == src && sl.n == n && sl.stride == stride && sl.state == 1) { sl.state = err.empty() ? 2 : -1; sl.err = err; }
+    c->stage_cv.notify_all();
+  }
+}
+
+// the staged copy of (xyz, n, stride), waiting for the copy thread if it is still on its way; nullptr = not staged
+const float* take_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, int* rc) {
+  *rc = SO_ICP_OK;
+  if (!c->stage_started) return nullptr;
+  std::unique_lock<std::mutex> lk(c->stage_mu);
+  for (so_icp_ctx::StageSlot& sl : c->stage) {
+    if (sl.state == 0 || sl.src != xyz || sl.n != n || sl.stride != stride_bytes) continue;
+    c->stage_cv.wait(lk, [&] { return sl.state != 1; });
+    if (sl.state == 2) return sl.dev.as<float>();
+    if (sl.state == -1) { c->err = sl.err; *rc = SO_ICP_E_HIP; sl.state = 0; }
+    return nullptr;
+  }
+  return nullptr;
+}
+
 }  // namespace
 
 so_icp_ctx::~so_icp_ctx() {
+  if (stage_started) {
+    { std::lock_guard<std::mutex> lk(stage_mu); stage_quit = true; }
+    stage_cv.notify_all();
+    if (stage_thread.joinable()) stage_thread.join();
+  }
+  for (StageSlot& sl : stage) { sl.dev.release(); if (sl.pinned) (void)hipHostFree(sl.pinned); }
+  if (copy_stream) (void)hipStreamDestroy(copy_stream);
   for (so_icp_ctx* w : workers) delete w;
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1, &d_chunks,
@@ -722,7 +813,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (want_dmap) {
     c->dmap = std::make_unique<DeviceMap>(c->stream);
     if (!c->dmap->supported_resolution(cfg->plane_res)) c->dmap.reset();  // leaf keys hold 9 bits per axis
-    else c->dmap->set_resolution(cfg->line_res, cfg->plane_res);
+    else { std::string e2; c->dmap->set_resolution(cfg->line_res, cfg->plane_res, e2); }
   }
   return c;
 }
@@ -738,7 +829,11 @@ void so_icp_destroy(so_icp_ctx* ctx) {
 int so_icp_set_resolution(so_icp_ctx* c, float line_res, float plane_res) {
   if (!c || !(plane_res > 0) || !(line_res > 0)) return SO_ICP_E_INVALID;
   if (c->dmap && !c->dmap->supported_resolution(plane_res)) return fail(c, SO_ICP_E_UNSUPPORTED, "device map needs plane_res >= 0.1");
-  if (c->dmap) { NEED_DEVICE(c); HIP_TRY(c, hipSetDevice(c->cfg.device_id)); c->dmap->set_resolution(line_res, plane_res); }
+  if (c->dmap) {
+    NEED_DEVICE(c);
+    HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+    if (c->dmap->set_resolution(line_res, plane_res, c->err) < 0) return SO_ICP_E_HIP;
+  }
   if (plane_res != c->map.plane_res()) c->uploaded_version = 0;  // cell size follows planeRes
   c->map.set_resolution(line_res, plane_res);
   c->cfg.line_res = line_res; c->cfg.plane_res = plane_res;
@@ -863,9 +958,39 @@ int so_icp_register(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_byt
   if (!c || !pose_in || !pose_out || (!xyz && n)) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);
   HIP_TRY(c, hipSetDevice(c->cfg.device_id));
-  const int rc = upload_scan_impl(c, xyz, n, stride_bytes, c->d_scan_own);
+  int rc = SO_ICP_OK;
+  if (const float* staged = take_staged(c, xyz, n, stride_bytes ? stride_bytes : 12, &rc)) {  // announced with so_icp_stage_scan
+    c->scan_staged = true;
+    rc = register_core(c, staged, n, pose_in, pose_out, st);
+    c->scan_staged = false;
+    return rc;
+  }
+  if (rc) return rc;
+  rc = upload_scan_impl(c, xyz, n, stride_bytes, c->d_scan_own);
   if (rc) return rc;
   return register_core(c, c->d_scan_own.as<float>(), n, pose_in, pose_out, st);
+}
+
+int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes) {
+  if (!c || (!xyz && n)) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  if (stride_bytes == 0) stride_bytes = 12;
+  if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
+  if (!c->stage_started) {
+    HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    c->stage_thread = std::thread(stage_worker, c);
+    c->stage_started = true;
+  }
+  {
+    std::unique_lock<std::mutex> lk(c->stage_mu);
+    so_icp_ctx::StageSlot& sl = c->stage[c->stage_next];
+    c->stage_next ^= 1;
+    c->stage_cv.wait(lk, [&] { return sl.state != 1; });  // (a slot still being copied: the caller staged three scans in a row)
+    sl.src = xyz; sl.n = n; sl.stride = stride_bytes; sl.state = 1; sl.err.clear();
+  }
+  c->stage_cv.notify_all();
+  return SO_ICP_OK;
 }
 
 int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, size_t n, size_t stride_bytes, const double* poses_in,
@@ -1015,39 +1140,48 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   if (!c || !T_in || !pose_out || (!xyz && n)) return SO_ICP_E_INVALID;
   if (stride_bytes == 0) stride_bytes = 12;
   if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
+  if (!c->host_only) HIP_TRY(c, hipSetDevice(c->cfg.device_id));  // (the caller may sit on another device / thread)
   const size_t sf = stride_bytes / 4;
-  auto transform_and_add = [&](const double T[7]) {  // transformAndAddToMap, LidarSlam.cpp:60-80; TransformPoint, superodom_utils.h:119-123
+  auto transform_and_add = [&](const double T[7]) -> int {  // transformAndAddToMap, LidarSlam.cpp:60-80; TransformPoint, superodom_utils.h:119-123
     std::vector<float> w(n * 3);
     for (size_t i = 0; i < n; ++i) {
       double ox, oy, oz;
       quat_rotate<double>(T + 3, (double)xyz[i * sf], (double)xyz[i * sf + 1], (double)xyz[i * sf + 2], ox, oy, oz);
       w[3 * i] = (float)(ox + T[0]); w[3 * i + 1] = (float)(oy + T[1]); w[3 * i + 2] = (float)(oz + T[2]);
     }
-    if (c->dmap) c->dmap->add_surf_host(w.data(), n, 3, c->err); else c->map.add_surf(w.data(), n, 3);
+    if (c->dmap) { const int r = c->dmap->add_surf_host(w.data(), n, 3, c->err); return r < 0 ? (r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP) : SO_ICP_OK; }
+    return c->map.add_surf(w.data(), n, 3) < 0 ? fail(c, SO_ICP_E_INVALID, "LocalMap insert failed") : SO_ICP_OK;
   };
-  auto transform_and_add_dev = [&](const double T[7]) -> int {  // same, entirely on the device (scan already resident in d_scan_own)
+  auto transform_and_add_dev = [&](const float* d_scan, const double T[7]) -> int {  // same, entirely on the device
     HIP_TRY(c, c->d_world.reserve((n + 64) * 12));
-    launch_transform_scan(c->d_scan_own.as<float>(), (uint32_t)n, pose_from_array(T), c->d_world.as<float>(), c->stream);
-    return c->dmap->add_surf_dev(c->d_world.as<float>(), n, 3, c->err) < 0 ? SO_ICP_E_HIP : SO_ICP_OK;
+    launch_transform_scan(d_scan, (uint32_t)n, pose_from_array(T), c->d_world.as<float>(), c->stream);
+    const int r = c->dmap->add_surf_dev(c->d_world.as<float>(), n, 3, c->err);
+    return r < 0 ? (r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP) : SO_ICP_OK;
   };
   if (!initialization) {  // initializeMapping, LidarSlam.cpp:83-94
     std::memcpy(pose_out, T_in, 7 * sizeof(double));
     if (st) std::memset(st, 0, sizeof(*st));
     if (c->dmap) c->dmap->set_origin(T_in); else c->map.set_origin(T_in);
-    transform_and_add(T_in);
+    const int r = transform_and_add(T_in);
+    if (r) return r;
     c->last_time = time_laser_odometry;
     return SO_ICP_MAP_SEEDED;
   }
   so_icp_stats local;
   if (!st) st = &local;
+  // (the scan the registration ran on -- staged slot or d_scan_own -- is still resident: the insert reuses it)
+  int src_rc = SO_ICP_OK;
+  const float* staged = c->host_only ? nullptr : take_staged(c, xyz, n, stride_bytes, &src_rc);
   const int rc = so_icp_register(c, xyz, n, stride_bytes, T_in, pose_out, st);
   if (rc != SO_ICP_OK) return rc;  // NOT_ENOUGH: the reference returns before the post-processing (LidarSlam.cpp:113-116)
   // checkMotionThresholds, LidarSlam.cpp:173-195: always accepts; only the startupCount side effect survives
   const double dt = time_laser_odometry - c->last_time;
   if (st->translation_from_last / dt > c->cfg.velocity_failure_threshold) c->startup_count = 5;
   st->startup_count = c->startup_count;
-  if (c->dmap) { const int r = transform_and_add_dev(pose_out); if (r) return r; }  // LidarSlam.cpp:163-167
-  else transform_and_add(pose_out);
+  int r;
+  if (c->dmap) r = transform_and_add_dev(staged ? staged : c->d_scan_own.as<float>(), pose_out);  // LidarSlam.cpp:163-167
+  else r = transform_and_add(pose_out);
+  if (r) return r;
   c->last_time = time_laser_odometry;
   return SO_ICP_OK;
 }
@@ -1186,10 +1320,10 @@ int so_icp_comm_unique_id(uint8_t id[SO_ICP_UNIQUE_ID_BYTES]) {
   Rccl r;
   std::string err;
   if (!rccl_load(r, err)) { g_create_error = err; return SO_ICP_E_RCCL; }
-  Uid u;
+  ncclUniqueId u;
   std::memset(&u, 0, sizeof(u));
-  const int rc = r.GetUniqueId(&u);
-  if (rc != 0) { g_create_error = "ncclGetUniqueId failed"; return SO_ICP_E_RCCL; }
+  const ncclResult_t rc = r.GetUniqueId(&u);
+  if (rc != ncclSuccess) { g_create_error = "ncclGetUniqueId failed"; return SO_ICP_E_RCCL; }
   std::memcpy(id, &u, SO_ICP_UNIQUE_ID_BYTES);
   return SO_ICP_OK;
 }
@@ -1199,10 +1333,10 @@ int so_icp_comm_init(so_icp_ctx* c, const uint8_t id[SO_ICP_UNIQUE_ID_BYTES]) {
   NEED_DEVICE(c);
   if (!rccl_load(c->rccl, c->err)) return SO_ICP_E_RCCL;
   HIP_TRY(c, hipSetDevice(c->cfg.device_id));
-  Uid u;
+  ncclUniqueId u;
   std::memcpy(&u, id, SO_ICP_UNIQUE_ID_BYTES);
-  const int rc = c->rccl.CommInitRank(&c->comm, c->cfg.world_size, u, c->cfg.rank);
-  if (rc != 0) { c->comm = nullptr; return fail(c, SO_ICP_E_RCCL, std::string("ncclCommInitRank: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(rc) : "?")); }
+  const ncclResult_t rc = c->rccl.CommInitRank(&c->comm, c->cfg.world_size, u, c->cfg.rank);
+  if (rc != ncclSuccess) { c->comm = nullptr; return fail(c, SO_ICP_E_RCCL, std::string("ncclCommInitRank: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(rc) : "?")); }
   return SO_ICP_OK;
 }
 
@@ -1264,6 +1398,16 @@ int so_icp_debug_knn_stamps(so_icp_ctx* c, uint64_t* out, size_t capacity_words,
   if (!out || !have) return SO_ICP_OK;
   if (capacity_words < have) return fail(c, SO_ICP_E_INVALID, "so_icp_debug_knn_stamps: buffer too small");
   HIP_TRY(c, hipMemcpy(out, c->d_kdbg.p, have * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return SO_ICP_OK;
+}
+int so_icp_debug_match_status(so_icp_ctx* c, uint8_t* out, size_t n) {
+  if (!c || (!out && n)) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  if (!n) return SO_ICP_OK;
+  if (n > c->d_status.cap) return fail(c, SO_ICP_E_INVALID, "so_icp_debug_match_status: more entries than the last scan had");
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(out, c->d_status.p, n, hipMemcpyDeviceToHost));
   return SO_ICP_OK;
 }
 int so_icp_synchronize(so_icp_ctx* c) { if (!c) return SO_ICP_E_INVALID; NEED_DEVICE(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return SO_ICP_OK; }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   const uint32_t kDropped = (map.n_slots + 1u) << cell_bits, kNoCube = map.n_slots << cell_bits;
   uint32_t key = kDropped;
   bool process = true;
-  if (max_surface_features > 0 && n > (uint32_t)max_surface_features) {  // calculateSamplingRate / shouldProcessPoint
+  if (max_surface_features >= 0 && n > (uint32_t)max_surface_features) {  // calculateSamplingRate / shouldProcessPoint (0: rate 0, every point dropped)
     const double rate = 1.0 * max_surface_features / n;
     const double rem = fmod((double)i * rate, 1.0);
     if (rem + 0.001 > rate) process = false;

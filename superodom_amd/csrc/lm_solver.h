@@ -247,6 +247,9 @@ SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7], unsigned 
     if (S.radius > LmConst::kMaxRadius) S.radius = LmConst::kMaxRadius;
     S.decrease_factor = 2.0;
     S.reuse_diagonal = 0;
+    // FinalizeIterationAndCheckIfMinimizerCanContinue tests MaxSolverIterationsReached before GradientToleranceReached
+    // [UPSTREAM ceres 2.0.0 trust_region_minimizer.cc]: both on the last iteration => termination 0, not 3
+    if (S.iter >= S.max_iter) { S.termination = 0; S.done = 1; return 0; }
     if (lm_gradient_converged(S.x, S.g)) { S.termination = 3; S.done = 1; return 0; }
   } else {  // HandleUnsuccessfulStep / StepRejected
     S.radius = S.radius / S.decrease_factor;

@@ -54,6 +54,7 @@ void launch_world_cube(const float* d_xyz, uint32_t n, uint32_t stride_floats, c
                        uint8_t* d_touched, uint32_t* d_n_inside, hipStream_t s);
 void launch_transform_scan(const float* d_scan, uint32_t n, const Pose& pose, float* d_out, hipStream_t s);
 void launch_map_insert(const MapInsertArgs& a, hipStream_t s);
+void launch_map_retable(const MapInsertArgs& a, hipStream_t s);  // resolution change: new cell tables over the resident points
 void launch_gather_export(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, float* d_out, hipStream_t s);
 
 }  // namespace soicp

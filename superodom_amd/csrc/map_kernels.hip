@@ -319,10 +319,14 @@ __global__ __launch_bounds__(256) void cell_place_kernel(const uint32_t* __restr
 }
 // pass 2: final position inside the cell = number of the cell's centroids with a smaller leaf key (one centroid per leaf:
 // the keys are distinct), i.e. ascending leaf order -- what the stable sort by (cell, leaf) produced
+// (After a resolution change -- launch_map_retable -- a cube may hold points of an older, different leaf grid, where two
+//  points can share a leaf key: the order then falls back on the coordinates' bit patterns and, for bitwise equal points,
+//  on the placement rank, so that every point keeps a position of its own.)
 __global__ __launch_bounds__(256) void cell_rank_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ n_cent,
                                                         const uint32_t* __restrict__ grid, const uint32_t* __restrict__ grid_scan,
                                                         const float4* __restrict__ cent, const float4* __restrict__ tmp, MapTouched tt,
-                                                        uint32_t cap, uint32_t ncell1, float inv_leaf, float4* __restrict__ pool) {
+                                                        uint32_t cap, uint32_t ncell1, float inv_leaf, float4* __restrict__ pool,
+                                                        const uint32_t* __restrict__ rank) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= *n_cent) return;
   const uint32_t k = keys2[o], t = k >> 18;
@@ -330,8 +334,19 @@ __global__ __launch_bounds__(256) void cell_rank_kernel(const uint32_t* __restri
   const uint32_t beg = grid_scan[gi], cnt = grid[gi];
   const float4 v = cent[o];
   const uint32_t kv = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t);
+  const uint32_t mine = rank[o];
   uint32_t r = 0;
-  for (uint32_t j = 0; j < cnt; ++j) r += (__float_as_uint(tmp[beg + j].w) < kv) ? 1u : 0u;
+  for (uint32_t j = 0; j < cnt; ++j) {
+    const float4 u = tmp[beg + j];
+    const uint32_t ku = __float_as_uint(u.w);
+    bool less = ku < kv;
+    if (ku == kv && j != mine) {
+      const uint32_t ux = __float_as_uint(u.x), uy = __float_as_uint(u.y), uz = __float_as_uint(u.z);
+      const uint32_t vx = __float_as_uint(v.x), vy = __float_as_uint(v.y), vz = __float_as_uint(v.z);
+      less = uz != vz ? uz < vz : (uy != vy ? uy < vy : (ux != vx ? ux < vx : j < mine));
+    }
+    r += less ? 1u : 0u;
+  }
   const uint32_t local = beg - grid_scan[(size_t)t * ncell1] + r;
   if (local < cap) pool[(size_t)tt.slot[t] * cap + local] = v;
 }
@@ -504,7 +519,7 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.tt, a.ncell1,
                        a.inv_leaf, a.spts);  // spts (leaf-sorted working set) is free after the centroids
     hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid, a.grid_scan, a.cent, a.spts, a.tt,
-                       a.cap, a.ncell1, a.inv_leaf, a.pool);
+                       a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1);
     return;
   }
   hipLaunchKernelGGL(pad_keys_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals0, a.d_n_cent, total);
@@ -512,6 +527,48 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
   (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable: leaf order inside a cell
   hipLaunchKernelGGL(scatter_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.d_n_cent, a.cent, a.tt, a.cap, a.pool, a.d_counts);
   hipLaunchKernelGGL(table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.keys1, a.d_n_cent, a.tt, a.cap, a.ncell1, a.cell_start);
+}
+// Resolution change (localMap.planeRes_ is pushed every frame, laserMapping.cpp:648-649): the points of a cube stay as they
+// are -- the reference re-filters a block only when the next insert touches it (LocalMap.h:617-641) -- only the cell
+// grid of the index follows the new planeRes.  The resident points take the place of the "centroids" of an insert's
+// second stage: counted into the new cell grids, scanned into the new tables, placed in ascending (old) leaf order.
+__global__ __launch_bounds__(256) void retable_gather_kernel(MapTouched tt, const float4* __restrict__ pool, uint32_t cap, uint32_t n_old, int nc,
+                                                             double inv_cell, float4* __restrict__ cent, uint32_t* __restrict__ keys2,
+                                                             uint32_t* __restrict__ n_cent) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0) *n_cent = n_old;
+  if (e >= n_old) return;
+  int t = 0;
+#pragma unroll
+  for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
+  const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
+  cent[e] = make_float4(p.x, p.y, p.z, 0.f);
+  int g[3];
+  const float c3[3] = {p.x, p.y, p.z};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int v = (int)floor(((double)c3[a] - tt.cube_min[t][a]) * inv_cell);
+    g[a] = v < 0 ? 0 : (v >= nc ? nc - 1 : v);
+  }
+  keys2[e] = ((uint32_t)t << 18) | (uint32_t)((g[2] * nc + g[1]) * nc + g[0]);
+}
+// a.inv_leaf = 1 / the planeRes the points were last filtered with (their leaf keys are distinct there); a.grid required
+void launch_map_retable(const MapInsertArgs& a, hipStream_t s) {
+  const uint32_t total = a.n_old;
+  if (!total) return;
+  hipLaunchKernelGGL(retable_gather_kernel, grid_for(total, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, total, a.nc, a.inv_cell, a.cent, a.keys0,
+                     a.d_n_cent);
+  const size_t gn = (size_t)a.tt.n * a.ncell1;
+  (void)hipMemsetAsync(a.grid, 0, gn * sizeof(uint32_t), s);
+  hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.ncell1, a.grid, a.vals1);
+  size_t tb = a.temp_bytes;
+  (void)rocprim::exclusive_scan(a.temp, tb, a.grid, a.grid_scan, 0u, gn, rocprim::plus<uint32_t>(), s);
+  hipLaunchKernelGGL(cell_table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.grid_scan, a.tt, a.cap, a.ncell1, a.cell_start,
+                     a.d_counts);
+  hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.tt, a.ncell1,
+                     a.inv_leaf, a.spts);
+  hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid, a.grid_scan, a.cent, a.spts, a.tt,
+                     a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1);
 }
 void launch_vg_stats(const float* d_xyz, uint32_t n, uint32_t stride_floats, double* d_part, int blocks, hipStream_t s) {
   hipLaunchKernelGGL(vg_stats_kernel, dim3(blocks), dim3(256), 0, s, d_xyz, n, stride_floats, d_part);
