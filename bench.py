@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- ICP registrations/sec on the BASELINE.json workload.
+"""bench.py -- ICP registrations/sec on the BASELINE.json workload (SURVEY.md section 8d).
 
     python bench.py --gpus 1 --steps K --warmup W            (default: N=1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE scan-to-map registration (so_icp_register_dev: spatial sort, then per outer iteration the
-k-NN + plane-fit kernel and the fused LM evaluations, <=5 outer x <=4 LM iterations) of a synthetic
-OS1-128 scan (131 072 points, already resident in HBM) against the 2M-point local map
-(BASELINE.json configs[2]).  N > 1: one process per GPU; the map is sharded by brick-hash of the voxel
-grid, every rank registers the SAME scan over its shard and the 45 fp64 normal-equation scalars are
-all-reduced over RCCL once per evaluation (configs[3]) -> total work is fixed: "scaling": "strong".
-Rank 0 prints ONE JSON line with the roofline of the dominant (k-NN) kernel, measured with HIP events on
-the library's stream inside the timed region, and the CPU baseline (the oracle restating the reference
-path, timed on this host's cores on a bounded sample)."""
+A "step" is ONE scan-to-map registration through so_icp_register -- HOST scan buffer in, pose + statistics out -- of a
+synthetic OS1-128 scan (131 072 points) against the 2M-point local map (BASELINE.json configs[2]): spatial binning, then
+per outer iteration the k-NN kernel and the persistent solve launch (plane fit + fused LM evaluations + controller),
+<= 5 outer x <= 4 LM iterations.  The scan's H2D copy is INSIDE the timed region (SURVEY 8d "scan H2D copy included"):
+the next scan is announced with so_icp_stage_scan (copy thread + copy stream) while the current one registers, like the
+node's feature callback would (laserMapping.cpp:21-25 receives the cloud long before process() reaches it).  The same
+line carries the resident-scan rate (so_icp_register_dev, no copy) and the serial rate (so_icp_register, copy then register).
+
+N > 1 (configs[3]): one process per GPU; the map is sharded by brick-hash of the voxel grid, every rank registers the
+SAME scan over its shard and the 45 fp64 normal-equation scalars are all-reduced over RCCL once per evaluation -> total
+work is fixed: "scaling": "strong".  Every line also carries `batch64` (configs[4]): 64 hypotheses per scan, the map
+replicated, the hypotheses split over the ranks, no collective.
+
+Rank 0 prints ONE JSON line with the roofline of the dominant (k-NN) kernel, measured with HIP events attached to the
+kernel's dispatch on the library's stream inside the timed region, and the CPU baselines (Oracle-A = restatement with an
+exact grid k-NN, Oracle-B = the same with the k-NN through the reference's own octree.h compiled into oracle/_ref),
+timed on this host's cores on a bounded sample."""
 import argparse
 import json
 import os
@@ -26,19 +34,35 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMD = 1024          # 256 CUs x 4 SIMDs
+
+
+def _load_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="os1_128_2m")
     ap.add_argument("--scans", type=int, default=4, help="distinct synthetic scans cycled through the steps")
+    ap.add_argument("--entry", default="staged", choices=["staged", "host", "resident"],
+                    help="entry point of the TIMED loop: staged = so_icp_register with the next scan announced by so_icp_stage_scan "
+                         "(default, PCIe inside the clock, overlapped); host = so_icp_register alone (copy, then register); "
+                         "resident = so_icp_register_dev on scans uploaded before the clock (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the resident / serial / batch64 measurements after the timed region")
     ap.add_argument("--max-outer", type=int, default=5, help="LocalizationICPMaxIter (5 = config of record)")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every kernel (adds bubbles)")
-    ap.add_argument("--cpu-sample", type=int, default=1, help="registrations timed for the CPU baseline")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="registrations timed for each CPU baseline")
     ap.add_argument("--shuffle-scan", action="store_true", help="experiment: random point order inside every scan (worst case for the binning atomics)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the k-NN launches (no roofline)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the kernel-split pass after the timed region (runs under rocprofv3 use it: one registration = one set of launches)")
@@ -64,19 +88,20 @@ def main():
     # ---------------- synthetic workload (seeded) ----------------
     sc = synth.Scene(args.workload)
     max_outer, lm_iters = args.max_outer, 4
-    slam = binding.LidarSlamGpu(device_id=int(os.environ.get("SOICP_BENCH_DEVICE", local_rank)), rank=rank, world_size=world, plane_res=sc.plane_res,
-                                line_res=sc.plane_res / 2, max_iterations=max_outer, lm_max_iterations=lm_iters,
-                                max_surface_features=-1, time_kernels=2 if args.time_all_kernels else (0 if args.no_kernel_events else 1))
+    device = int(os.environ.get("SOICP_BENCH_DEVICE", local_rank))
+    mk = dict(device_id=device, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_iterations=max_outer, lm_max_iterations=lm_iters,
+              max_surface_features=-1)
+    slam = binding.LidarSlamGpu(rank=rank, world_size=world, time_kernels=2 if args.time_all_kernels else (0 if args.no_kernel_events else 1), **mk)
     if world > 1:
         uid = [binding.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         slam.comm_init(uid[0])
     n_map = slam.add_surf_point_cloud(sc.map_points)
-    scans = [sc.scan(i) for i in range(args.scans)]
+    scans = [np.ascontiguousarray(sc.scan(i), dtype=np.float32) for i in range(args.scans)]
     if args.shuffle_scan:
-        scans = [s_[np.random.default_rng(77 + i).permutation(len(s_))] for i, s_ in enumerate(scans)]
+        scans = [np.ascontiguousarray(s_[np.random.default_rng(77 + i).permutation(len(s_))]) for i, s_ in enumerate(scans)]
     guesses = [sc.guess(i) for i in range(args.scans)]
-    d_scans = [slam.upload_scan(s) for s in scans]  # inputs resident in HBM before the timed region
+    d_scans = [slam.upload_scan(s) for s in scans]  # resident copies: the secondary / profiling loops and --entry resident
     Q = len(scans[0])
     map_total, map_rank = slam.map_size(this_rank=True)
 
@@ -85,49 +110,84 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    st = binding.Stats()
-    poses = []
-    for w in range(args.warmup):
-        i = w % args.scans
-        slam.register_dev(d_scans[i][0], d_scans[i][1], guesses[i], st)
-    # the timed loop only calls the C ABI: results land in preallocated structures and are examined afterwards; the
-    # ctypes arguments of every call are built before the clock starts
-    step_stats = [binding.Stats() for _ in range(args.steps)]
-    step_pose = [np.zeros(7) for _ in range(args.steps)]
+    def max_over_ranks(t):
+        if dist is None:
+            return t
+        import torch
+        tt = torch.tensor([t], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     g64 = [np.ascontiguousarray(g, dtype=np.float64) for g in guesses]
-    rcs = [0] * args.steps
-    calls = [slam.prepare_register_dev(d_scans[k % args.scans][0], d_scans[k % args.scans][1], g64[k % args.scans], step_stats[k], step_pose[k])
-             for k in range(args.steps)]
+
+    def timed_loop(entry, steps):
+        """`steps` registrations through one entry point, only C calls between the two clock reads (arguments pre-built)."""
+        stats = [binding.Stats() for _ in range(steps)]
+        pose = [np.zeros(7) for _ in range(steps)]
+        if entry == "resident":
+            calls = [slam.prepare_register_dev(d_scans[k % args.scans][0], d_scans[k % args.scans][1], g64[k % args.scans], stats[k], pose[k])
+                     for k in range(steps)]
+            stage = None
+        else:
+            calls = [slam.prepare_register(scans[k % args.scans], g64[k % args.scans], stats[k], pose[k]) for k in range(steps)]
+            stage = [slam.prepare_stage_scan(scans[k % args.scans]) for k in range(steps)] if entry == "staged" else None
+        rcs = [0] * steps
+        barrier()
+        t0 = time.perf_counter()
+        if stage:
+            stage[0]()
+            for k in range(steps):
+                if k + 1 < steps:
+                    stage[k + 1]()
+                rcs[k] = calls[k]()
+        else:
+            for k in range(steps):
+                rcs[k] = calls[k]()
+        slam.synchronize()
+        t_local = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        for k in range(steps):
+            assert rcs[k] == 0, (entry, k, rcs[k], slam.last_error())
+        return max_over_ranks(t_local), stats, pose
+
+    st = binding.Stats()
+    for w in range(args.warmup):  # untimed: the entry point of the timed loop, every scan of the rotation at least once
+        i = w % args.scans
+        if args.entry == "resident":
+            slam.register_dev(d_scans[i][0], d_scans[i][1], guesses[i], st)
+        else:
+            if args.entry == "staged":
+                slam.stage_scan(scans[i])
+            slam.register(scans[i], guesses[i])
     slam.reset_timing()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        rcs[k] = calls[k]()
-    slam.synchronize()
-    t_local = time.perf_counter() - t0
+    t_max, step_stats, step_pose = timed_loop(args.entry, args.steps)
+    tm = slam.timing()
     iters_outer = iters_lm = accepted = 0
+    poses, flags = [], 0
     for k in range(args.steps):
-        assert rcs[k] == 0, rcs[k]
-        st = step_stats[k]
-        iters_outer += st.n_iterations
-        for it in range(st.n_iterations):
-            iters_lm += st.iterations[it].lm_iterations
-        accepted += st.iterations[max(st.n_iterations - 1, 0)].num_surf_from_scan
+        s_ = step_stats[k]
+        flags |= s_.flags
+        iters_outer += s_.n_iterations
+        for it in range(s_.n_iterations):
+            iters_lm += s_.iterations[it].lm_iterations
+        accepted += s_.iterations[max(s_.n_iterations - 1, 0)].num_surf_from_scan
         if k < args.scans:
             poses.append(step_pose[k])
-    if dist is not None:
-        dist.barrier()
-        import torch
-        tt = torch.tensor([t_local], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_max = float(tt.item())
-    else:
-        t_max = t_local
-    tm = slam.timing()
-    # ---- kernel split of a registration: a profiling pass AFTER the timed region (every launch bracketed by events,
-    #      which would cost ~25 us per registration inside it); every rank runs it (the collectives need all of them)
+
+    # ---- secondary measurements, same process, after the timed region: the other entry points, the kernel split, batch64
+    secondary = {}
+    if not args.no_secondary:
+        slam.set_time_kernels(0)
+        for entry in ("resident", "host", "staged"):
+            if entry == args.entry:
+                continue
+            t_e, _, _ = timed_loop(entry, args.steps)
+            secondary[entry] = args.steps / t_e
     prof = None
     if not args.no_kernel_events and not args.no_profile_pass:
+        # kernel split of a registration: every launch bracketed by events (would cost ~25 us per registration inside the
+        # timed region); every rank runs it (the collectives need all of them)
         slam.set_time_kernels(2)
         slam.reset_timing()
         n_prof = 2 * args.scans
@@ -138,6 +198,42 @@ def main():
         prof = {"registrations": n_prof, "knn_ms": tp.knn_ms_total / n_prof, "solve_ms": tp.eval_ms_total / n_prof,
                 "binning_ms": tp.prep_ms_total / n_prof, "knn_launches": tp.knn_launches / n_prof, "solve_launches": tp.eval_launches / n_prof,
                 "host_ms": tp.host_ms_total / n_prof}
+        slam.set_time_kernels(0)
+    batch = None
+    if not args.no_secondary:
+        # BASELINE configs[4]: 64 hypotheses per scan (SURVEY 8d seeds: +-0.5 m / +-5 deg, 5000 + 64 i + h), map replicated on
+        # every rank, hypotheses h = rank, rank + N, ... per rank, no collective until the gather of the poses
+        full = slam if world == 1 else binding.LidarSlamGpu(rank=0, world_size=1, time_kernels=0, **mk)
+        if world > 1:
+            full.add_surf_point_cloud(sc.map_points)
+        reps = min(3, args.scans)
+        mine = list(range(rank, 64, world))
+        hyp = [np.stack([synth.perturb_pose(sc.gt_pose(i), 5000 + 64 * i + h, 0.5, 5.0) for h in mine]) for i in range(reps)]
+        d_full = d_scans if world == 1 else [full.upload_scan(s) for s in scans[:reps]]
+        full.register_batch(None, hyp[0], d_scan=d_full[0][0], n=d_full[0][1])  # warm: worker contexts + their buffers
+        full.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        outs = []
+        for i in range(reps):
+            outs.append(full.register_batch(None, hyp[i], d_scan=d_full[i][0], n=d_full[i][1]))
+        full.synchronize()
+        t_b = max_over_ranks(time.perf_counter() - t0)
+        ok = sum(o[0] for o in outs)
+        good = sum(1 for i, o in enumerate(outs) for h in range(len(mine)) if synth.pose_error(o[2][h], sc.gt_pose(i))[0] < 0.02)
+        outer_b = sum(s_.n_iterations for o in outs for s_ in o[3])
+        if dist is not None:
+            import torch
+            cnt = torch.tensor([ok, good, outer_b], dtype=torch.float64)
+            dist.all_reduce(cnt)
+            ok, good, outer_b = (int(v) for v in cnt.tolist())
+        batch = {"value": 64 * reps / t_b, "unit": "registrations/s", "hypotheses_per_scan": 64, "scans": reps,
+                 "hypotheses_per_rank": len(mine), "ms_per_batch": 1e3 * t_b / reps, "returned_ok": ok, "within_2cm_of_ground_truth": good,
+                 "outer_iterations_per_hypothesis": outer_b / (64.0 * reps),
+                 "parallelism": f"map replicated on {world} GPU(s), hypotheses split over the ranks, up to 8 concurrent lanes per GPU, no collective",
+                 "scaling": "strong"}
+        if world > 1:
+            full.close()
 
     if rank != 0:
         if dist is not None:
@@ -146,7 +242,7 @@ def main():
         return
 
     value = args.steps / t_max
-    # ---- roofline of the dominant kernel (k-NN + plane fit): algorithmic bytes per launch
+    # ---- roofline of the dominant kernel (k-NN): algorithmic bytes per launch
     #      B_knn = 12*Q (query xyz in) + 12*M_t (map xyz in) + 24*Q (n,d,w,status record out)
     #      M_t = map points in the 50 m cubes the scan touches, NOT the whole map
     knn_ms = tm.knn_ms_total / max(tm.knn_launches, 1)
@@ -165,88 +261,128 @@ def main():
     b_knn = 12.0 * q_per_launch + 12.0 * m_per_launch + 24.0 * q_per_launch
     b_knn_whole_map = 36.0 * q_per_launch + 12.0 * tm.knn_map_points / max(tm.knn_launches, 1)
     achieved = b_knn / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")  # PMC pass result (bytes per launch), see profiles/README.md
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    ms_per_step_for_split = 1e3 * t_max / args.steps
+    tr = _load_json("knn_traffic.json")     # PMC pass results (per launch), see profiles/README.md
+    traffic = tr.get("hbm_bytes_per_launch") if tr else None
+    ctr = _load_json("knn_counters.json")
+    valu = None
+    if ctr and ctr.get("valu_wave_insts_per_launch") and knn_ms > 0:
+        clk = float(ctr.get("shader_clock_ghz", 2.07))
+        insts = float(ctr["valu_wave_insts_per_launch"])
+        # a wave-instruction occupies its SIMD's VALU for 4 cycles (64 lanes on 16): issue-bound time = insts * 4 / 1024 SIMDs / clock
+        valu = {"valu_wave_insts_per_launch": insts, "shader_clock_ghz": clk, "issue_bound_ms": insts * 4 / N_SIMD / (clk * 1e9) * 1e3,
+                "valu_issue_frac": insts * 4 / N_SIMD / (clk * 1e9) / (knn_ms * 1e-3), "source": ctr.get("source")}
+    ms_per_step = 1e3 * t_max / args.steps
 
     errs = [synth.pose_error(poses[i], sc.gt_pose(i)) for i in range(len(poses))]
+    entry_text = {"staged": "so_icp_register on HOST scan buffers, the next scan announced with so_icp_stage_scan (copy thread + copy stream): "
+                            "every scan's H2D copy is inside the timed region, overlapped with the previous registration",
+                  "host": "so_icp_register on HOST scan buffers, copy then register (nothing overlapped)",
+                  "resident": "so_icp_register_dev on scans uploaded BEFORE the timed region"}[args.entry]
     out = {
         "metric": "icp_registrations_per_sec", "value": value, "unit": "registrations/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_max / args.steps,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: OS1-128 synthetic scan ({Q} pts, resident in HBM) vs {n_map}-pt local map, "
-                               f"full ICP loop (kNN + plane fit + Jacobian + 6x6 reduce) in HIP",
-                   "queries": Q, "map_points": int(map_total), "map_points_this_rank": int(map_rank),
+        "config": {"workload": f"{args.workload}: OS1-128 synthetic scan ({Q} pts) vs {n_map}-pt local map, "
+                               f"full ICP loop (kNN + plane fit + Jacobian + 6x6 reduce) in HIP; " + entry_text,
+                   "entry": args.entry, "queries": Q, "map_points": int(map_total), "map_points_this_rank": int(map_rank),
                    "max_iterations": max_outer, "lm_iterations": lm_iters, "plane_res": sc.plane_res, "k": 5,
                    "parallelism": ("single GPU" if world == 1 else f"map sharded by brick-hash x{world}, 45-fp64 RCCL all-reduce per evaluation"),
                    "distinct_scans": args.scans},
         "executed": {"outer_iterations_per_step": iters_outer / args.steps, "lm_iterations_per_step": iters_lm / args.steps,
-                     "accepted_correspondences": accepted / args.steps,
+                     "accepted_correspondences": accepted / args.steps, "stats_flags": int(flags),
                      "pose_error_vs_ground_truth_m_rad": [max(e[0] for e in errs), max(e[1] for e in errs)]},
+        # the same registrations through the other entry points, `steps` each, after the timed region
+        "entry_points": {"note": "registrations/s; 'staged' and 'host' include the scan's H2D copy (1.5 MB), 'resident' does not",
+                         args.entry: value, **secondary},
         "roofline": {"bound": "hbm", "kernel": "knn_plane_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": b_knn, "avg_launch_ms": knn_ms, "launches": int(tm.knn_launches),
                      "timing": "HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL) on the context's stream, inside the timed region, "
                                "on every 3rd registration (every launch with --time-all-kernels); no-op launches after convergence excluded",
                      "queries_per_launch": q_per_launch, "map_points_in_touched_cubes": m_per_launch,
-                     "note": "B = 36*Q + 12*M_t (SURVEY 8d); with M_t = whole map (BASELINE.md table) B would be %.0f and frac %.4f"
+                     "valu_issue": valu,
+                     "note": "B = 36*Q + 12*M_t (SURVEY 8d); with M_t = whole map (BASELINE.md table) B would be %.0f and frac %.4f; "
+                             "the kernel is VALU-issue bound, not HBM bound: see valu_issue (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / clock / time)"
                              % (b_knn_whole_map, (b_knn_whole_map / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if knn_ms > 0 else 0.0)},
         "host": {"c_abi_ms_per_step": tm.host_ms_total / max(tm.registrations, 1),
-                 "note": "wall time inside so_icp_register_dev (enqueue + wait + post-processing); ms_per_step - this = Python/ctypes overhead of the bench loop"},
+                 "note": "wall time inside the registration core (enqueue + wait + post-processing); ms_per_step - this = scan hand-over + Python/ctypes overhead"},
         # ms of one registration by kernel family, from the profiling pass after the timed region (real launches only:
         # no-op launches after convergence excluded).  solve = plane fit + every LM evaluation + controller (one persistent
         # launch per outer iteration on one GPU; eval + all-reduce + controller launches when the map is sharded).
-        "kernels": ({"note": "profiling pass after the timed region: every launch bracketed by HIP events",
+        "kernels": ({"note": "profiling pass after the timed region (resident scans): every launch bracketed by HIP events",
                      "registrations_profiled": prof["registrations"],
                      "knn_ms_per_registration": prof["knn_ms"], "solve_ms_per_registration": prof["solve_ms"],
                      "binning_ms_per_registration": prof["binning_ms"],
                      "knn_launches_per_registration": prof["knn_launches"], "solve_launches_per_registration": prof["solve_launches"],
-                     "rest_ms_per_registration": max(ms_per_step_for_split - prof["knn_ms"] - prof["solve_ms"] - prof["binning_ms"], 0.0)}
+                     "rest_ms_per_registration": max(ms_per_step - prof["knn_ms"] - prof["solve_ms"] - prof["binning_ms"], 0.0)}
                     if prof else None),
+        "batch64": batch,
     }
 
-    # ---- CPU baseline: the oracle (restatement of the reference CPU path), same scans, bounded sample
-    if not args.no_cpu_baseline:
+    # ---- CPU baselines: the oracle (restatement of the reference CPU path), same scans, bounded sample, N = 1 only
+    if not args.no_cpu_baseline and world == 1:
         import oracle_py
         om = oracle_py.OracleMap(plane_res=sc.plane_res)
-        om.add_surf(slam.export_map() if world == 1 else sc.map_points, raw=(world == 1))
-        cfg = oracle_py.default_config(max_iterations=max_outer, lm_max_iterations=lm_iters, use_grid_knn=1)
+        om.add_surf(slam.export_map(), raw=True)
+        cfg_a = oracle_py.default_config(max_iterations=max_outer, lm_max_iterations=lm_iters, use_grid_knn=1)
         om.ensure_grids()  # index build is map maintenance, not registration (the reference builds octrees at insert time)
         oracle_py.set_num_threads(1)  # faithful: the reference's correspondence loop is serial, Ceres num_threads = 1
+        n_cpu = max(1, args.cpu_sample)
         t0 = time.perf_counter()
         worst = (0.0, 0.0)
-        for i in range(args.cpu_sample):
-            orc, opose, ost, _ = om.register(scans[i % args.scans], guesses[i % args.scans], cfg)
+        oposes = []
+        for i in range(n_cpu):
+            orc, opose, ost, _ = om.register(scans[i % args.scans], guesses[i % args.scans], cfg_a)
+            oposes.append(opose)
             if i < len(poses):
                 e = synth.pose_error(poses[i], opose)
                 worst = (max(worst[0], e[0]), max(worst[1], e[1]))
         t_cpu = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": args.cpu_sample / t_cpu, "unit": "registrations/s", "cores": 1, "kind": "port",
-                               "sample": f"{args.cpu_sample} registration(s) of the same {Q}-pt scans vs the same map, oracle/liboracle.so "
-                                         f"(exact grid k-NN), 1 thread, {t_cpu:.1f} s",
+        out["cpu_baseline"] = {"value": n_cpu / t_cpu, "unit": "registrations/s", "cores": 1, "kind": "port",
+                               "sample": f"{n_cpu} registration(s) of the same {Q}-pt scans vs the same map, oracle/liboracle.so = Oracle-A "
+                                         f"(restatement of the reference path, exact grid k-NN), 1 thread, {t_cpu:.1f} s",
                                "host_cpu": _cpu_model(), "host_cores": os.cpu_count()}
-        # the "fair" CPU number: the same oracle with OpenMP over the queries on every host core
+        # Oracle-B: the same registration with the k-NN through the reference's OWN octree
+        # (flann/octree.h + nanoflann.h compiled into oracle/_ref, Octree::knnNeighbors oct.h:509-519, 1004-1055): the closest
+        # thing to the stock binary's CPU path that can run here.  Trees are built before the clock (insert time upstream).
+        try:
+            if oracle_py.enable_oracle_b():
+                cfg_b = oracle_py.default_config(max_iterations=max_outer, lm_max_iterations=lm_iters, use_grid_knn=2)
+                om.register(scans[0], guesses[0], cfg_b)  # builds one octree per map block (LocalMap.h:638), untimed
+                t0 = time.perf_counter()
+                dab = (0.0, 0.0)
+                for i in range(n_cpu):
+                    orc, bpose, bst, _ = om.register(scans[i % args.scans], guesses[i % args.scans], cfg_b)
+                    e = synth.pose_error(oposes[i], bpose)
+                    dab = (max(dab[0], e[0]), max(dab[1], e[1]))
+                t_b = time.perf_counter() - t0
+                out["cpu_baseline_oracle_b"] = {"value": n_cpu / t_b, "unit": "registrations/s", "cores": 1, "kind": "reference",
+                                                "sample": f"{n_cpu} registration(s), same scans; k-NN = the reference's flann/octree.h (oracle/_ref/libref_octree.so, "
+                                                          f"one tree per 50 m block), everything else = oracle/liboracle.so, 1 thread, {t_b:.1f} s",
+                                                "delta_pose_vs_oracle_a_m_rad": [dab[0], dab[1]],
+                                                "note": "the stock octree prunes wrongly (oct.h:384-385, 988-990): its neighbours differ for a share of the queries, hence the pose delta"}
+                oracle_py.reset_oracle_b()
+            else:
+                out["cpu_baseline_oracle_b"] = {"error": "oracle/_ref/libref_octree.so not built"}
+        except Exception as e:
+            out["cpu_baseline_oracle_b"] = {"error": str(e)}
+        # the "fair" CPU number: Oracle-A with OpenMP over the queries on every physical host core
         try:
             ncore = max(1, (os.cpu_count() or 2) // 2)  # physical cores (SMT siblings do not help the fp64 loops)
             oracle_py.set_num_threads(ncore)
-            om.register(scans[0], guesses[0], cfg)  # warm the threads
+            om.register(scans[0], guesses[0], cfg_a)  # warm the threads
             t0 = time.perf_counter()
-            reps = max(2, args.cpu_sample)
-            for i in range(reps):
-                om.register(scans[i % args.scans], guesses[i % args.scans], cfg)
-            t_all = (time.perf_counter() - t0) / reps
+            for i in range(n_cpu):
+                om.register(scans[i % args.scans], guesses[i % args.scans], cfg_a)
+            t_all = (time.perf_counter() - t0) / n_cpu
             out["cpu_baseline_all_cores"] = {"value": 1.0 / t_all, "unit": "registrations/s", "cores": ncore, "kind": "port",
-                                             "sample": f"{reps} registrations, oracle with OpenMP over the queries, {ncore} threads"}
+                                             "sample": f"{n_cpu} registrations, Oracle-A with OpenMP over the queries, {ncore} threads"}
             oracle_py.set_num_threads(1)
         except Exception as e:  # the number of record is the 1-thread baseline above
             out["cpu_baseline_all_cores"] = {"error": str(e)}
         out["parity_vs_oracle_m_rad"] = [worst[0], worst[1]]
-        out["speedup_vs_cpu_1thread"] = value * t_cpu / args.cpu_sample
+        out["parity_scans_checked"] = min(n_cpu, len(poses))
+        out["speedup_vs_cpu_1thread"] = value * t_cpu / n_cpu
     print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -261,6 +261,11 @@ int so_icp_prefilter_scan(so_icp_ctx *ctx, const float *surf_xyz, size_t n, size
 #define SO_ICP_UNIQUE_ID_BYTES 128
 int so_icp_comm_unique_id(uint8_t id[SO_ICP_UNIQUE_ID_BYTES]);                 /* rank 0: ncclGetUniqueId */
 int so_icp_comm_init(so_icp_ctx *ctx, const uint8_t id[SO_ICP_UNIQUE_ID_BYTES]); /* all ranks: ncclCommInitRank on ctx->rank/world_size */
+/* The same exchange without RCCL, for the shard contexts of ONE process (one thread + one context per GPU of the node, or
+ * several shard contexts on one GPU in a test): the contexts that pass the same key form a group of cfg.world_size members
+ * and sum their records through host memory in rank order.  Every member must run the same registrations, each from its
+ * own thread (a member waits inside so_icp_register until all members have contributed). */
+int so_icp_comm_init_inprocess(so_icp_ctx *ctx, uint64_t group_key);
 /* brick-hash ownership of the shard (host logic, testable without a GPU) */
 int so_icp_shard_owner_of_point(const float p[3], const int origin[3], float plane_res, int world_size);
 int so_icp_cells_per_cube(float plane_res, double *cell_size);

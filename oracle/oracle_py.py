@@ -86,8 +86,31 @@ def lib():
     L.orc_register.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, C.POINTER(Config), i32p, f64p, C.POINTER(Stats), vp]
     L.orc_transform_and_add.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p]
     L.orc_set_num_threads.argtypes = [C.c_int]
+    L.orc_set_knn_hook.argtypes = [C.c_void_p]
     _lib = L
     return L
+
+
+_ref_lib = None
+
+
+def enable_oracle_b():
+    """Oracle-B: route the k-NN of configs with use_grid_knn = 2 through the reference's own octree
+    (oracle/_ref/libref_octree.so = flann/octree.h compiled where it lies).  Returns False when oracle/_ref is absent."""
+    global _ref_lib
+    path = os.path.join(HERE, "_ref", "libref_octree.so")
+    if not os.path.exists(path):
+        return False
+    if _ref_lib is None:
+        _ref_lib = C.CDLL(path)
+        _ref_lib.ref_octree_cube_reset.restype = None
+    lib().orc_set_knn_hook(C.cast(_ref_lib.ref_octree_cube_knn, C.c_void_p))
+    return True
+
+
+def reset_oracle_b():
+    if _ref_lib is not None:
+        _ref_lib.ref_octree_cube_reset()
 
 
 def set_num_threads(n):

@@ -19,7 +19,34 @@ struct Handle {
 };
 }  // namespace
 
+namespace {
+// Oracle-B: one tree per LocalMap block, like MapBlock::octree_surf_ (LocalMap.h:45-53), rebuilt when the block's point
+// array changed (LocalMap.h:638 rebuilds after every insert into the block)
+struct CubeTree { const float* xyz = nullptr; size_t n = 0; Handle* h = nullptr; };
+CubeTree g_cube_trees[21 * 21 * 11];
+}  // namespace
+
 extern "C" {
+// signature = orc_knn_hook_t (oracle/so_oracle.h); single-threaded by design (the reference's correspondence loop is serial)
+void ref_octree_cube_knn(int cube_ind, const float* xyz, size_t n, const float q[3], int k, int64_t* idx, float* d2) {
+  CubeTree& t = g_cube_trees[cube_ind];
+  if (t.xyz != xyz || t.n != n || !t.h) {
+    delete t.h;
+    t.h = new Handle();
+    t.h->pts.resize(n);
+    for (size_t i = 0; i < n; ++i) t.h->pts[i] = Pt{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    t.h->tree.initialize(t.h->pts);
+    t.xyz = xyz; t.n = n;
+  }
+  std::vector<size_t> k_indices(k, 0);   // LocalMap.h:516: std::vector<size_t> k_indices(k)
+  std::vector<float> k_d2(k, 0.f);
+  Pt qq{q[0], q[1], q[2]};
+  t.h->tree.knnNeighbors<nanoflann::L2Distance<Pt>>(qq, (size_t)k, k_indices.data(), k_d2.data());
+  for (int j = 0; j < k; ++j) { idx[j] = (int64_t)k_indices[j]; d2[j] = k_d2[j]; }
+}
+void ref_octree_cube_reset(void) {
+  for (CubeTree& t : g_cube_trees) { delete t.h; t = CubeTree(); }
+}
 void* ref_octree_build(const float* xyz, size_t n) {
   Handle* h = new Handle();
   h->pts.resize(n);

@@ -514,12 +514,29 @@ static void knn_cube_grid(const orc_cube *c, const float q[3], knn_set *s) {
   }
 }
 
+/* Oracle-B: the k-NN of a cube answered by an EXTERNAL engine -- oracle/_ref/libref_octree.so, the reference's
+ * own flann/octree.h compiled where it lies (Octree::knnNeighbors, oct:509-519, 1004-1055, with its two pruning bugs) --
+ * while everything else stays this restatement.  use_grid_knn == 2 selects it; the hook owns one tree per cube. */
+static orc_knn_hook_t g_knn_hook = 0;
+void orc_set_knn_hook(orc_knn_hook_t h) { g_knn_hook = h; }
+
 int orc_knn_surf(const orc_map *m, const float q[3], int k, int use_grid, float *nbr, float *d2, int64_t *idx, int *cube_out) {
   int ci = map_cube_index(m, q); /* LM:488-502 */
   if (cube_out) *cube_out = ci;
   if (ci < 0) return 0;
   const orc_cube *c = m->cubes[ci];
   if (!c || c->n == 0) return 0; /* LM:506: no tree */
+  if (use_grid == 2 && g_knn_hook) { /* LM:516-523 with the stock octree: indices value-initialised to 0, distances resized */
+    int64_t id[16]; float dd[16];
+    for (int i = 0; i < k; ++i) { id[i] = 0; dd[i] = 0; }
+    g_knn_hook(ci, c->xyz, c->n, q, k, id, dd);
+    for (int i = 0; i < k; ++i) {
+      if (d2) d2[i] = dd[i];
+      if (idx) idx[i] = id[i];
+      if (nbr) memcpy(nbr + 3 * i, c->xyz + 3 * id[i], 12);
+    }
+    return 1;
+  }
   knn_set s;
   knn_init(&s, k);
   if (use_grid && c->grid_valid) knn_cube_grid(c, q, &s);
@@ -932,7 +949,7 @@ int orc_register(orc_map *m, const float *scan, size_t n, size_t stride, const d
   st->surf_from_map_num = orc_map_count_5x5(m, st->pos_in_map);                 /* LS:367 */
   st->surf_stack_num = (int32_t)n;
   if (!(st->surf_from_map_num > 50)) return 1;                                  /* LS:113-116, 379-381 */
-  if (cfg->use_grid_knn) map_ensure_grids(m);
+  if (cfg->use_grid_knn == 1) map_ensure_grids(m);
   int max_outer = cfg->max_iterations > 0 ? cfg->max_iterations : 4;
   if (max_outer > ORC_MAX_OUTER) max_outer = ORC_MAX_OUTER;
   orc_corr *corrs = last_corrs ? last_corrs : (orc_corr *)malloc((n ? n : 1) * sizeof(orc_corr));
@@ -940,7 +957,7 @@ int orc_register(orc_map *m, const float *scan, size_t n, size_t stride, const d
     orc_iter_stats *is = &st->iters[it];
     st->n_iterations = it + 1;
     /* processPlannerFeatures, LS:323-344 (serial in the reference; queries are independent) */
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 256) if (cfg->use_grid_knn != 2) /* Oracle-B: the hook builds its trees lazily -- serial, like the reference loop (LS:328) */
     for (size_t i = 0; i < n; ++i) {
       if (!orc_should_process(i, n, cfg->max_surface_features)) { memset(&corrs[i], 0, sizeof(orc_corr)); corrs[i].status = -1; continue; }
       orc_plane_match(m, T, scan + i * stride, cfg, &corrs[i]);

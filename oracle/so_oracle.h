@@ -65,7 +65,7 @@ typedef struct {
   int max_surface_features;  /* OptSet.max_surface_features; <0 means "all", 0 drops every point (LS:346-359) */
   int k;                     /* LocalizationPlaneDistanceNbrNeighbors = 5, LidarSlam.h:277 */
   int tukey_variant;         /* 0: Ceres<=2.0 (rho'=0.5(1-s/a^2)^2), 1: Ceres>=2.1 (rho'=(1-s/a^2)^2) */
-  int use_grid_knn;          /* 0: brute force inside the cube; 1: exact uniform-grid search */
+  int use_grid_knn;          /* 0: brute force inside the cube; 1: exact uniform-grid search; 2: orc_set_knn_hook engine (Oracle-B) */
   double yaw_ratio;          /* OptSet.yaw_ratio (0.0 in shipped calibrations) */
   double velocity_failure_threshold; /* 30 */
 } orc_config;
@@ -160,6 +160,11 @@ int orc_register(orc_map *m, const float *scan_xyz, size_t n, size_t stride_floa
                  double pose_out[7], orc_stats *stats, orc_corr *last_corrs /*nullable, n entries*/);
 /* transformAndAddToMap, LidarSlam.cpp:60-80 */
 int orc_transform_and_add(orc_map *m, const float *scan_xyz, size_t n, size_t stride_floats, const double pose[7]);
+
+/* Oracle-B: k-NN of one cube through an external engine (oracle/_ref: the reference's flann/octree.h); selected by
+ * orc_config::use_grid_knn == 2.  xyz / n = the cube's points (stable until the next insert into that cube). */
+typedef void (*orc_knn_hook_t)(int cube_ind, const float *xyz, size_t n, const float q[3], int k, int64_t *idx, float *d2);
+void orc_set_knn_hook(orc_knn_hook_t hook);
 
 int orc_num_threads(void);
 void orc_set_num_threads(int n);

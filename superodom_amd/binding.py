@@ -79,7 +79,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_register_dev", "so_icp_upload_scan", "so_icp_free_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
-            "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status"]
+            "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess"]
 
 _lib = None
 
@@ -137,6 +137,7 @@ def load():
     L.so_icp_set_time_kernels.argtypes = [vp, C.c_int]
     L.so_icp_stage_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
     L.so_icp_debug_match_status.argtypes = [vp, u8p, C.c_size_t]
+    L.so_icp_comm_init_inprocess.argtypes = [vp, C.c_uint64]
     _lib = L
     return L
 
@@ -351,6 +352,9 @@ class LidarSlamGpu:
     def comm_init(self, uid_bytes):
         uid = np.frombuffer(bytes(uid_bytes), dtype=np.uint8).copy()
         self._check(self.L.so_icp_comm_init(self.h, _p(uid, C.c_uint8)))
+
+    def comm_init_inprocess(self, group_key):
+        self._check(self.L.so_icp_comm_init_inprocess(self.h, int(group_key)))
 
     # ---- measurement ----
     def timing(self):

@@ -87,6 +87,35 @@ bool rccl_load(Rccl& r, std::string& err) {
 
 struct EventSpan { int kind; hipEvent_t a, b; uint32_t units; };  // kind 0 knn, 1 eval, 2 prep
 
+// In-process shard group (so_icp_comm_init_inprocess): the contexts of ONE process that share a key -- one thread and one
+// context per GPU, or several shard contexts on one GPU in a test -- sum their 45-double records through host memory.
+// Fixed order (rank 0, 1, ...): every member receives bit-identical sums and takes identical controller decisions.
+struct InprocGroup {
+  std::mutex mu; std::condition_variable cv;
+  int world = 0, arrived = 0, members = 0; unsigned long long generation = 0;
+  std::vector<LmSums> slot; LmSums total{};
+  void allreduce(int rank, LmSums* io) {
+    std::unique_lock<std::mutex> lk(mu);
+    slot[(size_t)rank] = *io;
+    if (++arrived == world) {
+      double* t = reinterpret_cast<double*>(&total);
+      for (size_t k = 0; k < sizeof(LmSums) / sizeof(double); ++k) {
+        double acc = 0;
+        for (int r = 0; r < world; ++r) acc += reinterpret_cast<const double*>(&slot[(size_t)r])[k];
+        t[k] = acc;
+      }
+      arrived = 0; ++generation;
+      cv.notify_all();
+    } else {
+      const unsigned long long g = generation;
+      cv.wait(lk, [&] { return generation != g; });
+    }
+    *io = total;
+  }
+};
+std::mutex g_groups_mu;
+std::vector<std::pair<uint64_t, std::shared_ptr<InprocGroup>>> g_groups;
+
 }  // namespace
 
 struct so_icp_ctx {
@@ -146,6 +175,7 @@ struct so_icp_ctx {
   so_icp_timing timing{};
   // RCCL
   Rccl rccl; ncclComm_t comm = nullptr;
+  std::shared_ptr<InprocGroup> group;  // so_icp_comm_init_inprocess
   // so_icp_stage_scan: a copy thread + copy stream bring the NEXT scan to HBM while the current registration runs
   struct StageSlot {
     const float* src = nullptr; size_t n = 0, stride = 0;  // identity of the staged host buffer
@@ -425,7 +455,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // part A: correspondences + plane fit + first evaluation; part B: the remaining evaluations + read-back
   // (concurrent hypotheses: two persistent launches could each hold part of the CUs and wait for the rest -- one launch per
   //  evaluation there; only workgroup 0 of a launch ever waits, for workgroups that finish unconditionally)
-  const bool persistent = c->persistent_solve && c->comm == nullptr && (!c->batch_mode || c->batch_single) && !(ep.ablate & 32);  // (ablated controller: per-evaluation launches)
+  const bool exchange = c->comm != nullptr || c->group != nullptr;  // the sums pass through a collective between evaluation and controller
+  const bool persistent = c->persistent_solve && !exchange && (!c->batch_mode || c->batch_single) && !(ep.ablate & 32);  // (ablated controller: per-evaluation launches)
   if (!persistent) st->flags |= SO_ICP_FLAG_PER_EVAL_LAUNCHES;
   // deferred report (see EvalParams::defer_publish): possible when the host always has the next k-NN launch in the queue
   // before it waits for a report
@@ -433,11 +464,17 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   mp.publish_prev = defer_reports ? 1 : 0;
   auto enqueue_eval = [&](int slot) -> int {
     span_begin(c, 1, (uint32_t)n);
-    const bool fuse_lm = (c->comm == nullptr);  // single device: the last workgroup of eval runs the LM controller itself
+    const bool fuse_lm = !exchange;  // single device: the last workgroup of eval runs the LM controller itself
     launch_eval(slot, fuse_lm, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep, c->d_partials,
                 c->d_ticket, c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, s);
     span_end(c);
-    if (!fuse_lm) {  // per-evaluation collective: 45 fp64 summed over the shards (xGMI, latency-bound), then the controller
+    if (!fuse_lm && c->group) {  // in-process group: through host memory (every member calls this the same number of times)
+      HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(LmSums), hipMemcpyDeviceToHost, s));
+      HIP_TRY(c, hipStreamSynchronize(s));
+      c->group->allreduce(c->cfg.rank, c->h_sums);
+      HIP_TRY(c, hipMemcpyAsync(c->d_sums, c->h_sums, sizeof(LmSums), hipMemcpyHostToDevice, s));
+      launch_lm_step(slot, ds, c->d_sums, c->d_hist, ep, s);
+    } else if (!fuse_lm) {  // per-evaluation collective: 45 fp64 summed over the shards (xGMI, latency-bound), then the controller
       const ncclResult_t nrc = c->rccl.AllReduce(c->d_sums, c->d_sums, sizeof(LmSums) / sizeof(double), ncclDouble, ncclSum, c->comm, s);
       if (nrc != ncclSuccess) return fail(c, SO_ICP_E_RCCL, std::string("ncclAllReduce: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(nrc) : "?"));
       launch_lm_step(slot, ds, c->d_sums, c->d_hist, ep, s);
@@ -445,6 +482,25 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     return SO_ICP_OK;
   };
   auto enqueue_outer_a = [&](int it) -> int {
+    if (it > 0 && c->cfg.world_size > 1 && n) {
+      // sharded map: ownership follows the query's cell under the CURRENT pose, so the scan is re-binned at the start of
+      // every outer iteration (a 1 degree correction at 50 m moves a point by more than the one-cell halo of a shard)
+      if (c->use_binning) {
+        const BinTable bt{c->d_bin_key.as<uint32_t>(), c->d_bin_cnt.as<uint32_t>(), c->d_bin_off.as<uint32_t>(), c->bin_log2};
+        launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
+                         c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), &bt, s, true);
+        launch_bin_offsets(bt, c->d_chunks.as<uint32_t>(), (uint32_t)(c->d_chunks.cap / 4), ds, s);
+        launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(),
+                         c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s, ds);
+      } else {
+        launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
+                         c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), nullptr, s, true);
+        launch_sort_pairs(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->d_keys0.as<uint32_t>(), c->d_keys1.as<uint32_t>(),
+                          c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, key_bits(c->view.n_slots), s);
+        launch_chunk_heads(c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_chunks.as<uint32_t>(), ds, d_scan,
+                           c->d_vals1.as<uint32_t>(), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
+      }
+    }
     // processPlannerFeatures: every kept query in parallel (LidarSlam.cpp:323-344)
     knn_span_of_outer.push_back(c->spans.size());
     hipEvent_t ka = nullptr, kb = nullptr;
@@ -1337,6 +1393,25 @@ int so_icp_comm_init(so_icp_ctx* c, const uint8_t id[SO_ICP_UNIQUE_ID_BYTES]) {
   std::memcpy(&u, id, SO_ICP_UNIQUE_ID_BYTES);
   const ncclResult_t rc = c->rccl.CommInitRank(&c->comm, c->cfg.world_size, u, c->cfg.rank);
   if (rc != ncclSuccess) { c->comm = nullptr; return fail(c, SO_ICP_E_RCCL, std::string("ncclCommInitRank: ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(rc) : "?")); }
+  return SO_ICP_OK;
+}
+
+int so_icp_comm_init_inprocess(so_icp_ctx* c, uint64_t group_key) {
+  if (!c) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  if (c->comm) return fail(c, SO_ICP_E_INVALID, "so_icp_comm_init_inprocess: the context already has an RCCL communicator");
+  std::lock_guard<std::mutex> lk(g_groups_mu);
+  std::shared_ptr<InprocGroup> g;
+  for (auto& kv : g_groups) if (kv.first == group_key) g = kv.second;
+  if (!g) {
+    g = std::make_shared<InprocGroup>();
+    g->world = c->cfg.world_size; g->slot.resize((size_t)g->world);
+    g_groups.emplace_back(group_key, g);
+  }
+  if (g->world != c->cfg.world_size) return fail(c, SO_ICP_E_INVALID, "so_icp_comm_init_inprocess: world_size differs from the group's");
+  if (g->members >= g->world) return fail(c, SO_ICP_E_INVALID, "so_icp_comm_init_inprocess: the group is complete already (use a new key)");
+  g->members++;
+  c->group = g;
   return SO_ICP_OK;
 }
 

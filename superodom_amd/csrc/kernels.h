@@ -129,13 +129,14 @@ struct BinTable {
 // per query: table slot (0xFFFFFFFF = dropped) and rank inside its bucket
 void launch_bin_offsets(const BinTable& bt, uint32_t* d_chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s);
 void launch_bin_place(const BinTable& bt, const float* d_scan_xyz, uint32_t n, const uint32_t* d_qslot, const uint32_t* d_qrank,
-                      uint32_t* d_perm, float* spx, float* spy, float* spz, hipStream_t s);
+                      uint32_t* d_perm, float* spx, float* spy, float* spz, hipStream_t s, const DevState* st_if_rebin = nullptr);
 
 // scan_keys also runs the registration prologue (reg_begin) in its first workgroup; n == 0 launches the prologue alone
 void launch_scan_keys(const float* d_scan_xyz, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max,
                       int32_t* d_hist, const DevMapView& map, int max_surface_features, int rank, int world, uint32_t* d_keys,
                       uint32_t* d_vals, uint8_t* d_status /* SO_MATCH_DROPPED for queries that are not processed */,
-                      const BinTable* bin /* non-null: d_keys / d_vals receive table slot / rank instead of key / index */, hipStream_t s);
+                      const BinTable* bin /* non-null: d_keys / d_vals receive table slot / rank instead of key / index */, hipStream_t s,
+                      bool rebin = false /* sharded map, outer iteration >= 1: keys under the CURRENT device-resident pose, no prologue */);
 void launch_sort_pairs(void* d_temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
                        const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, int end_bit, hipStream_t s);
 // chunk work list + gather of the scan into sorted SoA order

@@ -112,14 +112,20 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
                                                         DevMapView map,
                                                         int max_surface_features, int rank, int world,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint8_t* __restrict__ status, BinTable bt) {
-  if (blockIdx.x == 0) {
+                                                        uint8_t* __restrict__ status, BinTable bt, int rebin) {
+  // rebin (sharded map, outer iteration >= 1): ownership and binning are re-derived under the CURRENT pose -- a query that
+  // the pose update carried out of its owner's halo (1 degree at 50 m is more than a cell) is handed to its new owner, so
+  // every rank searches only queries whose whole gate ball lies inside its shard.  No prologue; a no-op once converged.
+  if (rebin) {
+    if (st->reg_done) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_kept = 0; st->n_chunks = 0; st->n_light = 0; }  // (bin_offsets / chunk_heads of this round add to them)
+  } else if (blockIdx.x == 0) {
     hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
     reg_begin_state(st, a, threadIdx.x);
   }
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Pose pose = pose_from_array(a.pose);
+  const Pose pose = pose_from_array(rebin ? st->T : a.pose);
   const int cell_bits = (map.n_slots + 2u <= 2048u) ? 21 : 18;  // == key_cell_bits()
   const uint32_t kDropped = (map.n_slots + 1u) << cell_bits, kNoCube = map.n_slots << cell_bits;
   uint32_t key = kDropped;
@@ -259,9 +265,10 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t
 __global__ __launch_bounds__(256) void bin_place_kernel(BinTable bt, const float* __restrict__ scan, uint32_t n,
                                                         const uint32_t* __restrict__ qslot, const uint32_t* __restrict__ qrank,
                                                         uint32_t* __restrict__ perm, float* __restrict__ spx, float* __restrict__ spy,
-                                                        float* __restrict__ spz) {
+                                                        float* __restrict__ spz, const DevState* __restrict__ st_if_rebin) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (st_if_rebin && st_if_rebin->reg_done) return;  // re-binning round of a registration that has converged: nothing to place
   const uint32_t sl = qslot[i];
   if (sl == 0xFFFFFFFFu) return;
   const uint32_t pos = bt.off[sl] + qrank[i];
@@ -284,6 +291,7 @@ __global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __res
                                                            float* __restrict__ spx, float* __restrict__ spy, float* __restrict__ spz) {
   __shared__ uint32_t wave_cnt[16];
   __shared__ uint32_t block_base;
+  if (st->reg_done) return;  // (re-binning round after convergence)
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t key = i < n ? keys[i] : kKeyDropped;
@@ -1957,21 +1965,21 @@ void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_
 }
 void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist,
                       const DevMapView& map, int max_sf, int rank, int world, uint32_t* keys, uint32_t* vals, uint8_t* status,
-                      const BinTable* bin, hipStream_t s) {
-  if (!n) { launch_reg_begin(st, pose, max_outer, lm_max, hist, s); return; }
+                      const BinTable* bin, hipStream_t s, bool rebin) {
+  if (!n) { if (!rebin) launch_reg_begin(st, pose, max_outer, lm_max, hist, s); return; }
   RegBeginArgs a;
   for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
   a.max_outer = max_outer; a.lm_max = lm_max;
   hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals, status,
-                     bin ? *bin : BinTable{nullptr, nullptr, nullptr, 0});
+                     bin ? *bin : BinTable{nullptr, nullptr, nullptr, 0}, rebin ? 1 : 0);
 }
 void launch_bin_offsets(const BinTable& bt, uint32_t* chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s) {
   hipLaunchKernelGGL(bin_offsets_kernel, dim3((1u << bt.log2_size) / 4096u), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st);
 }
 void launch_bin_place(const BinTable& bt, const float* d_scan, uint32_t n, const uint32_t* qslot, const uint32_t* qrank, uint32_t* perm,
-                      float* spx, float* spy, float* spz, hipStream_t s) {
+                      float* spx, float* spy, float* spz, hipStream_t s, const DevState* st_if_rebin) {
   if (!n) return;
-  hipLaunchKernelGGL(bin_place_kernel, grid_for(n, 256), dim3(256), 0, s, bt, d_scan, n, qslot, qrank, perm, spx, spy, spz);
+  hipLaunchKernelGGL(bin_place_kernel, grid_for(n, 256), dim3(256), 0, s, bt, d_scan, n, qslot, qrank, perm, spx, spy, spz, st_if_rebin);
 }
 void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo,
                        uint32_t n, int end_bit, hipStream_t s) {
