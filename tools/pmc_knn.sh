@@ -8,7 +8,7 @@ mkdir -p $OUT
 for a in ${1:-0}; do
   rm -rf /tmp/pmc_$a
   SOICP_ABLATE=$a rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d /tmp/pmc_$a -- \
-    python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile-pass > /tmp/pmc_$a.log 2>&1
+    python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile-pass --no-secondary > /tmp/pmc_$a.log 2>&1
   python - "$a" /tmp/pmc_$a > $OUT/ablate_$a.txt <<'PY'
 import sys, glob, csv, collections
 a, d = sys.argv[1], sys.argv[2]

@@ -11,7 +11,7 @@ mkdir -p $OUT
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -- \
-    python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile-pass > /tmp/pmc_$ctr.log 2>&1
+    python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile-pass --no-secondary > /tmp/pmc_$ctr.log 2>&1
 done
 python - $OUT <<'PY'
 import sys, glob, csv, collections, json

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-run}
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-profile-pass > /tmp/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-profile-pass --no-secondary > /tmp/prof_$TAG.log 2>&1
 mkdir -p $R/gpurun_out/prof_$TAG
 f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp $f $R/gpurun_out/prof_$TAG/kernel_stats.csv
@@ -12,7 +12,7 @@ grep "^{\"metric" /tmp/prof_$TAG.log | tail -1 > $R/gpurun_out/prof_$TAG/bench_l
 # second pass without speculative enqueue: every knn_plane_kernel / solve_kernel launch in it is a real one, so the
 # rocprofv3 averages can be compared directly with the HIP-event averages bench.py reports (which exclude no-op launches)
 rm -rf /tmp/prof_${TAG}_ns
-SOICP_SPECULATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_ns -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-profile-pass > /tmp/prof_${TAG}_ns.log 2>&1
+SOICP_SPECULATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_ns -- python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-profile-pass --no-secondary > /tmp/prof_${TAG}_ns.log 2>&1
 g=$(find /tmp/prof_${TAG}_ns -name "*kernel_stats.csv" | head -1)
 cp $g $R/gpurun_out/prof_$TAG/kernel_stats_no_speculation.csv
 grep "^{\"metric" /tmp/prof_${TAG}_ns.log | tail -1 > $R/gpurun_out/prof_$TAG/bench_line_no_speculation.json
