@@ -727,7 +727,10 @@ void stage_worker(so_icp_ctx* c) {
   }
 }
 
-// the staged copy of (xyz, n, stride), waiting for the copy thread if it is still on its way; nullptr = not staged
+// The staged copy of (xyz, n, stride), waiting for the copy thread if it is still on its way; nullptr = not staged.
+// A staged copy is consumed by the call that takes it: the caller may refill the same host buffer for a later frame, and a
+// later call without a new so_icp_stage_scan must not see the old contents.  (The HBM buffer itself stays valid until the
+// slot is staged again, i.e. for the whole call that took it.)
 const float* take_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, int* rc) {
   *rc = SO_ICP_OK;
   if (!c->stage_started) return nullptr;
@@ -735,11 +738,24 @@ const float* take_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t strid
   for (so_icp_ctx::StageSlot& sl : c->stage) {
     if (sl.state == 0 || sl.src != xyz || sl.n != n || sl.stride != stride_bytes) continue;
     c->stage_cv.wait(lk, [&] { return sl.state != 1; });
-    if (sl.state == 2) return sl.dev.as<float>();
-    if (sl.state == -1) { c->err = sl.err; *rc = SO_ICP_E_HIP; sl.state = 0; }
+    const int state = sl.state;
+    sl.state = 0; sl.src = nullptr;
+    if (state == 2) return sl.dev.as<float>();
+    if (state == -1) { c->err = sl.err; *rc = SO_ICP_E_HIP; }
     return nullptr;
   }
   return nullptr;
+}
+
+// the scan of this call in HBM: the staged copy when the caller announced it, else a plain upload into d_scan_own
+int resolve_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, const float** d_scan) {
+  int rc = SO_ICP_OK;
+  c->scan_staged = false;
+  if (const float* staged = take_staged(c, xyz, n, stride_bytes ? stride_bytes : 12, &rc)) { c->scan_staged = true; *d_scan = staged; return SO_ICP_OK; }
+  if (rc) return rc;
+  rc = upload_scan_impl(c, xyz, n, stride_bytes, c->d_scan_own);
+  *d_scan = c->d_scan_own.as<float>();
+  return rc;
 }
 
 }  // namespace
@@ -1014,17 +1030,12 @@ int so_icp_register(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_byt
   if (!c || !pose_in || !pose_out || (!xyz && n)) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);
   HIP_TRY(c, hipSetDevice(c->cfg.device_id));
-  int rc = SO_ICP_OK;
-  if (const float* staged = take_staged(c, xyz, n, stride_bytes ? stride_bytes : 12, &rc)) {  // announced with so_icp_stage_scan
-    c->scan_staged = true;
-    rc = register_core(c, staged, n, pose_in, pose_out, st);
-    c->scan_staged = false;
-    return rc;
-  }
+  const float* d_scan = nullptr;
+  int rc = resolve_scan(c, xyz, n, stride_bytes, &d_scan);  // the copy announced with so_icp_stage_scan, or a plain upload
   if (rc) return rc;
-  rc = upload_scan_impl(c, xyz, n, stride_bytes, c->d_scan_own);
-  if (rc) return rc;
-  return register_core(c, c->d_scan_own.as<float>(), n, pose_in, pose_out, st);
+  rc = register_core(c, d_scan, n, pose_in, pose_out, st);
+  c->scan_staged = false;
+  return rc;
 }
 
 int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes) {
@@ -1225,17 +1236,20 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   }
   so_icp_stats local;
   if (!st) st = &local;
-  // (the scan the registration ran on -- staged slot or d_scan_own -- is still resident: the insert reuses it)
-  int src_rc = SO_ICP_OK;
-  const float* staged = c->host_only ? nullptr : take_staged(c, xyz, n, stride_bytes, &src_rc);
-  const int rc = so_icp_register(c, xyz, n, stride_bytes, T_in, pose_out, st);
+  NEED_DEVICE(c);
+  // (the scan the registration ran on -- staged slot or d_scan_own -- is still resident afterwards: the insert reuses it)
+  const float* d_scan = nullptr;
+  int rc = resolve_scan(c, xyz, n, stride_bytes, &d_scan);
+  if (rc) return rc;
+  rc = register_core(c, d_scan, n, T_in, pose_out, st);
+  c->scan_staged = false;
   if (rc != SO_ICP_OK) return rc;  // NOT_ENOUGH: the reference returns before the post-processing (LidarSlam.cpp:113-116)
   // checkMotionThresholds, LidarSlam.cpp:173-195: always accepts; only the startupCount side effect survives
   const double dt = time_laser_odometry - c->last_time;
   if (st->translation_from_last / dt > c->cfg.velocity_failure_threshold) c->startup_count = 5;
   st->startup_count = c->startup_count;
   int r;
-  if (c->dmap) r = transform_and_add_dev(staged ? staged : c->d_scan_own.as<float>(), pose_out);  // LidarSlam.cpp:163-167
+  if (c->dmap) r = transform_and_add_dev(d_scan, pose_out);  // LidarSlam.cpp:163-167
   else r = transform_and_add(pose_out);
   if (r) return r;
   c->last_time = time_laser_odometry;

@@ -6,7 +6,7 @@ TAG=${1:-r02}
 shift
 cd $R
 mkdir -p gpurun_out
-( timeout 1500 python -m pytest tests -m gpu -q --maxfail=30 -x --durations=15 "$@" 2>&1 | tail -60 ) > gpurun_out/pytest_$TAG.log
+( timeout 1500 python -m pytest tests -m gpu -q --maxfail=30 --durations=12 "$@" 2>&1 | tail -60 ) > gpurun_out/pytest_$TAG.log
 tail -25 gpurun_out/pytest_$TAG.log
 ( timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 ) > gpurun_out/smoke_$TAG.log; cat gpurun_out/smoke_$TAG.log
 timeout 600 python bench.py 2> gpurun_out/bench_$TAG.err | tail -1 > gpurun_out/bench_$TAG.json
