@@ -185,6 +185,8 @@ struct so_icp_ctx {
   } stage[2];
   int stage_next = 0;
   bool stage_quit = false, stage_started = false;
+  std::atomic<int> stage_pending{0};      // queued slots the copy thread has not picked up yet
+  std::atomic<bool> stage_parked{false};  // the copy thread sleeps on stage_cv (it spins for a while after every job first)
   std::thread stage_thread; std::mutex stage_mu; std::condition_variable stage_cv;
   hipStream_t copy_stream = nullptr;
   bool retried = false;       // the current registration is the repeat of an abandoned one
@@ -296,6 +298,7 @@ MatchParams match_params(float plane_res, int ablate) {
   mp.max_point_dist = (double)plane_res / 2.0; // LidarSlam.cpp:820
   mp.ablate = ablate;  // SOICP_ABLATE, read when the context is created (a getenv per registration is a walk over environ)
   mp.kdbg = nullptr;
+  mp.packed_counts = 0;
   return mp;
 }
 EvalParams eval_params(float plane_res, int variant, int ablate) {
@@ -361,8 +364,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   so_icp_stats local;
   if (!st) st = &local;
   std::memset(st, 0, sizeof(*st));
-  // chunk descriptors keep a binned position in 26 bits (kernels.hip: bin_offsets_kernel / knn_plane_kernel)
-  if (n >= ((size_t)1 << 26)) return fail(c, SO_ICP_E_UNSUPPORTED, "scan of 2^26 points or more: chunk descriptors hold 26-bit positions");
+  // (kernels.hip: bin_offsets_kernel / knn_plane_kernel)
+  if (n >= ((size_t)1 << 21)) return fail(c, SO_ICP_E_UNSUPPORTED, "scan of 2^21 points or more: the work-list counters hold 21 bits each (chunk descriptors 26)");
   st->flags = (c->retried ? SO_ICP_FLAG_RETRIED : 0u) | (!c->dmap && !c->borrow.on ? SO_ICP_FLAG_HOST_MAP : 0u) |
               (c->use_binning ? 0u : SO_ICP_FLAG_SORT_BINNING) | (c->cfg.world_size > 1 ? SO_ICP_FLAG_SHARDED : 0u) |
               (c->scan_staged ? SO_ICP_FLAG_STAGED_SCAN : 0u) | (c->direct_readback ? 0u : SO_ICP_FLAG_COPY_READBACK);
@@ -429,6 +432,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
   MatchParams mp = match_params(plane_res_now, c->ablate);
   mp.chunk_cap = (uint32_t)(c->d_chunks.cap / 4);
+  mp.packed_counts = (c->use_binning && n) ? 1 : 0;
   if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
     HIP_TRY(c, c->d_kdbg.reserve((size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemsetAsync(c->d_kdbg.p, 0, (size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long), s));
@@ -637,7 +641,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
         if (sp.kind == 1 && it < (int)eval_span_first.size() && i >= eval_span_first[it] &&
             i < eval_span_first[it] + (persistent ? 1 : 1 + (size_t)std::max(H.iters[it].lm_iterations, 0))) keep = true;
       }
-      if (keep) { EventSpan r = sp; r.units = H.n_kept; real.push_back(r); }
+      if (keep) { EventSpan r = sp; r.units = mp.packed_counts ? (uint32_t)(H.bin_packed & 0x1FFFFFull) : H.n_kept; real.push_back(r); }
     }
     c->spans.swap(real);
     // profiling mode brackets the solve launches too: the last one has published its result but its stop event may not
@@ -695,8 +699,27 @@ void stage_worker(so_icp_ctx* c) {
   (void)hipSetDevice(c->cfg.device_id);
   std::unique_lock<std::mutex> lk(c->stage_mu);
   for (;;) {
-    c->stage_cv.wait(lk, [&] { return c->stage_quit || c->stage[0].state == 1 || c->stage[1].state == 1; });
+    if (!(c->stage_quit || c->stage[0].state == 1 || c->stage[1].state == 1)) {
+      // Nothing queued.  A registration stream announces the next scan within a few hundred microseconds: spin that long
+      // on the pending counter (no futex wake-up on the announcing thread's path), then park on the condition variable
+      // (a 10 Hz node finds the thread parked and pays one notify per frame).
+      lk.unlock();
+      const auto t0 = std::chrono::steady_clock::now();
+      bool got = false;
+      while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(400)) {
+        if (c->stage_pending.load(std::memory_order_acquire) > 0) { got = true; break; }
+        __builtin_ia32_pause();
+      }
+      lk.lock();
+      if (!got) {
+        c->stage_parked.store(true);
+        c->stage_cv.wait(lk, [&] { return c->stage_quit || c->stage[0].state == 1 || c->stage[1].state == 1; });
+        c->stage_parked.store(false);
+      }
+      continue;
+    }
     if (c->stage_quit) return;
+    c->stage_pending.fetch_sub(1, std::memory_order_acq_rel);
     so_icp_ctx::StageSlot& sl = c->stage[c->stage[0].state == 1 ? 0 : 1];
     const float* src = sl.src; const size_t n = sl.n, stride = sl.stride;
     lk.unlock();
@@ -763,6 +786,7 @@ int resolve_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes,
 so_icp_ctx::~so_icp_ctx() {
   if (stage_started) {
     { std::lock_guard<std::mutex> lk(stage_mu); stage_quit = true; }
+    stage_pending.fetch_add(1);
     stage_cv.notify_all();
     if (stage_thread.joinable()) stage_thread.join();
   }
@@ -1056,7 +1080,8 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
     c->stage_cv.wait(lk, [&] { return sl.state != 1; });  // (a slot still being copied: the caller staged three scans in a row)
     sl.src = xyz; sl.n = n; sl.stride = stride_bytes; sl.state = 1; sl.err.clear();
   }
-  c->stage_cv.notify_all();
+  c->stage_pending.fetch_add(1, std::memory_order_release);
+  if (c->stage_parked.load()) c->stage_cv.notify_all();
   return SO_ICP_OK;
 }
 

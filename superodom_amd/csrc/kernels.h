@@ -29,6 +29,7 @@ struct MatchParams {
   double max_point_dist;  // planeRes / 2.0 (LidarSlam.cpp:820)
   int32_t ablate;         // profiling only (env SOICP_ABLATE): bit0 skip plane fit, bit1 skip scan, bit2 skip re-rank
   unsigned long long* kdbg;  // profiling only (SOICP_ABLATE bit 7): 2 sweeps x 4*kKnnBlocks wavefront records of 16 stamps, else nullptr
+  int32_t packed_counts;  // 1: the work-list counters are in DevState::bin_packed (hash binning), 0: n_kept / n_chunks / n_light (sort path)
   uint32_t chunk_cap;     // entries of the chunk list buffer: LIGHT chunks (<= 16 queries) are listed from its top downwards
   // deferred report: when the solve of outer iteration i-1 left the publication of its state block to the k-NN launch of
   // iteration i (EvalParams::defer_publish), that launch's first workgroup writes it to hring[(i-1) & 1] (see EvalParams)
@@ -77,6 +78,9 @@ struct DevState {
   // device-side control
   int32_t outer_iter, reg_done, lm_more, n_iterations;
   uint32_t n_kept, n_chunks /* normal chunks */, n_light /* chunks of <= 16 queries, listed separately */, pad3;
+  // hash binning: the same three counters in ONE word (kept | normal << 21 | light << 42), so that a workgroup of
+  // bin_offsets_kernel reserves its three ranges with one atomic round trip instead of three (MatchParams::packed_counts)
+  unsigned long long bin_packed;
   double T[7];          // pose of the current outer iteration (T_w_lidar)
   double eval_pose[7];  // pose the next LM evaluation is requested at
   LmState S;

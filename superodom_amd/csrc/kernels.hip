@@ -96,7 +96,7 @@ __device__ __forceinline__ void reg_begin_state(DevState* st, const RegBeginArgs
   if (tid == 0) {
     st->max_outer = a.max_outer; st->lm_max = a.lm_max;
     st->outer_iter = 0; st->reg_done = 0; st->lm_more = 0; st->n_iterations = 0;
-    st->n_kept = 0; st->n_chunks = 0; st->n_light = 0;
+    st->n_kept = 0; st->n_chunks = 0; st->n_light = 0; st->bin_packed = 0ull;
   }
 }
 // stand-alone prologue (empty scan: scan_keys_kernel, which normally carries it, is not launched)
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   // every rank searches only queries whose whole gate ball lies inside its shard.  No prologue; a no-op once converged.
   if (rebin) {
     if (st->reg_done) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_kept = 0; st->n_chunks = 0; st->n_light = 0; }  // (bin_offsets / chunk_heads of this round add to them)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_kept = 0; st->n_chunks = 0; st->n_light = 0; st->bin_packed = 0ull; }  // (bin_offsets / chunk_heads of this round add to them)
   } else if (blockIdx.x == 0) {
     hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
     reg_begin_state(st, a, threadIdx.x);
@@ -236,9 +236,10 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t
       const uint32_t a = wq[w], b = wc[w], c = wl[w];
       wq[w] = sq; wc[w] = sc; wl[w] = sl; sq += a; sc += b; sl += c;
     }
-    base_q = sq ? atomicAdd(&st->n_kept, sq) : 0u;
-    base_c = sc ? atomicAdd(&st->n_chunks, sc) : 0u;
-    base_l = sl ? atomicAdd(&st->n_light, sl) : 0u;
+    // one atomic for the three ranges (21 bits each: scans of fewer than 2^21 points, checked by the host)
+    unsigned long long old = 0ull;
+    if (sq) old = atomicAdd(&st->bin_packed, (unsigned long long)sq | ((unsigned long long)sc << 21) | ((unsigned long long)sl << 42));
+    base_q = (uint32_t)(old & 0x1FFFFFull); base_c = (uint32_t)((old >> 21) & 0x1FFFFFull); base_l = (uint32_t)(old >> 42);
   }
   __syncthreads();
   if (tq) {
@@ -754,7 +755,11 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   // the report of the previous outer iteration, left to this launch by its solve (MatchParams::publish_prev)
   if (mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
     publish_state_to(mp.hring[(st->outer_iter - 1) & 1], st, mp.seq_base | (unsigned long long)st->outer_iter, (int)threadIdx.x, 256);
-  const uint32_t n_kept = st->n_kept, n_normal = st->n_chunks, n_light = st->n_light;
+  uint32_t n_kept = st->n_kept, n_normal = st->n_chunks, n_light = st->n_light;
+  if (mp.packed_counts) {
+    const unsigned long long pk = st->bin_packed;
+    n_kept = (uint32_t)(pk & 0x1FFFFFull); n_normal = (uint32_t)((pk >> 21) & 0x1FFFFFull); n_light = (uint32_t)(pk >> 42);
+  }
   // Logical order of the work list: [first half of the light chunks][normal chunks][second half of the light chunks].
   // Wavefront w takes positions w, w + 4096, ...: with up to 8 192 chunks the wavefronts that get a second chunk are the
   // ones whose first chunk is light, and their second chunk is light too -- two light chunks cost about as much as one
