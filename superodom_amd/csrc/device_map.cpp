@@ -33,6 +33,8 @@ void DeviceMap::clear() {
   std::fill(cube_slot_.begin(), cube_slot_.end(), -1);
   std::fill(slot_cube_.begin(), slot_cube_.end(), -1);
   std::fill(slot_count_.begin(), slot_count_.end(), 0u);
+  std::fill(slot_owned_.begin(), slot_owned_.end(), 0u);
+  std::fill(slot_full_.begin(), slot_full_.end(), 0u);
   slot_table_dirty_ = true;
 }
 
@@ -43,8 +45,8 @@ void DeviceMap::set_origin(const double t[3]) {  // LocalMap.h:146-164
 
 int DeviceMap::alloc_slot(int cube) {
   for (size_t s = 0; s < slot_cube_.size(); ++s)
-    if (slot_cube_[s] < 0) { slot_cube_[s] = cube; slot_count_[s] = 0; cube_slot_[cube] = (int)s; slot_table_dirty_ = true; return (int)s; }
-  slot_cube_.push_back(cube); slot_count_.push_back(0);
+    if (slot_cube_[s] < 0) { slot_cube_[s] = cube; slot_count_[s] = 0; slot_owned_[s] = 0; slot_full_[s] = 0; cube_slot_[cube] = (int)s; slot_table_dirty_ = true; return (int)s; }
+  slot_cube_.push_back(cube); slot_count_.push_back(0); slot_owned_.push_back(0); slot_full_.push_back(0);
   cube_slot_[cube] = (int)slot_cube_.size() - 1;
   slot_table_dirty_ = true;
   return cube_slot_[cube];
@@ -56,7 +58,7 @@ void DeviceMap::shift(const double t[3], int pos[3]) {
   int c[3] = {cube_coord(t[0], origin_[0]), cube_coord(t[1], origin_[1]), cube_coord(t[2], origin_[2])};
   const int dim[3] = {kMapW, kMapH, kMapD};
   auto at = [&](int i, int j, int k) -> int32_t& { return cube_slot_[cidx(i, j, k)]; };
-  auto drop = [&](int32_t& s) { if (s >= 0) { slot_cube_[s] = -1; slot_count_[s] = 0; } s = -1; };
+  auto drop = [&](int32_t& s) { if (s >= 0) { slot_cube_[s] = -1; slot_count_[s] = 0; slot_owned_[s] = 0; slot_full_[s] = 0; } s = -1; };
   bool moved = false;
   for (int axis = 0; axis < 3; ++axis) {
     while (c[axis] < 3 || c[axis] >= dim[axis] - 3) {
@@ -83,14 +85,27 @@ int DeviceMap::count_5x5(const int pos[3]) const {  // LocalMap.h:292-318
   int n = 0;
   for (int i = pos[0] - 2; i <= pos[0] + 2; ++i) for (int j = pos[1] - 2; j <= pos[1] + 2; ++j) for (int k = pos[2] - 1; k <= pos[2] + 1; ++k)
     if (i >= 0 && i < kMapW && j >= 0 && j < kMapH && k >= 0 && k < kMapD && cube_slot_[cidx(i, j, k)] >= 0)
-      n += (int)slot_count_[cube_slot_[cidx(i, j, k)]];
+      n += (int)(world_ > 1 ? slot_full_[cube_slot_[cidx(i, j, k)]] : slot_count_[cube_slot_[cidx(i, j, k)]]);
   return n;
 }
 
-size_t DeviceMap::size() const {
+size_t DeviceMap::size_local() const {
   size_t n = 0;
   for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) n += slot_count_[s];
   return n;
+}
+size_t DeviceMap::size() const {
+  if (world_ <= 1) return size_local();
+  size_t n = 0;
+  for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) n += slot_full_[s];
+  return n;
+}
+void DeviceMap::owned_counts(std::vector<int32_t>& out) const {
+  out.assign(kMapNum, 0);
+  for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) out[(size_t)slot_cube_[s]] = (int32_t)slot_owned_[s];
+}
+void DeviceMap::set_full_counts(const std::vector<int32_t>& full) {
+  for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) slot_full_[s] = (uint32_t)std::max(0, full[(size_t)slot_cube_[s]]);
 }
 
 int DeviceMap::ensure_pool(int slots_needed, std::string& err) {
@@ -117,9 +132,9 @@ int DeviceMap::ensure_work(size_t total, std::string& err) {
   if (!d_touched_) {
     DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_touched_), kMapNum));
     DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_touched_id_), kMapNum));
-    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_small_), 64 * sizeof(uint32_t)));
+    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_small_), 128 * sizeof(uint32_t)));
     DM_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_touched_), kMapNum));
-    DM_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small_), 64 * sizeof(uint32_t)));
+    DM_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small_), 128 * sizeof(uint32_t)));
   }
   if (total <= work_cap_) return 0;
   const size_t cap = total + total / 4 + 1024;
@@ -147,7 +162,7 @@ bool DeviceMap::view(DevMapView& v, std::string& err) {
   v.pts = d_pool_; v.cell_start = d_cell_start_; v.cube_slot = d_cube_slot_;
   v.nc = nc_; v.ncell1 = ncell1_; v.inv_cell = 1.0 / cell_;
   v.origin[0] = origin_[0]; v.origin[1] = origin_[1]; v.origin[2] = origin_[2];
-  v.n_points = (uint32_t)size();
+  v.n_points = (uint32_t)size_local();
   v.n_slots = (uint32_t)std::max<size_t>(1, slot_cube_.size());
   return true;
 }
@@ -159,7 +174,7 @@ int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err)
   line_res_ = line_res;
   if (plane_res == plane_res_ && nc_ > 1) return 0;
   const float old_res = plane_res_;
-  const bool had = size() > 0 && nc_ > 1;
+  const bool had = size_local() > 0 && nc_ > 1;
   plane_res_ = plane_res;
   finest_res_ = (had && finest_res_ > 0.f) ? std::min(finest_res_, std::min(old_res, plane_res)) : plane_res;
   double cell;
@@ -290,11 +305,14 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
       for (int ax = 0; ax < 3; ++ax) {
         tt.cube_min[t][ax] = w[ax] * kCube - kHalfCube;
         tt.leaf_lo[t][ax] = (int)std::floor((float)tt.cube_min[t][ax] * inv_leaf) - 2;
+        tt.wcube[t][ax] = w[ax];
       }
     }
     for (int t = tt.n; t <= kMaxTouched; ++t) tt.old_prefix[t] = n_old;
     for (int t = tt.n; t < kMaxTouched; ++t) tt.slot[t] = 0;
     if (ensure_work((size_t)n_old + n, err)) return -2;
+    a.rank = rank_; a.world = world_; a.d_owned = world_ > 1 ? d_small_ + 64 : nullptr;
+    if (world_ > 1) DM_TRY(hipMemsetAsync(d_small_ + 64, 0, kMaxTouched * sizeof(uint32_t), stream_));
     DM_TRY(hipMemcpyAsync(d_touched_id_, tid.data(), kMapNum, hipMemcpyHostToDevice, stream_));
     DM_TRY(hipMemsetAsync(d_small_, 0, 48 * sizeof(uint32_t), stream_));
     a.d_xyz = d_xyz; a.n_new = (uint32_t)n; a.stride_floats = (uint32_t)stride_floats; a.n_old = n_old;
@@ -311,12 +329,13 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     }
     a.temp = d_temp_; a.temp_bytes = temp_bytes_;
     launch_map_insert(a, stream_);
-    DM_TRY(hipMemcpyAsync(h_small_, d_small_, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+    DM_TRY(hipMemcpyAsync(h_small_, d_small_, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
     DM_TRY(hipStreamSynchronize(stream_));  // also keeps `tid` / the staging buffer alive long enough
     for (int t = 0; t < tt.n; ++t) {
       const uint32_t cnt = h_small_[8 + t];
       if (cnt > kCapPerSlot) { err = "DeviceMap: a 50 m cube exceeds the per-cube capacity of 1M points"; return -1; }
       slot_count_[tt.slot[t]] = cnt;
+      if (world_ > 1) slot_owned_[tt.slot[t]] = h_small_[64 + t];
     }
   }
   return inserted_total;

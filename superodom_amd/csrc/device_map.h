@@ -1,4 +1,4 @@
-// device_map.h -- the HBM-resident LocalMap (world_size == 1): the device pool is the authoritative store, the host
+// device_map.h -- the HBM-resident LocalMap (the whole map, or this rank's shard of it): the device pool is the authoritative store, the host
 // keeps only the block bookkeeping of include/super_odometry/LidarProcess/LocalMap.h (origin_, which block holds data,
 // per-block point counts).  Layout: every occupied 50 m cube owns a fixed region ("slot") of kCapPerSlot points in
 // one pool of {x,y,z,0} records plus its nc^3+1 cell table; canonical index = slot * kCapPerSlot + position, so a map
@@ -20,7 +20,12 @@ constexpr uint32_t kCapPerSlot = 1u << 20;  // points per cube region (16 MB); 4
 
 class DeviceMap {
  public:
-  explicit DeviceMap(hipStream_t s) : stream_(s) { origin_[0] = 10; origin_[1] = 10; origin_[2] = 5; cube_slot_.assign(kMapNum, -1); }
+  // rank / world: this rank keeps the leaves that can reach a cell within one cell of a brick it owns (see map_kernels.hip:
+  // shard_keeps_leaf); every rank inserts the SAME clouds, the per-cube point counts of the full map are summed over the
+  // ranks by the caller (owned_counts / set_full_counts) after every insert
+  explicit DeviceMap(hipStream_t s, int rank = 0, int world = 1) : stream_(s), rank_(rank), world_(world) {
+    origin_[0] = 10; origin_[1] = 10; origin_[2] = 5; cube_slot_.assign(kMapNum, -1);
+  }
   ~DeviceMap();
   // changing planeRes rebuilds the cell tables over the resident points (they are re-filtered when an insert next touches
   // their cube, like the reference); < 0: HIP error (text in err)
@@ -30,7 +35,12 @@ class DeviceMap {
   void set_origin(const double t[3]);
   void shift(const double t[3], int pos[3]);
   int count_5x5(const int pos[3]) const;
-  size_t size() const;
+  size_t size() const;        // points of the FULL map (all ranks; equals size_local() when world == 1 or before the counts were exchanged)
+  size_t size_local() const;  // points resident on this rank
+  bool sharded() const { return world_ > 1; }
+  // sharded map: per cube index, the number of resident points whose own cell this rank owns (sum over ranks = full count)
+  void owned_counts(std::vector<int32_t>& out) const;
+  void set_full_counts(const std::vector<int32_t>& full);
   void clear();
   // LocalMap::addSurfPointCloud on the device.  d_xyz: device pointer, stride in floats.  Returns #points inside the window or <0.
   int add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, std::string& err);
@@ -45,6 +55,8 @@ class DeviceMap {
   int ensure_grid(size_t gn, std::string& err);
   int alloc_slot(int cube);
   hipStream_t stream_;
+  int rank_ = 0, world_ = 1;
+  std::vector<uint32_t> slot_owned_, slot_full_;  // sharded map: see owned_counts / set_full_counts
   int origin_[3];
   float line_res_ = 0.2f, plane_res_ = 0.4f, finest_res_ = 0.f;
   int nc_ = 1; double cell_ = 50.0; uint32_t ncell1_ = 2;

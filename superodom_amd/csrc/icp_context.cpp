@@ -112,6 +112,24 @@ struct InprocGroup {
     }
     *io = total;
   }
+  // same for a vector of counters (per-cube point counts after a map insert)
+  std::vector<std::vector<int32_t>> islot; std::vector<int32_t> itotal;
+  void allreduce_i32(int rank, std::vector<int32_t>& io) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (islot.size() != (size_t)world) islot.resize((size_t)world);
+    islot[(size_t)rank] = io;
+    if (++arrived == world) {
+      itotal.assign(io.size(), 0);
+      for (int r = 0; r < world; ++r)
+        for (size_t k = 0; k < io.size() && k < islot[(size_t)r].size(); ++k) itotal[k] += islot[(size_t)r][k];
+      arrived = 0; ++generation;
+      cv.notify_all();
+    } else {
+      const unsigned long long g = generation;
+      cv.wait(lk, [&] { return generation != g; });
+    }
+    io = itotal;
+  }
 };
 std::mutex g_groups_mu;
 std::vector<std::pair<uint64_t, std::shared_ptr<InprocGroup>>> g_groups;
@@ -134,6 +152,7 @@ struct so_icp_ctx {
   // scan / correspondence buffers
   DevBuf d_scan_own, d_keys0, d_keys1, d_vals0, d_vals1, d_chunks, d_sort_tmp, d_spx, d_spy, d_spz, d_nd, d_coeff, d_status, d_nbr5;
   DevBuf d_kdbg;   // profiling only
+  DevBuf d_counts; // sharded device map: per-cube counters on their way through the all-reduce
   DevBuf d_small;  // hist[16] int32 | ticket | n_kept | fb_count | LmSums | partials
   int32_t* d_hist = nullptr; uint32_t* d_ticket = nullptr; uint32_t* d_nkept = nullptr; uint32_t* d_fbcount = nullptr;
   LmSums* d_sums = nullptr; double* d_partials = nullptr;
@@ -246,6 +265,27 @@ void spans_collect(so_icp_ctx* c) {  // stream must be idle
   }
   c->spans.clear();
   c->ev_used = 0;
+}
+
+// Sharded device map: every rank has inserted the same cloud into its shard; the per-cube point counts of the FULL map
+// (get5x5LocalMapFeatureSize, LocalMap.h:292-318, and the <= 50 check of LidarSlam.cpp:113-116 read them) are the sums of
+// the ranks' owned counts -- one small collective per insert (per scan), never per registration.
+int exchange_map_counts(so_icp_ctx* c) {
+  if (!c->dmap || !c->dmap->sharded()) return SO_ICP_OK;
+  std::vector<int32_t> v;
+  c->dmap->owned_counts(v);
+  if (c->group) {
+    c->group->allreduce_i32(c->cfg.rank, v);
+  } else if (c->comm) {
+    HIP_TRY(c, c->d_counts.reserve(v.size() * sizeof(int32_t)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_counts.p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    const ncclResult_t nrc = c->rccl.AllReduce(c->d_counts.p, c->d_counts.p, v.size(), ncclInt32, ncclSum, c->comm, c->stream);
+    if (nrc != ncclSuccess) return fail(c, SO_ICP_E_RCCL, std::string("ncclAllReduce(map counts): ") + (c->rccl.GetErrorString ? c->rccl.GetErrorString(nrc) : "?"));
+    HIP_TRY(c, hipMemcpyAsync(v.data(), c->d_counts.p, v.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }  // (a shard context without a communicator -- tests that drive the ranks one by one -- reports its own owned counts)
+  c->dmap->set_full_counts(v);
+  return SO_ICP_OK;
 }
 
 float map_plane_res(const so_icp_ctx* c) { return c->dmap ? c->dmap->plane_res() : c->map.plane_res(); }
@@ -727,7 +767,9 @@ void stage_worker(so_icp_ctx* c) {
     hipError_t e = sl.dev.reserve((n + 64) * 12);
     if (e == hipSuccess && n) {
       const float* from = src;
-      if (stride != 12) {  // strided input (e.g. 32-byte pcl::PointXYZI): pack through a pinned buffer
+      {  // always through the slot's pinned buffer (packing strided input, e.g. 32-byte pcl::PointXYZI, on the way): a copy
+         // from pinned memory runs on an SDMA engine, whereas the runtime may serve a pageable source with a blit kernel that
+         // competes for compute units with the persistent solve launch of the registration in flight
         if (sl.pinned_cap < n * 12) {
           if (sl.pinned) (void)hipHostFree(sl.pinned);
           sl.pinned = nullptr; sl.pinned_cap = 0;
@@ -736,7 +778,8 @@ void stage_worker(so_icp_ctx* c) {
         }
         if (e == hipSuccess) {
           const size_t sf = stride / 4;
-          for (size_t i = 0; i < n; ++i) { sl.pinned[3 * i] = src[i * sf]; sl.pinned[3 * i + 1] = src[i * sf + 1]; sl.pinned[3 * i + 2] = src[i * sf + 2]; }
+          if (sf == 3) std::memcpy(sl.pinned, src, n * 12);
+          else for (size_t i = 0; i < n; ++i) { sl.pinned[3 * i] = src[i * sf]; sl.pinned[3 * i + 1] = src[i * sf + 1]; sl.pinned[3 * i + 2] = src[i * sf + 2]; }
           from = sl.pinned;
         }
       }
@@ -797,7 +840,7 @@ so_icp_ctx::~so_icp_ctx() {
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1, &d_chunks,
                     &d_sort_tmp, &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist, &d_kdbg, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
-                    &pf_heads, &pf_temp, &d_bin_key, &d_bin_cnt, &d_bin_off})
+                    &pf_heads, &pf_temp, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_counts})
     b->release();
   for (DevBuf& b : resident_scans) b.release();
   d_state_buf.release();
@@ -905,9 +948,9 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_NO_DEFER")) c->no_defer = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BINNING")) c->use_binning = std::string(ev) != "sort";
-  const bool want_dmap = cfg->world_size == 1 && !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
-  if (want_dmap) {
-    c->dmap = std::make_unique<DeviceMap>(c->stream);
+  const bool want_dmap = !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
+  if (want_dmap) {  // world_size > 1: this rank's shard of the map, resident and updated on the device like the whole map is
+    c->dmap = std::make_unique<DeviceMap>(c->stream, cfg->rank, cfg->world_size);
     if (!c->dmap->supported_resolution(cfg->plane_res)) c->dmap.reset();  // leaf keys hold 9 bits per axis
     else { std::string e2; c->dmap->set_resolution(cfg->line_res, cfg->plane_res, e2); }
   }
@@ -961,7 +1004,9 @@ int so_icp_map_add_surf(so_icp_ctx* c, const float* xyz, size_t n, size_t stride
   if (c->dmap) {  // bin + VoxelGrid + index rebuild on the device (map_kernels.hip)
     HIP_TRY(c, hipSetDevice(c->cfg.device_id));
     const int r = c->dmap->add_surf_host(xyz, n, stride_bytes / 4, c->err);
-    return r < 0 ? SO_ICP_E_HIP : r;
+    if (r < 0) return r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP;
+    const int xr = exchange_map_counts(c);
+    return xr ? xr : r;
   }
   return c->map.add_surf(xyz, n, stride_bytes / 4);
 }
@@ -1241,14 +1286,14 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
       quat_rotate<double>(T + 3, (double)xyz[i * sf], (double)xyz[i * sf + 1], (double)xyz[i * sf + 2], ox, oy, oz);
       w[3 * i] = (float)(ox + T[0]); w[3 * i + 1] = (float)(oy + T[1]); w[3 * i + 2] = (float)(oz + T[2]);
     }
-    if (c->dmap) { const int r = c->dmap->add_surf_host(w.data(), n, 3, c->err); return r < 0 ? (r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP) : SO_ICP_OK; }
+    if (c->dmap) { const int r = c->dmap->add_surf_host(w.data(), n, 3, c->err); return r < 0 ? (r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP) : exchange_map_counts(c); }
     return c->map.add_surf(w.data(), n, 3) < 0 ? fail(c, SO_ICP_E_INVALID, "LocalMap insert failed") : SO_ICP_OK;
   };
   auto transform_and_add_dev = [&](const float* d_scan, const double T[7]) -> int {  // same, entirely on the device
     HIP_TRY(c, c->d_world.reserve((n + 64) * 12));
     launch_transform_scan(d_scan, (uint32_t)n, pose_from_array(T), c->d_world.as<float>(), c->stream);
     const int r = c->dmap->add_surf_dev(c->d_world.as<float>(), n, 3, c->err);
-    return r < 0 ? (r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP) : SO_ICP_OK;
+    return r < 0 ? (r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP) : exchange_map_counts(c);
   };
   if (!initialization) {  // initializeMapping, LidarSlam.cpp:83-94
     std::memcpy(pose_out, T_in, 7 * sizeof(double));
@@ -1304,7 +1349,8 @@ int so_icp_localization_dev(so_icp_ctx* c, int initialization, const double T_in
   auto transform_and_add_dev = [&](const double T[7]) -> int {  // transformAndAddToMap (LidarSlam.cpp:60-80) on the device
     HIP_TRY(c, c->d_world.reserve((n + 64) * 12));
     launch_transform_scan(static_cast<const float*>(d_scan), (uint32_t)n, pose_from_array(T), c->d_world.as<float>(), c->stream);
-    return c->dmap->add_surf_dev(c->d_world.as<float>(), n, 3, c->err) < 0 ? SO_ICP_E_HIP : SO_ICP_OK;
+    const int r = c->dmap->add_surf_dev(c->d_world.as<float>(), n, 3, c->err);
+    return r < 0 ? (r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP) : exchange_map_counts(c);
   };
   if (!initialization) {  // initializeMapping, LidarSlam.cpp:83-94
     std::memcpy(pose_out, T_in, 7 * sizeof(double));

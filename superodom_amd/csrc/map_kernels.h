@@ -17,6 +17,7 @@ struct MapTouched {
   uint32_t slot[kMaxTouched];            // pool slot of touched cube t
   uint32_t old_prefix[kMaxTouched + 1];  // exclusive prefix of the cubes' current point counts
   int32_t leaf_lo[kMaxTouched][3];       // floor(cube_min * inv_leaf) - 1: common leaf offset of the cube
+  int32_t wcube[kMaxTouched][3];         // WORLD id of the cube (shard ownership hashes it: stable under shiftMap)
   double cube_min[kMaxTouched][3];       // world coordinates of the cube's min corner
 };
 
@@ -32,6 +33,11 @@ struct MapInsertArgs {
   float4* wpts; float4* cent; float4* spts /* working set in leaf-sorted order */; uint32_t* heads /* first index of leaf o; [n_leaves] = end */;
   uint32_t *keys0, *keys1, *vals0, *vals1, *flags, *pos;
   uint32_t* d_n_cent; uint32_t* d_counts;  // [1], [kMaxTouched]
+  // sharded map (world > 1): this rank keeps the LEAVES that can put a centroid into a cell within one cell of a brick it
+  // owns (whole leaves, so that a kept centroid is the centroid of ALL the points of its leaf), and counts the points whose
+  // own cell it owns (d_owned: summed over the ranks = the cube's full point count, LocalMap.h:292-318)
+  int32_t rank, world;
+  uint32_t* d_owned;                       // [kMaxTouched], zeroed by the caller; nullptr when world == 1
   uint32_t *grid, *grid_scan;              // [tt.n * ncell1] each, or nullptr: second stage by sort + binary-search table
   void* temp; size_t temp_bytes;
 };

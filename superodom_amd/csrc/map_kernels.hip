@@ -96,10 +96,37 @@ __global__ __launch_bounds__(256) void gather_old_kernel(MapTouched tt, const fl
   vals[e] = e;
 }
 
+// Sharded map: does rank `rank` keep the leaf that the point (x, y, z) of touched cube t falls into?  The decision is a
+// function of the LEAF (its float index per axis, exactly as pcl::VoxelGrid computes it), so all the points of a leaf share
+// it and every kept centroid is the centroid of the whole leaf -- bit-identical to the unsharded map.  A leaf is kept when
+// its box (widened by the rounding of x * inv_leaf) overlaps a cell within one cell of a brick the rank owns: the shard
+// then holds every centroid that can lie in the gate ball of a query it owns.
+__device__ __forceinline__ bool shard_keeps_leaf(float x, float y, float z, float inv_leaf, const MapTouched& tt, int t, int nc,
+                                                 double inv_cell, int rank, int world) {
+  const float p[3] = {x, y, z};
+  int blo[3], bhi[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double l = (double)floorf(p[a] * inv_leaf);
+    const double leaf = 1.0 / (double)inv_leaf;
+    const double margin = 1e-3 + fabs(l * leaf) * 1e-6;
+    const double x0 = l * leaf - margin, x1 = (l + 1.0) * leaf + margin;
+    int c0 = (int)floor((x0 - tt.cube_min[t][a]) * inv_cell) - 1, c1 = (int)floor((x1 - tt.cube_min[t][a]) * inv_cell) + 1;
+    c0 = c0 < 0 ? 0 : (c0 >= nc ? nc - 1 : c0); c1 = c1 < 0 ? 0 : (c1 >= nc ? nc - 1 : c1);
+    blo[a] = c0 / kBrickCells; bhi[a] = c1 / kBrickCells;
+  }
+  for (int bz = blo[2]; bz <= bhi[2]; ++bz)
+    for (int by = blo[1]; by <= bhi[1]; ++by)
+      for (int bx = blo[0]; bx <= bhi[0]; ++bx)
+        if ((int)(brick_hash(tt.wcube[t][0], tt.wcube[t][1], tt.wcube[t][2], bx, by, bz) % (uint32_t)world) == rank) return true;
+  return false;
+}
+
 __global__ __launch_bounds__(256) void append_new_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats,
                                                          const int32_t* __restrict__ cube_of, const int8_t* __restrict__ touched_id,
                                                          MapTouched tt, float inv_leaf, uint32_t n_old, float4* __restrict__ wpts,
-                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int nc, double inv_cell,
+                                                         int rank, int world) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* p = xyz + (size_t)i * stride_floats;
@@ -110,7 +137,31 @@ __global__ __launch_bounds__(256) void append_new_kernel(const float* __restrict
   if (cube < 0) { keys[e] = 0xFFFFFFFFu; return; }  // outside the 21x21x11 window: dropped (LocalMap.h:605)
   const int t = touched_id[cube];
   if (t < 0) { keys[e] = 0xFFFFFFFFu; return; }     // a cube handled by another round of this insert
+  if (world > 1 && !shard_keeps_leaf(p[0], p[1], p[2], inv_leaf, tt, t, nc, inv_cell, rank, world)) { keys[e] = 0xFFFFFFFFu; return; }  // another rank's leaf
   keys[e] = leaf_key(p[0], p[1], p[2], inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t);
+}
+
+// sharded map: number of the cube's points whose OWN cell lies in a brick of this rank (every point of the full map is
+// counted by exactly one rank: the sum over the ranks is the block's cloud size the reference reports, LocalMap.h:292-318)
+__global__ __launch_bounds__(256) void count_owned_kernel(const float4* __restrict__ pool, uint32_t cap, MapTouched tt,
+                                                          const uint32_t* __restrict__ counts, int nc, double inv_cell, int rank, int world,
+                                                          uint32_t* __restrict__ owned) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  bool mine = false;
+  if (i < counts[t] && i < cap) {
+    const float4 p = pool[(size_t)tt.slot[t] * cap + i];
+    const float c3[3] = {p.x, p.y, p.z};
+    int g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int v = (int)floor(((double)c3[a] - tt.cube_min[t][a]) * inv_cell);
+      g[a] = v < 0 ? 0 : (v >= nc ? nc - 1 : v);
+    }
+    mine = (int)(brick_hash(tt.wcube[t][0], tt.wcube[t][1], tt.wcube[t][2], g[0] / kBrickCells, g[1] / kBrickCells, g[2] / kBrickCells) % (uint32_t)world) == rank;
+  }
+  const unsigned long long m = __ballot(mine);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&owned[t], (uint32_t)__popcll(m));
 }
 
 __global__ __launch_bounds__(256) void leaf_flags_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ flags) {
@@ -495,7 +546,7 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(gather_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0);
   if (a.n_new)
     hipLaunchKernelGGL(append_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of, a.d_touched_id,
-                       a.tt, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0);
+                       a.tt, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0, a.nc, a.inv_cell, a.rank, a.world);
   size_t tb = a.temp_bytes;
   (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable
   hipLaunchKernelGGL(leaf_flags_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, total, a.flags);
@@ -520,6 +571,9 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
                        a.inv_leaf, a.spts);  // spts (leaf-sorted working set) is free after the centroids
     hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid, a.grid_scan, a.cent, a.spts, a.tt,
                        a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1);
+    if (a.world > 1 && a.d_owned)
+      hipLaunchKernelGGL(count_owned_kernel, dim3((total + 255) / 256, a.tt.n), dim3(256), 0, s, a.pool, a.cap, a.tt, a.d_counts, a.nc, a.inv_cell,
+                         a.rank, a.world, a.d_owned);
     return;
   }
   hipLaunchKernelGGL(pad_keys_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals0, a.d_n_cent, total);
@@ -527,6 +581,9 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
   (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable: leaf order inside a cell
   hipLaunchKernelGGL(scatter_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.d_n_cent, a.cent, a.tt, a.cap, a.pool, a.d_counts);
   hipLaunchKernelGGL(table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.keys1, a.d_n_cent, a.tt, a.cap, a.ncell1, a.cell_start);
+  if (a.world > 1 && a.d_owned)
+    hipLaunchKernelGGL(count_owned_kernel, dim3((total + 255) / 256, a.tt.n), dim3(256), 0, s, a.pool, a.cap, a.tt, a.d_counts, a.nc, a.inv_cell, a.rank,
+                       a.world, a.d_owned);
 }
 // Resolution change (localMap.planeRes_ is pushed every frame, laserMapping.cpp:648-649): the points of a cube stay as they
 // are -- the reference re-filters a block only when the next insert touches it (LocalMap.h:617-641) -- only the cell

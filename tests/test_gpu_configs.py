@@ -158,7 +158,7 @@ def test_stats_flags_name_the_degraded_modes(oracle, gpu_slam_factory, soicp, mo
     sh = gpu_slam_factory(plane_res=sc.plane_res, max_surface_features=-1, max_iterations=1, rank=0, world_size=2)
     sh.add_surf_point_cloud(sc.map_points)
     rc, _, s5 = sh.register(scan, guess)
-    assert rc == 0 and (s5.flags & soicp.FLAG_SHARDED) and (s5.flags & soicp.FLAG_HOST_MAP)
+    assert rc == 0 and (s5.flags & soicp.FLAG_SHARDED) and not (s5.flags & soicp.FLAG_HOST_MAP)  # the shard is device-resident too
 
 
 def test_resolution_change_keeps_the_points_until_their_cube_is_touched(oracle, gpu_slam_factory):
@@ -251,3 +251,64 @@ def test_two_shard_ranks_follow_the_queries_across_outer_iterations(oracle, gpu_
                 assert list(a.reject_hist) == list(b.reject_hist) and list(a.obs_hist) == list(b.obs_hist), (r, it)
             ok, dt, dr = pose_close(res[r][1], pose, 1e-9, 1e-9)
             assert ok, (r, dt, dr)
+
+
+def _in_threads(fns):
+    import threading
+    res = [None] * len(fns)
+
+    def run(k):
+        res[k] = fns[k]()
+    th = [threading.Thread(target=run, args=(k,)) for k in range(len(fns))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(180)
+    assert all(r is not None for r in res), "a shard rank did not return"
+    return res
+
+
+def test_sharded_localization_keeps_the_shard_resident_and_exact(oracle, gpu_slam_factory):
+    """Localization() over consecutive scans with the map SHARDED over two ranks (both on this GPU, in-process group): each
+    rank keeps its shard in HBM and inserts every scan on the device -- whole VoxelGrid leaves, so every resident centroid
+    is bit-identical to the single-context map's, the shards' union is the whole map, the per-cube counts of the full map
+    come out of one small collective per insert, and the poses follow the single-context run."""
+    sc = synth.Scene("tiny")
+    mk = dict(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=4)
+    one = gpu_slam_factory(**mk)
+    shards = [gpu_slam_factory(rank=r, world_size=2, **mk) for r in (0, 1)]
+    for sh in shards:
+        sh.comm_init_inprocess(0x7A7A)
+    T0 = sc.gt_pose(0)
+    assert one.localization(False, T0, sc.scan(0), 0.0)[0] == 2
+    assert [r[0] for r in _in_threads([lambda sh=sh: sh.localization(False, T0, sc.scan(0), 0.0) for sh in shards])] == [2, 2]
+    n_ok = 0
+    for i in range(1, 5):
+        scan, guess = sc.scan(i), sc.guess(i)
+        rc, pose, st = one.localization(True, guess, scan, 0.1 * i)
+        res = _in_threads([lambda sh=sh: sh.localization(True, guess, scan, 0.1 * i) for sh in shards])
+        assert [r[0] for r in res] == [rc, rc]
+        assert np.array_equal(res[0][1], res[1][1])
+        if rc == 0:
+            n_ok += 1
+            for r in res:
+                assert r[2].n_iterations == st.n_iterations and r[2].laser_cloud_surf_from_map_num == st.laser_cloud_surf_from_map_num
+                for it in range(st.n_iterations):
+                    assert list(r[2].iterations[it].reject_hist) == list(st.iterations[it].reject_hist)
+                    assert list(r[2].iterations[it].obs_hist) == list(st.iterations[it].obs_hist)
+                ok, dt, dr = pose_close(r[1], pose, 1e-9, 1e-9)
+                assert ok, (i, dt, dr)
+        full = one.export_map()
+        key = lambda a: {tuple(v) for v in a.view(np.uint32).reshape(-1, 3).tolist()}
+        kfull = key(full)
+        union = set()
+        for sh in shards:
+            total, mine = sh.map_size(this_rank=True)
+            assert total == len(full), "full-map count from the per-insert collective"
+            part = sh.export_map()
+            assert len(part) == mine < len(full)
+            kp = key(part)
+            assert kp <= kfull, "every resident centroid is a centroid of the unsharded map, bit for bit"
+            union |= kp
+        assert union == kfull, "the shards cover the map"
+    assert n_ok >= 3

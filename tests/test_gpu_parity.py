@@ -423,14 +423,16 @@ def test_sharded_map_covers_every_query_exactly_once(oracle, gpu_slam_factory):
     scan, guess = sc.scan(3), sc.guess(3)
     rc, _, st = full.register(scan, guess)
     want_rej = np.array(list(st.iterations[0].reject_hist)); want_obs = np.array(list(st.iterations[0].obs_hist))
-    got_rej = np.zeros(7, int); got_obs = np.zeros(9, int); sizes = []
+    got_rej = np.zeros(7, int); got_obs = np.zeros(9, int); sizes = []; owned = []
     for rank in (0, 1):
         sh = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=1,
                               rank=rank, world_size=2)
         sh.add_surf_point_cloud(sc.map_points)
-        total, mine = sh.map_size(this_rank=True)
-        sizes.append(mine)
+        total, mine = sh.map_size(this_rank=True)  # without a communicator `total` = the points this rank OWNS (a partition of the map)
+        assert total <= mine
+        sizes.append(mine); owned.append(total)
         rc, _, s2 = sh.register(scan, guess)
         got_rej += np.array(list(s2.iterations[0].reject_hist)); got_obs += np.array(list(s2.iterations[0].obs_hist))
     assert np.array_equal(got_rej, want_rej) and np.array_equal(got_obs, want_obs)
-    assert all(0 < m < total for m in sizes), "each rank holds a strict subset of the map"
+    assert sum(owned) == len(sc.map_points), "every point is owned by exactly one rank"
+    assert all(0 < m < len(sc.map_points) for m in sizes), "each rank holds a strict subset of the map (its bricks + a one-cell halo)"
