@@ -266,6 +266,22 @@ int so_icp_comm_init(so_icp_ctx *ctx, const uint8_t id[SO_ICP_UNIQUE_ID_BYTES]);
  * and sum their records through host memory in rank order.  Every member must run the same registrations, each from its
  * own thread (a member waits inside so_icp_register until all members have contributed). */
 int so_icp_comm_init_inprocess(so_icp_ctx *ctx, uint64_t group_key);
+/* Peer exchange: the per-evaluation collective replaced by the ranks' persistent solve launches trading their 45-double
+ * records themselves -- tagged 16-byte chunks pushed into every rank's inbox (device memory mapped across processes with
+ * hipIpc, across the contexts of one process by pointer) with system-scope stores over xGMI, polled by the receiving
+ * launch.  One launch per outer iteration survives N > 1 (with a collective per evaluation the solve falls apart into
+ * ~25 launches + collectives per registration).  Transport-agnostic like the unique id above:
+ *   1. every rank: so_icp_peer_export -> handle;  2. exchange the handles (rank order) by any means;
+ *   3. every rank, at about the same time: so_icp_peer_connect (maps the inboxes and runs a self-test with the very
+ *      stores / loads of the exchange; *self_test_ok = 0 when a mapping or a chunk is missing: not an error);
+ *   4. agree on the minimum of the self-test results and call so_icp_peer_enable(agreed) on every rank -- with 0 the
+ *      context keeps the collective path (RCCL / in-process group).  The map-count collective of a map insert still needs
+ *      one of those.  While enabled, a registration that loses a rank returns SO_ICP_E_HIP (no silent fall-back: the
+ *      decision to leave the peer path would have to be collective). */
+#define SO_ICP_PEER_HANDLE_BYTES 80
+int so_icp_peer_export(so_icp_ctx *ctx, uint8_t handle[SO_ICP_PEER_HANDLE_BYTES]);
+int so_icp_peer_connect(so_icp_ctx *ctx, const uint8_t *handles /* world_size x SO_ICP_PEER_HANDLE_BYTES, rank order */, int *self_test_ok);
+int so_icp_peer_enable(so_icp_ctx *ctx, int on);
 /* brick-hash ownership of the shard (host logic, testable without a GPU) */
 int so_icp_shard_owner_of_point(const float p[3], const int origin[3], float plane_res, int world_size);
 int so_icp_cells_per_cube(float plane_res, double *cell_size);

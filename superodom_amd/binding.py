@@ -10,7 +10,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libsoicp.so")
-N_REJECT, N_OBS, MAX_OUTER, UID_BYTES = 7, 9, 16, 128
+N_REJECT, N_OBS, MAX_OUTER, UID_BYTES, PEER_HANDLE_BYTES = 7, 9, 16, 128, 80
 
 OK, NOT_ENOUGH_MAP_FEATURES, MAP_SEEDED = 0, 1, 2
 
@@ -79,7 +79,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_register_dev", "so_icp_upload_scan", "so_icp_free_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
-            "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess"]
+            "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable"]
 
 _lib = None
 
@@ -138,6 +138,9 @@ def load():
     L.so_icp_stage_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
     L.so_icp_debug_match_status.argtypes = [vp, u8p, C.c_size_t]
     L.so_icp_comm_init_inprocess.argtypes = [vp, C.c_uint64]
+    L.so_icp_peer_export.argtypes = [vp, u8p]
+    L.so_icp_peer_connect.argtypes = [vp, u8p, i32p]
+    L.so_icp_peer_enable.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -355,6 +358,21 @@ class LidarSlamGpu:
 
     def comm_init_inprocess(self, group_key):
         self._check(self.L.so_icp_comm_init_inprocess(self.h, int(group_key)))
+
+    def peer_export(self):
+        h = np.zeros(PEER_HANDLE_BYTES, np.uint8)
+        self._check(self.L.so_icp_peer_export(self.h, _p(h, C.c_uint8)))
+        return h.tobytes()
+
+    def peer_connect(self, handles):
+        """handles: list of world_size byte strings in rank order; returns the self-test result (bool)."""
+        buf = np.frombuffer(b"".join(bytes(h) for h in handles), dtype=np.uint8).copy()
+        ok = C.c_int32(0)
+        self._check(self.L.so_icp_peer_connect(self.h, _p(buf, C.c_uint8), C.byref(ok)))
+        return bool(ok.value)
+
+    def peer_enable(self, on):
+        self._check(self.L.so_icp_peer_enable(self.h, int(bool(on))))
 
     # ---- measurement ----
     def timing(self):

@@ -5,6 +5,7 @@
 // (paths relative to /root/reference/super_odometry/).  There is NO CPU fallback: without a usable
 // HIP device so_icp_create() fails and says so.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
@@ -195,6 +196,11 @@ struct so_icp_ctx {
   // RCCL
   Rccl rccl; ncclComm_t comm = nullptr;
   std::shared_ptr<InprocGroup> group;  // so_icp_comm_init_inprocess
+  // peer exchange (so_icp_peer_export / _connect / _enable): tagged-chunk push between the ranks' persistent solve launches
+  void* peer_own = nullptr;                 // this rank's inbox (uncached / fine-grained device memory)
+  void* peer_inbox[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool peer_opened[8] = {false, false, false, false, false, false, false, false};  // mapped with hipIpcOpenMemHandle (to be closed)
+  bool peer_connected = false, peer_on = false;
   // so_icp_stage_scan: a copy thread + copy stream bring the NEXT scan to HBM while the current registration runs
   struct StageSlot {
     const float* src = nullptr; size_t n = 0, stride = 0;  // identity of the staged host buffer
@@ -350,6 +356,9 @@ EvalParams eval_params(float plane_res, int variant, int ablate) {
   ep.hring[0] = ep.hring[1] = nullptr;
   ep.seq_base = 0;
   ep.n_queries = 0; ep.q_stride = 1;
+  ep.defer_publish = 0;
+  for (void*& p : ep.peer_inbox) p = nullptr;
+  ep.peer_rank = 0; ep.peer_world = 0;
   return ep;
 }
 
@@ -499,7 +508,10 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // part A: correspondences + plane fit + first evaluation; part B: the remaining evaluations + read-back
   // (concurrent hypotheses: two persistent launches could each hold part of the CUs and wait for the rest -- one launch per
   //  evaluation there; only workgroup 0 of a launch ever waits, for workgroups that finish unconditionally)
-  const bool exchange = c->comm != nullptr || c->group != nullptr;  // the sums pass through a collective between evaluation and controller
+  const bool peer = c->peer_on && c->cfg.world_size > 1 && c->persistent_solve && !c->batch_mode && !(ep.ablate & 32);
+  if (peer) { for (int r = 0; r < 8; ++r) ep.peer_inbox[r] = c->peer_inbox[r]; ep.peer_rank = c->cfg.rank; ep.peer_world = c->cfg.world_size; }
+  // (peer exchange: the ranks' persistent solve launches trade their records themselves, see EvalParams::peer_inbox)
+  const bool exchange = !peer && (c->comm != nullptr || c->group != nullptr);  // the sums pass through a collective between evaluation and controller
   const bool persistent = c->persistent_solve && !exchange && (!c->batch_mode || c->batch_single) && !(ep.ablate & 32);  // (ablated controller: per-evaluation launches)
   if (!persistent) st->flags |= SO_ICP_FLAG_PER_EVAL_LAUNCHES;
   // deferred report (see EvalParams::defer_publish): possible when the host always has the next k-NN launch in the queue
@@ -599,6 +611,9 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
         if (*seq == want) break;
         HIP_TRY(c, hipStreamSynchronize(s));
         if (*seq == want) break;
+        if (persistent && peer)
+          return fail(c, SO_ICP_E_HIP, "peer exchange: a solve launch was abandoned (a rank's records did not arrive within 50 ms, or the "
+                                       "workgroups were not co-resident); every rank must run the same registrations");
         if (persistent) {
           // The persistent solve launch needs all of its workgroups resident at once.  If the device could not provide that
           // (compute units held by another process, a partitioned device, ...) its waits gave up after 50 ms: fall back to
@@ -834,6 +849,8 @@ so_icp_ctx::~so_icp_ctx() {
     if (stage_thread.joinable()) stage_thread.join();
   }
   for (StageSlot& sl : stage) { sl.dev.release(); if (sl.pinned) (void)hipHostFree(sl.pinned); }
+  for (int r = 0; r < 8; ++r) if (peer_opened[r] && peer_inbox[r]) (void)hipIpcCloseMemHandle(peer_inbox[r]);
+  if (peer_own) (void)hipFree(peer_own);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
   for (so_icp_ctx* w : workers) delete w;
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
@@ -1497,6 +1514,73 @@ int so_icp_comm_init_inprocess(so_icp_ctx* c, uint64_t group_key) {
   if (g->members >= g->world) return fail(c, SO_ICP_E_INVALID, "so_icp_comm_init_inprocess: the group is complete already (use a new key)");
   g->members++;
   c->group = g;
+  return SO_ICP_OK;
+}
+
+// ---- peer exchange -------------------------------------------------------------------------------------------------
+namespace {
+struct PeerHandle { hipIpcMemHandle_t ipc; uint64_t pid; uint64_t ptr; };
+static_assert(sizeof(PeerHandle) == SO_ICP_PEER_HANDLE_BYTES, "SO_ICP_PEER_HANDLE_BYTES");
+}  // namespace
+
+int so_icp_peer_export(so_icp_ctx* c, uint8_t handle[SO_ICP_PEER_HANDLE_BYTES]) {
+  if (!c || !handle) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  if (c->cfg.world_size < 2 || c->cfg.world_size > kPeerMaxWorld) return fail(c, SO_ICP_E_UNSUPPORTED, "peer exchange: world_size must be 2..8");
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  PeerHandle h;
+  std::memset(&h, 0, sizeof(h));
+  if (!c->peer_own) {
+    // memory another device writes while a kernel of this one polls it: uncached (else fine-grained) device memory
+    hipError_t e = hipExtMallocWithFlags(&c->peer_own, kPeerInboxBytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&c->peer_own, kPeerInboxBytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&c->peer_own, kPeerInboxBytes); }
+    if (e != hipSuccess) { c->peer_own = nullptr; return fail(c, SO_ICP_E_HIP, std::string("peer exchange: inbox allocation: ") + hipGetErrorString(e)); }
+    HIP_TRY(c, hipMemset(c->peer_own, 0, kPeerInboxBytes));
+  }
+  if (hipIpcGetMemHandle(&h.ipc, c->peer_own) != hipSuccess) {
+    (void)hipGetLastError();  // contexts of ONE process need no IPC handle (pid + pointer below); across processes connect() will refuse
+    std::memset(&h.ipc, 0, sizeof(h.ipc));
+  }
+  h.pid = (uint64_t)getpid(); h.ptr = (uint64_t)(uintptr_t)c->peer_own;
+  std::memcpy(handle, &h, sizeof(h));
+  return SO_ICP_OK;
+}
+
+int so_icp_peer_connect(so_icp_ctx* c, const uint8_t* handles, int* self_test_ok) {
+  if (!c || !handles || !self_test_ok) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  *self_test_ok = 0;
+  if (!c->peer_own) return fail(c, SO_ICP_E_INVALID, "so_icp_peer_connect: call so_icp_peer_export first");
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  const int world = c->cfg.world_size;
+  for (int r = 0; r < world; ++r) {
+    PeerHandle h;
+    std::memcpy(&h, handles + (size_t)r * SO_ICP_PEER_HANDLE_BYTES, sizeof(h));
+    if (r == c->cfg.rank) { c->peer_inbox[r] = c->peer_own; continue; }
+    if (h.pid == (uint64_t)getpid()) { c->peer_inbox[r] = (void*)(uintptr_t)h.ptr; continue; }  // same address space
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h.ipc, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); c->err = std::string("peer exchange: hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(e); return SO_ICP_OK; }  // self_test_ok stays 0
+    c->peer_inbox[r] = p; c->peer_opened[r] = true;
+  }
+  c->peer_connected = true;
+  // self-test with the very stores / loads of the solve's exchange (every rank runs it; waits up to 2 s for the others)
+  int32_t* d_ok = reinterpret_cast<int32_t*>(c->d_fbcount);
+  HIP_TRY(c, hipMemsetAsync(d_ok, 0, 4, c->stream));
+  launch_peer_selftest(c->peer_inbox, c->cfg.rank, world, 0x7E57u, d_ok, c->stream);
+  HIP_TRY(c, hipMemcpyAsync(c->h_u32, d_ok, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *self_test_ok = c->h_u32[0] == 1 ? 1 : 0;
+  if (!*self_test_ok) c->err = "peer exchange: self-test chunks did not arrive from every rank";
+  return SO_ICP_OK;
+}
+
+int so_icp_peer_enable(so_icp_ctx* c, int on) {
+  if (!c) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  if (on && !c->peer_connected) return fail(c, SO_ICP_E_INVALID, "so_icp_peer_enable: not connected");
+  c->peer_on = on != 0;
   return SO_ICP_OK;
 }
 

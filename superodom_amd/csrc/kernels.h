@@ -53,7 +53,16 @@ struct EvalParams {
   // 1: a solve that does NOT end the registration leaves the publication to the next k-NN launch (already enqueued by the
   // host): the L2 write-back + system fence + PCIe stores (2.7 us) then overlap that sweep instead of delaying it
   int32_t defer_publish;
+  // Peer exchange (sharded map, persistent solve): every rank's inbox is mapped into this process (hipIpc, or the plain
+  // pointer for contexts of one process).  After a pass's local reduction, workgroup 0 of every rank PUSHES its record
+  // (29 sums, + 16 histogram counters in the fit pass) as tagged 16-byte chunks into every rank's inbox with system-scope
+  // stores and polls its own inbox until the chunks of all ranks carry the pass's sequence number; the records are added
+  // in rank order, so every rank holds bit-identical sums and runs the same controller -- no collective launch, no host.
+  void* peer_inbox[8];
+  int32_t peer_rank, peer_world;  // peer_world <= 1: off
 };
+constexpr int kPeerMaxWorld = 8, kPeerChunks = 48;                     // chunks per (parity, source rank): 45 used
+constexpr size_t kPeerInboxBytes = (size_t)(2 * kPeerMaxWorld * kPeerChunks + kPeerMaxWorld) * 16;  // + one self-test chunk per source
 
 // per-correspondence record written by the k-NN + plane-fit kernel, read by the evaluation kernel
 struct CorrBuffers {
@@ -86,6 +95,7 @@ struct DevState {
   LmState S;
   double JtJ[36], Jtr[6];
   DevIterStats iters[16];
+  unsigned long long peer_seq;  // peer exchange: passes exchanged so far by this context (tag and double-buffer parity; equal on all ranks)
   unsigned long long dbg[16];  // profiling aid (SOICP_ABLATE bit 7): wall-clock stamps of the last evaluation's phases
   unsigned long long seq;      // host mirror only: publication word (see EvalParams::hring), written last
 };
@@ -160,6 +170,8 @@ void launch_solve(int lm_max, const float* spx, const float* spy, const float* s
                   const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist, LmSums* d_sums,
                   const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper, uint32_t max_blocks, hipStream_t s);
 void launch_lm_step(int slot, DevState* st, const LmSums* d_sums, int32_t* d_hist, const EvalParams& ep, hipStream_t s);
+// peer exchange self-test: every rank writes a tagged chunk into every inbox and waits (<= 2 s) for all of them in its own; *d_ok = 1 on success
+void launch_peer_selftest(void* const inbox[8], int rank, int world, uint32_t tag, int32_t* d_ok, hipStream_t s);
 // Seam B
 void launch_knn_only(const float* d_q_xyz, uint32_t nq, int k, const DevMapView& map, float gate_d2, float* d_nbr,
                      float* d_d2, int32_t* d_idx, uint8_t* d_found, uint32_t* d_fallback_list,

@@ -1217,6 +1217,14 @@ __device__ __forceinline__ u4v load16_sc1(const u4v* p) {
   return v;
 }
 
+// system-scope 16-byte store / load (sc0 sc1): the peer-exchange inboxes are written over xGMI by other devices
+__device__ __forceinline__ void store16_sys(u4v* p, u4v v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u4v load16_sys(const u4v* p) {
+  u4v v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 #define SO_LM_INLINE __forceinline__  // (out of line, the callee-saved registers go through scratch: +1 us per call)
 // hand / want / pose_out (persistent solve): the controller's thread publishes the hand-off record {next pose, more?}
 // straight from its registers, BEFORE the state goes back to LDS -- the other workgroups are already evaluating the
@@ -1339,6 +1347,7 @@ struct EvalShared {
   int32_t hpart[8][16];
   int reg_done;  // set by the controller thread when the solve it just finished ends the registration
   bool is_last;
+  unsigned long long peer_seq;  // peer exchange: running pass number of this context (loaded when the launch starts)
 };
 // the (at most) two accepted correspondences a thread of a persistent solve owns, kept in LDS between the passes
 struct CorrCache {
@@ -1603,6 +1612,47 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       o[kNAcc + (tid - 32)] = (double)h;
     }
     __syncthreads();
+    if (ep.peer_world > 1) {
+      // ---- peer exchange: this rank's record to every rank's inbox, then everybody's records out of the own inbox.
+      //      Double-buffered by the parity of the pass number: a rank can run at most one pass ahead of another (it
+      //      needs that rank's record of the pass before), so a chunk is never overwritten before it was read.
+      const int nx = FIT ? (kNAcc + 16) : kNAcc;  // (the histogram counters travel with the fit pass only)
+      const unsigned int xtag = (unsigned int)(sh.peer_seq + 1ull);
+      const int par = (int)(xtag & 1u);
+      if (tid < nx) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(o[tid]);
+        const u4v v = {(unsigned int)b, (unsigned int)(b >> 32), xtag, (unsigned int)ep.peer_rank};
+        for (int p = 0; p < ep.peer_world; ++p)
+          store16_sys(reinterpret_cast<u4v*>(ep.peer_inbox[p]) + (size_t)(par * kPeerMaxWorld + ep.peer_rank) * kPeerChunks + tid, v);
+      }
+      const u4v* own = reinterpret_cast<const u4v*>(ep.peer_inbox[ep.peer_rank]) + (size_t)par * kPeerMaxWorld * kPeerChunks;
+      const int total = nx * ep.peer_world;  // <= 360 chunks: two per thread at most
+      const int c0 = tid, c1 = tid + 256;
+      const bool h0 = c0 < total, h1 = c1 < total;
+      const int s0 = h0 ? c0 / nx : 0, a0 = h0 ? c0 - s0 * nx : 0, s1 = h1 ? c1 / nx : 0, a1 = h1 ? c1 - s1 * nx : 0;
+      bool d0 = !h0, d1 = !h1;
+      unsigned long long v0 = 0, v1 = 0;
+      const unsigned long long tp = wall_clock64();
+      bool okx = true;
+      for (;;) {
+        if (!d0) { const u4v v = load16_sys(own + (size_t)s0 * kPeerChunks + a0); if (v.z == xtag) { d0 = true; v0 = ((unsigned long long)v.y << 32) | v.x; } }
+        if (!d1) { const u4v v = load16_sys(own + (size_t)s1 * kPeerChunks + a1); if (v.z == xtag) { d1 = true; v1 = ((unsigned long long)v.y << 32) | v.x; } }
+        if (__syncthreads_and((d0 && d1) ? 1 : 0)) break;
+        if (__syncthreads_or((wall_clock64() - tp > 5000000ull) ? 1 : 0)) { okx = false; break; }  // 50 ms: a rank is missing -- give up (uniformly), the host reports it
+      }
+      if (!__syncthreads_and(okx ? 1 : 0)) return kPassNotLast;
+      double (*xs)[48] = reinterpret_cast<double (*)[48]>(&red[0][0]);  // (the reduction buffer is free here)
+      if (h0) xs[s0][a0] = __longlong_as_double((long long)v0);
+      if (h1) xs[s1][a1] = __longlong_as_double((long long)v1);
+      __syncthreads();
+      if (tid < nx) {
+        double tot = 0;
+        for (int r = 0; r < ep.peer_world; ++r) tot += xs[r][tid];  // rank order: the same bits on every rank
+        o[tid] = tot;
+      }
+      if (tid == 0) sh.peer_seq = (unsigned long long)xtag;
+      __syncthreads();
+    }
     if (stamp) t_sums = wall_clock64();
     if (tid == 0) sh_more = lm_control(slot, st, sh_S, sh_sums, sh_ctl, true, hand, want, sh.pose, &sh.reg_done);  // (publishes the hand-off)
     __syncthreads();
@@ -1610,6 +1660,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     if (stamp) t_ctl = wall_clock64();
     if (!sh_more) {  // the solve is over: histogram replicas cleared for the next outer iteration, state to memory, publish
       hist[tid] = 0; hist[256 + tid] = 0;
+      if (ep.peer_world > 1 && tid == 0) st->peer_seq = sh.peer_seq;
       if (tid < (int)(sizeof(LmState) / 8))
         __hip_atomic_store(reinterpret_cast<double*>(&st->S) + tid, reinterpret_cast<const double*>(&sh_S)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // (a solve that does not end the registration may leave the report to the next k-NN launch, see EvalParams)
@@ -1773,6 +1824,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
   const unsigned long long e0 = sh.epoch;
   Pose pose = pose_from_array(st->T);
   if (tid == 0) {  // the controller's inputs are constant over the launch (read here, next to the pose: no fetch inside a pass)
+    sh.peer_seq = st->peer_seq;
     for (int i = 0; i < 3; ++i) sh.ctl.T[i] = pose.t[i];
     for (int i = 0; i < 4; ++i) sh.ctl.T[3 + i] = pose.q[i];
     sh.ctl.lm_max = st->lm_max; sh.ctl.outer_iter = st->outer_iter; sh.ctl.max_outer = st->max_outer;
@@ -2034,6 +2086,34 @@ void launch_solve(int lm_max, const float* spx, const float* spy, const float* s
 }
 void launch_lm_step(int slot, DevState* st, const LmSums* sums, int32_t* hist, const EvalParams& ep, hipStream_t s) {
   hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, s, slot, st, sums, hist, ep);
+}
+// peer exchange self-test (so_icp_peer_connect): the same stores and loads as the solve's exchange, one chunk per rank pair
+__global__ __launch_bounds__(64) void peer_selftest_kernel(EvalParams ep, uint32_t tag, int32_t* __restrict__ ok_out) {
+  const int tid = threadIdx.x;
+  const size_t base = (size_t)2 * kPeerMaxWorld * kPeerChunks;
+  if (tid < ep.peer_world) {
+    const u4v v = {0x50454552u, (unsigned int)ep.peer_rank, tag, (unsigned int)tid};
+    store16_sys(reinterpret_cast<u4v*>(ep.peer_inbox[tid]) + base + ep.peer_rank, v);
+  }
+  bool done = tid >= ep.peer_world;
+  const unsigned long long t0 = wall_clock64();
+  bool ok = true;
+  for (;;) {
+    if (!done) {
+      const u4v v = load16_sys(reinterpret_cast<const u4v*>(ep.peer_inbox[ep.peer_rank]) + base + tid);
+      if (v.z == tag && v.x == 0x50454552u && v.y == (unsigned int)tid) done = true;
+    }
+    if (__ballot(!done) == 0ull) break;
+    if (wall_clock64() - t0 > 200000000ull) { ok = false; break; }  // 2 s
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (tid == 0) *ok_out = ok ? 1 : 0;
+}
+void launch_peer_selftest(void* const inbox[8], int rank, int world, uint32_t tag, int32_t* d_ok, hipStream_t s) {
+  EvalParams ep{};
+  for (int i = 0; i < 8; ++i) ep.peer_inbox[i] = inbox[i];
+  ep.peer_rank = rank; ep.peer_world = world;
+  hipLaunchKernelGGL(peer_selftest_kernel, dim3(1), dim3(64), 0, s, ep, tag, d_ok);
 }
 void launch_knn_only(const float* q, uint32_t nq, int k, const DevMapView& map, float gate_d2, float* nbr, float* d2,
                      int32_t* idx, uint8_t* found, uint32_t* fb_list, uint32_t* fb_count, hipStream_t s) {

@@ -1,0 +1,140 @@
+"""-m gpu: the peer exchange (so_icp_peer_export / _connect / _enable) -- the ranks' persistent solve launches trade their
+records through inboxes mapped into each other's address space instead of a collective per evaluation.  Both ranks sit on
+this box's single GPU (RCCL refuses two ranks on one device; IPC handles and same-process pointers do not), each with
+SOICP_SOLVE_WORKGROUPS=100 so that the two persistent launches are co-resident:
+  * two shard contexts of ONE process, each driven from its own thread (inboxes connected by pointer);
+  * two PROCESSES (torch.multiprocessing spawn, gloo as the control plane that carries the handles and the agreement),
+    inboxes mapped with hipIpcOpenMemHandle -- the path bench.py takes for --gpus N.
+Results must equal the single-context registration: iteration counts, termination codes, histograms; poses to 1e-9."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import pose_close
+from superodom_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = ((3, 0.4, 3.0), (9, 0.1, 1.0), (14, 0.1, 1.0))  # (scan, guess dt, guess dtheta): the first needs several outer iterations
+
+
+def _reference(soicp, sc):
+    one = soicp.LidarSlamGpu(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5)
+    one.add_surf_point_cloud(sc.map_points)
+    out = [one.register(sc.scan(i), sc.guess(i, dt=dt, dth_deg=dth)) for i, dt, dth in CASES]
+    one.close()
+    return out
+
+
+def _same(a, b, tag):
+    (rc_a, pose_a, st_a), (rc_b, pose_b, st_b) = a, b
+    assert rc_a == rc_b == 0, (tag, rc_a, rc_b)
+    assert st_a.n_iterations == st_b.n_iterations, tag
+    for it in range(st_b.n_iterations):
+        x, y = st_a.iterations[it], st_b.iterations[it]
+        assert (x.lm_iterations, x.num_successful_steps, x.termination, x.num_surf_from_scan) == \
+               (y.lm_iterations, y.num_successful_steps, y.termination, y.num_surf_from_scan), (tag, it)
+        assert list(x.reject_hist) == list(y.reject_hist) and list(x.obs_hist) == list(y.obs_hist), (tag, it)
+    ok, dt, dr = pose_close(pose_a, pose_b, 1e-9, 1e-9)
+    assert ok, (tag, dt, dr)
+
+
+def test_peer_exchange_between_two_contexts_of_one_process(soicp, monkeypatch):
+    sc = synth.Scene("small")
+    ref = _reference(soicp, sc)
+    assert ref[0][2].n_iterations >= 3
+    monkeypatch.setenv("SOICP_SOLVE_WORKGROUPS", "100")
+    shards = [soicp.LidarSlamGpu(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5,
+                                 rank=r, world_size=2) for r in (0, 1)]
+    for sh in shards:
+        sh.add_surf_point_cloud(sc.map_points)
+    handles = [sh.peer_export() for sh in shards]
+    oks = [None, None]
+
+    def connect(r):
+        oks[r] = shards[r].peer_connect(handles)
+    th = [threading.Thread(target=connect, args=(r,)) for r in (0, 1)]
+    [t.start() for t in th]; [t.join(60) for t in th]
+    assert oks == [True, True], [sh.last_error() for sh in shards]
+    for sh in shards:
+        sh.peer_enable(True)
+    for k, (i, dt, dth) in enumerate(CASES):
+        scan, guess = sc.scan(i), sc.guess(i, dt=dt, dth_deg=dth)
+        res = [None, None]
+
+        def run(r):
+            res[r] = shards[r].register(scan, guess)
+        th = [threading.Thread(target=run, args=(r,)) for r in (0, 1)]
+        [t.start() for t in th]; [t.join(120) for t in th]
+        assert all(r is not None for r in res)
+        assert np.array_equal(res[0][1], res[1][1]), "both ranks hold the same sums: identical decisions, identical bits"
+        for r in (0, 1):
+            _same(res[r], ref[k], ("in-process", i, r))
+            assert not (res[r][2].flags & soicp.FLAG_PER_EVAL_LAUNCHES), "the persistent solve launch must survive N = 2"
+
+
+def _peer_worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["SOICP_SOLVE_WORKGROUPS"] = "100"
+    import torch
+    import torch.distributed as dist
+    from superodom_amd import binding as soicp, synth as sy
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = sy.Scene("small")
+        sh = soicp.LidarSlamGpu(device_id=0, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5,
+                                rank=rank, world_size=world)
+        sh.add_surf_point_cloud(sc.map_points)
+        handles = [None] * world
+        dist.all_gather_object(handles, sh.peer_export())
+        dist.barrier()
+        ok = sh.peer_connect(handles)
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        agreed = bool(t.item())
+        sh.peer_enable(agreed)
+        out = []
+        for i, dt, dth in CASES:
+            dist.barrier()
+            rc, pose, st = sh.register(sc.scan(i), sc.guess(i, dt=dt, dth_deg=dth))
+            out.append((rc, pose.tolist(), st.n_iterations, st.flags,
+                        [(st.iterations[it].lm_iterations, st.iterations[it].num_successful_steps, st.iterations[it].termination,
+                          st.iterations[it].num_surf_from_scan, list(st.iterations[it].reject_hist), list(st.iterations[it].obs_hist))
+                         for it in range(st.n_iterations)]))
+        out_q.put((rank, agreed, sh.last_error() if not agreed else "", out))
+        dist.barrier()
+        sh.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_exchange_between_two_processes_over_hip_ipc(soicp):
+    import torch.multiprocessing as mp
+    sc = synth.Scene("small")
+    ref = _reference(soicp, sc)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q)) for r in (0, 1)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1], f"hipIpc mapping / self-test failed: {res[0][2]} | {res[1][2]}"
+    for k, (i, dt, dth) in enumerate(CASES):
+        a, b = res[0][3][k], res[1][3][k]
+        assert a[0] == b[0] == 0 and a[1] == b[1], "the two processes must return identical poses"
+        assert not (a[3] & soicp.FLAG_PER_EVAL_LAUNCHES)
+        rc, pose, st = ref[k]
+        assert a[2] == st.n_iterations
+        for it in range(st.n_iterations):
+            y = st.iterations[it]
+            assert a[4][it] == (y.lm_iterations, y.num_successful_steps, y.termination, y.num_surf_from_scan, list(y.reject_hist), list(y.obs_hist)), (i, it)
+        ok, dt_, dr_ = pose_close(np.array(a[1]), pose, 1e-9, 1e-9)
+        assert ok, (i, dt_, dr_)
