@@ -96,6 +96,23 @@ def main():
         uid = [binding.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         slam.comm_init(uid[0])
+    peer = False
+    if world > 1 and not os.environ.get("SOICP_BENCH_NO_PEER"):
+        # peer exchange: the ranks' persistent solve launches trade their records through hipIpc-mapped inboxes instead of an
+        # RCCL all-reduce per evaluation.  gloo carries the handles and the agreement on the self-test (include/so_icp.h).
+        import torch
+        try:
+            handles = [None] * world
+            dist.all_gather_object(handles, slam.peer_export())
+            dist.barrier()
+            ok = slam.peer_connect(handles)
+        except Exception as e:  # noqa: BLE001 -- any failure means "use the collective path"
+            print(f"rank {rank}: peer exchange unavailable: {e}", file=sys.stderr)
+            ok = False
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        peer = bool(t.item())
+        slam.peer_enable(peer)
     n_map = slam.add_surf_point_cloud(sc.map_points)
     scans = [np.ascontiguousarray(sc.scan(i), dtype=np.float32) for i in range(args.scans)]
     if args.shuffle_scan:
@@ -152,14 +169,34 @@ def main():
         return max_over_ranks(t_local), stats, pose
 
     st = binding.Stats()
-    for w in range(args.warmup):  # untimed: the entry point of the timed loop, every scan of the rotation at least once
-        i = w % args.scans
-        if args.entry == "resident":
-            slam.register_dev(d_scans[i][0], d_scans[i][1], guesses[i], st)
-        else:
-            if args.entry == "staged":
-                slam.stage_scan(scans[i])
-            slam.register(scans[i], guesses[i])
+
+    def warm():
+        for w in range(args.warmup):  # untimed: the entry point of the timed loop, every scan of the rotation at least once
+            i = w % args.scans
+            if args.entry == "resident":
+                slam.register_dev(d_scans[i][0], d_scans[i][1], guesses[i], st)
+            else:
+                if args.entry == "staged":
+                    slam.stage_scan(scans[i])
+                slam.register(scans[i], guesses[i])
+    if peer:  # the first registrations over the peer path decide, collectively, whether the timed region uses it
+        import torch
+        try:
+            warm()
+            good = 1
+        except Exception as e:  # noqa: BLE001
+            print(f"rank {rank}: peer exchange failed in warm-up, falling back to the RCCL all-reduce: {e}", file=sys.stderr)
+            good = 0
+        t = torch.tensor([good])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if not bool(t.item()):
+            peer = False
+            slam.peer_enable(False)
+            slam.synchronize()
+            dist.barrier()
+            warm()
+    else:
+        warm()
     slam.reset_timing()
     t_max, step_stats, step_pose = timed_loop(args.entry, args.steps)
     tm = slam.timing()
@@ -286,7 +323,11 @@ def main():
                                f"full ICP loop (kNN + plane fit + Jacobian + 6x6 reduce) in HIP; " + entry_text,
                    "entry": args.entry, "queries": Q, "map_points": int(map_total), "map_points_this_rank": int(map_rank),
                    "max_iterations": max_outer, "lm_iterations": lm_iters, "plane_res": sc.plane_res, "k": 5,
-                   "parallelism": ("single GPU" if world == 1 else f"map sharded by brick-hash x{world}, 45-fp64 RCCL all-reduce per evaluation"),
+                   "parallelism": ("single GPU" if world == 1 else
+                                   (f"map sharded by brick-hash x{world}, ownership re-derived every outer iteration, persistent solve launches trading their "
+                                    f"45-double records through hipIpc-mapped inboxes over xGMI (peer exchange)" if peer else
+                                    f"map sharded by brick-hash x{world}, ownership re-derived every outer iteration, 45-fp64 RCCL all-reduce per evaluation")),
+                   "peer_exchange": bool(peer),
                    "distinct_scans": args.scans},
         "executed": {"outer_iterations_per_step": iters_outer / args.steps, "lm_iterations_per_step": iters_lm / args.steps,
                      "accepted_correspondences": accepted / args.steps, "stats_flags": int(flags),

@@ -3,7 +3,7 @@ records through inboxes mapped into each other's address space instead of a coll
 this box's single GPU (RCCL refuses two ranks on one device; IPC handles and same-process pointers do not), each with
 SOICP_SOLVE_WORKGROUPS=100 so that the two persistent launches are co-resident:
   * two shard contexts of ONE process, each driven from its own thread (inboxes connected by pointer);
-  * two PROCESSES (torch.multiprocessing spawn, gloo as the control plane that carries the handles and the agreement),
+  * two PROCESSES (multiprocessing spawn; the parent is the control plane that carries the handles and the agreement over pipes),
     inboxes mapped with hipIpcOpenMemHandle -- the path bench.py takes for --gpus N.
 Results must equal the single-context registration: iteration counts, termination codes, histograms; poses to 1e-9."""
 import os
@@ -76,59 +76,73 @@ def test_peer_exchange_between_two_contexts_of_one_process(soicp, monkeypatch):
             assert not (res[r][2].flags & soicp.FLAG_PER_EVAL_LAUNCHES), "the persistent solve launch must survive N = 2"
 
 
-def _peer_worker(rank, world, port, out_q):
+def _peer_worker(rank, world, conn):
+    """One rank = one process.  The parent is the control plane (it carries the handles, the agreement and the barriers
+    over pipes -- any transport will do, bench.py uses gloo)."""
     sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     os.environ["SOICP_SOLVE_WORKGROUPS"] = "100"
-    import torch
-    import torch.distributed as dist
     from superodom_amd import binding as soicp, synth as sy
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        sc = sy.Scene("small")
-        sh = soicp.LidarSlamGpu(device_id=0, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5,
-                                rank=rank, world_size=world)
-        sh.add_surf_point_cloud(sc.map_points)
-        handles = [None] * world
-        dist.all_gather_object(handles, sh.peer_export())
-        dist.barrier()
-        ok = sh.peer_connect(handles)
-        t = torch.tensor([1 if ok else 0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        agreed = bool(t.item())
-        sh.peer_enable(agreed)
-        out = []
-        for i, dt, dth in CASES:
-            dist.barrier()
-            rc, pose, st = sh.register(sc.scan(i), sc.guess(i, dt=dt, dth_deg=dth))
-            out.append((rc, pose.tolist(), st.n_iterations, st.flags,
-                        [(st.iterations[it].lm_iterations, st.iterations[it].num_successful_steps, st.iterations[it].termination,
-                          st.iterations[it].num_surf_from_scan, list(st.iterations[it].reject_hist), list(st.iterations[it].obs_hist))
-                         for it in range(st.n_iterations)]))
-        out_q.put((rank, agreed, sh.last_error() if not agreed else "", out))
-        dist.barrier()
-        sh.close()
-    finally:
-        dist.destroy_process_group()
+    sc = sy.Scene("small")
+    sh = soicp.LidarSlamGpu(device_id=0, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5,
+                            rank=rank, world_size=world)
+    sh.add_surf_point_cloud(sc.map_points)
+    conn.send(sh.peer_export())
+    handles = conn.recv()                 # all ranks' handles, rank order (doubles as a barrier)
+    ok = sh.peer_connect(handles)
+    conn.send((ok, sh.last_error()))
+    agreed = conn.recv()
+    sh.peer_enable(agreed)
+    out = []
+    for i, dt, dth in CASES:
+        conn.recv()                       # barrier: both ranks start the registration together
+        rc, pose, st = sh.register(sc.scan(i), sc.guess(i, dt=dt, dth_deg=dth))
+        out.append((rc, pose.tolist(), st.n_iterations, st.flags,
+                    [(st.iterations[it].lm_iterations, st.iterations[it].num_successful_steps, st.iterations[it].termination,
+                      st.iterations[it].num_surf_from_scan, list(st.iterations[it].reject_hist), list(st.iterations[it].obs_hist))
+                     for it in range(st.n_iterations)]))
+        conn.send(True)
+    conn.send(out)
+    conn.recv()
+    sh.close()
 
 
 def test_peer_exchange_between_two_processes_over_hip_ipc(soicp):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     sc = synth.Scene("small")
     ref = _reference(soicp, sc)
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1500)
-    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q)) for r in (0, 1)]
+    pipes = [ctx.Pipe() for _ in range(2)]
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, pipes[r][1])) for r in (0, 1)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    conns = [pp[0] for pp in pipes]
+
+    def recv_all():
+        out = []
+        for c in conns:
+            assert c.poll(240), "a rank process did not answer"
+            out.append(c.recv())
+        return out
+    handles = recv_all()
+    for c in conns:
+        c.send(handles)
+    oks = recv_all()
+    agreed = all(o[0] for o in oks)
+    for c in conns:
+        c.send(agreed)
+    assert agreed, f"hipIpc mapping / self-test failed: {oks}"
+    for _ in CASES:
+        for c in conns:
+            c.send("go")
+        recv_all()
+    res = recv_all()
+    for c in conns:
+        c.send("bye")
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert res[0][1] and res[1][1], f"hipIpc mapping / self-test failed: {res[0][2]} | {res[1][2]}"
     for k, (i, dt, dth) in enumerate(CASES):
-        a, b = res[0][3][k], res[1][3][k]
+        a, b = res[0][k], res[1][k]
         assert a[0] == b[0] == 0 and a[1] == b[1], "the two processes must return identical poses"
         assert not (a[3] & soicp.FLAG_PER_EVAL_LAUNCHES)
         rc, pose, st = ref[k]
