@@ -92,7 +92,7 @@ def main():
     mk = dict(device_id=device, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_iterations=max_outer, lm_max_iterations=lm_iters,
               max_surface_features=-1)
     slam = binding.LidarSlamGpu(rank=rank, world_size=world, time_kernels=2 if args.time_all_kernels else (0 if args.no_kernel_events else 1), **mk)
-    if world > 1:
+    if world > 1 and not os.environ.get("SOICP_BENCH_NO_RCCL"):  # (NO_RCCL: development on a one-GPU box, where RCCL refuses two ranks per device)
         uid = [binding.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         slam.comm_init(uid[0])
