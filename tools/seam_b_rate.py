@@ -39,6 +39,7 @@ try:
     t = time.perf_counter(); of, on, od = om.knn(sub, 5)[:3]; dc = time.perf_counter() - t
     f8 = found[::8].astype(bool)
     same = np.array_equal(np.asarray(of).astype(bool), f8) and np.array_equal(np.asarray(od)[f8].view(np.uint32), d2[::8][f8].view(np.uint32))
+    assert same, "Seam B parity violated: found flags / d2 differ from the CPU restatement"  # (the -m gpu suite checks all 28 800: tests/test_gpu_configs.py)
     print("CPU restatement (cube-restricted exact grid k-NN, one ctypes call per query, every 8th query): found flags and d2 bit-identical to the GPU: %s" % same)
 except Exception as e:  # the oracle is optional here
     print("oracle not available:", e)
