@@ -649,214 +649,6 @@ __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const d
 }
 
 // ------------------------------------------------------------------------------------------------
-// Two plane fits in ONE branch-free instruction stream.
-//
-// The fit pass runs one wavefront per SIMD (solve_kernel holds one workgroup per compute unit), and a plane fit is a
-// dependent chain of ~1400 fp64 operations (26 divisions among them): alone it issues one instruction every ~9 cycles.
-// A thread fits two queries per trip; here both chains advance in lock step, statement by statement, so that the
-// scheduler always has an independent instruction of the other query at hand.  Every query goes through exactly the
-// operations of plane_from_neighbours() above, in the same order -- bit-identical results -- but without early exits:
-// a query rejected by a gate runs on (its later results are discarded; ~94 % of the queries pass all gates anyway).
-// Only the Newton iteration keeps a loop: three predicated steps for both queries, then a (rare) wave-uniform loop for
-// near-double roots.
-// ------------------------------------------------------------------------------------------------
-#define SO_2(q) _Pragma("unroll") for (int q = 0; q < 2; ++q)
-__device__ __forceinline__ void plane_from_neighbours_x2(const float (&nb)[2][15], const double (&pw)[2][3], const Pose& pose,
-                                                         const MatchParams& mp, double (&nd)[2][4], double (&coeff)[2], int (&obs)[2][3],
-                                                         int (&status)[2]) {
-  // ---- PCA (LidarSlam.cpp:756-775, utils/superodom_utils.h:143-151)
-  double mx[2], my[2], mz[2];
-  SO_2(q) { mx[q] = 0; my[q] = 0; mz[q] = 0; }
-#pragma unroll
-  for (int j = 0; j < 5; ++j) SO_2(q) { mx[q] += (double)nb[q][3 * j]; my[q] += (double)nb[q][3 * j + 1]; mz[q] += (double)nb[q][3 * j + 2]; }
-  SO_2(q) { mx[q] = fdiv(mx[q], 5.0); my[q] = fdiv(my[q], 5.0); mz[q] = fdiv(mz[q], 5.0); }
-  double a00[2], a01[2], a02[2], a11[2], a12[2], a22[2];
-  SO_2(q) { a00[q] = 0; a01[q] = 0; a02[q] = 0; a11[q] = 0; a12[q] = 0; a22[q] = 0; }
-#pragma unroll
-  for (int j = 0; j < 5; ++j) SO_2(q) {
-    const double a = (double)nb[q][3 * j] - mx[q], b = (double)nb[q][3 * j + 1] - my[q], c = (double)nb[q][3 * j + 2] - mz[q];
-    a00[q] += a * a; a01[q] += a * b; a02[q] += a * c; a11[q] += b * b; a12[q] += b * c; a22[q] += c * c;
-  }
-  // ---- eig3_sym_direct, two-wide
-  double ev[2][3], nrm[2][3];
-  {
-    double mxn[2], c2[2], c1[2], c0[2], l[2];
-    bool zero[2], run[2];
-    SO_2(q) {
-      mxn[q] = fmax(fmax(fmax(fabs(a00[q]), fabs(a11[q])), fabs(a22[q])), fmax(fmax(fabs(a01[q]), fabs(a02[q])), fabs(a12[q])));
-      zero[q] = !(mxn[q] > 0.0);
-    }
-    SO_2(q) {
-      const double is = fdiv(1.0, zero[q] ? 1.0 : mxn[q]);
-      a00[q] *= is; a01[q] *= is; a02[q] *= is; a11[q] *= is; a12[q] *= is; a22[q] *= is;
-    }
-    SO_2(q) {
-      c2[q] = a00[q] + a11[q] + a22[q];
-      const double m00 = a11[q] * a22[q] - a12[q] * a12[q], m11 = a00[q] * a22[q] - a02[q] * a02[q], m22 = a00[q] * a11[q] - a01[q] * a01[q];
-      c1[q] = m00 + m11 + m22;
-      c0[q] = a00[q] * m00 - a01[q] * (a01[q] * a22[q] - a12[q] * a02[q]) + a02[q] * (a01[q] * a12[q] - a11[q] * a02[q]);
-      l[q] = 0.0; run[q] = !zero[q];
-    }
-    // one Newton step of both queries (a query that has stopped keeps its iterate)
-    auto newton = [&]() {
-      double f[2], df[2], step[2];
-      SO_2(q) { f[q] = ((-l[q] + c2[q]) * l[q] - c1[q]) * l[q] + c0[q]; df[q] = (-3.0 * l[q] + 2.0 * c2[q]) * l[q] - c1[q]; }
-      SO_2(q) { run[q] = run[q] && (df[q] < 0.0) && (f[q] > 0.0); }
-      SO_2(q) { step[q] = fdiv(f[q], run[q] ? df[q] : -1.0); }
-      SO_2(q) { if (run[q]) { l[q] -= step[q]; run[q] = (-step[q] > 4e-16); } }
-    };
-    newton(); newton(); newton();
-    int it = 3;
-    while (__ballot(run[0] || run[1]) != 0ull && it < 60) { newton(); ++it; }  // linear convergence towards a double root only
-    SO_2(q) { if (!(l[q] > 0.0)) l[q] = fmax(l[q], 0.0); }
-    double l1[2], l2[2];
-    SO_2(q) {
-      const double sm = c2[q] - l[q], pr = c1[q] - l[q] * sm;
-      double disc = sm * sm - 4.0 * pr;
-      disc = disc > 0.0 ? sqrt(disc) : 0.0;
-      l2[q] = 0.5 * (sm + disc);
-      l1[q] = fdiv(pr, (l2[q] > 0.0) ? l2[q] : 1.0);
-      if (!(l2[q] > 0.0)) l1[q] = 0.0;
-    }
-    SO_2(q) { ev[q][0] = l[q] * mxn[q]; ev[q][1] = l1[q] * mxn[q]; ev[q][2] = l2[q] * mxn[q]; }
-    SO_2(q) {
-      const double r00 = a00[q] - l[q], r11 = a11[q] - l[q], r22 = a22[q] - l[q];
-      const double x0 = a01[q] * a12[q] - a02[q] * r11, x1 = a02[q] * a01[q] - r00 * a12[q], x2 = r00 * r11 - a01[q] * a01[q];
-      const double y0 = a01[q] * r22 - a02[q] * a12[q], y1 = a02[q] * a02[q] - r00 * r22, y2 = r00 * a12[q] - a01[q] * a02[q];
-      const double z0 = r11 * r22 - a12[q] * a12[q], z1 = a12[q] * a02[q] - a01[q] * r22, z2 = a01[q] * a12[q] - r11 * a02[q];
-      const double nx = x0 * x0 + x1 * x1 + x2 * x2, ny = y0 * y0 + y1 * y1 + y2 * y2, nz = z0 * z0 + z1 * z1 + z2 * z2;
-      double v0 = x0, v1 = x1, v2 = x2, nn = nx;
-      if (ny > nn) { v0 = y0; v1 = y1; v2 = y2; nn = ny; }
-      if (nz > nn) { v0 = z0; v1 = z1; v2 = z2; nn = nz; }
-      const bool flat = !(nn > 0.0);
-      const double inv = rsqrt(flat ? 1.0 : nn);
-      nrm[q][0] = flat ? 1.0 : v0 * inv; nrm[q][1] = flat ? 0.0 : v1 * inv; nrm[q][2] = flat ? 0.0 : v2 * inv;
-      if (zero[q]) { ev[q][0] = ev[q][1] = ev[q][2] = 0.0; nrm[q][0] = 1.0; nrm[q][1] = 0.0; nrm[q][2] = 0.0; }
-    }
-  }
-  bool bad_pca[2];
-  SO_2(q) { bad_pca[q] = ev[q][0] < 1e-6 || fdiv(ev[q][1], ev[q][2]) < 0.1; }  // LidarSlam.cpp:772
-  // ---- plane_ls5, two-wide: column-pivoted Householder QR of the 5x3 neighbour matrix, A x = -1 (LidarSlam.cpp:798-806)
-  double A[2][3][5], bb[2][5], xs[2][3];
-  int perm[2][3];
-  bool finite[2];
-  SO_2(q) {
-    perm[q][0] = 0; perm[q][1] = 1; perm[q][2] = 2;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { A[q][0][i] = (double)nb[q][3 * i]; A[q][1][i] = (double)nb[q][3 * i + 1]; A[q][2][i] = (double)nb[q][3 * i + 2]; bb[q][i] = -1.0; }
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    double best[2], alpha[2], vn2[2], v[2][5];
-    bool act[2];
-    SO_2(q) {
-      double nrmc[3] = {0, 0, 0};
-#pragma unroll
-      for (int j = k; j < 3; ++j) {
-        double sacc = 0;
-#pragma unroll
-        for (int i = k; i < 5; ++i) sacc += A[q][j][i] * A[q][j][i];
-        nrmc[j] = sacc;
-      }
-      int piv = k;
-      best[q] = nrmc[k];
-#pragma unroll
-      for (int j = k + 1; j < 3; ++j)
-        if (nrmc[j] > best[q]) { best[q] = nrmc[j]; piv = j; }
-#pragma unroll
-      for (int j = k + 1; j < 3; ++j)
-        if (piv == j) {
-#pragma unroll
-          for (int i = 0; i < 5; ++i) { const double t = A[q][k][i]; A[q][k][i] = A[q][j][i]; A[q][j][i] = t; }
-          const int t = perm[q][k]; perm[q][k] = perm[q][j]; perm[q][j] = t;
-        }
-    }
-    SO_2(q) {
-      alpha[q] = sqrt(best[q]);
-      act[q] = alpha[q] != 0.0;
-      if (A[q][k][k] > 0) alpha[q] = -alpha[q];
-#pragma unroll
-      for (int i = k; i < 5; ++i) v[q][i] = A[q][k][i];
-      v[q][k] -= alpha[q];
-      vn2[q] = 0;
-#pragma unroll
-      for (int i = k; i < 5; ++i) vn2[q] += v[q][i] * v[q][i];
-      act[q] = act[q] && (vn2[q] != 0.0);
-    }
-#pragma unroll
-    for (int j = k + 1; j < 3; ++j) {
-      double f[2];
-      SO_2(q) {
-        double dot = 0;
-#pragma unroll
-        for (int i = k; i < 5; ++i) dot += v[q][i] * A[q][j][i];
-        f[q] = fdiv(2.0 * dot, act[q] ? vn2[q] : 1.0);
-      }
-      SO_2(q) {
-        if (act[q]) {
-#pragma unroll
-          for (int i = k; i < 5; ++i) A[q][j][i] -= f[q] * v[q][i];
-        }
-      }
-    }
-    {
-      double f[2];
-      SO_2(q) {
-        double dot = 0;
-#pragma unroll
-        for (int i = k; i < 5; ++i) dot += v[q][i] * bb[q][i];
-        f[q] = fdiv(2.0 * dot, act[q] ? vn2[q] : 1.0);
-      }
-      SO_2(q) {
-        if (act[q]) {
-#pragma unroll
-          for (int i = k; i < 5; ++i) bb[q][i] -= f[q] * v[q][i];
-          A[q][k][k] = alpha[q];
-        }
-      }
-    }
-  }
-  {
-    double y0[2], y1[2], y2[2];
-    SO_2(q) y2[q] = fdiv(bb[q][2], A[q][2][2]);
-    SO_2(q) y1[q] = fdiv(bb[q][1] - A[q][2][1] * y2[q], A[q][1][1]);
-    SO_2(q) y0[q] = fdiv(bb[q][0] - A[q][1][0] * y1[q] - A[q][2][0] * y2[q], A[q][0][0]);
-    SO_2(q) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) xs[q][a] = (perm[q][0] == a) ? y0[q] : ((perm[q][1] == a) ? y1[q] : y2[q]);
-      finite[q] = isfinite(xs[q][0]) && isfinite(xs[q][1]) && isfinite(xs[q][2]);
-    }
-  }
-  // ---- normal / offset, inlier gate, coefficient (LidarSlam.cpp:815-841, 568), observability labels
-  double nn[2], dd[2], n0[2], n1[2], n2[2], sum[2];
-  bool too_far[2];
-  SO_2(q) nn[q] = sqrt(xs[q][0] * xs[q][0] + xs[q][1] * xs[q][1] + xs[q][2] * xs[q][2]);
-  SO_2(q) dd[q] = fdiv(1.0, nn[q]);
-  SO_2(q) n0[q] = fdiv(xs[q][0], nn[q]);
-  SO_2(q) n1[q] = fdiv(xs[q][1], nn[q]);
-  SO_2(q) n2[q] = fdiv(xs[q][2], nn[q]);
-  SO_2(q) { sum[q] = 0; too_far[q] = false; }
-#pragma unroll
-  for (int j = 0; j < 5; ++j) SO_2(q) {
-    const double dist = fabs(n0[q] * (double)nb[q][3 * j] + n1[q] * (double)nb[q][3 * j + 1] + n2[q] * (double)nb[q][3 * j + 2] + dd[q]);
-    too_far[q] |= dist > mp.max_point_dist;
-    sum[q] += dist;
-  }
-  double mean_abs[2];
-  SO_2(q) mean_abs[q] = fdiv(sum[q], 5.0);
-  SO_2(q) {
-    if (pw[q][0] * nrm[q][0] + pw[q][1] * nrm[q][1] + pw[q][2] * nrm[q][2] < 0) { nrm[q][0] = -nrm[q][0]; nrm[q][1] = -nrm[q][1]; nrm[q][2] = -nrm[q][2]; }
-  }
-  SO_2(q) observability(pw[q], ev[q], nrm[q], pose, obs[q][0], obs[q][1], obs[q][2]);
-  SO_2(q) coeff[q] = 1.0 - sqrt(fdiv(mean_abs[q], (double)mp.sq_max_dist_f));
-  SO_2(q) {
-    nd[q][0] = n0[q]; nd[q][1] = n1[q]; nd[q][2] = n2[q]; nd[q][3] = dd[q];
-    status[q] = bad_pca[q] ? SO_MATCH_BAD_PCA : (!finite[q] ? SO_MATCH_INVALID : (too_far[q] ? SO_MATCH_MSE : SO_MATCH_SUCCESS));
-  }
-}
-#undef SO_2
-
-// ------------------------------------------------------------------------------------------------
 // knn_plane_kernel -- wave-cooperative exact 5-NN (the plane fit follows in eval_kernel<true>).
 //
 // A wavefront owns one CHUNK of the spatially sorted scan: <= 64 queries that shared one half-cell octant of the map
@@ -1710,56 +1502,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
         nbA[3 * t] = a.x; nbA[3 * t + 1] = a.y; nbA[3 * t + 2] = a.z;
         nbB[3 * t] = b.x; nbB[3 * t + 1] = b.y; nbB[3 * t + 2] = b.z;
       }
-      if (mp.ablate & 512) {  // profiling / test switch: the iterative (Jacobi) eigen-solver, one query after the other
-        body(jA, stA, nbA, first ? 0 : -1);
-        if (hasB) body(jB, stB, nbB, first ? 1 : -1);
-        first = false;
-        continue;
-      }
-      // ---- both queries of the trip through ONE instruction stream (plane_from_neighbours_x2)
-      const uint32_t jq[2] = {jA, jBs};
-      int stq[2] = {stA, stB};
-      float fq[2][3];
-      double pq[2][3], wq[2][3];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        fq[q][0] = spx[(size_t)jq[q] * qs]; fq[q][1] = spy[(size_t)jq[q] * qs]; fq[q][2] = spz[(size_t)jq[q] * qs];
-        pq[q][0] = (double)fq[q][0]; pq[q][1] = (double)fq[q][1]; pq[q][2] = (double)fq[q][2];
-        quat_rotate<double>(pose.q, pq[q][0], pq[q][1], pq[q][2], wq[q][0], wq[q][1], wq[q][2]);  // lidarOptimization.cpp:59 == LidarSlam.cpp:397-398
-        wq[q][0] += pose.t[0]; wq[q][1] += pose.t[1]; wq[q][2] += pose.t[2];
-      }
-      if (PERSIST && first) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { cc->px[q][tid] = fq[q][0]; cc->py[q][tid] = fq[q][1]; cc->pz[q][tid] = fq[q][2]; }
-      }
-      float nb2[2][15];
-#pragma unroll
-      for (int t = 0; t < 15; ++t) { nb2[0][t] = nbA[t]; nb2[1][t] = nbB[t]; }
-      double nd2[2][4], cf2[2];
-      int ob2[2][3], fs2[2];
-      plane_from_neighbours_x2(nb2, wq, pose, mp, nd2, cf2, ob2, fs2);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (q == 1 && !hasB) break;
-        int status = stq[q];
-        if (status == SO_MATCH_DROPPED) continue;
-        if (status == SO_MATCH_PENDING) status = fs2[q];
-        const bool okq = status == SO_MATCH_SUCCESS;
-        const double4 ndq = okq ? make_double4(nd2[q][0], nd2[q][1], nd2[q][2], nd2[q][3]) : make_double4(0, 0, 0, 0);
-        const double cq = okq ? cf2[q] : 0.0;
-        const uint32_t j = jq[q];
-        __builtin_nontemporal_store(ndq.x, &corr.nd[j].x); __builtin_nontemporal_store(ndq.y, &corr.nd[j].y);
-        __builtin_nontemporal_store(ndq.z, &corr.nd[j].z); __builtin_nontemporal_store(ndq.w, &corr.nd[j].w);
-        __builtin_nontemporal_store(cq, &corr.coeff[j]); __builtin_nontemporal_store((uint8_t)status, &corr.status[j]);
-        atomicAdd(&lh[status], 1);                                          // MatchRejectionHistogramPlane, LidarSlam.cpp:341
-        if (!okq) continue;
-        atomicAdd(&lh[7 + ob2[q][0]], 1); atomicAdd(&lh[7 + ob2[q][1]], 1); atomicAdd(&lh[7 + ob2[q][2]], 1);
-        if (PERSIST && first) {
-          cc->nx[q][tid] = ndq.x; cc->ny[q][tid] = ndq.y; cc->nz[q][tid] = ndq.z; cc->nw[q][tid] = ndq.w;
-          cc->c[q][tid] = cq;  // >= 0 marks the entry as an accepted correspondence
-        }
-        tail(pq[q][0], pq[q][1], pq[q][2], wq[q][0], wq[q][1], wq[q][2], ndq, cq);
-      }
+      body(jA, stA, nbA, first ? 0 : -1);
+      if (hasB) body(jB, stB, nbB, first ? 1 : -1);
       first = false;
     }
   } else if (PERSIST) {
