@@ -11,7 +11,7 @@ mkdir -p $OUT
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -- \
-    python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile-pass --no-secondary > /tmp/pmc_$ctr.log 2>&1
+    python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile-pass --no-secondary --entry resident > /tmp/pmc_$ctr.log 2>&1
 done
 python - $OUT <<'PY'
 import sys, glob, csv, collections, json
@@ -32,7 +32,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     real = [x for x in v if x > 0.2 * max(v)] if v else []
     res[ctr] = (sum(real) / len(real)) if real else None
     res[ctr + "_launches"] = len(real)
-j = {"kernel": "soicp::knn_plane_kernel", "round": 1,
+j = {"kernel": "soicp::knn_plane_kernel", "round": 2,
      "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, bench.py --steps 4 --warmup 1); no-op launches excluded",
      "FETCH_SIZE_KB_per_launch": res["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": res["WRITE_SIZE"],
      "launches": [res["FETCH_SIZE_launches"], res["WRITE_SIZE_launches"]],
