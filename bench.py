@@ -50,8 +50,8 @@ def _load_json(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="os1_128_2m")
     ap.add_argument("--scans", type=int, default=4, help="distinct synthetic scans cycled through the steps")
     ap.add_argument("--entry", default="staged", choices=["staged", "host", "resident"],

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-run}
 cd $R
 mkdir -p gpurun_out
-python bench.py --steps 240 --warmup 8 2> gpurun_out/bench_$TAG.err | tail -1 > gpurun_out/bench_$TAG.json
+python bench.py 2> gpurun_out/bench_$TAG.err | tail -1 > gpurun_out/bench_$TAG.json
 cat gpurun_out/bench_$TAG.json
 bash tools/prof_stats.sh $TAG 2>&1 | tail -40
 bash tools/pmc_traffic.sh $TAG 2>&1 | tail -3
