@@ -12,10 +12,12 @@ the next scan is announced with so_icp_stage_scan (copy thread + copy stream) wh
 node's feature callback would (laserMapping.cpp:21-25 receives the cloud long before process() reaches it).  The same
 line carries the resident-scan rate (so_icp_register_dev, no copy) and the serial rate (so_icp_register, copy then register).
 
-N > 1 (configs[3]): one process per GPU; the map is sharded by brick-hash of the voxel grid, every rank registers the
-SAME scan over its shard and the 45 fp64 normal-equation scalars are all-reduced over RCCL once per evaluation -> total
-work is fixed: "scaling": "strong".  Every line also carries `batch64` (configs[4]): 64 hypotheses per scan, the map
-replicated, the hypotheses split over the ranks, no collective.
+N > 1 (configs[3]): one process per GPU; the map is sharded by brick-hash of the voxel grid (device-resident shards, query
+ownership re-derived every outer iteration), every rank registers the SAME scan over its shard, and the 45 fp64
+normal-equation scalars of every evaluation are summed over the ranks -- by the persistent solve launches themselves
+through hipIpc-mapped inboxes (peer exchange; gloo carries the handles and the agreement on its self-test), or, when that
+is unavailable, by an RCCL all-reduce per evaluation -> total work is fixed: "scaling": "strong".  Every line also carries
+`batch64` (configs[4]): 64 hypotheses per scan, the map replicated, the hypotheses split over the ranks, no collective.
 
 Rank 0 prints ONE JSON line with the roofline of the dominant (k-NN) kernel, measured with HIP events attached to the
 kernel's dispatch on the library's stream inside the timed region, and the CPU baselines (Oracle-A = restatement with an
