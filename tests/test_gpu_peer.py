@@ -42,38 +42,45 @@ def _same(a, b, tag):
     assert ok, (tag, dt, dr)
 
 
-def test_peer_exchange_between_two_contexts_of_one_process(soicp, monkeypatch):
+@pytest.mark.parametrize("world,wgs", [(2, 100), (4, 60), (8, 30)])
+def test_peer_exchange_between_contexts_of_one_process(soicp, monkeypatch, world, wgs):
+    """N = 2, 4, 8 shard contexts on this one GPU (N x wgs <= 256 compute units, so that all persistent solve launches are
+    co-resident), each driven from its own thread; the map-count collective of the inserts goes through an in-process group."""
     sc = synth.Scene("small")
     ref = _reference(soicp, sc)
     assert ref[0][2].n_iterations >= 3
-    monkeypatch.setenv("SOICP_SOLVE_WORKGROUPS", "100")
+    monkeypatch.setenv("SOICP_SOLVE_WORKGROUPS", str(wgs))
+    ranks = list(range(world))
     shards = [soicp.LidarSlamGpu(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5,
-                                 rank=r, world_size=2) for r in (0, 1)]
+                                 rank=r, world_size=world) for r in ranks]
     for sh in shards:
-        sh.add_surf_point_cloud(sc.map_points)
-    handles = [sh.peer_export() for sh in shards]
-    oks = [None, None]
+        sh.comm_init_inprocess(0x9000 + world)
 
-    def connect(r):
-        oks[r] = shards[r].peer_connect(handles)
-    th = [threading.Thread(target=connect, args=(r,)) for r in (0, 1)]
-    [t.start() for t in th]; [t.join(60) for t in th]
-    assert oks == [True, True], [sh.last_error() for sh in shards]
+    def in_threads(fn):
+        out = [None] * world
+
+        def run(r):
+            out[r] = fn(r)
+        th = [threading.Thread(target=run, args=(r,)) for r in ranks]
+        [t.start() for t in th]; [t.join(180) for t in th]
+        assert all(o is not None for o in out), "a rank did not return"
+        return out
+    in_threads(lambda r: shards[r].add_surf_point_cloud(sc.map_points) or True)  # collective: the full-map counts are summed
+    sizes = [sh.map_size(this_rank=True) for sh in shards]
+    assert all(t == len(sc.map_points) and m < t for t, m in sizes)
+    handles = [sh.peer_export() for sh in shards]
+    oks = in_threads(lambda r: shards[r].peer_connect(handles))
+    assert oks == [True] * world, [sh.last_error() for sh in shards]
     for sh in shards:
         sh.peer_enable(True)
     for k, (i, dt, dth) in enumerate(CASES):
         scan, guess = sc.scan(i), sc.guess(i, dt=dt, dth_deg=dth)
-        res = [None, None]
-
-        def run(r):
-            res[r] = shards[r].register(scan, guess)
-        th = [threading.Thread(target=run, args=(r,)) for r in (0, 1)]
-        [t.start() for t in th]; [t.join(120) for t in th]
-        assert all(r is not None for r in res)
-        assert np.array_equal(res[0][1], res[1][1]), "both ranks hold the same sums: identical decisions, identical bits"
-        for r in (0, 1):
-            _same(res[r], ref[k], ("in-process", i, r))
-            assert not (res[r][2].flags & soicp.FLAG_PER_EVAL_LAUNCHES), "the persistent solve launch must survive N = 2"
+        res = in_threads(lambda r: shards[r].register(scan, guess))
+        for r in ranks:
+            assert np.array_equal(res[r][1], res[0][1]), "all ranks hold the same sums: identical decisions, identical bits"
+            _same(res[r], ref[k], ("in-process", world, i, r))
+            assert res[r][2].laser_cloud_surf_from_map_num == ref[k][2].laser_cloud_surf_from_map_num
+            assert not (res[r][2].flags & soicp.FLAG_PER_EVAL_LAUNCHES), "the persistent solve launch must survive N > 1"
 
 
 def _peer_worker(rank, world, conn):
