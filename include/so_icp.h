@@ -264,7 +264,9 @@ int so_icp_comm_init(so_icp_ctx *ctx, const uint8_t id[SO_ICP_UNIQUE_ID_BYTES]);
 /* The same exchange without RCCL, for the shard contexts of ONE process (one thread + one context per GPU of the node, or
  * several shard contexts on one GPU in a test): the contexts that pass the same key form a group of cfg.world_size members
  * and sum their records through host memory in rank order.  Every member must run the same registrations, each from its
- * own thread (a member waits inside so_icp_register until all members have contributed). */
+ * own thread (a member waits inside so_icp_register until all members have contributed).  The streams of one process share its
+ * hardware queues (HIP: GPU_MAX_HW_QUEUES, 4 by default): with the peer exchange enabled, where every member's solve launch
+ * must be running at the same time, keep the number of members per DEVICE at or below that. */
 int so_icp_comm_init_inprocess(so_icp_ctx *ctx, uint64_t group_key);
 /* Peer exchange: the per-evaluation collective replaced by the ranks' persistent solve launches trading their 45-double
  * records themselves -- tagged 16-byte chunks pushed into every rank's inbox (device memory mapped across processes with
