@@ -1,11 +1,15 @@
 #!/bin/bash
-# development aid: bench.py with 2 ranks on ONE GPU (peer exchange only; RCCL refuses two ranks per device)
+# development aid: bench.py with N ranks on ONE GPU (peer exchange only; RCCL refuses two ranks per device).
+# usage: bash tools/two_rank_one_gpu.sh [N=2]   -- N x SOICP_SOLVE_WORKGROUPS must stay <= the device's compute units
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-export SOICP_BENCH_DEVICE=0 SOICP_BENCH_NO_RCCL=1 SOICP_SOLVE_WORKGROUPS=100
-timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29711 bench.py --gpus 2 --steps 24 --warmup 4 --no-cpu-baseline 2> gpurun_out/two_rank.err | tail -1 > gpurun_out/two_rank.json
-tail -5 gpurun_out/two_rank.err
+N=${1:-2}
+export SOICP_BENCH_DEVICE=0 SOICP_BENCH_NO_RCCL=1 SOICP_SOLVE_WORKGROUPS=$((200 / N))
+mkdir -p gpurun_out
+timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29711 bench.py --gpus $N --steps 24 --warmup 4 --no-cpu-baseline 2> gpurun_out/ranks$N.err | tail -1 > gpurun_out/ranks$N.json
+grep -v "hostname of the client\|amdgpu.ids\|^$" gpurun_out/ranks$N.err | tail -5
 python - <<PY
 import json
-d=json.load(open("gpurun_out/two_rank.json"))
-print(d["value"], d["ms_per_step"], d["config"]["parallelism"], d["config"]["peer_exchange"], d["entry_points"], d["kernels"], d["batch64"]["value"], d["executed"])
+d=json.load(open("gpurun_out/ranks$N.json"))
+print("N=$N value %.0f reg/s (%.3f ms) peer_exchange=%s | %s" % (d["value"], d["ms_per_step"], d["config"]["peer_exchange"], d["config"]["parallelism"][:60]))
+print("   entry_points", {k: round(v) for k, v in d["entry_points"].items() if k != "note"}, "| batch64 %.0f (%d per rank) | executed %s" % (d["batch64"]["value"], d["batch64"]["hypotheses_per_rank"], d["executed"]))
 PY
