@@ -269,7 +269,7 @@ def main():
         batch = {"value": 64 * reps / t_b, "unit": "registrations/s", "hypotheses_per_scan": 64, "scans": reps,
                  "hypotheses_per_rank": len(mine), "ms_per_batch": 1e3 * t_b / reps, "returned_ok": ok, "within_2cm_of_ground_truth": good,
                  "outer_iterations_per_hypothesis": outer_b / (64.0 * reps),
-                 "parallelism": f"map replicated on {world} GPU(s), hypotheses split over the ranks, up to 8 concurrent lanes per GPU, no collective",
+                 "parallelism": f"map replicated on {world} GPU(s), hypotheses split over the ranks, up to 16 concurrent lanes per GPU, no collective",
                  "scaling": "strong"}
         if world > 1:
             full.close()

@@ -1165,8 +1165,8 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
   std::memcpy(c->last_pos, pos, sizeof(pos));
   int rc = upload_map(c);
   if (rc) return rc;
-  static const int want_lanes = std::getenv("SOICP_BATCH_LANES") ? std::atoi(std::getenv("SOICP_BATCH_LANES")) : 8;
-  const int lanes = std::max(1, std::min({want_lanes, n_hyp, 8}));
+  static const int want_lanes = std::getenv("SOICP_BATCH_LANES") ? std::atoi(std::getenv("SOICP_BATCH_LANES")) : 16;
+  const int lanes = std::max(1, std::min({want_lanes, n_hyp, 64}));
   // worker contexts: own stream / buffers / device state, no map of their own (they borrow this context's resident map)
   while ((int)c->workers.size() < lanes - 1) {
     so_icp_config wc = c->cfg;

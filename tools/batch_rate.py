@@ -27,5 +27,5 @@ for i in range(a.scans + 1):
     slam.free_scan(d)
 errs = np.array(errs)
 print("lanes %s: %d hypotheses/scan, %.2f ms per batch, %.0f registrations/s; converged to < 1 cm: %d / %d; outer iterations of the last batch: mean %.2f" % (
-    os.environ.get("SOICP_BATCH_LANES", "8"), a.hyp, 1e3 * tot_t / a.scans, a.hyp * a.scans / tot_t, int(np.sum(errs < 0.01)), len(errs),
+    os.environ.get("SOICP_BATCH_LANES", "16"), a.hyp, 1e3 * tot_t / a.scans, a.hyp * a.scans / tot_t, int(np.sum(errs < 0.01)), len(errs),
     np.mean([s.n_iterations for s in sts])))
