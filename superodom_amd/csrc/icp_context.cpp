@@ -212,10 +212,6 @@ struct so_icp_ctx {
   bool stage_quit = false, stage_started = false;
   std::atomic<int> stage_pending{0};      // queued slots the copy thread has not picked up yet
   std::atomic<bool> stage_parked{false};  // the copy thread sleeps on stage_cv (it spins for a while after every job first)
-  // what the registration thread is doing: 0 idle, 1 enqueuing launches, 2 waiting for the device.  The copy thread submits its
-  // copy only while this is not 1: two threads inside the HIP runtime at once delay each other's submissions (runtime locks),
-  // and the registration's launches are on the critical path whereas the copy has a whole registration of slack
-  std::atomic<int> host_phase{0};
   std::thread stage_thread; std::mutex stage_mu; std::condition_variable stage_cv;
   hipStream_t copy_stream = nullptr;
   bool retried = false;       // the current registration is the repeat of an abandoned one
@@ -414,7 +410,6 @@ void yaw_correction(double T[7], const double last[7], double yaw_ratio) {
 constexpr int kRetryWithoutPersistentSolve = -1000;  // internal: never leaves register_core
 int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const double pose_in[7], double pose_out[7], so_icp_stats* st) {
   const auto t_begin = std::chrono::steady_clock::now();
-  struct PhaseGuard { std::atomic<int>& p; explicit PhaseGuard(std::atomic<int>& q) : p(q) { p.store(1, std::memory_order_release); } ~PhaseGuard() { p.store(0, std::memory_order_release); } } phase_guard(c->host_phase);
   so_icp_stats local;
   if (!st) st = &local;
   std::memset(st, 0, sizeof(*st));
@@ -608,7 +603,6 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     if (!direct_rb) { HIP_TRY(c, hipEventSynchronize(c->ev_outer[it & 1])); return SO_ICP_OK; }
     volatile unsigned long long* seq = &c->h_ring[it & 1]->seq;
     const unsigned long long want = seq_base | (unsigned long long)(it + 1);
-    struct Waiting { std::atomic<int>& p; explicit Waiting(std::atomic<int>& q) : p(q) { p.store(2, std::memory_order_release); } ~Waiting() { p.store(1, std::memory_order_release); } } waiting(c->host_phase);
     for (unsigned spin = 1;; ++spin) {
       if (*seq == want) break;
       if ((spin & 0x3FFu) == 0 && hipEventQuery(c->ev_outer[it & 1]) == hipSuccess) {
@@ -803,10 +797,6 @@ void stage_worker(so_icp_ctx* c) {
           else for (size_t i = 0; i < n; ++i) { sl.pinned[3 * i] = src[i * sf]; sl.pinned[3 * i + 1] = src[i * sf + 1]; sl.pinned[3 * i + 2] = src[i * sf + 2]; }
           from = sl.pinned;
         }
-      }
-      if (e == hipSuccess) {  // submit while the registration thread is not inside its own launches (bounded wait)
-        const auto tq = std::chrono::steady_clock::now();
-        while (c->host_phase.load(std::memory_order_acquire) == 1 && std::chrono::steady_clock::now() - tq < std::chrono::microseconds(300)) __builtin_ia32_pause();
       }
       if (e == hipSuccess) e = hipMemcpyAsync(sl.dev.p, from, n * 12, hipMemcpyHostToDevice, c->copy_stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
