@@ -163,7 +163,9 @@ int so_icp_map_set_origin(so_icp_ctx *ctx, const double t_w_cur[3], int origin_o
 int so_icp_map_shift(so_icp_ctx *ctx, const double t_w_cur[3], int pos_in_map[3]);      /* LocalMap::shiftMap,  LM.h:169-287 */
 /* LocalMap::addSurfPointCloud, LM.h:591-645: world-frame points (stride in bytes, 12 for packed xyz,
  * 32 for pcl::PointXYZI); bins into 50 m cubes, VoxelGrid(planeRes) per touched cube, rebuilds the
- * device index.  Returns the number of points that fell inside the 21x21x11 window, or <0. */
+ * device index.  Returns the number of points that fell inside the 21x21x11 window, or <0.
+ * world_size > 1: every rank passes the SAME cloud and keeps its shard of it; with a communicator (RCCL or in-process
+ * group) the call is collective -- the per-block point counts of the full map are summed over the ranks. */
 int so_icp_map_add_surf(so_icp_ctx *ctx, const float *xyz, size_t n, size_t stride_bytes);
 int so_icp_map_count_5x5(so_icp_ctx *ctx, const int pos[3], int *n_edge, int *n_surf);  /* get5x5LocalMapFeatureSize, LM.h:292-318 */
 /* getAllLocalMap / get5x5LocalMap (LM.h:646-688): points in the canonical (device) order */

@@ -68,9 +68,11 @@ def test_all_32_seeded_scans_of_the_trajectory(oracle, gpu_slam_factory, scene):
     for i in range(32):
         scan, guess, gt = sc.scan(i), sc.guess(i), sc.gt_pose(i)
         rc, pose, st = slam.register(scan, guess)
-        orc, opose, ost, _ = om.register(scan, guess, cfg)
+        orc, opose, ost, corrs = om.register(scan, guess, cfg, want_corrs=True)
         assert rc == orc == 0, (scene, i)
         _assert_registration_equal(st, ost, pose, opose, (scene, i))
+        # per-query MatchingResult of the last outer iteration: the accepted sets are the SAME set (Jaccard 1), not just equally large
+        assert np.array_equal(slam.match_status(len(scan)), corrs["status"].astype(np.uint8)), (scene, i)
         e = synth.pose_error(pose, gt)
         assert e[0] < 0.05 and e[1] < 0.02, (scene, i, e)
         outer.append(st.n_iterations)
