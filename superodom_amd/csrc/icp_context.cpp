@@ -842,6 +842,12 @@ int resolve_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes,
 }  // namespace
 
 so_icp_ctx::~so_icp_ctx() {
+  if (group) {  // the registry forgets a group when its last member goes
+    std::lock_guard<std::mutex> lk(g_groups_mu);
+    if (--group->members <= 0)
+      for (size_t i = 0; i < g_groups.size(); ++i)
+        if (g_groups[i].second == group) { g_groups.erase(g_groups.begin() + (long)i); break; }
+  }
   if (stage_started) {
     { std::lock_guard<std::mutex> lk(stage_mu); stage_quit = true; }
     stage_pending.fetch_add(1);
