@@ -163,6 +163,7 @@ struct so_icp_ctx {
   DevState* d_ring[2] = {nullptr, nullptr};  // device-side addresses of the pinned mirrors
   bool direct_readback = true; unsigned long long reg_counter = 0;
   bool persistent_solve = true;  // SOICP_PERSISTENT=0: one launch per evaluation
+  unsigned long long solve_launches = 0;  // persistent solve launches so far (EvalParams::epoch_base)
   bool use_binning = true;       // SOICP_BINNING=sort: rocPRIM sort of (key, index) pairs + run-based chunk list
   DevBuf d_bin_key, d_bin_cnt, d_bin_off; uint32_t bin_log2 = 0; bool bin_dirty = true;
   int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
@@ -357,6 +358,7 @@ EvalParams eval_params(float plane_res, int variant, int ablate) {
   ep.seq_base = 0;
   ep.n_queries = 0; ep.q_stride = 1;
   ep.defer_publish = 0;
+  ep.epoch_base = 0;
   for (void*& p : ep.peer_inbox) p = nullptr;
   ep.peer_rank = 0; ep.peer_world = 0;
   return ep;
@@ -584,6 +586,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     if (persistent) {  // the whole solve in one launch (workgroups hand the next pose to each other on the device)
       EvalParams ep_it = ep;
       ep_it.defer_publish = deferred ? 1 : 0;
+      ep_it.epoch_base = (++c->solve_launches) << 5;
       span_begin(c, 1, (uint32_t)n);
       launch_solve(lm_max, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep_it, c->d_partials, c->d_ticket,
                    c->d_hist, c->d_sums, c->view, c->d_nbr5.as<uint32_t>(), mp, (uint32_t)n, (uint32_t)c->n_cus, s);

@@ -53,6 +53,8 @@ struct EvalParams {
   // 1: a solve that does NOT end the registration leaves the publication to the next k-NN launch (already enqueued by the
   // host): the L2 write-back + system fence + PCIe stores (2.7 us) then overlap that sweep instead of delaying it
   int32_t defer_publish;
+  // persistent solve: epoch base of the launch (hand-off epochs and pass tags count up from it; strictly increasing per context)
+  unsigned long long epoch_base;
   // Peer exchange (sharded map, persistent solve): every rank's inbox is mapped into this process (hipIpc, or the plain
   // pointer for contexts of one process).  After a pass's local reduction, workgroup 0 of every rank PUSHES its record
   // (29 sums, + 16 histogram counters in the fit pass) as tagged 16-byte chunks into every rank's inbox with system-scope

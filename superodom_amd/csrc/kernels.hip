@@ -1341,7 +1341,6 @@ struct EvalShared {
   LmState S;
   LmCtl ctl;
   double pose[7];
-  unsigned long long epoch;
   int more;
   int32_t lh[16];
   int32_t hpart[8][16];
@@ -1817,11 +1816,9 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
   // unit), so a reader that sees the expected epoch in a chunk has that chunk's value: no second round trip, no
   // publisher-side wait between data and flag.  Chunks 0..6 = next pose, chunk 7 = "another evaluation follows".
   u4v* hand = reinterpret_cast<u4v*>(ticket + kHandoffWordOffset);
-  // epoch before this launch: read before this workgroup adds its first arrival, i.e. before the controller of this
-  // launch can have advanced it
-  if (tid == 0) { const u4v v = load16_sc1(hand + 7); sh.epoch = ((unsigned long long)v.w << 32) | v.z; }
-  __syncthreads();
-  const unsigned long long e0 = sh.epoch;
+  // epoch base of this launch: a kernel argument (the host counts its solve launches; 32 epochs per launch), larger than
+  // every epoch an earlier launch left in the hand-off record -- no memory round trip before the first pass can start
+  const unsigned long long e0 = ep.epoch_base;
   Pose pose = pose_from_array(st->T);
   if (tid == 0) {  // the controller's inputs are constant over the launch (read here, next to the pose: no fetch inside a pass)
     sh.peer_seq = st->peer_seq;
