@@ -259,7 +259,9 @@ typedef struct {
 int so_icp_prefilter_scan(so_icp_ctx *ctx, const float *surf_xyz, size_t n, size_t stride_bytes, int auto_voxel_size,
                           float line_res, float plane_res, void **d_filtered_out, size_t *n_out, so_icp_prefilter_info *info);
 
-/* -------- multi-GPU: one process per GPU, one collective (sum of 45 fp64) per evaluation ------- */
+/* -------- multi-GPU: one process per GPU; the map is sharded by brick-hash of the voxel grid and the 45 fp64 sums of every
+ * evaluation are summed over the ranks: by RCCL (below), by an in-process group, or by the solve launches themselves
+ * (peer exchange, further below) -------------------------------------------------------------------------------------- */
 #define SO_ICP_UNIQUE_ID_BYTES 128
 int so_icp_comm_unique_id(uint8_t id[SO_ICP_UNIQUE_ID_BYTES]);                 /* rank 0: ncclGetUniqueId */
 int so_icp_comm_init(so_icp_ctx *ctx, const uint8_t id[SO_ICP_UNIQUE_ID_BYTES]); /* all ranks: ncclCommInitRank on ctx->rank/world_size */

@@ -11,9 +11,10 @@
 //                       coefficient, observability labels; LidarSlam.cpp:514-693) + every LM evaluation (residual,
 //                       Tukey x coefficient weight, 6-DoF Jacobian, the 21+6+1+1 fp64 normal-equation sums;
 //                       lidarOptimization.cpp:55-80) + the Ceres-equivalent LM controller (lm_solver.h), with
-//                       device-side hand-offs between the passes
-//   eval_kernel / lm_step_kernel   the same passes as one launch per evaluation (sharded map: the sums pass through the
-//                       RCCL all-reduce; concurrent hypotheses of so_icp_register_batch)
+//                       device-side hand-offs between the passes; with a sharded map (N > 1) the ranks' launches trade their
+//                       records through peer-mapped inboxes (EvalParams::peer_inbox) and every rank runs the controller
+//   eval_kernel / lm_step_kernel   the same passes as one launch per evaluation (sharded map without the peer exchange: the
+//                       sums pass through a collective; concurrent hypotheses of so_icp_register_batch)
 //   knn_only / knn_fallback   Seam B (LocalMap::nearestKSearchSurf, LocalMap.h:481-525)
 //
 // Nothing here is a dense contraction, so no MFMA: these are HBM/latency-bound gather-scan-reduce
