@@ -194,7 +194,8 @@ int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t str
  * so_icp_localization with the SAME (scan_xyz, n, stride_bytes) consumes the staged copy instead of uploading again
  * (so_icp_stats::flags carries SO_ICP_FLAG_STAGED_SCAN); any other call simply ignores it.  The caller's buffer must stay
  * valid and unchanged until that call (or the next so_icp_stage_scan) returns.  Two slots: one scan may be staged while
- * the previous one is being registered. */
+ * the previous one is being registered.  Unlike the other entry points this one may be called from ANOTHER thread than
+ * the registration calls (the node's feature callback, lmap.cpp:21-25). */
 int so_icp_stage_scan(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes);
 /* same, scan already resident in HBM as packed float xyz (n*3 floats, device pointer) */
 int so_icp_register_dev(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n,

@@ -206,9 +206,10 @@ struct so_icp_ctx {
   struct StageSlot {
     const float* src = nullptr; size_t n = 0, stride = 0;  // identity of the staged host buffer
     DevBuf dev; float* pinned = nullptr; size_t pinned_cap = 0;
-    int state = 0;  // 0 empty, 1 queued, 2 ready, -1 failed
+    int state = 0;  // 0 empty, 1 queued (the copy thread owns it), 2 ready, 3 in use by the registration in flight, -1 failed
     std::string err;
   } stage[2];
+  StageSlot* stage_in_use = nullptr;  // the slot the current registration reads (released when the call returns)
   int stage_next = 0;
   bool stage_quit = false, stage_started = false;
   std::atomic<int> stage_pending{0};      // queued slots the copy thread has not picked up yet
@@ -817,18 +818,25 @@ void stage_worker(so_icp_ctx* c) {
 // slot is staged again, i.e. for the whole call that took it.)
 const float* take_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, int* rc) {
   *rc = SO_ICP_OK;
-  if (!c->stage_started) return nullptr;
   std::unique_lock<std::mutex> lk(c->stage_mu);
+  if (!c->stage_started) return nullptr;
   for (so_icp_ctx::StageSlot& sl : c->stage) {
     if (sl.state == 0 || sl.src != xyz || sl.n != n || sl.stride != stride_bytes) continue;
     c->stage_cv.wait(lk, [&] { return sl.state != 1; });
     const int state = sl.state;
-    sl.state = 0; sl.src = nullptr;
-    if (state == 2) return sl.dev.as<float>();
+    sl.src = nullptr;
+    if (state == 2) { sl.state = 3; c->stage_in_use = &sl; return sl.dev.as<float>(); }  // (so_icp_stage_scan -- possibly on another thread -- leaves it alone)
+    sl.state = 0;
     if (state == -1) { c->err = sl.err; *rc = SO_ICP_E_HIP; }
     return nullptr;
   }
   return nullptr;
+}
+void release_staged(so_icp_ctx* c) {
+  if (!c->stage_in_use) return;
+  std::lock_guard<std::mutex> lk(c->stage_mu);
+  c->stage_in_use->state = 0;
+  c->stage_in_use = nullptr;
 }
 
 // the scan of this call in HBM: the staged copy when the caller announced it, else a plain upload into d_scan_own
@@ -1130,6 +1138,7 @@ int so_icp_register(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_byt
   if (rc) return rc;
   rc = register_core(c, d_scan, n, pose_in, pose_out, st);
   c->scan_staged = false;
+  release_staged(c);
   return rc;
 }
 
@@ -1138,17 +1147,24 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
   NEED_DEVICE(c);
   if (stride_bytes == 0) stride_bytes = 12;
   if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
-  if (!c->stage_started) {
-    HIP_TRY(c, hipSetDevice(c->cfg.device_id));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    c->stage_thread = std::thread(stage_worker, c);
-    c->stage_started = true;
-  }
   {
+    // (this entry point may be called from ANOTHER thread than the registration calls -- the node's feature callback --,
+    //  so everything it touches lives under stage_mu)
     std::unique_lock<std::mutex> lk(c->stage_mu);
-    so_icp_ctx::StageSlot& sl = c->stage[c->stage_next];
-    c->stage_next ^= 1;
+    if (!c->stage_started) {
+      HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+      HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+      c->stage_thread = std::thread(stage_worker, c);
+      c->stage_started = true;
+    }
+    // the slot after the last one used, unless the registration in flight is reading it: then the other one (an older staged
+    // scan that was never registered is dropped)
+    int k = c->stage_next;
+    if (c->stage[k].state == 3) k ^= 1;
+    so_icp_ctx::StageSlot& sl = c->stage[k];
+    c->stage_next = k ^ 1;
     c->stage_cv.wait(lk, [&] { return sl.state != 1; });  // (a slot still being copied: the caller staged three scans in a row)
+    if (sl.state == 3) return fail(c, SO_ICP_E_INVALID, "so_icp_stage_scan: both staging slots are in use");  // (cannot happen with one registration in flight)
     sl.src = xyz; sl.n = n; sl.stride = stride_bytes; sl.state = 1; sl.err.clear();
   }
   c->stage_pending.fetch_add(1, std::memory_order_release);
@@ -1339,7 +1355,7 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   if (rc) return rc;
   rc = register_core(c, d_scan, n, T_in, pose_out, st);
   c->scan_staged = false;
-  if (rc != SO_ICP_OK) return rc;  // NOT_ENOUGH: the reference returns before the post-processing (LidarSlam.cpp:113-116)
+  if (rc != SO_ICP_OK) { release_staged(c); return rc; }  // NOT_ENOUGH: the reference returns before the post-processing (LidarSlam.cpp:113-116)
   // checkMotionThresholds, LidarSlam.cpp:173-195: always accepts; only the startupCount side effect survives
   const double dt = time_laser_odometry - c->last_time;
   if (st->translation_from_last / dt > c->cfg.velocity_failure_threshold) c->startup_count = 5;
@@ -1347,6 +1363,7 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   int r;
   if (c->dmap) r = transform_and_add_dev(d_scan, pose_out);  // LidarSlam.cpp:163-167
   else r = transform_and_add(pose_out);
+  release_staged(c);
   if (r) return r;
   c->last_time = time_laser_odometry;
   return SO_ICP_OK;

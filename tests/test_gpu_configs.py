@@ -124,6 +124,25 @@ def test_staged_scan_is_the_same_registration(oracle, gpu_slam_factory, soicp):
     assert rc == 0 and not (st.flags & soicp.FLAG_STAGED_SCAN) and np.array_equal(pose, ref[3][1])
     rc, pose, st = slam.register(scans[2], sc.guess(2))  # still there
     assert rc == 0 and (st.flags & soicp.FLAG_STAGED_SCAN) and np.array_equal(pose, ref[2][1])
+    # a feeder THREAD (the node's feature callback) announces scans while this thread registers: it may run ahead by more than
+    # one scan (older announcements are dropped, the registration uploads those itself) but never touches the slot in use
+    import threading
+    import time
+    order = [k % 4 for k in range(24)]
+
+    def feeder():
+        for k in order:
+            slam.stage_scan(scans[k])
+            time.sleep(0.0002)
+    th = threading.Thread(target=feeder)
+    th.start()
+    staged = 0
+    for k in order:
+        rc, pose, st = slam.register(scans[k], sc.guess(k))
+        assert rc == 0 and np.array_equal(pose, ref[k][1]) and np.array_equal(np.array(st.JtJ), np.array(ref[k][2].JtJ)), k
+        staged += 1 if (st.flags & soicp.FLAG_STAGED_SCAN) else 0
+    th.join(30)
+    assert staged >= 1
     # Localization() consumes a staged scan too and inserts it from the staged copy
     twin = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5)
     twin.add_surf_point_cloud(sc.map_points)
