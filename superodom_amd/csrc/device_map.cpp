@@ -189,7 +189,6 @@ int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err)
   }
   if (!had) return 0;
   std::vector<int> occupied;
-  size_t most = 0;
   for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) occupied.push_back((int)s);
   const float inv_leaf = 1.0f / finest_res_;  // the points' leaf keys are distinct on the finest grid they were filtered on
   for (size_t r0 = 0; r0 < occupied.size(); r0 += kMaxTouched) {
@@ -211,7 +210,6 @@ int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err)
     }
     for (int t = tt.n; t <= kMaxTouched; ++t) tt.old_prefix[t] = n_old;
     for (int t = tt.n; t < kMaxTouched; ++t) tt.slot[t] = 0;
-    most = std::max<size_t>(most, n_old);
     if (ensure_work(n_old, err)) return -2;
     if (ensure_grid((size_t)tt.n * ncell1_ + 1024, err)) return -2;
     DM_TRY(hipMemsetAsync(d_small_, 0, 48 * sizeof(uint32_t), stream_));

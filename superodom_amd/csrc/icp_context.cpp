@@ -1177,6 +1177,8 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
   if (!c || !poses_in || !poses_out || n_hyp < 0 || (!xyz && !d_scan && n)) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);
   HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  if (c->cfg.world_size != 1)  // (hypotheses are independent: replicate the map and split THEM over the ranks -- bench.py's batch64)
+    return fail(c, SO_ICP_E_UNSUPPORTED, "so_icp_register_batch needs the whole map on one device (world_size == 1)");
   if (n_hyp == 0) return 0;
   const float* scan = static_cast<const float*>(d_scan);
   if (!scan) {
