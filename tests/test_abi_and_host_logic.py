@@ -174,3 +174,26 @@ def test_registration_error_matches_numpy_oracle(soicp, oracle):
         assert abs(abs(np.dot(np.array(e.orientation_error_direction), o["orientation_error_direction"])) - 1) < 1e-8
     sing = soicp.Stats()  # all-zero J^T J: singular
     assert soicp.registration_error(sing) is None
+
+
+def test_cpp_adapter_builds_and_fails_loudly_without_a_device(soicp, tmp_path):
+    """The compiled reference-side adapter (adapter/, built by __graft_entry__.build()): on a box without a GPU the C++
+    driver must report the missing device the way the node would (an exception caught by process(), laserMapping.cpp:788-790,
+    here: exit code 1 + the library's message) -- never a silent CPU path."""
+    import struct
+    import subprocess
+    driver = os.path.join(ROOT, "adapter", "adapter_driver")
+    if not os.path.exists(driver):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "adapter"),
+                               os.path.join(ROOT, "adapter", "lidar_slam_soicp.cpp"), os.path.join(ROOT, "adapter", "adapter_driver.cpp"), "-o", driver,
+                               "-L", os.path.join(ROOT, "superodom_amd", "lib"), "-lsoicp", "-Wl,-rpath,$ORIGIN/../superodom_amd/lib",
+                               "-Wl,-rpath-link,/opt/rocm/lib"])
+    if soicp.load().so_icp_device_available():
+        pytest.skip("a GPU is present; tests/test_gpu_adapter.py runs the driver for real")
+    fin = tmp_path / "in.bin"
+    pts = np.random.default_rng(0).random((64, 3)).astype(np.float32)
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<ifii", 1, 0.2, 4, -1))
+        f.write(struct.pack("<i", len(pts))); f.write(np.array([0, 0, 0, 0, 0, 0, 1.0]).tobytes()); f.write(struct.pack("<d", 0.0)); f.write(pts.tobytes())
+    r = subprocess.run([driver, str(fin), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no HIP device" in r.stderr, (r.returncode, r.stderr)
