@@ -56,25 +56,16 @@ void LidarSLAM::StageNextScan(const PointCloud<Point>::Ptr& planner_point) {
     throw std::runtime_error(so_icp_last_error(gpu_));
 }
 
-void LidarSLAM::Localization(bool initialization, PredictionSource /*predictodom: only the dead VIO prior reads it, LidarSlam.cpp:281-283*/,
-                             Transformd position, PointCloud<Point>::Ptr /*edge_point: dead path, LidarSlam.cpp:402-512*/,
-                             PointCloud<Point>::Ptr planner_point, double timeLaserOdometry) {
-  ensure_context();
+void LidarSLAM::push_knobs() {
   // knobs the node writes into public fields before every call (laserMapping.cpp:648-649, 703-711)
   if (so_icp_set_resolution(gpu_, localMap.lineRes_, localMap.planeRes_) < 0) throw std::runtime_error(so_icp_last_error(gpu_));
   so_icp_set_max_surface_features(gpu_, OptSet.max_surface_features);
   so_icp_set_max_iterations(gpu_, (int)LocalizationICPMaxIter);
+}
 
-  const double T_in[7] = {position.pos.x(), position.pos.y(), position.pos.z(),
-                          position.rot.x(), position.rot.y(), position.rot.z(), position.rot.w()};
-  double T_out[7];
-  so_icp_stats& st = last_raw;
-  const float* xyz = planner_point && !planner_point->points.empty() ? reinterpret_cast<const float*>(planner_point->points.data()) : nullptr;
-  const size_t n = planner_point ? planner_point->points.size() : 0;
-  last_status = so_icp_localization(gpu_, initialization ? 1 : 0, T_in, xyz, n, sizeof(Point), timeLaserOdometry, T_out, &st);
-  if (last_status < 0) throw std::runtime_error(std::string("so_icp_localization: ") + so_icp_last_error(gpu_));
+void LidarSLAM::read_back(int32_t n_edge_points, const double T_out[7], double timeLaserOdometry) {
+  const so_icp_stats& st = last_raw;
   last_flags = st.flags;
-
   T_w_lidar.pos = Vector3d(T_out[0], T_out[1], T_out[2]);                 // read back at laserMapping.cpp:734-737
   T_w_lidar.rot = Quaterniond(T_out[6], T_out[3], T_out[4], T_out[5]);
   last_T_w_lidar = T_w_lidar;                                            // LidarSlam.cpp:197
@@ -85,7 +76,8 @@ void LidarSLAM::Localization(bool initialization, PredictionSource /*predictodom
   // OptimizationStats message (laserMapping.cpp:581-596; LidarSlam.cpp:198-210, 242-251, 371-377, 969-974)
   stats.laser_cloud_surf_from_map_num = st.laser_cloud_surf_from_map_num;
   stats.laser_cloud_surf_stack_num = st.laser_cloud_surf_stack_num;
-  stats.laser_cloud_corner_from_map_num = 0; stats.laser_cloud_corner_stack_num = 0;
+  stats.laser_cloud_corner_from_map_num = 0;                  // no corner map exists: nothing calls addEdgePointCloud
+  stats.laser_cloud_corner_stack_num = n_edge_points;         // EdgesPoints->size(), LidarSlam.cpp:374
   stats.total_translation = st.total_translation; stats.total_rotation = st.total_rotation;
   stats.translation_from_last = st.translation_from_last; stats.rotation_from_last = st.rotation_from_last;
   stats.time_elapsed = st.time_elapsed_ms;
@@ -99,6 +91,43 @@ void LidarSLAM::Localization(bool initialization, PredictionSource /*predictodom
     it.num_surf_from_scan = st.iterations[i].num_surf_from_scan; it.num_corner_from_scan = 0;
     stats.iterations.push_back(it);
   }
+}
+
+void LidarSLAM::Localization(bool initialization, PredictionSource /*predictodom: only the dead VIO prior reads it, LidarSlam.cpp:281-283*/,
+                             Transformd position, PointCloud<Point>::Ptr edge_point /*dead path, LidarSlam.cpp:402-512: only its size is reported*/,
+                             PointCloud<Point>::Ptr planner_point, double timeLaserOdometry) {
+  ensure_context();
+  push_knobs();
+  const double T_in[7] = {position.pos.x(), position.pos.y(), position.pos.z(),
+                          position.rot.x(), position.rot.y(), position.rot.z(), position.rot.w()};
+  double T_out[7];
+  const float* xyz = planner_point && !planner_point->points.empty() ? reinterpret_cast<const float*>(planner_point->points.data()) : nullptr;
+  const size_t n = planner_point ? planner_point->points.size() : 0;
+  last_status = so_icp_localization(gpu_, initialization ? 1 : 0, T_in, xyz, n, sizeof(Point), timeLaserOdometry, T_out, &last_raw);
+  if (last_status < 0) throw std::runtime_error(std::string("so_icp_localization: ") + so_icp_last_error(gpu_));
+  read_back(edge_point ? (int32_t)edge_point->points.size() : 0, T_out, timeLaserOdometry);
+}
+
+void LidarSLAM::PrefilterSurf(const float* xyz, size_t n, size_t stride_bytes, bool auto_voxel_size, float line_res, float plane_res,
+                              so_icp_prefilter_info* info, const void** d_filtered, size_t* n_filtered) {
+  ensure_context();
+  void* d = nullptr;
+  const int rc = so_icp_prefilter_scan(gpu_, xyz, n, stride_bytes, auto_voxel_size ? 1 : 0, line_res, plane_res, &d, n_filtered, info);
+  if (rc < 0) throw std::runtime_error(std::string("so_icp_prefilter_scan: ") + so_icp_last_error(gpu_));
+  *d_filtered = d;
+  if (info) { localMap.lineRes_ = info->line_res; localMap.planeRes_ = info->plane_res; }  // laserMapping.cpp:648-649
+}
+
+void LidarSLAM::LocalizationPrefiltered(bool initialization, PredictionSource, Transformd position, const void* d_planner_xyz, size_t n_planner,
+                                        int32_t n_edge_points, double timeLaserOdometry) {
+  ensure_context();
+  push_knobs();
+  const double T_in[7] = {position.pos.x(), position.pos.y(), position.pos.z(),
+                          position.rot.x(), position.rot.y(), position.rot.z(), position.rot.w()};
+  double T_out[7];
+  last_status = so_icp_localization_dev(gpu_, initialization ? 1 : 0, T_in, d_planner_xyz, n_planner, timeLaserOdometry, T_out, &last_raw);
+  if (last_status < 0) throw std::runtime_error(std::string("so_icp_localization_dev: ") + so_icp_last_error(gpu_));
+  read_back(n_edge_points, T_out, timeLaserOdometry);
 }
 
 }  // namespace super_odometry_soicp

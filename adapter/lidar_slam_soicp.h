@@ -71,6 +71,13 @@ class LidarSLAM {
                     PointCloud<Point>::Ptr planner_point, double timeLaserOdometry);
   // optional: announce the planar cloud of the NEXT frame (the feature callback has it before process() reaches it)
   void StageNextScan(const PointCloud<Point>::Ptr& planner_point);
+  // laserMapping::adjustVoxelSize (laserMapping.cpp:600-651) for the surf cloud on the device: cloud statistic (auto voxel size),
+  // VoxelGrid at planeRes, localMap.lineRes_/planeRes_ updated; *d_filtered stays in HBM (valid until the next call) and
+  // feeds LocalizationPrefiltered -- the filtered cloud never visits the host.  xyz may point into a PointCloud2 payload.
+  void PrefilterSurf(const float* xyz, size_t n, size_t stride_bytes, bool auto_voxel_size, float line_res, float plane_res,
+                     so_icp_prefilter_info* info, const void** d_filtered, size_t* n_filtered);
+  void LocalizationPrefiltered(bool initialization, PredictionSource predictodom, Transformd T_w_lidar_in, const void* d_planner_xyz,
+                               size_t n_planner, int32_t n_edge_points, double timeLaserOdometry);
 
   // ---- public fields laserMapping.cpp reads / writes (same names) ----
   Transformd T_w_lidar, last_T_w_lidar;
@@ -95,6 +102,8 @@ class LidarSLAM {
  private:
   friend class LocalMapFacade;
   void ensure_context();
+  void push_knobs();
+  void read_back(int32_t n_edge_points, const double T_out[7], double timeLaserOdometry);
   so_icp_ctx* gpu_ = nullptr;
 };
 

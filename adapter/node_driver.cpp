@@ -1,0 +1,60 @@
+// node_driver.cpp -- runs the laser_mapping_node shell (laser_mapping_soicp.{h,cpp}) over a recorded sequence of
+// serialised super_odometry_msgs/LaserFeature messages, the way a rosbag2 replay feeds the reference node, and records
+// everything the node publishes (test binary: built by __graft_entry__.build(), run by tests/test_gpu_node.py).
+//
+//   node_driver <bag.bin> <out.bin>
+// bag.bin: float32 planeRes, float32 lineRes, int32 max_iterations, int32 max_surface_features, int32 auto_voxel_size,
+//          int32 debug_view, int32 n_messages; per message: uint32 length, CDR bytes
+// out.bin: per published message: uint32 frame, uint32 len + topic, uint32 len + type, uint32 len + CDR bytes;
+//          trailer: uint32 0xFFFFFFFF, int32 frames_failed, uint32 len + last error text
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+
+#include "laser_mapping_soicp.h"
+
+using namespace super_odometry_soicp;
+
+template <typename T> static T rd(FILE* f) { T v; if (fread(&v, sizeof(T), 1, f) != 1) throw std::runtime_error("short input"); return v; }
+template <typename T> static void wr(FILE* f, const T& v) { fwrite(&v, sizeof(T), 1, f); }
+static void wr_blob(FILE* f, const void* p, size_t n) { wr<uint32_t>(f, (uint32_t)n); fwrite(p, 1, n, f); }
+
+struct Recorder : Outbox {
+  FILE* f = nullptr;
+  uint32_t frame = 0;
+  void publish(const std::string& topic, const std::string& type, std::vector<uint8_t>&& cdr) override {
+    wr<uint32_t>(f, frame); wr_blob(f, topic.data(), topic.size()); wr_blob(f, type.data(), type.size()); wr_blob(f, cdr.data(), cdr.size());
+  }
+};
+
+int main(int argc, char** argv) {
+  if (argc < 3) { fprintf(stderr, "usage: %s bag.bin out.bin\n", argv[0]); return 2; }
+  try {
+    FILE* in = fopen(argv[1], "rb");
+    Recorder rec;
+    rec.f = fopen(argv[2], "wb");
+    if (!in || !rec.f) throw std::runtime_error("cannot open files");
+    NodeConfig cfg;
+    cfg.planeRes = rd<float>(in); cfg.lineRes = rd<float>(in);
+    cfg.max_iterations = rd<int32_t>(in); cfg.max_surface_features = rd<int32_t>(in);
+    cfg.auto_voxel_size = rd<int32_t>(in) != 0; cfg.debug_view_enabled = rd<int32_t>(in) != 0;
+    cfg.ProjectName = "/super_odometry";
+    const int n_msgs = rd<int32_t>(in);
+    laserMapping node(cfg, &rec);
+    node.initInterface();
+    std::vector<uint8_t> buf;
+    for (int k = 0; k < n_msgs; ++k) {
+      buf.resize(rd<uint32_t>(in));
+      if (!buf.empty() && fread(buf.data(), 1, buf.size(), in) != buf.size()) throw std::runtime_error("short message");
+      rec.frame = (uint32_t)k;
+      node.laserFeatureInfoHandler(buf.data(), buf.size());  // the subscription callback ...
+      while (node.processOnce()) {}                          // ... and the process() loop
+    }
+    wr<uint32_t>(rec.f, 0xFFFFFFFFu); wr<int32_t>(rec.f, node.frames_failed); wr_blob(rec.f, node.last_error.data(), node.last_error.size());
+    fclose(in); fclose(rec.f);
+  } catch (const std::exception& e) {
+    fprintf(stderr, "node_driver: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

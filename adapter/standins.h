@@ -1,4 +1,4 @@
-// standins.h -- 60-line stand-ins for the third-party types that appear in the signature and in the public fields of
+// standins.h -- stand-ins for the third-party types that appear in the signature and in the public fields of
 // the reference's LidarSLAM, so that the adapter (lidar_slam_soicp.{h,cpp}) compiles and runs where Eigen, PCL and ROS 2
 // are absent.  In a real build of super_odometry define SUPERODOM_HAVE_ROS: the adapter then uses the node's own
 // headers (utils/Twist.h, pcl/point_types.h, super_odometry_msgs) and this file is not read.
@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <memory>
 #include <vector>
+
+#include "wire/messages.h"
 
 namespace so_standins {
 
@@ -48,19 +50,8 @@ template <typename P> struct PointCloud {
   bool empty() const { return points.empty(); }
   void push_back(const P& p) { points.push_back(p); }
 };
-// super_odometry_msgs/msg/IterationStats.msg, OptimizationStats.msg (the fields LidarSlam.cpp fills)
-struct IterationStats {
-  double translation_norm = 0, rotation_norm = 0;
-  int32_t num_surf_from_scan = 0, num_corner_from_scan = 0;
-};
-struct OptimizationStats {
-  int32_t laser_cloud_surf_from_map_num = 0, laser_cloud_corner_from_map_num = 0, laser_cloud_surf_stack_num = 0, laser_cloud_corner_stack_num = 0;
-  double total_translation = 0, total_rotation = 0, translation_from_last = 0, rotation_from_last = 0, time_elapsed = 0, latency = 0;
-  int32_t n_iterations = 0;
-  double average_distance = 0;
-  double uncertainty_x = 0, uncertainty_y = 0, uncertainty_z = 0, uncertainty_roll = 0, uncertainty_pitch = 0, uncertainty_yaw = 0;
-  int32_t prediction_source = 0;
-  std::vector<IterationStats> iterations;
-};
+// super_odometry_msgs/msg/IterationStats.msg, OptimizationStats.msg: field for field the message definitions (wire/messages.h)
+using IterationStats = so_wire::IterationStats;
+using OptimizationStats = so_wire::OptimizationStats;
 
 }  // namespace so_standins
