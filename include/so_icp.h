@@ -260,6 +260,33 @@ typedef struct {
 int so_icp_prefilter_scan(so_icp_ctx *ctx, const float *surf_xyz, size_t n, size_t stride_bytes, int auto_voxel_size,
                           float line_res, float plane_res, void **d_filtered_out, size_t *n_out, so_icp_prefilter_info *info);
 
+/* -------- two steps before Seam A: featureExtraction::removePointDistortion
+ * (src/FeatureExtraction/featureExtraction.cpp:223-314) on the device.  Every finite point of the sweep is moved to the
+ * sensor frame of the sweep start: pose buffer (IMU orientations or VIO odometry, strictly increasing times: the
+ * reference keeps them in a std::map) interpolated at lidar_start_time + point.time (slerp / lerp between the two
+ * neighbours, the first pose before the buffer starts), T_final = T_w_original^-1 * T_w_current, wrapped in
+ * T_l_i * . * T_i_l when the buffer is the IMU's (then positions are ignored: :231-235).  Records: float x y z at byte
+ * 0 4 8, float time at time_offset_bytes (point_os::PointcloudXYZITR: stride 32, time at 20); rewritten in place.
+ * A point stamped at or after the last pose has no successor in the buffer (undefined in the reference, which only
+ * de-skews once a later measurement has arrived, :185-201): it gets the last pose and is counted in n_clamped. */
+typedef struct {
+  double time;
+  double pos[3];
+  double rot[4]; /* x y z w */
+} so_icp_stamped_pose;
+typedef struct {
+  double q_w_original_l[4]; /* x y z w: orientation of the sweep-start sensor frame (featureExtraction.cpp:289) */
+  double t_w_original_l[3]; /* :290 */
+  uint32_t n_clamped, reserved;
+} so_icp_deskew_info;
+int so_icp_deskew_scan(so_icp_ctx *ctx, void *points /* host, rewritten in place */, size_t n, size_t stride_bytes,
+                       size_t time_offset_bytes, double lidar_start_time, const so_icp_stamped_pose *poses, size_t n_poses,
+                       int poses_are_imu, const double T_i_l[7] /* tx ty tz qx qy qz qw; NULL = identity */, so_icp_deskew_info *info);
+/* same on records already resident in HBM (rewritten there) */
+int so_icp_deskew_scan_dev(so_icp_ctx *ctx, void *d_points, size_t n, size_t stride_bytes, size_t time_offset_bytes,
+                           double lidar_start_time, const so_icp_stamped_pose *poses, size_t n_poses, int poses_are_imu,
+                           const double T_i_l[7], so_icp_deskew_info *info);
+
 /* -------- multi-GPU: one process per GPU; the map is sharded by brick-hash of the voxel grid and the 45 fp64 sums of every
  * evaluation are summed over the ranks: by RCCL (below), by an in-process group, or by the solve launches themselves
  * (peer exchange, further below) -------------------------------------------------------------------------------------- */

@@ -85,6 +85,8 @@ def lib():
     L.orc_yaw_correction.argtypes = [f64p, f64p, C.c_double]
     L.orc_register.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, C.POINTER(Config), i32p, f64p, C.POINTER(Stats), vp]
     L.orc_transform_and_add.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p]
+    L.orc_deskew.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, f64p, C.c_size_t, C.c_int, f64p, f64p]
+    L.orc_deskew.restype = C.c_size_t
     L.orc_set_num_threads.argtypes = [C.c_int]
     L.orc_set_knn_hook.argtypes = [C.c_void_p]
     _lib = L
@@ -257,6 +259,20 @@ def voxel_grid(xyz, leaf):
     L = lib(); xyz = _f32(xyz).reshape(-1, 3); out = np.zeros_like(xyz)
     n = L.orc_voxel_grid(_p(xyz, C.c_float), len(xyz), float(leaf), _p(out, C.c_float))
     return out[:n].copy()
+
+
+def deskew(records, time_off, t0, poses, imu, T_i_l=None):
+    """featureExtraction::removePointDistortion.  records: uint8 array [n, stride] (float x y z at 0 4 8, float time at
+    time_off), returned rewritten; poses: [n_poses, 8] = time, position, quaternion (x y z w).
+    Returns (records, start_sensor[7] = t_w_original_l + q_w_original_l, n points beyond the last pose)."""
+    L = lib()
+    rec = np.ascontiguousarray(records, np.uint8).copy()
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 8)
+    start = np.zeros(7)
+    til = None if T_i_l is None else np.ascontiguousarray(T_i_l, np.float64)
+    nb = L.orc_deskew(rec.ctypes.data_as(C.c_void_p), rec.shape[0], rec.shape[1], int(time_off), float(t0), _p(poses, C.c_double), len(poses),
+                      int(bool(imu)), None if til is None else _p(til, C.c_double), _p(start, C.c_double))
+    return rec, start, int(nb)
 
 
 class RefOctree:

@@ -1015,3 +1015,122 @@ int orc_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ============================================================================================
+ * featureExtraction::removePointDistortion (src/FeatureExtraction/featureExtraction.cpp:223-314), the de-skew in front of
+ * the feature extraction whose planar cloud this path registers.  Transformd algebra: include/super_odometry/utils/Twist.h
+ * (:165-172 inverse, :180-185 product through Eigen::Transform, :187 point).  Eigen 3.4 routines written out:
+ * QuaternionBase::toRotationMatrix, quaternionbase_assign_impl<Matrix3>, normalized(), slerp().  [UPSTREAM Eigen]
+ * ============================================================================================ */
+typedef struct { double q[4]; double p[3]; } dsk_tf; /* rot x y z w, pos */
+
+static void dsk_unit(const double q[4], double o[4]) {
+  double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (n2 > 0) { double n = sqrt(n2); for (int i = 0; i < 4; ++i) o[i] = q[i] / n; }
+  else for (int i = 0; i < 4; ++i) o[i] = q[i];
+}
+static void dsk_rotmat(const double q[4], double R[3][3]) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0][0] = 1 - (tyy + tzz); R[0][1] = txy - twz; R[0][2] = txz + twy;
+  R[1][0] = txy + twz; R[1][1] = 1 - (txx + tzz); R[1][2] = tyz - twx;
+  R[2][0] = txz - twy; R[2][1] = tyz + twx; R[2][2] = 1 - (txx + tyy);
+}
+static void dsk_quat_of(const double R[3][3], double q[4]) {
+  double t = R[0][0] + R[1][1] + R[2][2];
+  if (t > 0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[2][1] - R[1][2]) * t; q[1] = (R[0][2] - R[2][0]) * t; q[2] = (R[1][0] - R[0][1]) * t;
+  } else {
+    int i = 0;
+    if (R[1][1] > R[0][0]) i = 1;
+    if (R[2][2] > R[i][i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[k][j] - R[j][k]) * t; q[j] = (R[j][i] + R[i][j]) * t; q[k] = (R[k][i] + R[i][k]) * t;
+  }
+}
+static dsk_tf dsk_mul(const dsk_tf *a, const dsk_tf *b) { /* Twist::operator* */
+  double ua[4], ub[4], A[3][3], B[3][3], Cm[3][3], q[4];
+  dsk_unit(a->q, ua); dsk_unit(b->q, ub);
+  dsk_rotmat(ua, A); dsk_rotmat(ub, B);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Cm[i][j] = A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j];
+  dsk_tf o;
+  dsk_quat_of(Cm, q);
+  dsk_unit(q, o.q);
+  for (int i = 0; i < 3; ++i) o.p[i] = A[i][0] * b->p[0] + A[i][1] * b->p[1] + A[i][2] * b->p[2] + a->p[i];
+  return o;
+}
+static dsk_tf dsk_inv(const dsk_tf *a) { /* Twist::inverse */
+  dsk_tf o;
+  double R[3][3];
+  o.q[0] = -a->q[0]; o.q[1] = -a->q[1]; o.q[2] = -a->q[2]; o.q[3] = a->q[3];
+  dsk_rotmat(o.q, R);
+  for (int i = 0; i < 3; ++i) o.p[i] = -(R[i][0] * a->p[0] + R[i][1] * a->p[1] + R[i][2] * a->p[2]);
+  return o;
+}
+static void dsk_slerp(const double a[4], const double b[4], double t, double o[4]) { /* QuaternionBase::slerp */
+  const double one = 1.0 - DBL_EPSILON;
+  double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3], ad = fabs(d), s0, s1;
+  if (ad >= one) { s0 = 1.0 - t; s1 = t; }
+  else { double th = acos(ad), sn = sin(th); s0 = sin((1.0 - t) * th) / sn; s1 = sin(t * th) / sn; }
+  if (d < 0) s1 = -s1;
+  for (int i = 0; i < 4; ++i) o[i] = s0 * a[i] + s1 * b[i];
+}
+/* getInterpolatedPoseAtTime, :257-276 */
+static dsk_tf dsk_pose_at(const double *poses, size_t n, int imu, double ts, int *beyond) {
+  size_t after = 0;
+  while (after < n && !(poses[8 * after] > ts)) ++after; /* std::map::upper_bound */
+  dsk_tf r;
+  if (after == n || after == 0) {
+    size_t e = after == n ? n - 1 : 0;
+    if (after == n) *beyond = 1;
+    for (int i = 0; i < 3; ++i) r.p[i] = imu ? 0.0 : poses[8 * e + 1 + i];
+    for (int i = 0; i < 4; ++i) r.q[i] = poses[8 * e + 4 + i];
+    return r;
+  }
+  const double *pb = poses + 8 * (after - 1), *pa = poses + 8 * after;
+  double ratio = (ts - pb[0]) / (pa[0] - pb[0]);
+  dsk_slerp(pb + 4, pa + 4, ratio, r.q);
+  for (int i = 0; i < 3; ++i) r.p[i] = imu ? (1 - ratio) * 0.0 + ratio * 0.0 : (1 - ratio) * pb[1 + i] + ratio * pa[1 + i];
+  return r;
+}
+
+size_t orc_deskew(void *points, size_t n, size_t stride, size_t time_off, double t0, const double *poses, size_t n_poses, int imu,
+                  const double T_i_l[7], double start_sensor[7]) {
+  dsk_tf il, li;
+  if (T_i_l) { for (int i = 0; i < 3; ++i) il.p[i] = T_i_l[i]; for (int i = 0; i < 4; ++i) il.q[i] = T_i_l[3 + i]; }
+  else { il.p[0] = il.p[1] = il.p[2] = 0; il.q[0] = il.q[1] = il.q[2] = 0; il.q[3] = 1; }
+  li = dsk_inv(&il);
+  int beyond = 0;
+  dsk_tf w_original = dsk_pose_at(poses, n_poses, imu, t0, &beyond);              /* :279-282 */
+  dsk_tf sensor = imu ? dsk_mul(&w_original, &il) : w_original;                    /* :283-290 */
+  if (start_sensor) { for (int i = 0; i < 3; ++i) start_sensor[i] = sensor.p[i]; for (int i = 0; i < 4; ++i) start_sensor[3 + i] = sensor.q[i]; }
+  dsk_tf w_original_inv = dsk_inv(&w_original);
+  size_t n_beyond = 0;
+  for (size_t k = 0; k < n; ++k) {                                                 /* :292-312 */
+    float *xyz = (float *)((char *)points + k * stride);
+    if (!isfinite(xyz[0]) || !isfinite(xyz[1]) || !isfinite(xyz[2])) continue;
+    float tm;
+    memcpy(&tm, (char *)points + k * stride + time_off, 4);
+    double ts = tm + t0;
+    beyond = 0;
+    dsk_tf w_current = dsk_pose_at(poses, n_poses, imu, ts, &beyond);
+    n_beyond += (size_t)beyond;
+    dsk_tf oc = dsk_mul(&w_original_inv, &w_current), fin = oc;
+    if (imu) { dsk_tf tmp = dsk_mul(&li, &oc); fin = dsk_mul(&tmp, &il); }
+    /* T_final * pt: rot * p + pos, Eigen's _transformVector */
+    double v[3] = {xyz[0], xyz[1], xyz[2]}, *u = fin.q;
+    double uv[3] = {2 * (u[1] * v[2] - u[2] * v[1]), 2 * (u[2] * v[0] - u[0] * v[2]), 2 * (u[0] * v[1] - u[1] * v[0])};
+    double r[3] = {v[0] + u[3] * uv[0] + (u[1] * uv[2] - u[2] * uv[1]), v[1] + u[3] * uv[1] + (u[2] * uv[0] - u[0] * uv[2]),
+                   v[2] + u[3] * uv[2] + (u[0] * uv[1] - u[1] * uv[0])};
+    xyz[0] = (float)(r[0] + fin.p[0]); xyz[1] = (float)(r[1] + fin.p[1]); xyz[2] = (float)(r[2] + fin.p[2]);
+  }
+  return n_beyond;
+}

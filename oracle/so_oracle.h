@@ -166,6 +166,15 @@ int orc_transform_and_add(orc_map *m, const float *scan_xyz, size_t n, size_t st
 typedef void (*orc_knn_hook_t)(int cube_ind, const float *xyz, size_t n, const float q[3], int k, int64_t *idx, float *d2);
 void orc_set_knn_hook(orc_knn_hook_t hook);
 
+/* ---- featureExtraction::removePointDistortion, featureExtraction.cpp:223-314 -----------------------
+ * points: records of stride bytes, float x y z at 0 4 8, float time at time_off; rewritten in place.
+ * poses: n_poses x 8 doubles {time, px py pz, qx qy qz qw}, strictly increasing times.  imu != 0: the buffer holds IMU
+ * orientations (positions ignored) and the result is wrapped in T_l_i * . * T_i_l (T_i_l = {tx ty tz qx qy qz qw}).
+ * start_sensor[7] receives {t_w_original_l, q_w_original_l}.  Returns the number of points stamped at / after the last
+ * pose (no successor in the buffer: undefined in the reference; the last pose is used). */
+size_t orc_deskew(void *points, size_t n, size_t stride, size_t time_off, double lidar_start_time, const double *poses, size_t n_poses,
+                  int imu, const double T_i_l[7], double start_sensor[7]);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

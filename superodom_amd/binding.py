@@ -56,6 +56,10 @@ class PrefilterInfo(C.Structure):
                 ("line_res", C.c_float), ("plane_res", C.c_float)]
 
 
+class DeskewInfo(C.Structure):
+    _fields_ = [("q_w_original_l", C.c_double * 4), ("t_w_original_l", C.c_double * 3), ("n_clamped", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class Timing(C.Structure):
     _fields_ = [("knn_ms_total", C.c_double), ("knn_launches", C.c_int64), ("knn_queries", C.c_int64), ("knn_map_points", C.c_int64),
                 ("eval_ms_total", C.c_double), ("eval_launches", C.c_int64), ("eval_points", C.c_int64),
@@ -79,7 +83,8 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_register_dev", "so_icp_upload_scan", "so_icp_free_scan", "so_icp_localization", "so_icp_comm_unique_id", "so_icp_comm_init",
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
-            "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable"]
+            "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
+            "so_icp_deskew_scan", "so_icp_deskew_scan_dev"]
 
 _lib = None
 
@@ -131,6 +136,9 @@ def load():
     L.so_icp_registration_error.argtypes = [C.POINTER(Stats), C.POINTER(RegistrationError)]
     L.so_icp_localization_dev.argtypes = [vp, C.c_int, f64p, vp, C.c_size_t, C.c_double, f64p, C.POINTER(Stats)]
     L.so_icp_download_scan.argtypes = [vp, vp, C.c_size_t, f32p]
+    for fn in (L.so_icp_deskew_scan, L.so_icp_deskew_scan_dev):
+        fn.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(C.c_double), C.c_size_t, C.c_int, C.POINTER(C.c_double),
+                       C.POINTER(DeskewInfo)]
     L.so_icp_prefilter_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_float, C.c_float, C.POINTER(vp),
                                         C.POINTER(C.c_size_t), C.POINTER(PrefilterInfo)]
     L.so_icp_debug_knn_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
@@ -350,6 +358,18 @@ class LidarSlamGpu:
         self._check(self.L.so_icp_prefilter_scan(self.h, _p(pts, C.c_float), len(pts), 12, int(bool(auto_voxel_size)), float(line_res),
                                                  float(plane_res), C.byref(d), C.byref(n), C.byref(info)))
         return d.value, n.value, info
+
+    def deskew_scan(self, records, time_off, lidar_start_time, poses, poses_are_imu, T_i_l=None):
+        """featureExtraction::removePointDistortion on the device.  records: uint8 [n, stride] (float x y z at 0 4 8, float time
+        at time_off); poses: [n_poses, 8] = time, position, quaternion x y z w.  Returns (rewritten records, DeskewInfo)."""
+        rec = np.ascontiguousarray(records, np.uint8).copy()
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 8)
+        til = None if T_i_l is None else np.ascontiguousarray(T_i_l, np.float64)
+        info = DeskewInfo()
+        self._check(self.L.so_icp_deskew_scan(self.h, rec.ctypes.data_as(C.c_void_p), rec.shape[0], rec.shape[1], int(time_off),
+                                              float(lidar_start_time), _p(poses, C.c_double), len(poses), int(bool(poses_are_imu)),
+                                              None if til is None else _p(til, C.c_double), C.byref(info)))
+        return rec, info
 
     # ---- multi-GPU ----
     def comm_init(self, uid_bytes):

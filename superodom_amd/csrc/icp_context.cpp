@@ -28,6 +28,7 @@
 #include "../../include/so_icp.h"
 #include "kernels.h"
 #include "lm_solver.h"
+#include "deskew_math.h"
 #include "device_map.h"
 #include "local_map.h"
 #include "so_math.h"
@@ -1368,6 +1369,79 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   release_staged(c);
   if (r) return r;
   c->last_time = time_laser_odometry;
+  return SO_ICP_OK;
+}
+
+// featureExtraction::removePointDistortion, featureExtraction.cpp:223-314 (kernel: map_kernels.hip deskew_kernel)
+static int deskew_core(so_icp_ctx* c, void* d_points, size_t n, size_t stride, size_t time_off, double t0, const so_icp_stamped_pose* poses,
+                       size_t n_poses, int imu, const double T_i_l[7], so_icp_deskew_info* info) {
+  static_assert(sizeof(so_icp_stamped_pose) == kStampedPoseDoubles * sizeof(double), "stamped pose = 8 doubles");
+  const double* tab = reinterpret_cast<const double*>(poses);
+  for (size_t k = 0; k + 1 < n_poses; ++k)
+    if (!(poses[k].time < poses[k + 1].time)) return fail(c, SO_ICP_E_INVALID, "pose buffer times must increase strictly (the reference keeps them in a std::map)");
+  DeskewFrames f;
+  f.imu = imu ? 1 : 0;
+  if (T_i_l) { for (int k = 0; k < 3; ++k) f.i_l.t[k] = T_i_l[k]; for (int k = 0; k < 4; ++k) f.i_l.q[k] = T_i_l[3 + k]; }
+  else { f.i_l.t[0] = f.i_l.t[1] = f.i_l.t[2] = 0; f.i_l.q[0] = f.i_l.q[1] = f.i_l.q[2] = 0; f.i_l.q[3] = 1; }
+  f.l_i = rigid_inverse(f.i_l);  // parameter.cpp:193
+  bool clamped_start = false;
+  Rigid start = interpolated_pose(tab, (uint32_t)n_poses, t0, &clamped_start);  // :279
+  if (imu) start.t[0] = start.t[1] = start.t[2] = 0;                             // extractPose, :231-235
+  f.w_original_inv = rigid_inverse(start);
+  const Rigid sensor = imu ? rigid_mul(start, f.i_l) : start;                    // :284-290
+  if (info) {
+    std::memset(info, 0, sizeof(*info));
+    for (int k = 0; k < 4; ++k) info->q_w_original_l[k] = sensor.q[k];
+    for (int k = 0; k < 3; ++k) info->t_w_original_l[k] = sensor.t[k];
+  }
+  if (!n) return SO_ICP_OK;
+  hipStream_t s = c->stream;
+  std::vector<double> host_tab(tab, tab + n_poses * kStampedPoseDoubles);
+  if (imu) for (size_t k = 0; k < n_poses; ++k) host_tab[k * 8 + 1] = host_tab[k * 8 + 2] = host_tab[k * 8 + 3] = 0.0;
+  HIP_TRY(c, c->pf_small.reserve(host_tab.size() * sizeof(double) + 64));
+  HIP_TRY(c, hipMemcpyAsync(c->pf_small.p, host_tab.data(), host_tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  uint32_t* d_cnt = reinterpret_cast<uint32_t*>(c->pf_small.as<uint8_t>() + host_tab.size() * sizeof(double));
+  HIP_TRY(c, hipMemsetAsync(d_cnt, 0, 8, s));
+  launch_deskew(static_cast<uint8_t*>(d_points), (uint32_t)n, (uint32_t)stride, (uint32_t)time_off, t0, c->pf_small.as<double>(), (uint32_t)n_poses, f, d_cnt, s);
+  HIP_TRY(c, hipGetLastError());
+  uint32_t cnt = 0;
+  HIP_TRY(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));  // also keeps host_tab alive until the upload has been consumed
+  if (info) info->n_clamped = cnt;
+  return SO_ICP_OK;
+}
+
+static int deskew_check(so_icp_ctx* c, const void* points, size_t n, size_t stride, size_t time_off, const so_icp_stamped_pose* poses, size_t n_poses) {
+  if (!c || (!points && n) || !poses || !n_poses) return SO_ICP_E_INVALID;
+  if (stride < 16 || stride % 4 || time_off % 4 || time_off < 12 || time_off + 4 > stride)
+    return fail(c, SO_ICP_E_INVALID, "records: x y z at 0 4 8, a float time at a 4-byte aligned offset in [12, stride - 4], stride a multiple of 4");
+  if (n >= ((size_t)1 << 31) || n_poses >= ((size_t)1 << 24)) return fail(c, SO_ICP_E_UNSUPPORTED, "too many points / poses");
+  return SO_ICP_OK;
+}
+
+int so_icp_deskew_scan_dev(so_icp_ctx* c, void* d_points, size_t n, size_t stride, size_t time_off, double t0, const so_icp_stamped_pose* poses,
+                           size_t n_poses, int imu, const double T_i_l[7], so_icp_deskew_info* info) {
+  const int rc = deskew_check(c, d_points, n, stride, time_off, poses, n_poses);
+  if (rc) return rc;
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  return deskew_core(c, d_points, n, stride, time_off, t0, poses, n_poses, imu, T_i_l, info);
+}
+
+int so_icp_deskew_scan(so_icp_ctx* c, void* points, size_t n, size_t stride, size_t time_off, double t0, const so_icp_stamped_pose* poses,
+                       size_t n_poses, int imu, const double T_i_l[7], so_icp_deskew_info* info) {
+  int rc = deskew_check(c, points, n, stride, time_off, poses, n_poses);
+  if (rc) return rc;
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  if (n) {
+    HIP_TRY(c, c->pf_in.reserve(n * stride + 64));
+    HIP_TRY(c, hipMemcpyAsync(c->pf_in.p, points, n * stride, hipMemcpyHostToDevice, c->stream));
+  }
+  rc = deskew_core(c, c->pf_in.p, n, stride, time_off, t0, poses, n_poses, imu, T_i_l, info);
+  if (rc || !n) return rc;
+  HIP_TRY(c, hipMemcpyAsync(points, c->pf_in.p, n * stride, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SO_ICP_OK;
 }
 

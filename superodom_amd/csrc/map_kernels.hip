@@ -23,6 +23,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include "deskew_math.h"
 #include "map_kernels.h"
 #include "so_math.h"
 
@@ -644,6 +645,48 @@ void launch_voxel_filter(const VoxelFilterArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(vg_centroid_kernel, grid_for(n, 256), dim3(256), 0, s, a.heads, a.d_n_cent, a.spts, a.d_out, a.flags, a.d_n_cent + 1);
   hipLaunchKernelGGL(vg_centroid_long_kernel, dim3(kMaxLongLeaves / 4), dim3(256), 0, s, a.heads, a.spts, a.d_out, a.flags, a.d_n_cent + 1);
 }
+// ---- featureExtraction::removePointDistortion (featureExtraction.cpp:223-314): SURVEY 8(f) row f4, the step that produces
+// the cloud the feature extraction (and through it this path) consumes.  One thread per point: pose of the stamped-pose
+// buffer interpolated at the point's own time, T_final = [T_l_i] T_w_original^-1 T_w_current [T_i_l], x y z rewritten in
+// place.  The buffer (tens of entries for a 0.1 s sweep against a 200 Hz IMU) sits in LDS; every thread runs its own
+// upper_bound over it.  32 B read + 12 B written per point, ~1.5 k fp64 operations: bound by neither at these sizes.
+constexpr uint32_t kDeskewLdsPoses = 512;
+template <bool LDS>
+__global__ __launch_bounds__(256) void deskew_kernel(uint8_t* __restrict__ pts, uint32_t n, uint32_t stride, uint32_t time_off, double t0,
+                                                     const double* __restrict__ poses, uint32_t n_poses, DeskewFrames f,
+                                                     uint32_t* __restrict__ n_clamped) {
+  __shared__ double tab_lds[LDS ? kDeskewLdsPoses * kStampedPoseDoubles : 1];
+  if (LDS) {
+    for (uint32_t k = threadIdx.x; k < n_poses * kStampedPoseDoubles; k += blockDim.x) tab_lds[k] = poses[k];
+    __syncthreads();
+  }
+  const double* tab = LDS ? tab_lds : poses;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool clamped = false;
+  if (i < n) {
+    uint8_t* rec = pts + (size_t)i * stride;
+    float* xyz = reinterpret_cast<float*>(rec);
+    const float x = xyz[0], y = xyz[1], z = xyz[2];
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {  // :293-295
+      const double ts = (double)*reinterpret_cast<const float*>(rec + time_off) + t0;  // :297
+      const Rigid T = deskew_transform(tab, n_poses, ts, f, &clamped);
+      double ox, oy, oz;
+      quat_rotate<double>(T.q, (double)x, (double)y, (double)z, ox, oy, oz);  // Twist::operator*(Tangent3): rot * p + pos
+      xyz[0] = (float)(ox + T.t[0]); xyz[1] = (float)(oy + T.t[1]); xyz[2] = (float)(oz + T.t[2]);
+    }
+  }
+  const unsigned long long m = __ballot(clamped);
+  if (m && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) atomicAdd(n_clamped, (uint32_t)__popcll(m));
+}
+
+void launch_deskew(uint8_t* d_pts, uint32_t n, uint32_t stride, uint32_t time_off, double t0, const double* d_poses, uint32_t n_poses,
+                   const DeskewFrames& f, uint32_t* d_n_clamped, hipStream_t s) {
+  if (!n) return;
+  const uint32_t blocks = (n + 255) / 256;
+  if (n_poses <= kDeskewLdsPoses) deskew_kernel<true><<<blocks, 256, 0, s>>>(d_pts, n, stride, time_off, t0, d_poses, n_poses, f, d_n_clamped);
+  else deskew_kernel<false><<<blocks, 256, 0, s>>>(d_pts, n, stride, time_off, t0, d_poses, n_poses, f, d_n_clamped);
+}
+
 void launch_gather_export(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, float* d_out, hipStream_t s) {
   if (!count) return;
   hipLaunchKernelGGL(gather_export_kernel, grid_for(count, 256), dim3(256), 0, s, pool, cap, slot, count, d_out);

@@ -1,0 +1,73 @@
+"""-m gpu: so_icp_deskew_scan (featureExtraction::removePointDistortion on the device) against the CPU
+restatement on the same records.  Both sides run the same fp64 operation sequence; the only functions whose last bit
+may differ are acos / sin inside slerp (glibc on the host, the device math library on the GPU), so the float32 output
+must be bit-identical for all but a sliver of the points and within one float32 spacing for those."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation as R
+
+import deskew_data as dd
+
+pytestmark = pytest.mark.gpu
+T0 = 1.7e9 + 0.25
+
+
+def close_in_ulps(a, b):
+    """(fraction of bit-identical values, largest difference in units of the float32 spacing at that magnitude)"""
+    a, b = a.reshape(-1), b.reshape(-1)
+    same = a.view(np.uint32) == b.view(np.uint32)
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))[~(same | both_nan)]
+    ulp = np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64)[~(same | both_nan)]
+    return (same | both_nan).mean(), (d / ulp).max() if len(d) else 0.0
+
+
+@pytest.mark.parametrize("imu,stride,time_off,n_poses_rate", [(True, 32, 20, 200.0), (False, 32, 20, 200.0), (False, 16, 12, 50.0), (True, 32, 20, 8000.0)])
+def test_deskew_matches_the_oracle(gpu_slam_factory, oracle, imu, stride, time_off, n_poses_rate):
+    slam = gpu_slam_factory()
+    n = 131072  # the BASELINE sweep: 128 x 1024
+    rec = dd.sweep(n, stride, time_off, seed=21, nan_every=4099)
+    poses = dd.pose_buffer(T0, rate_hz=n_poses_rate, seed=22, translate=not imu, flip_signs=True)
+    if n_poses_rate > 5000:
+        assert len(poses) > 512, "this case takes the kernel's global-memory table path"
+    T_i_l = np.concatenate([[0.05, -0.02, 0.1], R.from_rotvec([0.01, -0.02, 0.5]).as_quat()]) if imu else None
+    want, wstart, wbeyond = oracle.deskew(rec, time_off, T0, poses, imu, T_i_l)
+    got, info = slam.deskew_scan(rec, time_off, T0, poses, imu, T_i_l)
+    assert info.n_clamped == wbeyond == 0
+    assert list(info.t_w_original_l) + list(info.q_w_original_l) == list(wstart), "the sweep-start frame is host arithmetic on both sides"
+    keep = np.ones(stride, bool); keep[:12] = False
+    assert np.array_equal(got[:, keep], rec[:, keep]), "only x y z are rewritten"
+    frac, worst = close_in_ulps(dd.xyz_of(got), dd.xyz_of(want))
+    assert frac > 0.999 and worst <= 1.0, (frac, worst)
+    bad = ~np.isfinite(dd.xyz_of(rec)).all(1)
+    assert bad.sum() > 10 and np.array_equal(got[bad], rec[bad]), "non-finite points are left alone (featureExtraction.cpp:293-295)"
+    # and against scipy, as the oracle itself is checked
+    ref = dd.scipy_deskew(rec, time_off, T0, poses, imu, T_i_l)
+    assert np.abs(dd.xyz_of(got)[~bad].astype(np.float64) - ref[~bad]).max() < 1e-5
+
+
+def test_deskew_edges_and_errors(gpu_slam_factory, oracle, soicp):
+    slam = gpu_slam_factory()
+    rec = dd.sweep(5000, seed=31)
+    poses = dd.pose_buffer(T0, seed=32, after_s=0.05)  # ends inside the sweep: the tail has no successor in the buffer
+    want, _, wbeyond = oracle.deskew(rec, 20, T0, poses, False, None)
+    got, info = slam.deskew_scan(rec, 20, T0, poses, False, None)
+    assert info.n_clamped == wbeyond > 0
+    frac, worst = close_in_ulps(dd.xyz_of(got), dd.xyz_of(want))
+    assert frac > 0.999 and worst <= 1.0
+    # single pose, empty sweep
+    got, info = slam.deskew_scan(rec, 20, T0, poses[:1], True, None)
+    assert info.n_clamped == 5000 and np.allclose(dd.xyz_of(got), dd.xyz_of(rec), atol=2e-5)
+    got, info = slam.deskew_scan(rec[:0], 20, T0, poses, True, None)
+    assert got.shape == (0, 32) and info.n_clamped == 0
+    # a motionless buffer is the identity to rounding (size-independent property)
+    still = poses.copy(); still[:, 1:4] = [1.0, 2.0, 3.0]; still[:, 4:8] = still[0, 4:8]
+    got, _ = slam.deskew_scan(rec, 20, T0, still, False, None)
+    assert np.allclose(dd.xyz_of(got), dd.xyz_of(rec), atol=2e-5)
+    # errors: unsorted buffer, time field outside the record, misaligned stride
+    with pytest.raises(soicp.SoIcpError, match="increase strictly"):
+        slam.deskew_scan(rec, 20, T0, poses[::-1], False, None)
+    with pytest.raises(soicp.SoIcpError):
+        slam.deskew_scan(rec, 30, T0, poses, False, None)
+    with pytest.raises(soicp.SoIcpError):
+        slam.deskew_scan(rec[:, :30], 20, T0, poses, False, None)
