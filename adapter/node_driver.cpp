@@ -7,6 +7,7 @@
 //          int32 debug_view, int32 n_messages; per message: uint32 length, CDR bytes
 // out.bin: per published message: uint32 frame, uint32 len + topic, uint32 len + type, uint32 len + CDR bytes;
 //          trailer: uint32 0xFFFFFFFF, int32 frames_failed, uint32 len + last error text
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
@@ -42,14 +43,20 @@ int main(int argc, char** argv) {
     const int n_msgs = rd<int32_t>(in);
     laserMapping node(cfg, &rec);
     node.initInterface();
-    std::vector<uint8_t> buf;
+    std::vector<std::vector<uint8_t>> bag(n_msgs);
     for (int k = 0; k < n_msgs; ++k) {
-      buf.resize(rd<uint32_t>(in));
-      if (!buf.empty() && fread(buf.data(), 1, buf.size(), in) != buf.size()) throw std::runtime_error("short message");
-      rec.frame = (uint32_t)k;
-      node.laserFeatureInfoHandler(buf.data(), buf.size());  // the subscription callback ...
-      while (node.processOnce()) {}                          // ... and the process() loop
+      bag[k].resize(rd<uint32_t>(in));
+      if (!bag[k].empty() && fread(bag[k].data(), 1, bag[k].size(), in) != bag[k].size()) throw std::runtime_error("short message");
     }
+    double busy = 0;  // seconds inside callback + process() turn, first (seeding) frame excluded
+    for (int k = 0; k < n_msgs; ++k) {
+      rec.frame = (uint32_t)k;
+      const auto t0 = std::chrono::steady_clock::now();
+      node.laserFeatureInfoHandler(bag[k].data(), bag[k].size());  // the subscription callback ...
+      while (node.processOnce()) {}                                // ... and the process() loop
+      if (k) busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (n_msgs > 1) fprintf(stderr, "node_driver: %d frames, %.3f ms per frame (deserialise + guess + prefilter + Localization + publish)\n", n_msgs - 1, 1e3 * busy / (n_msgs - 1));
     wr<uint32_t>(rec.f, 0xFFFFFFFFu); wr<int32_t>(rec.f, node.frames_failed); wr_blob(rec.f, node.last_error.data(), node.last_error.size());
     fclose(in); fclose(rec.f);
   } catch (const std::exception& e) {

@@ -197,3 +197,22 @@ def test_cpp_adapter_builds_and_fails_loudly_without_a_device(soicp, tmp_path):
         f.write(struct.pack("<i", len(pts))); f.write(np.array([0, 0, 0, 0, 0, 0, 1.0]).tobytes()); f.write(struct.pack("<d", 0.0)); f.write(pts.tobytes())
     r = subprocess.run([driver, str(fin), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "no HIP device" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_node_shell_fails_loudly_without_a_device(soicp, tmp_path):
+    """adapter/node_driver (the laser_mapping_node shell): without a GPU the first thing the node does --
+    LocalMap::setOrigin in initializationParam, laserMapping.cpp:159 -- reports the missing device; nothing is published."""
+    import struct
+    import subprocess
+    driver = os.path.join(ROOT, "adapter", "node_driver")
+    if not os.path.exists(driver):
+        import __graft_entry__
+        __graft_entry__.build()
+    if soicp.load().so_icp_device_available():
+        pytest.skip("a GPU is present; tests/test_gpu_node.py runs the shell for real")
+    fin, fout = tmp_path / "bag.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<ffiiiii", 0.2, 0.1, 4, -1, 0, 0, 0))
+    r = subprocess.run([driver, str(fin), str(fout)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no HIP device" in r.stderr, (r.returncode, r.stderr)
+    assert os.path.getsize(fout) == 0

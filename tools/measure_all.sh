@@ -13,3 +13,4 @@ bash tools/pmc_traffic.sh $TAG 2>&1 | tail -3
 bash tools/pmc_knn.sh 0 2>&1 | tail -20
 python tools/localization_rate.py 2>&1 | tail -2 | tee gpurun_out/localization_$TAG.txt
 python tools/seam_b_rate.py 2>&1 | tail -4 | tee gpurun_out/seam_b_$TAG.txt
+python tools/f4_rates.py 2>&1 | grep "^deskew\|^node shell" | tee gpurun_out/f4_rates_$TAG.txt
