@@ -15,6 +15,7 @@ cp $R/gpurun_out/pmc_knn/knn_counters.json $D/pmc/knn_counters.json
 cp $R/gpurun_out/localization_$TAG.txt $D/localization_rate.txt
 cp $R/gpurun_out/seam_b_$TAG.txt $D/seam_b_rate.txt
 [ -f $R/gpurun_out/f4_rates_$TAG.txt ] && cp $R/gpurun_out/f4_rates_$TAG.txt $D/f4_rates.txt
+for f in deskew_kernel_stats.csv localization_kernel_stats.csv; do [ -f $R/gpurun_out/prof_$TAG/$f ] && cp $R/gpurun_out/prof_$TAG/$f $D/$f; done
 for n in 2 4 8; do [ -f $R/gpurun_out/ranks$n.json ] && cp $R/gpurun_out/ranks$n.json $D/ranks${n}_on_one_gpu_bench_line.json; done
 # the two files bench.py reads (current round)
 cp $D/pmc/knn_traffic.json $R/profiles/knn_traffic.json
