@@ -24,13 +24,14 @@ namespace super_odometry_soicp {
 
 // laser_mapping_config (laserMapping.h:38-69) + the globals of src/parameter/parameter.cpp the node reads (:284-297)
 struct NodeConfig {
-  float lineRes = 0.2f, planeRes = 0.4f;          // mapping_line_resolution / mapping_plane_resolution
+  // defaults = the values readParameters declares (laserMapping.cpp:182-203); node_config.h fills this from a parameter file
+  float lineRes = 0.1f, planeRes = 0.2f;          // mapping_line_resolution / mapping_plane_resolution
   int max_iterations = 4;
   bool debug_view_enabled = false, enable_ouster_data = false, publish_only_feature_points = false;
   bool use_imu_roll_pitch = false;
   int max_surface_features = 2000;
   double velocity_failure_threshold = 30.0;
-  bool auto_voxel_size = false, forget_far_chunks = false;
+  bool auto_voxel_size = true, forget_far_chunks = false;
   double visual_confidence_factor = 1.0, pos_degeneracy_threshold = 1.0, ori_degeneracy_threshold = 1.0;
   float yaw_ratio = 0.f;
   std::string map_dir;

@@ -2,7 +2,7 @@
 // serialised super_odometry_msgs/LaserFeature messages, the way a rosbag2 replay feeds the reference node, and records
 // everything the node publishes (test binary: built by __graft_entry__.build(), run by tests/test_gpu_node.py).
 //
-//   node_driver <bag.bin> <out.bin>
+//   node_driver <bag.bin> <out.bin> [params.yaml]
 // bag.bin: float32 planeRes, float32 lineRes, int32 max_iterations, int32 max_surface_features, int32 auto_voxel_size,
 //          int32 debug_view, int32 n_messages; per message: uint32 length, CDR bytes
 // out.bin: per published message: uint32 frame, uint32 len + topic, uint32 len + type, uint32 len + CDR bytes;
@@ -13,6 +13,7 @@
 #include <stdexcept>
 
 #include "laser_mapping_soicp.h"
+#include "node_config.h"
 
 using namespace super_odometry_soicp;
 
@@ -40,6 +41,12 @@ int main(int argc, char** argv) {
     cfg.max_iterations = rd<int32_t>(in); cfg.max_surface_features = rd<int32_t>(in);
     cfg.auto_voxel_size = rd<int32_t>(in) != 0; cfg.debug_view_enabled = rd<int32_t>(in) != 0;
     cfg.ProjectName = "/super_odometry";
+    if (argc >= 4) {  // a ROS 2 parameter file in the reference's layout takes the place of the bag header's knobs
+      const NodeConfig from_file = load_node_config(argv[3]);
+      const std::string project = from_file.ProjectName.empty() ? cfg.ProjectName : from_file.ProjectName;
+      cfg = from_file;
+      cfg.ProjectName = project;
+    }
     const int n_msgs = rd<int32_t>(in);
     laserMapping node(cfg, &rec);
     node.initInterface();

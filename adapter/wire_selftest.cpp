@@ -2,11 +2,13 @@
 // tests/test_wire_formats.py in the CPU suite):
 //   wire_selftest roundtrip <Type> <in.cdr> <out.cdr>   deserialise a message of <Type>, serialise it again
 //   wire_selftest emit <Type> <out.cdr>                 serialise a message with fixed field values (the test knows them)
+//   wire_selftest params <file.yaml>                    node_config.h: ROS 2 parameter file -> NodeConfig, printed
 // Types: String Float32 Header PointCloud2 Odometry Path IterationStats OptimizationStats LaserFeature
 #include <cstdio>
 #include <cstring>
 #include <string>
 
+#include "node_config.h"
 #include "wire/cdr.h"
 
 using namespace so_wire;
@@ -110,7 +112,18 @@ int main(int argc, char** argv) {
       spit(argv[3], out);
       return 0;
     }
-    fprintf(stderr, "usage: %s roundtrip <Type> in out | emit <Type> out\n", argv[0]);
+    if (argc == 3 && !strcmp(argv[1], "params")) {  // the node's parameter surface: file -> NodeConfig, printed as key=value
+      const super_odometry_soicp::NodeConfig c = super_odometry_soicp::load_node_config(argv[2]);
+      printf("lineRes=%.9g\nplaneRes=%.9g\nmax_iterations=%d\ndebug_view=%d\nenable_ouster_data=%d\npublish_only_feature_points=%d\n", c.lineRes, c.planeRes,
+             c.max_iterations, (int)c.debug_view_enabled, (int)c.enable_ouster_data, (int)c.publish_only_feature_points);
+      printf("max_surface_features=%d\nvelocity_failure_threshold=%.17g\nauto_voxel_size=%d\nforget_far_chunks=%d\nvisual_confidence_factor=%.17g\n",
+             c.max_surface_features, c.velocity_failure_threshold, (int)c.auto_voxel_size, (int)c.forget_far_chunks, c.visual_confidence_factor);
+      printf("localization_mode=%d\nmap_dir=%s\ninit=%.9g %.9g %.9g %.9g %.9g %.9g\nuse_imu_roll_pitch=%d\nworld_frame=%s\nsensor_frame=%s\nPROJECT_NAME=%s\n",
+             (int)c.localization_mode, c.map_dir.c_str(), c.init_x, c.init_y, c.init_z, c.init_roll, c.init_pitch, c.init_yaw, (int)c.use_imu_roll_pitch,
+             c.WORLD_FRAME.c_str(), c.SENSOR_FRAME.c_str(), c.ProjectName.c_str());
+      return 0;
+    }
+    fprintf(stderr, "usage: %s roundtrip <Type> in out | emit <Type> out | params <file.yaml>\n", argv[0]);
     return 2;
   } catch (const std::exception& e) {
     fprintf(stderr, "wire_selftest: %s\n", e.what());

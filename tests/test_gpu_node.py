@@ -45,7 +45,7 @@ def make_frames(sc, n_frames, with_imu=True):
     return frames
 
 
-def run_node(tmp_path, frames, plane_res, line_res, max_it, msf, auto_voxel=0, debug_view=0):
+def run_node(tmp_path, frames, plane_res, line_res, max_it, msf, auto_voxel=0, debug_view=0, params=None):
     assert os.path.exists(DRIVER), "adapter/node_driver not built: run python __graft_entry__.py"
     fin, fout = tmp_path / "bag.bin", tmp_path / "out.bin"
     with open(fin, "wb") as f:
@@ -53,7 +53,7 @@ def run_node(tmp_path, frames, plane_res, line_res, max_it, msf, auto_voxel=0, d
         for fr in frames:
             raw = cdr_py.encode("LaserFeature", fr["msg"])
             f.write(struct.pack("<I", len(raw))); f.write(raw)
-    r = subprocess.run([DRIVER, str(fin), str(fout)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([DRIVER, str(fin), str(fout)] + ([str(params)] if params else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     raw = open(fout, "rb").read()
     at, pubs = 0, []
@@ -196,7 +196,12 @@ def test_node_shell_auto_voxel_size_map_topics_and_missing_imu(gpu_slam_factory,
     sc = synth.Scene("tiny")
     n_frames = 5
     frames = make_frames(sc, n_frames, with_imu=False)
-    pubs, failed, err = run_node(tmp_path, frames, 0.4, 0.2, 4, 2000, auto_voxel=1, debug_view=1)
+    # the knobs come from a ROS 2 parameter file in the reference's layout (adapter/node_config.h); the bag header's are overridden
+    params = tmp_path / "params.yaml"
+    params.write_text("/**:\n  ros__parameters:\n    world_frame: \"sensor_init\"\n    laser_mapping_node:\n        mapping_line_resolution: 0.2\n"
+                      "        mapping_plane_resolution: 0.4\n        max_iterations: 4\n        max_surface_features: 2000\n        debug_view: true\n"
+                      "        # auto_voxel_size: declared default true (laserMapping.cpp:192)\n")
+    pubs, failed, err = run_node(tmp_path, frames, 0.05, 0.05, 1, 7, auto_voxel=0, debug_view=0, params=params)
     assert failed == 0, err
     msgs, order = by_frame(pubs, n_frames)
     slam = gpu_slam_factory(plane_res=0.4, line_res=0.2, max_surface_features=2000, max_iterations=4)
