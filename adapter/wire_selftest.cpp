@@ -68,6 +68,36 @@ int main(int argc, char** argv) {
       spit(argv[4], out);
       return 0;
     }
+    if (argc == 5 && !strcmp(argv[1], "roundtrip-many")) {  // in / out: concatenated [uint32 length][message]; a message that fails to parse yields length 0xFFFFFFFF
+      const std::string t = argv[2];
+      const std::vector<uint8_t> in = slurp(argv[3]);
+      std::vector<uint8_t> out;
+      size_t at = 0;
+      while (at + 4 <= in.size()) {
+        uint32_t len;
+        std::memcpy(&len, in.data() + at, 4);
+        at += 4;
+        if (len > in.size() - at) throw std::runtime_error("short frame");
+        const std::vector<uint8_t> one(in.begin() + at, in.begin() + at + len);
+        at += len;
+        std::vector<uint8_t> res;
+        uint32_t rl = 0xFFFFFFFFu;
+        try {
+          if (t == "LaserFeature") res = again<LaserFeature>(one);
+          else if (t == "OptimizationStats") res = again<OptimizationStats>(one);
+          else if (t == "Odometry") res = again<Odometry>(one);
+          else if (t == "Path") res = again<Path>(one);
+          else if (t == "PointCloud2") res = again<PointCloud2>(one);
+          else throw std::invalid_argument("unknown type " + t);
+          rl = (uint32_t)res.size();
+        } catch (const std::runtime_error&) { res.clear(); }
+        const uint8_t* pl = reinterpret_cast<const uint8_t*>(&rl);
+        out.insert(out.end(), pl, pl + 4);
+        out.insert(out.end(), res.begin(), res.end());
+      }
+      spit(argv[4], out);
+      return 0;
+    }
     if (argc == 4 && !strcmp(argv[1], "emit")) {
       const std::string t = argv[2];
       std::vector<uint8_t> out;
