@@ -218,6 +218,7 @@ struct so_icp_ctx {
   std::thread stage_thread; std::mutex stage_mu; std::condition_variable stage_cv;
   hipStream_t copy_stream = nullptr;
   bool retried = false;       // the current registration is the repeat of an abandoned one
+  unsigned long long peer_timeout_ticks = 100000000ull;  // 1 s at 100 MHz: patience of a solve launch with the peer exchange (SOICP_PEER_TIMEOUT_MS)
   bool scan_staged = false;   // the scan of the current registration came from a stage slot
 
   ~so_icp_ctx();
@@ -363,6 +364,7 @@ EvalParams eval_params(float plane_res, int variant, int ablate) {
   ep.epoch_base = 0;
   for (void*& p : ep.peer_inbox) p = nullptr;
   ep.peer_rank = 0; ep.peer_world = 0;
+  ep.timeout_ticks = 5000000ull;  // 50 ms
   return ep;
 }
 
@@ -513,7 +515,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // (concurrent hypotheses: two persistent launches could each hold part of the CUs and wait for the rest -- one launch per
   //  evaluation there; only workgroup 0 of a launch ever waits, for workgroups that finish unconditionally)
   const bool peer = c->peer_on && c->cfg.world_size > 1 && c->persistent_solve && !c->batch_mode && !(ep.ablate & 32);
-  if (peer) { for (int r = 0; r < 8; ++r) ep.peer_inbox[r] = c->peer_inbox[r]; ep.peer_rank = c->cfg.rank; ep.peer_world = c->cfg.world_size; }
+  if (peer) { for (int r = 0; r < 8; ++r) ep.peer_inbox[r] = c->peer_inbox[r]; ep.peer_rank = c->cfg.rank; ep.peer_world = c->cfg.world_size; ep.timeout_ticks = c->peer_timeout_ticks; }
   // (peer exchange: the ranks' persistent solve launches trade their records themselves, see EvalParams::peer_inbox)
   const bool exchange = !peer && (c->comm != nullptr || c->group != nullptr);  // the sums pass through a collective between evaluation and controller
   const bool persistent = c->persistent_solve && !exchange && (!c->batch_mode || c->batch_single) && !(ep.ablate & 32);  // (ablated controller: per-evaluation launches)
@@ -617,7 +619,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
         HIP_TRY(c, hipStreamSynchronize(s));
         if (*seq == want) break;
         if (persistent && peer)
-          return fail(c, SO_ICP_E_HIP, "peer exchange: a solve launch was abandoned (a rank's records did not arrive within 50 ms, or the "
+          return fail(c, SO_ICP_E_HIP, "peer exchange: a solve launch was abandoned (a rank's records did not arrive within SOICP_PEER_TIMEOUT_MS, or the "
                                        "workgroups were not co-resident); every rank must run the same registrations");
         if (persistent) {
           // The persistent solve launch needs all of its workgroups resident at once.  If the device could not provide that
@@ -981,6 +983,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_SPECULATE")) c->speculate = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_ABLATE")) c->ablate = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_NO_DEFER")) c->no_defer = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BINNING")) c->use_binning = std::string(ev) != "sort";
   const bool want_dmap = !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));

@@ -62,6 +62,11 @@ struct EvalParams {
   // in rank order, so every rank holds bit-identical sums and runs the same controller -- no collective launch, no host.
   void* peer_inbox[8];
   int32_t peer_rank, peer_world;  // peer_world <= 1: off
+  // How long (ticks of the 100 MHz wall clock) the waits inside a persistent solve launch hold out before the launch is
+  // abandoned and the host reports it.  50 ms without peers (only a missing co-resident workgroup can be late); with the
+  // peer exchange a whole RANK can be late -- its process descheduled, its queue waiting for a time slice of a shared
+  // device -- so the host passes SOICP_PEER_TIMEOUT_MS (default 1 000 ms) there.
+  unsigned long long timeout_ticks;
 };
 constexpr int kPeerMaxWorld = 8, kPeerChunks = 48;                     // chunks per (parity, source rank): 45 used
 constexpr size_t kPeerInboxBytes = (size_t)(2 * kPeerMaxWorld * kPeerChunks + kPeerMaxWorld) * 16;  // + one self-test chunk per source

@@ -1580,7 +1580,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       ok = ok || !poller;
       if (ep.ablate & 8192) { ok = false; break; }  // test hook: behave as if the records never arrived (the launch is abandoned)
       if (__ballot(!ok) == 0ull) break;
-      if (wall_clock64() - t0 > 5000000ull) break;  // 50 ms: give up instead of hanging the device
+      if (wall_clock64() - t0 > ep.timeout_ticks) break;  // give up instead of hanging the device (EvalParams::timeout_ticks)
     }
     if (!__syncthreads_and(ok ? 1 : 0)) return kPassNotLast;  // timeout: the solve is abandoned, the host reports the missing publication
     if (stamp) t_ticket = t_loaded = wall_clock64();
@@ -1638,7 +1638,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
         if (!d0) { const u4v v = load16_sys(own + (size_t)s0 * kPeerChunks + a0); if (v.z == xtag) { d0 = true; v0 = ((unsigned long long)v.y << 32) | v.x; } }
         if (!d1) { const u4v v = load16_sys(own + (size_t)s1 * kPeerChunks + a1); if (v.z == xtag) { d1 = true; v1 = ((unsigned long long)v.y << 32) | v.x; } }
         if (__syncthreads_and((d0 && d1) ? 1 : 0)) break;
-        if (__syncthreads_or((wall_clock64() - tp > 5000000ull) ? 1 : 0)) { okx = false; break; }  // 50 ms: a rank is missing -- give up (uniformly), the host reports it
+        if (__syncthreads_or((wall_clock64() - tp > ep.timeout_ticks) ? 1 : 0)) { okx = false; break; }  // a rank is missing -- give up (uniformly), the host reports it
       }
       if (!__syncthreads_and(okx ? 1 : 0)) return kPassNotLast;
       double (*xs)[48] = reinterpret_cast<double (*)[48]>(&red[0][0]);  // (the reduction buffer is free here)
@@ -1698,7 +1698,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       uint32_t v = 0;
       if (tid < (int)lanes) v = __hip_atomic_load(&ticket[tid * kArriveStrideWords], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__ballot(v != expect) == 0ull) { ok = true; break; }
-      if (wall_clock64() - t0 > 5000000ull) break;  // 50 ms: give up instead of hanging the device
+      if (wall_clock64() - t0 > ep.timeout_ticks) break;  // give up instead of hanging the device (EvalParams::timeout_ticks)
     }
     if (tid < (int)lanes) __hip_atomic_store(&ticket[tid * kArriveStrideWords], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
     if (tid == 0) is_last = ok;
@@ -1847,7 +1847,8 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
           if (tag - e0 >= (unsigned long long)slot && tag - e0 <= 64ull) { done = true; val = ((unsigned long long)v.y << 32) | v.x; }
         }
         if (__ballot(!done) == 0ull) break;
-        if (wall_clock64() - t0 > 5000000ull) { ok = false; break; }  // 50 ms at 100 MHz: give up instead of hanging the device
+        // (the controller's workgroup may itself be waiting for the other ranks' records: twice its patience + the local 50 ms)
+        if (wall_clock64() - t0 > 2ull * ep.timeout_ticks + 5000000ull) { ok = false; break; }  // give up instead of hanging the device
         __builtin_amdgcn_s_sleep(1);
       }
       if (tid < 7) sh.pose[tid] = __longlong_as_double((long long)val);

@@ -87,7 +87,17 @@ def test_peer_exchange_between_contexts_of_one_process(soicp, monkeypatch, world
 
 def _peer_worker(rank, world, wgs, conn):
     """One rank = one process.  The parent is the control plane (it carries the handles, the agreement and the barriers
-    over pipes -- any transport will do, bench.py uses gloo)."""
+    over pipes -- any transport will do, bench.py uses gloo).  An exception travels to the parent as ("error", text), so
+    that the test fails at once instead of waiting for an answer that will not come."""
+    try:
+        _peer_worker_body(rank, world, wgs, conn)
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        conn.send(("error", f"rank {rank}: {e!r}\n{traceback.format_exc()}"))
+        raise
+
+
+def _peer_worker_body(rank, world, wgs, conn):
     sys.path.insert(0, ROOT)
     os.environ["SOICP_SOLVE_WORKGROUPS"] = str(wgs)
     from superodom_amd import binding as soicp, synth as sy
@@ -133,6 +143,11 @@ def test_peer_exchange_between_processes_over_hip_ipc(soicp, world, wgs):
         for c in conns:
             assert c.poll(240), "a rank process did not answer"
             out.append(c.recv())
+        errors = [o[1] for o in out if isinstance(o, tuple) and len(o) == 2 and o[0] == "error"]
+        if errors:
+            for p in procs:
+                p.kill()
+            pytest.fail("a rank process failed:\n" + "\n".join(errors))
         return out
     handles = recv_all()
     for c in conns:
