@@ -70,21 +70,23 @@ void LidarSLAM::read_back(int32_t n_edge_points, const double T_out[7], double t
   T_w_lidar.rot = Quaterniond(T_out[6], T_out[3], T_out[4], T_out[5]);
   last_T_w_lidar = T_w_lidar;                                            // LidarSlam.cpp:197
   lasttimeLaserOdometry = timeLaserOdometry;
-  if (last_status != SO_ICP_OK) return;  // seeding (LidarSlam.cpp:45-46) / not enough map features (:113-116): no statistics
-  startupCount = st.startup_count;                                       // laserMapping.cpp:738
-  pos_in_localmap = Vector3i(st.pos_in_localmap[0], st.pos_in_localmap[1], st.pos_in_localmap[2]);  // :439
-  // OptimizationStats message (laserMapping.cpp:581-596; LidarSlam.cpp:198-210, 242-251, 371-377, 969-974)
+  if (last_status == SO_ICP_MAP_SEEDED) return;  // initialization == false (LidarSlam.cpp:45-46): initializeMapping only
+  // from here on the call went through EstimateLidarUncertainty (:47) and prepareOptimizationState (:361-377)
+  pos_in_localmap = Vector3i(st.pos_in_localmap[0], st.pos_in_localmap[1], st.pos_in_localmap[2]);  // :363, read at laserMapping.cpp:439
   stats.laser_cloud_surf_from_map_num = st.laser_cloud_surf_from_map_num;
   stats.laser_cloud_surf_stack_num = st.laser_cloud_surf_stack_num;
   stats.laser_cloud_corner_from_map_num = 0;                  // no corner map exists: nothing calls addEdgePointCloud
   stats.laser_cloud_corner_stack_num = n_edge_points;         // EdgesPoints->size(), LidarSlam.cpp:374
+  stats.uncertainty_x = st.uncertainty[0]; stats.uncertainty_y = st.uncertainty[1]; stats.uncertainty_z = st.uncertainty[2];
+  stats.uncertainty_roll = st.uncertainty[3]; stats.uncertainty_pitch = st.uncertainty[4]; stats.uncertainty_yaw = st.uncertainty[5];
+  stats.iterations.clear();                                   // updateFeatureStats, :376
+  if (last_status != SO_ICP_OK) return;  // "Not enough features for optimization" (:113-116): the rest of the statistics keeps its values
+  startupCount = st.startup_count;                                       // laserMapping.cpp:738
+  // OptimizationStats message (laserMapping.cpp:581-596; LidarSlam.cpp:198-210, 242-251, 969-974)
   stats.total_translation = st.total_translation; stats.total_rotation = st.total_rotation;
   stats.translation_from_last = st.translation_from_last; stats.rotation_from_last = st.rotation_from_last;
   stats.time_elapsed = st.time_elapsed_ms;
-  stats.uncertainty_x = st.uncertainty[0]; stats.uncertainty_y = st.uncertainty[1]; stats.uncertainty_z = st.uncertainty[2];
-  stats.uncertainty_roll = st.uncertainty[3]; stats.uncertainty_pitch = st.uncertainty[4]; stats.uncertainty_yaw = st.uncertainty[5];
   stats.prediction_source = 0;
-  stats.iterations.clear();
   for (int i = 0; i < st.n_iterations; ++i) {
     IterationStats it;
     it.translation_norm = st.iterations[i].translation_norm; it.rotation_norm = st.iterations[i].rotation_norm;

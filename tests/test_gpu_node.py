@@ -230,3 +230,28 @@ def test_node_shell_auto_voxel_size_map_topics_and_missing_imu(gpu_slam_factory,
     ref = slam.export_map(only_5x5=True, pos=list(st.pos_in_localmap))
     assert sur["header"]["frame_id"] == "sensor_init" and len(xyz) == len(ref) > 1000
     assert np.array_equal(xyz[np.lexsort(xyz.T)], ref[np.lexsort(ref.T)])
+
+
+def test_node_shell_when_the_map_has_too_few_features(gpu_slam_factory, tmp_path):
+    """"Not enough features for optimization" (LidarSlam.cpp:113-116): the first frame seeds only 30 points, so every later frame
+    returns early -- no registration, no insert; the node still publishes the guess as the pose and the statistics of
+    prepareOptimizationState (counts, cleared iteration list padded to four, uncertainties of an empty histogram)."""
+    sc = synth.Scene("tiny")
+    frames = make_frames(sc, 3)
+    few = frames[0]["scan"][:30]
+    frames[0]["msg"]["cloud_surface"] = cdr_py.cloud_msg(few, stamp=(100, 0))
+    pubs, failed, err = run_node(tmp_path, frames, sc.plane_res, sc.plane_res / 2, 4, -1)
+    assert failed == 0, err
+    msgs, order = by_frame(pubs, 3)
+    mirror = node_ref.NodeMirror()
+    for k, fr in enumerate(frames):
+        guess = mirror.initial_guess(fr["imu"])
+        pose = pose_of(msgs[k][P + "/laser_odometry"])
+        assert np.allclose(pose[:3], guess[:3], atol=1e-12) and node_ref.same_rotation(pose[3:], guess[3:], 1e-12), k
+        mirror.update(pose, 0, fr["time"])
+        st = msgs[k][P + "/super_odometry_stats"]
+        assert st["n_iterations"] == 0 and len(st["iterations"]) == 4 and all(it["num_surf_from_scan"] == 0 for it in st["iterations"])
+        if k:
+            assert 0 < st["laser_cloud_surf_from_map_num"] <= 30 and st["laser_cloud_surf_stack_num"] > 1000
+            assert [st["uncertainty_" + a] for a in ("x", "y", "z", "roll", "pitch", "yaw")] == [0.0] * 6
+            assert [msgs[k][P + "uncertainty_" + a]["data"] for a in ("X", "Y", "Z", "roll", "pitch", "yaw")] == [0.0] * 6
