@@ -93,7 +93,7 @@ def pose_of(odom):
 
 def test_node_shell_replay_against_the_mirror_the_oracle_and_ground_truth(gpu_slam_factory, oracle, tmp_path):
     sc = synth.Scene("tiny")
-    n_frames, max_it, line_res = 6, 4, sc.plane_res / 2
+    n_frames, max_it, line_res = 16, 4, sc.plane_res / 2
     frames = make_frames(sc, n_frames)
     pubs, failed, err = run_node(tmp_path, frames, sc.plane_res, line_res, max_it, -1)
     assert failed == 0, err
