@@ -2,7 +2,7 @@
 // serialised super_odometry_msgs/LaserFeature messages, the way a rosbag2 replay feeds the reference node, and records
 // everything the node publishes (test binary: built by __graft_entry__.build(), run by tests/test_gpu_node.py).
 //
-//   node_driver <bag.bin> <out.bin> [params.yaml]
+//   node_driver <bag.bin> <out.bin> [params.yaml [prior_map.f32]]
 // bag.bin: float32 planeRes, float32 lineRes, int32 max_iterations, int32 max_surface_features, int32 auto_voxel_size,
 //          int32 debug_view, int32 n_messages; per message: uint32 length, CDR bytes
 // out.bin: per published message: uint32 frame, uint32 len + topic, uint32 len + type, uint32 len + CDR bytes;
@@ -50,6 +50,16 @@ int main(int argc, char** argv) {
     const int n_msgs = rd<int32_t>(in);
     laserMapping node(cfg, &rec);
     node.initInterface();
+    if (argc >= 5) {  // localization mode: the prior map (laserMapping.cpp:161-171 reads map_dir through PCL; here: packed float32 xyz)
+      FILE* pm = fopen(argv[4], "rb");
+      if (!pm) throw std::runtime_error("cannot open the prior map");
+      std::vector<float> xyz;
+      float tmp[3 * 4096];
+      size_t k;
+      while ((k = fread(tmp, sizeof(float), 3 * 4096, pm)) > 0) xyz.insert(xyz.end(), tmp, tmp + k);
+      fclose(pm);
+      node.loadPriorMap(xyz.data(), xyz.size() / 3, 12);
+    }
     std::vector<std::vector<uint8_t>> bag(n_msgs);
     for (int k = 0; k < n_msgs; ++k) {
       bag[k].resize(rd<uint32_t>(in));

@@ -371,6 +371,16 @@ class LidarSlamGpu:
                                               None if til is None else _p(til, C.c_double), C.byref(info)))
         return rec, info
 
+    def deskew_scan_dev(self, d_records, n, stride, time_off, lidar_start_time, poses, poses_are_imu, T_i_l=None):
+        """the same on records resident in HBM (d_records: device address), rewritten there; returns DeskewInfo"""
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 8)
+        til = None if T_i_l is None else np.ascontiguousarray(T_i_l, np.float64)
+        info = DeskewInfo()
+        self._check(self.L.so_icp_deskew_scan_dev(self.h, C.c_void_p(d_records), int(n), int(stride), int(time_off), float(lidar_start_time),
+                                                  _p(poses, C.c_double), len(poses), int(bool(poses_are_imu)),
+                                                  None if til is None else _p(til, C.c_double), C.byref(info)))
+        return info
+
     # ---- multi-GPU ----
     def comm_init(self, uid_bytes):
         uid = np.frombuffer(bytes(uid_bytes), dtype=np.uint8).copy()

@@ -71,3 +71,29 @@ def test_deskew_edges_and_errors(gpu_slam_factory, oracle, soicp):
         slam.deskew_scan(rec, 30, T0, poses, False, None)
     with pytest.raises(soicp.SoIcpError):
         slam.deskew_scan(rec[:, :30], 20, T0, poses, False, None)
+
+
+def test_deskew_on_records_resident_in_hbm(gpu_slam_factory, oracle):
+    """so_icp_deskew_scan_dev: the caller owns the device buffer (here: hipMalloc through ctypes), the records are rewritten there"""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    slam = gpu_slam_factory()
+    rec = dd.sweep(30000, seed=41)
+    poses = dd.pose_buffer(T0, seed=42)
+    d = C.c_void_p()
+    assert hip.hipMalloc(C.byref(d), rec.nbytes) == 0
+    try:
+        assert hip.hipMemcpy(d, rec.ctypes.data_as(C.c_void_p), rec.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        info = slam.deskew_scan_dev(d.value, rec.shape[0], rec.shape[1], 20, T0, poses, False, None)
+        got = np.empty_like(rec)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), d, rec.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+    finally:
+        hip.hipFree(d)
+    host, hinfo = slam.deskew_scan(rec, 20, T0, poses, False, None)
+    assert np.array_equal(got, host) and info.n_clamped == hinfo.n_clamped == 0, "the two entry points run the same kernel"
+    want, _, _ = oracle.deskew(rec, 20, T0, poses, False, None)
+    frac, worst = close_in_ulps(dd.xyz_of(got), dd.xyz_of(want))
+    assert frac > 0.999 and worst <= 1.0

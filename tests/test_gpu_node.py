@@ -45,7 +45,7 @@ def make_frames(sc, n_frames, with_imu=True):
     return frames
 
 
-def run_node(tmp_path, frames, plane_res, line_res, max_it, msf, auto_voxel=0, debug_view=0, params=None):
+def run_node(tmp_path, frames, plane_res, line_res, max_it, msf, auto_voxel=0, debug_view=0, params=None, prior=None):
     assert os.path.exists(DRIVER), "adapter/node_driver not built: run python __graft_entry__.py"
     fin, fout = tmp_path / "bag.bin", tmp_path / "out.bin"
     with open(fin, "wb") as f:
@@ -53,7 +53,7 @@ def run_node(tmp_path, frames, plane_res, line_res, max_it, msf, auto_voxel=0, d
         for fr in frames:
             raw = cdr_py.encode("LaserFeature", fr["msg"])
             f.write(struct.pack("<I", len(raw))); f.write(raw)
-    r = subprocess.run([DRIVER, str(fin), str(fout)] + ([str(params)] if params else []), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([DRIVER, str(fin), str(fout)] + ([str(params)] if params else []) + ([str(prior)] if prior else []), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     raw = open(fout, "rb").read()
     at, pubs = 0, []
@@ -255,3 +255,38 @@ def test_node_shell_when_the_map_has_too_few_features(gpu_slam_factory, tmp_path
             assert 0 < st["laser_cloud_surf_from_map_num"] <= 30 and st["laser_cloud_surf_stack_num"] > 1000
             assert [st["uncertainty_" + a] for a in ("x", "y", "z", "roll", "pitch", "yaw")] == [0.0] * 6
             assert [msgs[k][P + "uncertainty_" + a]["data"] for a in ("X", "Y", "Z", "roll", "pitch", "yaw")] == [0.0] * 6
+
+
+def test_node_shell_localization_mode_against_a_prior_map(tmp_path):
+    """localization_mode (laserMapping.cpp:161-171, 305-313): the prior map is loaded before the first frame, the first pose comes
+    from init_x .. init_yaw (tf2 setRPY), the map's frame is the world frame -- the poses must follow the ground truth of the
+    synthetic trajectory directly -- and the prior cloud goes out on /overall_map with every 20th frame."""
+    sc = synth.Scene("tiny")
+    n_frames = 20
+    frames = make_frames(sc, n_frames)
+    g0 = sc.gt_pose(0)
+    roll, pitch, yaw = R.from_quat(g0[3:]).as_euler("xyz")
+    params = tmp_path / "loc.yaml"
+    params.write_text(f"/**:\n  ros__parameters:\n    laser_mapping_node:\n        mapping_line_resolution: {sc.plane_res / 2}\n"
+                      f"        mapping_plane_resolution: {sc.plane_res}\n        max_iterations: 4\n        max_surface_features: -1\n"
+                      f"        auto_voxel_size: false\n        localization_mode: true\n        init_x: {float(g0[0])!r}\n        init_y: {float(g0[1])!r}\n"
+                      f"        init_z: {float(g0[2])!r}\n        init_roll: {float(roll)!r}\n        init_pitch: {float(pitch)!r}\n        init_yaw: {float(yaw)!r}\n")
+    prior = tmp_path / "prior.f32"
+    np.ascontiguousarray(sc.map_points, np.float32).tofile(prior)
+    pubs, failed, err = run_node(tmp_path, frames, 0.05, 0.05, 1, 7, params=params, prior=prior)
+    assert failed == 0, err
+    msgs, order = by_frame(pubs, n_frames)
+    for k in range(n_frames):
+        pose = pose_of(msgs[k][P + "/laser_odometry"])
+        dt, dr = synth.pose_error(pose, sc.gt_pose(k))
+        # frame 0 is the configured start pose (float parameters: 1e-7), the others are registered against prior map + scans
+        assert dt < (1e-6 if k == 0 else 0.02) and dr < (1e-6 if k == 0 else 0.005), (k, dt, dr)
+        if k:
+            assert msgs[k][P + "/super_odometry_stats"]["laser_cloud_surf_from_map_num"] > 5000
+    assert [P + "/overall_map" in o for o in order] == [False] * 19 + [True]
+    assert [P + "/laser_cloud_map" in o for o in order] == [False] * 19 + [True]
+    over = msgs[19][P + "/overall_map"]
+    assert over["header"]["frame_id"] == "sensor_init" and over["header"]["stamp"] == msgs[19][P + "/laser_odometry"]["header"]["stamp"]
+    assert np.array_equal(cdr_py.cloud_xyz(over), np.ascontiguousarray(sc.map_points, np.float32))
+    whole = cdr_py.cloud_xyz(msgs[19][P + "/laser_cloud_map"])
+    assert len(whole) >= len(sc.map_points)  # prior map + the 20 inserted scans, voxel-filtered
