@@ -23,7 +23,7 @@ static inline int cidx(int i, int j, int k) { return i + kMapW * j + kMapW * kMa
 DeviceMap::~DeviceMap() {
   for (void* p : {(void*)d_pool_, (void*)d_cell_start_, (void*)d_cube_slot_, (void*)d_wpts_, (void*)d_cent_, (void*)d_k0_, (void*)d_k1_,
                   (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, (void*)d_spts_, (void*)d_heads_, (void*)d_grid_, (void*)d_grid_scan_, d_temp_, (void*)d_cube_of_, (void*)d_touched_,
-                  (void*)d_touched_id_, (void*)d_small_, (void*)d_stage_})
+                  (void*)d_touched_id_, (void*)d_small_, (void*)d_stage_, (void*)d_ht_key_, (void*)d_ht_cnt_, (void*)d_ht_off_})
     if (p) (void)hipFree(p);
   if (h_touched_) (void)hipHostFree(h_touched_);
   if (h_small_) (void)hipHostFree(h_small_);
@@ -45,8 +45,8 @@ void DeviceMap::set_origin(const double t[3]) {  // LocalMap.h:146-164
 
 int DeviceMap::alloc_slot(int cube) {
   for (size_t s = 0; s < slot_cube_.size(); ++s)
-    if (slot_cube_[s] < 0) { slot_cube_[s] = cube; slot_count_[s] = 0; slot_owned_[s] = 0; slot_full_[s] = 0; cube_slot_[cube] = (int)s; slot_table_dirty_ = true; return (int)s; }
-  slot_cube_.push_back(cube); slot_count_.push_back(0); slot_owned_.push_back(0); slot_full_.push_back(0);
+    if (slot_cube_[s] < 0) { slot_cube_[s] = cube; slot_count_[s] = 0; slot_owned_[s] = 0; slot_full_[s] = 0; slot_res_[s] = 0.f; cube_slot_[cube] = (int)s; slot_table_dirty_ = true; return (int)s; }
+  slot_cube_.push_back(cube); slot_count_.push_back(0); slot_owned_.push_back(0); slot_full_.push_back(0); slot_res_.push_back(0.f);
   cube_slot_[cube] = (int)slot_cube_.size() - 1;
   slot_table_dirty_ = true;
   return cube_slot_[cube];
@@ -58,7 +58,7 @@ void DeviceMap::shift(const double t[3], int pos[3]) {
   int c[3] = {cube_coord(t[0], origin_[0]), cube_coord(t[1], origin_[1]), cube_coord(t[2], origin_[2])};
   const int dim[3] = {kMapW, kMapH, kMapD};
   auto at = [&](int i, int j, int k) -> int32_t& { return cube_slot_[cidx(i, j, k)]; };
-  auto drop = [&](int32_t& s) { if (s >= 0) { slot_cube_[s] = -1; slot_count_[s] = 0; slot_owned_[s] = 0; slot_full_[s] = 0; } s = -1; };
+  auto drop = [&](int32_t& s) { if (s >= 0) { slot_cube_[s] = -1; slot_count_[s] = 0; slot_owned_[s] = 0; slot_full_[s] = 0; slot_res_[s] = 0.f; } s = -1; };
   bool moved = false;
   for (int axis = 0; axis < 3; ++axis) {
     while (c[axis] < 3 || c[axis] >= dim[axis] - 3) {
@@ -125,6 +125,25 @@ int DeviceMap::ensure_pool(int slots_needed, std::string& err) {
   d_pool_ = np; d_cell_start_ = nt; slots_alloc_ = want;
   if (!d_cube_slot_) DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cube_slot_), kMapNum * sizeof(int32_t)));
   slot_table_dirty_ = true;
+  return 0;
+}
+
+// hash table of the insert's first stage: one slot per distinct leaf of the NEW points, load factor <= 1/2, at least one
+// workgroup's worth of slots for the offsets kernel; empty (keys 0xFFFFFFFF, counts 0) between inserts
+int DeviceMap::ensure_leaf_table(size_t n_new, std::string& err) {
+  uint32_t lg = 12;
+  while (((size_t)1 << lg) < 2 * (n_new + 1)) ++lg;
+  if (lg > 30) { err = "DeviceMap: too many new points for the leaf table"; return -1; }
+  if (lg <= ht_log2_ && d_ht_key_) return 0;
+  for (void* p : {(void*)d_ht_key_, (void*)d_ht_cnt_, (void*)d_ht_off_}) if (p) (void)hipFree(p);
+  d_ht_key_ = d_ht_cnt_ = d_ht_off_ = nullptr; ht_log2_ = 0;
+  const size_t slots = (size_t)1 << lg;
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_ht_key_), slots * sizeof(uint32_t)));
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_ht_cnt_), slots * sizeof(uint32_t)));
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_ht_off_), slots * sizeof(uint32_t)));
+  DM_TRY(hipMemsetAsync(d_ht_key_, 0xFF, slots * sizeof(uint32_t), stream_));
+  DM_TRY(hipMemsetAsync(d_ht_cnt_, 0, slots * sizeof(uint32_t), stream_));
+  ht_log2_ = lg;
   return 0;
 }
 
@@ -326,13 +345,36 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
       a.grid = d_grid_; a.grid_scan = d_grid_scan_;
     }
     a.temp = d_temp_; a.temp_bytes = temp_bytes_;
+    // first stage: leaf grouping through a hash table (default) or the stable radix sort of the whole working set
+    // (the hash grouping lets an old point that shares its leaf with no NEW point pass through: valid when the cube holds one
+    //  point per leaf of the CURRENT grid, i.e. it was last filtered at this planeRes; after a resolution change the first
+    //  insert that touches a cube re-filters all of it, LocalMap.h:617-641 -- through the sort)
+    bool one_point_per_leaf = true;
+    for (int t = 0; t < tt.n; ++t) one_point_per_leaf = one_point_per_leaf && (slot_count_[tt.slot[t]] == 0 || slot_res_[tt.slot[t]] == plane_res_);
+    if (hash_grouping_ && use_grid && one_point_per_leaf) {
+      if (ensure_leaf_table(n, err)) return -2;
+      a.ht_key = d_ht_key_; a.ht_cnt = d_ht_cnt_; a.ht_off = d_ht_off_;
+      a.ht_log2 = 12;  // this round's share of the (all-empty) table: the kernels hash into / scan the first 2^ht_log2 slots only
+      while (((size_t)1 << a.ht_log2) < 2 * (n + 1)) ++a.ht_log2;
+    }
     launch_map_insert(a, stream_);
     DM_TRY(hipMemcpyAsync(h_small_, d_small_, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
     DM_TRY(hipStreamSynchronize(stream_));  // also keeps `tid` / the staging buffer alive long enough
+    if (a.ht_key && h_small_[5]) {
+      // a leaf with more members than the grouping kernels sort in LDS: the second stage stood still (nothing of the map was
+      // rewritten); the round is repeated with the sort-based first stage
+      a.ht_key = a.ht_cnt = a.ht_off = nullptr;
+      DM_TRY(hipMemsetAsync(d_small_, 0, 48 * sizeof(uint32_t), stream_));
+      if (world_ > 1) DM_TRY(hipMemsetAsync(d_small_ + 64, 0, kMaxTouched * sizeof(uint32_t), stream_));
+      launch_map_insert(a, stream_);
+      DM_TRY(hipMemcpyAsync(h_small_, d_small_, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+      DM_TRY(hipStreamSynchronize(stream_));
+    }
     for (int t = 0; t < tt.n; ++t) {
       const uint32_t cnt = h_small_[8 + t];
       if (cnt > kCapPerSlot) { err = "DeviceMap: a 50 m cube exceeds the per-cube capacity of 1M points"; return -1; }
       slot_count_[tt.slot[t]] = cnt;
+      slot_res_[tt.slot[t]] = plane_res_;  // the whole cube has just been filtered at this leaf size
       if (world_ > 1) slot_owned_[tt.slot[t]] = h_small_[64 + t];
     }
   }

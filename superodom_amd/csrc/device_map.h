@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,8 @@ class DeviceMap {
   // ranks by the caller (owned_counts / set_full_counts) after every insert
   explicit DeviceMap(hipStream_t s, int rank = 0, int world = 1) : stream_(s), rank_(rank), world_(world) {
     origin_[0] = 10; origin_[1] = 10; origin_[2] = 5; cube_slot_.assign(kMapNum, -1);
+    const char* ev = std::getenv("SOICP_MAP_GROUPING");  // "sort": first stage of an insert by the stable radix sort (read per context)
+    hash_grouping_ = !(ev && std::string(ev) == "sort");
   }
   ~DeviceMap();
   // changing planeRes rebuilds the cell tables over the resident points (they are re-filtered when an insert next touches
@@ -63,7 +66,9 @@ class DeviceMap {
   std::vector<int32_t> cube_slot_;   // kMapNum: slot or -1
   std::vector<int32_t> slot_cube_;   // slot -> cube or -1 (free)
   std::vector<uint32_t> slot_count_;
+  std::vector<float> slot_res_;      // planeRes the slot's cube was last filtered with (0: empty)
   bool slot_table_dirty_ = true;
+  bool hash_grouping_ = true;
   // device
   float4* d_pool_ = nullptr; uint32_t* d_cell_start_ = nullptr; int32_t* d_cube_slot_ = nullptr; int slots_alloc_ = 0;
   // work buffers
@@ -71,6 +76,8 @@ class DeviceMap {
   float4 *d_wpts_ = nullptr, *d_cent_ = nullptr, *d_spts_ = nullptr;
   uint32_t *d_k0_ = nullptr, *d_k1_ = nullptr, *d_v0_ = nullptr, *d_v1_ = nullptr, *d_flags_ = nullptr, *d_pos_ = nullptr, *d_heads_ = nullptr;
   uint32_t *d_grid_ = nullptr, *d_grid_scan_ = nullptr; size_t grid_cap_ = 0;  // dense cell grids of the touched cubes (second stage)
+  uint32_t *d_ht_key_ = nullptr, *d_ht_cnt_ = nullptr, *d_ht_off_ = nullptr; uint32_t ht_log2_ = 0;  // leaf hash table of the first stage (map_kernels.hip)
+  int ensure_leaf_table(size_t n_new, std::string& err);
   void* d_temp_ = nullptr; size_t temp_bytes_ = 0;
   int32_t* d_cube_of_ = nullptr; uint8_t* d_touched_ = nullptr; int8_t* d_touched_id_ = nullptr; uint32_t* d_small_ = nullptr;
   float* d_stage_ = nullptr; size_t stage_cap_ = 0;  // host->device staging of new points / export

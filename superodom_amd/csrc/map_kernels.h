@@ -32,7 +32,10 @@ struct MapInsertArgs {
   float4* pool; uint32_t cap; uint32_t* cell_start;
   float4* wpts; float4* cent; float4* spts /* working set in leaf-sorted order */; uint32_t* heads /* first index of leaf o; [n_leaves] = end */;
   uint32_t *keys0, *keys1, *vals0, *vals1, *flags, *pos;
-  uint32_t* d_n_cent; uint32_t* d_counts;  // [1], [kMaxTouched]
+  uint32_t* d_n_cent; uint32_t* d_counts;  // [8] (zeroed by the caller: [0] centroids, [1] long leaves, [2..3] member / group cursor, [4] giant leaves, [5] halt), [kMaxTouched]
+  // first stage by hash grouping (default; nullptr = sort-based first stage): table of 2^ht_log2 >= max(4096, 2 n_new) slots,
+  // keys 0xFFFFFFFF and counts 0 between inserts (the offsets kernel leaves it that way)
+  uint32_t *ht_key, *ht_cnt, *ht_off; uint32_t ht_log2;
   // sharded map (world > 1): this rank keeps the LEAVES that can put a centroid into a cell within one cell of a brick it
   // owns (whole leaves, so that a kept centroid is the centroid of ALL the points of its leaf), and counts the points whose
   // own cell it owns (d_owned: summed over the ranks = the cube's full point count, LocalMap.h:292-318)

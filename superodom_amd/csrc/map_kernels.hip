@@ -189,7 +189,7 @@ __device__ __forceinline__ void emit_centroid(uint32_t o, uint32_t key, float s0
     g[a] = v < 0 ? 0 : (v >= nc ? nc - 1 : v);
   }
   keys2[o] = ((uint32_t)t << 18) | (uint32_t)((g[2] * nc + g[1]) * nc + g[0]);  // linear cell index, as in the cube's table
-  vals2[o] = o;
+  if (vals2) vals2[o] = o;  // (only the sort-based second stage reads it)
 }
 
 // leaf-sorted working set made contiguous (spts[i] = wpts[vals[i]]) + first index of every leaf (heads[ordinal]; the
@@ -280,6 +280,359 @@ __global__ __launch_bounds__(256) void leaf_centroid_long_kernel(const uint32_t*
   if (lane == 0) emit_centroid(o, keys[beg], s0, s1, s2, end - beg, tt, nc, inv_cell, cent, keys2, vals2);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Leaf grouping WITHOUT a sort (default first stage of an insert).  The radix sort of the whole working set (~550 k
+// keys for a 131 k-point scan against the touched cubes: nine launches, ~90 us) only served to bring the points of a leaf
+// together in input order.  Most leaves of the touched cubes receive no new point: their old centroid passes through
+// unchanged.  So: the NEW points claim the slots of a hash table keyed by leaf (one slot per distinct leaf, counted in
+// per wavefront); every OLD point probes the table read-only -- no slot: it is its leaf's only point and becomes the
+// centroid directly; a slot: it joins the group.  A scan over the table hands every group a range of a member list, the
+// members are placed, and each group is summed in ascending working-set index (old centroid first, then the new points in
+// scan order: the order a stable sort would have produced -- float addition is not associative, pcl::VoxelGrid accumulates
+// in input order).  Arrival order at a slot is not deterministic, so the members of a group are sorted by index: a
+// four-element network per thread, a 64-lane bitonic network per wavefront, an LDS bitonic sort per workgroup for the
+// leaves under the sensor (hundreds of points).  Centroid index space: [0, n_old) = the old points (a matched one leaves
+// a hole: cell key 0xFFFFFFFF, skipped by the second stage), n_old + g = group g.
+struct LeafTable { uint32_t *key, *cnt, *off; uint32_t log2_size; };
+constexpr uint32_t kLeafEmpty = 0xFFFFFFFFu, kGiantLeaf = 64, kGiantCap = 4096;
+
+__device__ __forceinline__ uint32_t leaf_hash(uint32_t key, uint32_t log2_size) { return (key * 2654435761u) >> (32 - log2_size); }
+
+__global__ __launch_bounds__(256) void leafhash_insert_new_kernel(const uint32_t* __restrict__ keys, uint32_t n_old, uint32_t total, LeafTable ht,
+                                                                  uint32_t* __restrict__ mslot, uint32_t* __restrict__ mrank) {
+  const uint32_t e = n_old + blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t key = e < total ? keys[e] : kLeafEmpty;
+  const bool kept = key != kLeafEmpty;
+  const int lane = threadIdx.x & 63;
+  // the wavefront's points grouped by key first: one lane per distinct key touches the table, and the members a wavefront
+  // adds to a group stay in lane (= scan) order
+  uint32_t my_idx = 0, my_cnt = 0;
+  int lead = lane;
+  unsigned long long todo = __ballot(kept);
+  while (todo) {
+    const int L = __ffsll((long long)todo) - 1;
+    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
+    const unsigned long long m = __ballot(kept && key == kk);
+    if (kept && key == kk) { my_idx = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); my_cnt = (uint32_t)__popcll(m); lead = L; }
+    todo &= ~m;
+  }
+  uint32_t slot = kLeafEmpty, base = 0;
+  if (kept && lead == lane) {
+    const uint32_t mask = (1u << ht.log2_size) - 1u;
+    uint32_t h = leaf_hash(key, ht.log2_size);
+    for (;;) {
+      uint32_t k = ht.key[h];
+      if (k == kLeafEmpty) k = atomicCAS(&ht.key[h], kLeafEmpty, key);
+      if (k == kLeafEmpty || k == key) break;
+      h = (h + 1) & mask;
+    }
+    slot = h;
+    base = atomicAdd(&ht.cnt[slot], my_cnt);
+  }
+  slot = (uint32_t)__shfl((int)slot, lead, 64);
+  base = (uint32_t)__shfl((int)base, lead, 64);
+  if (e < total) { mslot[e] = kept ? slot : kLeafEmpty; mrank[e] = base + my_idx; }
+}
+
+// (launched after leafhash_insert_new_kernel has completed: the table's keys are final, only the counts still move)
+__global__ __launch_bounds__(256) void leafhash_match_old_kernel(const uint32_t* __restrict__ keys, uint32_t n_old, const float4* __restrict__ wpts,
+                                                                 LeafTable ht, uint32_t* __restrict__ mslot, uint32_t* __restrict__ mrank,
+                                                                 MapTouched tt, int nc, double inv_cell, float4* __restrict__ cent,
+                                                                 uint32_t* __restrict__ keys2) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_old) return;
+  const uint32_t key = keys[e];
+  const uint32_t mask = (1u << ht.log2_size) - 1u;
+  uint32_t h = leaf_hash(key, ht.log2_size), slot = kLeafEmpty;
+  for (;;) {
+    const uint32_t k = ht.key[h];
+    if (k == key) { slot = h; break; }
+    if (k == kLeafEmpty) break;
+    h = (h + 1) & mask;
+  }
+  mslot[e] = slot;
+  if (slot != kLeafEmpty) {
+    mrank[e] = atomicAdd(&ht.cnt[slot], 1u);
+    keys2[e] = kLeafEmpty;  // a hole of the centroid index space: the point lives on in its group
+    return;
+  }
+  const float4 p = wpts[e];  // the only point of its leaf: sum = 0 + p, count = 1
+  emit_centroid(e, key, 0.f + p.x, 0.f + p.y, 0.f + p.z, 1u, tt, nc, inv_cell, cent, keys2, nullptr);
+}
+
+// member-list ranges + group ordinals from the table counts (four slots per thread, 1024 threads per workgroup: workgroup
+// scan, ONE packed atomic per workgroup: members in the low word, groups in the high word -- the ranges only have to be
+// disjoint, not ordered); leaves the table empty for the next insert
+__global__ __launch_bounds__(1024) void leafhash_offsets_kernel(LeafTable ht, uint32_t* __restrict__ gstart, uint32_t* __restrict__ gcount,
+                                                                unsigned long long* __restrict__ cursor) {
+  __shared__ uint32_t wm[16], wg[16], base_m, base_g;
+  const uint32_t t4 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint4 c4 = reinterpret_cast<const uint4*>(ht.cnt)[t4];
+  const uint32_t cnt[4] = {c4.x, c4.y, c4.z, c4.w};
+  uint32_t tm = 0, tg = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { tm += cnt[k]; tg += cnt[k] ? 1u : 0u; }
+  uint32_t im = tm, ig = tg;
+  if (__ballot(tm != 0)) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t a = (uint32_t)__shfl_up((int)im, d, 64), b = (uint32_t)__shfl_up((int)ig, d, 64);
+      if (lane >= d) { im += a; ig += b; }
+    }
+  }
+  if (lane == 63) { wm[wave] = im; wg[wave] = ig; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t sm = 0, sg = 0;
+    for (int w = 0; w < 16; ++w) { const uint32_t a = wm[w], b = wg[w]; wm[w] = sm; wg[w] = sg; sm += a; sg += b; }
+    unsigned long long old = 0ull;
+    if (sm) old = atomicAdd(cursor, (unsigned long long)sm | ((unsigned long long)sg << 32));
+    base_m = (uint32_t)old; base_g = (uint32_t)(old >> 32);
+  }
+  __syncthreads();
+  if (tm) {
+    uint32_t off = base_m + wm[wave] + (im - tm), g = base_g + wg[wave] + (ig - tg);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!cnt[k]) continue;
+      ht.off[4 * t4 + k] = off;
+      gstart[g] = off; gcount[g] = cnt[k];
+      off += cnt[k]; ++g;
+      ht.key[4 * t4 + k] = kLeafEmpty;
+    }
+    reinterpret_cast<uint4*>(ht.cnt)[t4] = make_uint4(0, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void leafhash_place_kernel(const uint32_t* __restrict__ mslot, const uint32_t* __restrict__ mrank, uint32_t total,
+                                                             const uint32_t* __restrict__ off, uint32_t* __restrict__ members) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const uint32_t sl = mslot[e];
+  if (sl != kLeafEmpty) members[off[sl] + mrank[e]] = e;
+}
+
+// one thread per group for up to 16 members (sorting network in registers): 95 % of the groups of a raw 128-beam sweep.
+// Groups of 17..64 go to leafhash_medium_kernel's list (one wavefront each), larger ones to leafhash_giant_kernel's.
+__global__ __launch_bounds__(256) void leafhash_centroid_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
+                                                                const unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ members,
+                                                                const float4* __restrict__ wpts, const uint32_t* __restrict__ leaf_keys,
+                                                                uint32_t n_old, MapTouched tt, int nc, double inv_cell, float4* __restrict__ cent,
+                                                                uint32_t* __restrict__ keys2, uint32_t* __restrict__ n_cent,
+                                                                uint32_t* __restrict__ medium_list, uint32_t* __restrict__ medium_count,
+                                                                uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_groups = (uint32_t)(*cursor >> 32);
+  if (g == 0) *n_cent = n_old + n_groups;
+  const int lane = threadIdx.x & 63;
+  const bool have = g < n_groups;
+  const uint32_t cnt = have ? gcount[g] : 0u, beg = have ? gstart[g] : 0u;
+  // the larger groups: one list append per wavefront and list
+  {
+    const bool med = cnt > 16u && cnt <= kGiantLeaf, big = cnt > kGiantLeaf;
+    const unsigned long long mm = __ballot(med), mb = __ballot(big);
+    uint32_t bm = 0, bb = 0;
+    if (lane == 0 && mm) bm = atomicAdd(medium_count, (uint32_t)__popcll(mm));
+    if (lane == 0 && mb) bb = atomicAdd(giant_count, (uint32_t)__popcll(mb));
+    bm = (uint32_t)__shfl((int)bm, 0, 64); bb = (uint32_t)__shfl((int)bb, 0, 64);
+    if (med) medium_list[bm + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = g;
+    if (big) giant_list[bb + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull))] = g;
+  }
+  if (!have || cnt > 16u) return;
+  uint32_t e[16];
+  if (cnt <= 4u) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = (uint32_t)k < cnt ? members[beg + k] : kLeafEmpty;
+    uint32_t t;
+#define SO_CSWAP(a, b) { t = min(a, b); b = max(a, b); a = t; }
+    SO_CSWAP(e[0], e[1]) SO_CSWAP(e[2], e[3]) SO_CSWAP(e[0], e[2]) SO_CSWAP(e[1], e[3]) SO_CSWAP(e[1], e[2])
+#undef SO_CSWAP
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float4 p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = wpts[(uint32_t)k < cnt ? e[k] : e[0]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((uint32_t)k < cnt) { s0 += p[k].x; s1 += p[k].y; s2 += p[k].z; }
+    emit_centroid(n_old + g, leaf_keys[e[0]], s0, s1, s2, cnt, tt, nc, inv_cell, cent, keys2, nullptr);
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) e[k] = (uint32_t)k < cnt ? members[beg + k] : kLeafEmpty;
+  // bitonic network over 16 registers (absent members = 0xFFFFFFFF end up behind the real ones)
+#pragma unroll
+  for (int k = 2; k <= 16; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const uint32_t lo = min(e[i], e[l]), hi = max(e[i], e[l]);
+          const bool up = (i & k) == 0;
+          e[i] = up ? lo : hi; e[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+  float4 p[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) p[k] = wpts[(uint32_t)k < cnt ? e[k] : e[0]];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if ((uint32_t)k < cnt) { s0 += p[k].x; s1 += p[k].y; s2 += p[k].z; }
+  emit_centroid(n_old + g, leaf_keys[e[0]], s0, s1, s2, cnt, tt, nc, inv_cell, cent, keys2, nullptr);
+}
+
+// groups of 17..64 members: one wavefront each (bitonic network over the lanes, then the sum in lane order)
+__global__ __launch_bounds__(256) void leafhash_medium_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
+                                                              const uint32_t* __restrict__ members, const float4* __restrict__ wpts,
+                                                              const uint32_t* __restrict__ leaf_keys, uint32_t n_old, MapTouched tt, int nc,
+                                                              double inv_cell, float4* __restrict__ cent, uint32_t* __restrict__ keys2,
+                                                              const uint32_t* __restrict__ medium_list, const uint32_t* __restrict__ medium_count) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_medium = *medium_count, n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_medium; w += n_waves) {
+  const uint32_t g = medium_list[w];
+  const uint32_t c = gcount[g], b = gstart[g];
+  uint32_t v = (uint32_t)lane < c ? members[b + lane] : kLeafEmpty;
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)v, j, 64);
+      const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+      v = keep_min ? min(v, o) : max(v, o);
+    }
+  }
+  // lane i now holds the group's i-th member in working-set order; lanes behind the end contribute +0.0f (s + 0.0f == s)
+  const float4 p = wpts[(uint32_t)lane < c ? v : 0u];
+  const bool live = (uint32_t)lane < c;
+  const float x = live ? p.x : 0.f, y = live ? p.y : 0.f, z = live ? p.z : 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    s0 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), k));
+    s1 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), k));
+    s2 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), k));
+  }
+  const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+  if (lane == 0) emit_centroid(n_old + g, leaf_keys[first], s0, s1, s2, c, tt, nc, inv_cell, cent, keys2, nullptr);
+  }
+}
+
+// leaves with more than 64 points (the ground under the sensor: up to ~1 600 points of a raw 128-beam sweep in one 0.2 m
+// leaf): one workgroup per leaf.  The member list is a sequence of RUNS in arrival order -- the points one wavefront of
+// leafhash_insert_new_kernel added (contiguous, in scan order) -- plus the odd old point.  A new point's place in
+// working-set order follows from its wavefront: members are counted per wavefront (a direct-address table in LDS, one
+// entry per 64 scan points), a scan turns the counts into run positions, and inside its run a member sits where it
+// sits in the list.  (A 2 048-element bitonic sort in LDS took 150 us here, ranking the runs against each other 35 us.)
+// The points are gathered into LDS in final order and three wavefronts add up x, y and z in sequence, 64 values per
+// round out of their lanes.  More members than kGiantCap, more than 64 x kGiantCap new points in the round, or more than
+// 64 old points in one leaf: *overflow is raised, the second stage stands still and the host repeats the round with the
+// sort-based first stage.
+constexpr size_t kGiantLds = (size_t)kGiantCap * 5 * 4;  // x, y, z, per-wavefront counts, per-wavefront first list position
+constexpr int kGiantThreads = 1024;                       // four members per thread at most: one round trip per phase
+__global__ __launch_bounds__(kGiantThreads) void leafhash_giant_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
+                                                             const uint32_t* __restrict__ members, const float4* __restrict__ wpts,
+                                                             const uint32_t* __restrict__ leaf_keys, uint32_t n_old, uint32_t n_new,
+                                                             MapTouched tt, int nc, double inv_cell, float4* __restrict__ cent,
+                                                             uint32_t* __restrict__ keys2, const uint32_t* __restrict__ giant_list,
+                                                             const uint32_t* __restrict__ giant_count, uint32_t* __restrict__ overflow) {
+  extern __shared__ uint32_t lds[];
+  float* sx = reinterpret_cast<float*>(lds);
+  float* sy = reinterpret_cast<float*>(lds + kGiantCap);
+  float* sz = reinterpret_cast<float*>(lds + 2 * kGiantCap);
+  uint32_t* hist = lds + 3 * kGiantCap;
+  uint32_t* fpos = lds + 4 * kGiantCap;
+  __shared__ uint32_t wsum[kGiantThreads], olds[64], n_olds, first_e;
+  const int tid = threadIdx.x, lane = threadIdx.x & 63;
+  constexpr int kPer = kGiantCap / kGiantThreads;  // 4
+  const uint32_t n_giant = *giant_count;
+  const uint32_t nb = (n_new + 63u) >> 6;  // wavefronts of leafhash_insert_new_kernel
+  for (uint32_t w = blockIdx.x; w < n_giant; w += gridDim.x) {
+    const uint32_t g = giant_list[w];
+    const uint32_t cnt = gcount[g], beg = gstart[g];
+    if (cnt > kGiantCap || nb > kGiantCap) { if (tid == 0) *overflow = 1u; continue; }
+    __syncthreads();  // (the previous leaf of this workgroup is done with the arrays)
+    uint32_t e[kPer];
+    float4 p[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const uint32_t i = (uint32_t)tid + (uint32_t)k * kGiantThreads;
+      e[k] = i < cnt ? members[beg + i] : kLeafEmpty;
+      hist[i] = 0u; fpos[i] = 0xFFFFFFFFu;
+    }
+    if (tid == 0) n_olds = 0u;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) p[k] = wpts[e[k] != kLeafEmpty ? e[k] : 0u];  // (on their way while the places are worked out)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const uint32_t i = (uint32_t)tid + (uint32_t)k * kGiantThreads;
+      if (e[k] == kLeafEmpty) continue;
+      if (e[k] >= n_old) { const uint32_t b = (e[k] - n_old) >> 6; atomicAdd(&hist[b], 1u); atomicMin(&fpos[b], i); }
+      else { const uint32_t at = atomicAdd(&n_olds, 1u); if (at < 64u) olds[at] = e[k]; }
+    }
+    __syncthreads();
+    const uint32_t n_o = n_olds;
+    if (n_o > 64u) { if (tid == 0) *overflow = 1u; continue; }  // (uniform: every thread read the same n_olds)
+    // exclusive scan of the per-wavefront counts: four entries per thread, then the 1 024 partial sums
+    uint32_t local[kPer], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { local[k] = sum; sum += hist[kPer * tid + k]; }
+    wsum[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < kGiantThreads; d <<= 1) {
+      const uint32_t v = tid >= d ? wsum[tid - d] : 0u;
+      __syncthreads();
+      wsum[tid] += v;
+      __syncthreads();
+    }
+    const uint32_t before = wsum[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) hist[kPer * tid + k] = before + local[k];
+    __syncthreads();
+    // points into their final places: the old points first (in index order), then wavefront after wavefront; inside its
+    // wavefront's run a member keeps its distance from the run's first list position
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const uint32_t i = (uint32_t)tid + (uint32_t)k * kGiantThreads;
+      if (e[k] == kLeafEmpty) continue;
+      uint32_t at;
+      if (e[k] < n_old) {
+        at = 0;
+        for (uint32_t q = 0; q < n_o; ++q) at += olds[q] < e[k] ? 1u : 0u;
+      } else {
+        const uint32_t b = (e[k] - n_old) >> 6;
+        at = n_o + hist[b] + (i - fpos[b]);
+      }
+      sx[at] = p[k].x; sy[at] = p[k].y; sz[at] = p[k].z;
+      if (at == 0) first_e = e[k];  // the first member in working-set order (its leaf key goes with the centroid)
+    }
+    __syncthreads();
+    if (tid < 192) {  // wavefronts 0, 1, 2 add x, y, z: three independent chains of dependent additions
+      const float* src = tid < 64 ? sx : (tid < 128 ? sy : sz);
+      float acc = 0.f;
+      float cur = (uint32_t)lane < cnt ? src[lane] : 0.f;
+      for (uint32_t j = 0; j < cnt; j += 64) {
+        const uint32_t jn = j + 64u + (uint32_t)lane;
+        const float nxt = jn < cnt ? src[jn] : 0.f;  // (lanes behind the end contribute +0.0f: s + 0.0f == s)
+#pragma unroll
+        for (int k = 0; k < 64; ++k) acc += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cur), k));
+        cur = nxt;
+      }
+      if (lane == 0) wsum[tid >> 6] = __float_as_uint(acc);
+    }
+    __syncthreads();
+    if (tid == 0)
+      emit_centroid(n_old + g, leaf_keys[first_e], __uint_as_float(wsum[0]), __uint_as_float(wsum[1]), __uint_as_float(wsum[2]), cnt, tt, nc, inv_cell,
+                    cent, keys2, nullptr);
+  }
+}
+
 __global__ __launch_bounds__(256) void pad_keys_kernel(uint32_t* __restrict__ keys2, uint32_t* __restrict__ vals2,
                                                        const uint32_t* __restrict__ n_cent, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -340,19 +693,39 @@ static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1)
 // result equals the stable sort by (cell, leaf) it replaces).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cell_count_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ n_cent,
-                                                         uint32_t ncell1, uint32_t* __restrict__ grid, uint32_t* __restrict__ rank) {
+                                                         uint32_t ncell1, uint32_t* __restrict__ grid, uint32_t* __restrict__ rank,
+                                                         const uint32_t* __restrict__ halt) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= *n_cent) return;
-  const uint32_t k = keys2[o];
-  rank[o] = atomicAdd(&grid[(size_t)(k >> 18) * ncell1 + (k & 0x3FFFFu)], 1u);
+  if (*halt) return;
+  // hole of the centroid index space (hash grouping: an old point that joined a group): key 0xFFFFFFFF
+  const uint32_t k = o < *n_cent ? keys2[o] : 0xFFFFFFFFu;
+  const bool kept = k != 0xFFFFFFFFu;
+  // one atomic per DISTINCT cell of the wavefront: with the old points in pool order (cell after cell) the lanes of a
+  // wavefront hit two or three counters, and 64 atomics on one word serialise
+  const int lane = threadIdx.x & 63;
+  uint32_t my_idx = 0, my_cnt = 0;
+  int lead = lane;
+  unsigned long long todo = __ballot(kept);
+  while (todo) {
+    const int L = __ffsll((long long)todo) - 1;
+    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)k, L);
+    const unsigned long long m = __ballot(kept && k == kk);
+    if (kept && k == kk) { my_idx = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); my_cnt = (uint32_t)__popcll(m); lead = L; }
+    todo &= ~m;
+  }
+  uint32_t base = 0;
+  if (kept && lead == lane) base = atomicAdd(&grid[(size_t)(k >> 18) * ncell1 + (k & 0x3FFFFu)], my_cnt);
+  base = (uint32_t)__shfl((int)base, lead, 64);
+  if (kept) rank[o] = base + my_idx;
 }
 // grid_scan = exclusive scan of grid over all touched cubes; per cube: table entry = slot*cap + (scan - scan at the cube's
 // first cell); the entry behind the last cell = the cube's new point count
 __global__ __launch_bounds__(256) void cell_table_kernel(const uint32_t* __restrict__ grid_scan, MapTouched tt, uint32_t cap, uint32_t ncell1,
-                                                         uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts) {
+                                                         uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ halt) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t t = blockIdx.y;
-  if (c >= ncell1) return;
+  if (c >= ncell1 || *halt) return;
   const uint32_t local = grid_scan[(size_t)t * ncell1 + c] - grid_scan[(size_t)t * ncell1];
   cell_start[(size_t)tt.slot[t] * ncell1 + c] = tt.slot[t] * cap + local;
   if (c == ncell1 - 1) counts[t] = local;
@@ -361,13 +734,16 @@ __global__ __launch_bounds__(256) void cell_table_kernel(const uint32_t* __restr
 __global__ __launch_bounds__(256) void cell_place_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ rank,
                                                          const uint32_t* __restrict__ n_cent, const uint32_t* __restrict__ grid_scan,
                                                          const float4* __restrict__ cent, MapTouched tt, uint32_t ncell1, float inv_leaf,
-                                                         float4* __restrict__ tmp) {
+                                                         float4* __restrict__ tmp, uint32_t* __restrict__ tmpk,
+                                                         const uint32_t* __restrict__ halt) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= *n_cent) return;
+  if (o >= *n_cent || *halt) return;
   const uint32_t k = keys2[o], t = k >> 18;
-  float4 v = cent[o];
-  v.w = __uint_as_float(leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t));
-  tmp[grid_scan[(size_t)t * ncell1 + (k & 0x3FFFFu)] + rank[o]] = v;  // global position over all touched cubes
+  if (k == 0xFFFFFFFFu) return;
+  const float4 v = cent[o];
+  const uint32_t at = grid_scan[(size_t)t * ncell1 + (k & 0x3FFFFu)] + rank[o];  // global position over all touched cubes
+  tmp[at] = v;
+  tmpk[at] = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t);  // (the ranking pass reads 4 bytes per comparison)
 }
 // pass 2: final position inside the cell = number of the cell's centroids with a smaller leaf key (one centroid per leaf:
 // the keys are distinct), i.e. ascending leaf order -- what the stable sort by (cell, leaf) produced
@@ -376,12 +752,14 @@ __global__ __launch_bounds__(256) void cell_place_kernel(const uint32_t* __restr
 //  on the placement rank, so that every point keeps a position of its own.)
 __global__ __launch_bounds__(256) void cell_rank_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ n_cent,
                                                         const uint32_t* __restrict__ grid, const uint32_t* __restrict__ grid_scan,
-                                                        const float4* __restrict__ cent, const float4* __restrict__ tmp, MapTouched tt,
+                                                        const float4* __restrict__ cent, const float4* __restrict__ tmp,
+                                                        const uint32_t* __restrict__ tmpk, MapTouched tt,
                                                         uint32_t cap, uint32_t ncell1, float inv_leaf, float4* __restrict__ pool,
-                                                        const uint32_t* __restrict__ rank) {
+                                                        const uint32_t* __restrict__ rank, const uint32_t* __restrict__ halt) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= *n_cent) return;
+  if (o >= *n_cent || *halt) return;
   const uint32_t k = keys2[o], t = k >> 18;
+  if (k == 0xFFFFFFFFu) return;
   const size_t gi = (size_t)t * ncell1 + (k & 0x3FFFFu);
   const uint32_t beg = grid_scan[gi], cnt = grid[gi];
   const float4 v = cent[o];
@@ -389,10 +767,10 @@ __global__ __launch_bounds__(256) void cell_rank_kernel(const uint32_t* __restri
   const uint32_t mine = rank[o];
   uint32_t r = 0;
   for (uint32_t j = 0; j < cnt; ++j) {
-    const float4 u = tmp[beg + j];
-    const uint32_t ku = __float_as_uint(u.w);
+    const uint32_t ku = tmpk[beg + j];
     bool less = ku < kv;
     if (ku == kv && j != mine) {
+      const float4 u = tmp[beg + j];
       const uint32_t ux = __float_as_uint(u.x), uy = __float_as_uint(u.y), uz = __float_as_uint(u.z);
       const uint32_t vx = __float_as_uint(v.x), vy = __float_as_uint(v.y), vz = __float_as_uint(v.z);
       less = uz != vz ? uz < vz : (uy != vy ? uy < vy : (ux != vx ? ux < vx : j < mine));
@@ -549,29 +927,59 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(append_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of, a.d_touched_id,
                        a.tt, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0, a.nc, a.inv_cell, a.rank, a.world);
   size_t tb = a.temp_bytes;
-  (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable
-  hipLaunchKernelGGL(leaf_flags_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, total, a.flags);
-  tb = a.temp_bytes;
-  (void)rocprim::exclusive_scan(a.temp, tb, a.flags, a.pos, 0u, (size_t)total, rocprim::plus<uint32_t>(), s);
-  hipLaunchKernelGGL(leaf_heads_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.flags, a.pos, total, a.wpts, a.spts, a.heads,
-                     a.d_n_cent);
-  // d_n_cent + 1 = number of long leaves (cleared with d_small_), list = the flags array (free after the scan)
-  hipLaunchKernelGGL(leaf_centroid_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.heads, a.d_n_cent, a.spts, a.tt, a.nc, a.inv_cell,
-                     a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
-  hipLaunchKernelGGL(leaf_centroid_long_kernel, dim3(kMaxLongLeaves / 4), dim3(256), 0, s, a.keys1, a.heads, a.spts, a.tt, a.nc, a.inv_cell,
-                     a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
+  const bool hashed = a.ht_key != nullptr && a.grid != nullptr;
+  uint32_t* keys2 = a.keys0;  // cell key per centroid, input of the second stage
+  if (hashed) {
+    // first stage without a sort (see leafhash_insert_new_kernel): mslot = keys1, mrank = vals1, member list = pos, group ranges =
+    // heads / flags, giant list = keys1 again (free once the members are placed), cell keys = vals0; counters in d_n_cent[2..5]
+    const LeafTable ht{a.ht_key, a.ht_cnt, a.ht_off, a.ht_log2};
+    unsigned long long* cursor = reinterpret_cast<unsigned long long*>(a.d_n_cent + 2);
+    keys2 = a.vals0;
+    if (a.n_new) hipLaunchKernelGGL(leafhash_insert_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.keys0, a.n_old, total, ht, a.keys1, a.vals1);
+    if (a.n_old)
+      hipLaunchKernelGGL(leafhash_match_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.keys0, a.n_old, a.wpts, ht, a.keys1, a.vals1, a.tt, a.nc,
+                         a.inv_cell, a.cent, keys2);
+    hipLaunchKernelGGL(leafhash_offsets_kernel, dim3((1u << a.ht_log2) / 4096u), dim3(1024), 0, s, ht, a.heads, a.flags, cursor);
+    hipLaunchKernelGGL(leafhash_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, total, a.ht_off, a.pos);
+    // lists of the larger groups in keys1 (free once the members are placed): at most n_new / 17 medium, n_new / 65 giant ones
+    uint32_t* medium_list = a.keys1;
+    uint32_t* giant_list = a.keys1 + a.n_new / 2 + 1;
+    const uint32_t max_medium = a.n_new / 17u + 1u, max_giant = a.n_new / 65u + 1u;
+    hipLaunchKernelGGL(leafhash_centroid_kernel, grid_for(a.n_new ? a.n_new : 1u, 256), dim3(256), 0, s, a.heads, a.flags, cursor, a.pos, a.wpts, a.keys0,
+                       a.n_old, a.tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, giant_list, a.d_n_cent + 4);
+    hipLaunchKernelGGL(leafhash_medium_kernel, dim3(max_medium < 2048u ? (max_medium + 3u) / 4u : 512u), dim3(256), 0, s, a.heads, a.flags, a.pos, a.wpts, a.keys0, a.n_old, a.tt,
+                       a.nc, a.inv_cell, a.cent, keys2, medium_list, a.d_n_cent + 6);
+    static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(leafhash_giant_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)kGiantLds);
+    (void)lds_ok;
+    hipLaunchKernelGGL(leafhash_giant_kernel, dim3(max_giant < 1024u ? max_giant : 1024u), dim3(kGiantThreads), kGiantLds, s, a.heads, a.flags, a.pos, a.wpts, a.keys0,
+                       a.n_old, a.n_new, a.tt, a.nc, a.inv_cell, a.cent, keys2, giant_list, a.d_n_cent + 4, a.d_n_cent + 5);
+  } else {
+    (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable
+    hipLaunchKernelGGL(leaf_flags_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, total, a.flags);
+    tb = a.temp_bytes;
+    (void)rocprim::exclusive_scan(a.temp, tb, a.flags, a.pos, 0u, (size_t)total, rocprim::plus<uint32_t>(), s);
+    hipLaunchKernelGGL(leaf_heads_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.flags, a.pos, total, a.wpts, a.spts, a.heads,
+                       a.d_n_cent);
+    // d_n_cent + 1 = number of long leaves (cleared with d_small_), list = the flags array (free after the scan)
+    hipLaunchKernelGGL(leaf_centroid_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.heads, a.d_n_cent, a.spts, a.tt, a.nc, a.inv_cell,
+                       a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
+    hipLaunchKernelGGL(leaf_centroid_long_kernel, dim3(kMaxLongLeaves / 4), dim3(256), 0, s, a.keys1, a.heads, a.spts, a.tt, a.nc, a.inv_cell,
+                       a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
+  }
   if (a.grid) {  // second stage by counting into the cell grids (no sort)
     const size_t gn = (size_t)a.tt.n * a.ncell1;
+    const uint32_t* halt = a.d_n_cent + 5;  // raised by leafhash_giant_kernel: the round is repeated with the sort-based first stage
     (void)hipMemsetAsync(a.grid, 0, gn * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.ncell1, a.grid, a.vals1);
+    hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.ncell1, a.grid, a.vals1, halt);
     tb = a.temp_bytes;
     (void)rocprim::exclusive_scan(a.temp, tb, a.grid, a.grid_scan, 0u, gn, rocprim::plus<uint32_t>(), s);
     hipLaunchKernelGGL(cell_table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.grid_scan, a.tt, a.cap, a.ncell1, a.cell_start,
-                       a.d_counts);
-    hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.tt, a.ncell1,
-                       a.inv_leaf, a.spts);  // spts (leaf-sorted working set) is free after the centroids
-    hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid, a.grid_scan, a.cent, a.spts, a.tt,
-                       a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1);
+                       a.d_counts, halt);
+    hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.tt, a.ncell1,
+                       a.inv_leaf, a.spts, a.flags, halt);  // spts / flags (first-stage scratch) are free after the centroids
+    hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.grid, a.grid_scan, a.cent, a.spts, a.flags, a.tt,
+                       a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1, halt);
     if (a.world > 1 && a.d_owned)
       hipLaunchKernelGGL(count_owned_kernel, dim3((total + 255) / 256, a.tt.n), dim3(256), 0, s, a.pool, a.cap, a.tt, a.d_counts, a.nc, a.inv_cell,
                          a.rank, a.world, a.d_owned);
@@ -618,15 +1026,15 @@ void launch_map_retable(const MapInsertArgs& a, hipStream_t s) {
                      a.d_n_cent);
   const size_t gn = (size_t)a.tt.n * a.ncell1;
   (void)hipMemsetAsync(a.grid, 0, gn * sizeof(uint32_t), s);
-  hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.ncell1, a.grid, a.vals1);
+  hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.ncell1, a.grid, a.vals1, a.d_n_cent + 5);
   size_t tb = a.temp_bytes;
   (void)rocprim::exclusive_scan(a.temp, tb, a.grid, a.grid_scan, 0u, gn, rocprim::plus<uint32_t>(), s);
   hipLaunchKernelGGL(cell_table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.grid_scan, a.tt, a.cap, a.ncell1, a.cell_start,
-                     a.d_counts);
+                     a.d_counts, a.d_n_cent + 5);
   hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.tt, a.ncell1,
-                     a.inv_leaf, a.spts);
-  hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid, a.grid_scan, a.cent, a.spts, a.tt,
-                     a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1);
+                     a.inv_leaf, a.spts, a.flags, a.d_n_cent + 5);
+  hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid, a.grid_scan, a.cent, a.spts, a.flags, a.tt,
+                     a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1, a.d_n_cent + 5);
 }
 void launch_vg_stats(const float* d_xyz, uint32_t n, uint32_t stride_floats, double* d_part, int blocks, hipStream_t s) {
   hipLaunchKernelGGL(vg_stats_kernel, dim3(blocks), dim3(256), 0, s, d_xyz, n, stride_floats, d_part);

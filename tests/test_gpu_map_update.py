@@ -142,3 +142,29 @@ def test_scan_prefilter_matches_pcl_voxelgrid_restatement(oracle, gpu_slam_facto
     slam3.shift_map(sc.gt_pose(0)[:3])
     rc3, pose3, _ = slam3.localization(True, sc.guess(1), host, 0.1)
     assert rc3 == 0 and np.array_equal(pose, pose3) and slam2.map_size() == slam3.map_size()
+
+
+def test_leaf_group_sizes_of_every_code_path(oracle, gpu_slam_factory, monkeypatch):
+    """The first stage of an insert groups the points of a leaf through a hash table and sums them in input order: four
+    code paths by group size (one thread <= 16 members, one wavefront <= 64, one workgroup <= 4 096, beyond that the round
+    is repeated with the stable sort).  Leaves of every size, old centroid present or not, members arriving interleaved
+    with other leaves: every centroid must equal the oracle's sequential float sum bit for bit -- and so must the
+    sort-based first stage (SOICP_MAP_GROUPING=sort)."""
+    rng = np.random.default_rng(11)
+    sizes = [1, 2, 3, 4, 5, 9, 16, 17, 33, 63, 64, 65, 130, 700, 1636, 4096, 4097, 9000]
+    centres = np.array([[3.1 + 0.6 * k, -7.3 + 0.2 * (k % 5), 1.1 + 0.2 * (k % 3)] for k in range(len(sizes))])
+    def burst(scale=1.0):
+        parts = [c + rng.uniform(-0.09, 0.09, (int(n * scale) or 1, 3)) for c, n in zip(centres, sizes)]
+        pts = np.concatenate(parts + [noisy_planes_cloud(20000, rng, offset=(0, 0, 0))]).astype(np.float32)
+        return pts[rng.permutation(len(pts))]  # members of one leaf scattered over the whole input
+    clouds = [burst(), burst(0.5), burst()]
+    results = []
+    for mode in ("hash", "sort"):
+        monkeypatch.setenv("SOICP_MAP_GROUPING", mode)
+        slam = gpu_slam_factory(plane_res=0.2)
+        om = oracle.OracleMap(plane_res=0.2)
+        for step, pts in enumerate(clouds):  # the second and third insert meet the old centroids of the first
+            assert slam.add_surf_point_cloud(pts) == om.add_surf(pts)
+            assert _same_points(slam.export_map(), om.export()), (mode, step)
+        results.append(slam.export_map())
+    assert np.array_equal(results[0], results[1]), "both first stages leave the same map in the same canonical order"
