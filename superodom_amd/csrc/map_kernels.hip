@@ -298,10 +298,24 @@ constexpr uint32_t kLeafEmpty = 0xFFFFFFFFu, kGiantLeaf = 64, kGiantCap = 4096;
 
 __device__ __forceinline__ uint32_t leaf_hash(uint32_t key, uint32_t log2_size) { return (key * 2654435761u) >> (32 - log2_size); }
 
-__global__ __launch_bounds__(256) void leafhash_insert_new_kernel(const uint32_t* __restrict__ keys, uint32_t n_old, uint32_t total, LeafTable ht,
+// (the new points' part of the working set -- append_new_kernel's job on the sort path -- is produced here as well: one launch less)
+__global__ __launch_bounds__(256) void leafhash_insert_new_kernel(const float* __restrict__ xyz, uint32_t n_new, uint32_t stride_floats,
+                                                                  const int32_t* __restrict__ cube_of, const int8_t* __restrict__ touched_id,
+                                                                  MapTouched tt, float inv_leaf, int nc, double inv_cell, int rank, int world,
+                                                                  float4* __restrict__ wpts, uint32_t* __restrict__ keys, uint32_t n_old, LeafTable ht,
                                                                   uint32_t* __restrict__ mslot, uint32_t* __restrict__ mrank) {
-  const uint32_t e = n_old + blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t key = e < total ? keys[e] : kLeafEmpty;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t e = n_old + i, total = n_old + n_new;
+  uint32_t key = kLeafEmpty;
+  if (i < n_new) {
+    const float* p = xyz + (size_t)i * stride_floats;
+    wpts[e] = make_float4(p[0], p[1], p[2], 0.f);
+    const int cube = cube_of[i];
+    const int t = cube < 0 ? -1 : (int)touched_id[cube];  // outside the 21x21x11 window (LocalMap.h:605) / a cube of another round: dropped
+    if (t >= 0 && !(world > 1 && !shard_keeps_leaf(p[0], p[1], p[2], inv_leaf, tt, t, nc, inv_cell, rank, world)))
+      key = leaf_key(p[0], p[1], p[2], inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t);
+    keys[e] = key;
+  }
   const bool kept = key != kLeafEmpty;
   const int lane = threadIdx.x & 63;
   // the wavefront's points grouped by key first: one lane per distinct key touches the table, and the members a wavefront
@@ -335,13 +349,20 @@ __global__ __launch_bounds__(256) void leafhash_insert_new_kernel(const uint32_t
 }
 
 // (launched after leafhash_insert_new_kernel has completed: the table's keys are final, only the counts still move)
-__global__ __launch_bounds__(256) void leafhash_match_old_kernel(const uint32_t* __restrict__ keys, uint32_t n_old, const float4* __restrict__ wpts,
+// (the old points' part of the working set -- gather_old_kernel's job on the sort path -- is produced here as well)
+__global__ __launch_bounds__(256) void leafhash_match_old_kernel(const float4* __restrict__ pool, uint32_t cap, float inv_leaf, uint32_t* __restrict__ keys,
+                                                                 uint32_t n_old, float4* __restrict__ wpts,
                                                                  LeafTable ht, uint32_t* __restrict__ mslot, uint32_t* __restrict__ mrank,
                                                                  MapTouched tt, int nc, double inv_cell, float4* __restrict__ cent,
                                                                  uint32_t* __restrict__ keys2) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_old) return;
-  const uint32_t key = keys[e];
+  int t = 0;
+#pragma unroll
+  for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
+  const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
+  const uint32_t key = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t);
+  wpts[e] = p; keys[e] = key;
   const uint32_t mask = (1u << ht.log2_size) - 1u;
   uint32_t h = leaf_hash(key, ht.log2_size), slot = kLeafEmpty;
   for (;;) {
@@ -356,7 +377,7 @@ __global__ __launch_bounds__(256) void leafhash_match_old_kernel(const uint32_t*
     keys2[e] = kLeafEmpty;  // a hole of the centroid index space: the point lives on in its group
     return;
   }
-  const float4 p = wpts[e];  // the only point of its leaf: sum = 0 + p, count = 1
+  // the only point of its leaf: sum = 0 + p, count = 1
   emit_centroid(e, key, 0.f + p.x, 0.f + p.y, 0.f + p.z, 1u, tt, nc, inv_cell, cent, keys2, nullptr);
 }
 
@@ -921,13 +942,15 @@ void launch_transform_scan(const float* d_scan, uint32_t n, const Pose& pose, fl
 void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
   const uint32_t total = a.n_old + a.n_new;
   if (!total) return;
-  if (a.n_old)
-    hipLaunchKernelGGL(gather_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0);
-  if (a.n_new)
-    hipLaunchKernelGGL(append_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of, a.d_touched_id,
-                       a.tt, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0, a.nc, a.inv_cell, a.rank, a.world);
   size_t tb = a.temp_bytes;
   const bool hashed = a.ht_key != nullptr && a.grid != nullptr;
+  if (!hashed) {  // (the hash grouping's first two kernels build the working set themselves)
+    if (a.n_old)
+      hipLaunchKernelGGL(gather_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0);
+    if (a.n_new)
+      hipLaunchKernelGGL(append_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of, a.d_touched_id,
+                         a.tt, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0, a.nc, a.inv_cell, a.rank, a.world);
+  }
   uint32_t* keys2 = a.keys0;  // cell key per centroid, input of the second stage
   if (hashed) {
     // first stage without a sort (see leafhash_insert_new_kernel): mslot = keys1, mrank = vals1, member list = pos, group ranges =
@@ -935,10 +958,12 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
     const LeafTable ht{a.ht_key, a.ht_cnt, a.ht_off, a.ht_log2};
     unsigned long long* cursor = reinterpret_cast<unsigned long long*>(a.d_n_cent + 2);
     keys2 = a.vals0;
-    if (a.n_new) hipLaunchKernelGGL(leafhash_insert_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.keys0, a.n_old, total, ht, a.keys1, a.vals1);
+    if (a.n_new)
+      hipLaunchKernelGGL(leafhash_insert_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of,
+                         a.d_touched_id, a.tt, a.inv_leaf, a.nc, a.inv_cell, a.rank, a.world, a.wpts, a.keys0, a.n_old, ht, a.keys1, a.vals1);
     if (a.n_old)
-      hipLaunchKernelGGL(leafhash_match_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.keys0, a.n_old, a.wpts, ht, a.keys1, a.vals1, a.tt, a.nc,
-                         a.inv_cell, a.cent, keys2);
+      hipLaunchKernelGGL(leafhash_match_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.pool, a.cap, a.inv_leaf, a.keys0, a.n_old, a.wpts, ht,
+                         a.keys1, a.vals1, a.tt, a.nc, a.inv_cell, a.cent, keys2);
     hipLaunchKernelGGL(leafhash_offsets_kernel, dim3((1u << a.ht_log2) / 4096u), dim3(1024), 0, s, ht, a.heads, a.flags, cursor);
     hipLaunchKernelGGL(leafhash_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, total, a.ht_off, a.pos);
     // lists of the larger groups in keys1 (free once the members are placed): at most n_new / 17 medium, n_new / 65 giant ones
