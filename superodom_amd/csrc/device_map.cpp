@@ -241,6 +241,7 @@ int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err)
     a.grid = d_grid_; a.grid_scan = d_grid_scan_;
     a.temp = d_temp_; a.temp_bytes = temp_bytes_;
     launch_map_retable(a, stream_);
+    DM_TRY(hipGetLastError());
     DM_TRY(hipStreamSynchronize(stream_));  // `a` travels by value, but the next round reuses the work buffers
   }
   return 0;
@@ -358,6 +359,7 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
       while (((size_t)1 << a.ht_log2) < 2 * (n + 1)) ++a.ht_log2;
     }
     launch_map_insert(a, stream_);
+    DM_TRY(hipGetLastError());  // a refused launch must not pass for an insert
     DM_TRY(hipMemcpyAsync(h_small_, d_small_, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
     DM_TRY(hipStreamSynchronize(stream_));  // also keeps `tid` / the staging buffer alive long enough
     if (a.ht_key && h_small_[5]) {
@@ -367,6 +369,8 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
       DM_TRY(hipMemsetAsync(d_small_, 0, 48 * sizeof(uint32_t), stream_));
       if (world_ > 1) DM_TRY(hipMemsetAsync(d_small_ + 64, 0, kMaxTouched * sizeof(uint32_t), stream_));
       launch_map_insert(a, stream_);
+      DM_TRY(hipGetLastError());
+    DM_TRY(hipGetLastError());  // a refused launch must not pass for an insert
       DM_TRY(hipMemcpyAsync(h_small_, d_small_, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
       DM_TRY(hipStreamSynchronize(stream_));
     }

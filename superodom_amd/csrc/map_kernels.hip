@@ -974,9 +974,8 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
                        a.n_old, a.tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, giant_list, a.d_n_cent + 4);
     hipLaunchKernelGGL(leafhash_medium_kernel, dim3(max_medium < 2048u ? (max_medium + 3u) / 4u : 512u), dim3(256), 0, s, a.heads, a.flags, a.pos, a.wpts, a.keys0, a.n_old, a.tt,
                        a.nc, a.inv_cell, a.cent, keys2, medium_list, a.d_n_cent + 6);
-    static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(leafhash_giant_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         (int)kGiantLds);
-    (void)lds_ok;
+    // (per launch, not once per process: the attribute belongs to the current device, and one process may drive several)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leafhash_giant_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGiantLds);
     hipLaunchKernelGGL(leafhash_giant_kernel, dim3(max_giant < 1024u ? max_giant : 1024u), dim3(kGiantThreads), kGiantLds, s, a.heads, a.flags, a.pos, a.wpts, a.keys0,
                        a.n_old, a.n_new, a.tt, a.nc, a.inv_cell, a.cent, keys2, giant_list, a.d_n_cent + 4, a.d_n_cent + 5);
   } else {
