@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -326,12 +327,31 @@ void laserMapping::publishTopic() {  // :415-597
     if (slam.localization_mode) { priorCloudMsg.header.stamp = stamp; publish(P + "/overall_map", "sensor_msgs/msg/PointCloud2", priorCloudMsg); }
   }
 
-  {  // registered scan (:464-493): the full-resolution cloud in the world frame, points within 0.1 m of the origin dropped
+  {  // registered scan (:464-493): the full-resolution cloud in the world frame, points within 0.1 m of the origin dropped.
+     // Written straight into the message payload (pcl::PointXYZI records), no intermediate cloud.
     const size_t n = (size_t)fullRes_.width * fullRes_.height;
-    PointCloud<Point> clean;
-    if (n) {
-      const XyzLayout L = xyz_layout(fullRes_);
-      clean.points.reserve(n);
+    so_wire::PointCloud2 m = to_ros_msg(PointCloud<Point>());
+    size_t kept = 0;
+    const XyzLayout L0 = n ? xyz_layout(fullRes_) : XyzLayout{0, 0, 0, 0, false, false};
+    // (below ~32 k points the two PCIe copies cost what the host loop costs: 20 ns a point; SOICP_NODE_DEVICE_TRANSFORM_MIN moves the threshold)
+    static const size_t device_min = std::getenv("SOICP_NODE_DEVICE_TRANSFORM_MIN") ? (size_t)std::atol(std::getenv("SOICP_NODE_DEVICE_TRANSFORM_MIN")) : 32768;
+    if (n >= device_min && n && fullRes_.point_step == sizeof(Point) && L0.contiguous && L0.off_x == 0 && L0.has_intensity && L0.off_intensity == 16) {
+      // the message already holds pcl::PointXYZI records: transformed on the device in place (so_icp_transform_cloud), the
+      // rare dropped points squeezed out here
+      m.data.assign(fullRes_.data.begin(), fullRes_.data.begin() + n * sizeof(Point));
+      Transformd Tw; Tw.rot = q_w_curr; Tw.pos = t_w_curr;
+      std::vector<uint8_t> keep;
+      kept = slam.TransformCloud(m.data.data(), n, sizeof(Point), Tw, keep);
+      if (kept != n) {
+        Point* rec = reinterpret_cast<Point*>(m.data.data());
+        size_t o = 0;
+        for (size_t i = 0; i < n; ++i) if (keep[i]) rec[o++] = rec[i];
+        m.data.resize(kept * sizeof(Point));
+      }
+    } else if (n) {
+      const XyzLayout L = L0;
+      m.data.resize(n * sizeof(Point));
+      Point* out = reinterpret_cast<Point*>(m.data.data());
       for (size_t i = 0; i < n; ++i) {
         const uint8_t* p = fullRes_.data.data() + i * fullRes_.point_step;
         Point q;
@@ -341,10 +361,11 @@ void laserMapping::publishTopic() {  // :415-597
           const Vector3d w = qrot(q_w_curr, Vector3d(q.x, q.y, q.z));
           q.x = (float)(w.x() + t_w_curr.x()); q.y = (float)(w.y() + t_w_curr.y()); q.z = (float)(w.z() + t_w_curr.z());
         }
-        if (q.x * q.x + q.y * q.y + q.z * q.z > 0.01) clean.points.push_back(q);
+        if (q.x * q.x + q.y * q.y + q.z * q.z > 0.01) out[kept++] = q;
       }
+      m.data.resize(kept * sizeof(Point));
     }
-    so_wire::PointCloud2 m = to_ros_msg(clean);
+    m.width = (uint32_t)kept; m.row_step = m.point_step * m.width;
     m.header.stamp = stamp; m.header.frame_id = config_.WORLD_FRAME;
     publish(P + "/registered_scan", "sensor_msgs/msg/PointCloud2", m);
   }
@@ -389,16 +410,23 @@ void laserMapping::publishTopic() {  // :415-597
 }
 
 bool laserMapping::processOnce() {  // the loop body of process(), :768-793
+  using clk = std::chrono::steady_clock;
+  auto lap = [this](int k, clk::time_point& t) { const auto n = clk::now(); phase_seconds[k] += std::chrono::duration<double>(n - t).count(); t = n; };
+  auto t = clk::now();
   {
     std::lock_guard<std::mutex> lk(mBuf);
     if (!checkDataAvailable()) return false;
     sensorMeas = extractSensorData();
     clearSensorData();
   }
+  lap(0, t);
   try {
     setInitialGuess();
+    lap(1, t);
     adjustVoxelSize();
+    lap(2, t);
     performSLAMOptimization();
+    lap(3, t);
     if (initialization) {
       // EstimateLidarUncertainty publishes the six Float32 topics from inside Localization (LidarSlam.cpp:47, 965-966) on every
       // frame after the seeding one; note the missing '/' after ProjectName (LidarSlam.cpp:22-27)
@@ -407,6 +435,7 @@ bool laserMapping::processOnce() {  // the loop body of process(), :768-793
       for (int k = 0; k < 6; ++k) { so_wire::Float32 f; f.data = (float)u[k]; publish(config_.ProjectName + names[k], "std_msgs/msg/Float32", f); }
     }
     updatePoseAndPublish();
+    lap(4, t);
   } catch (const std::exception& e) {  // RCLCPP_ERROR("Error in frame processing: %s") and on to the next frame
     ++frames_failed;
     last_error = e.what();

@@ -11,6 +11,7 @@
 // Paths relative to /root/reference/super_odometry/.  In a ROS 2 workspace the same class body sits under an rclcpp::Node
 // ("node shell").
 #pragma once
+#include <chrono>
 #include <functional>
 #include <mutex>
 #include <queue>
@@ -64,6 +65,7 @@ class laserMapping {
 
   LidarSLAM slam;
   PredictionSource prediction_source = PredictionSource::IMU_ORIENTATION;
+  double phase_seconds[5] = {0, 0, 0, 0, 0};  // accumulated wall time: extract, initial guess, adjustVoxelSize, Localization, publish
   int frames_failed = 0;           // frames whose processing threw (process() logs and continues, :788-790)
   std::string last_error;
 

@@ -120,6 +120,16 @@ void LidarSLAM::PrefilterSurf(const float* xyz, size_t n, size_t stride_bytes, b
   if (info) { localMap.lineRes_ = info->line_res; localMap.planeRes_ = info->plane_res; }  // laserMapping.cpp:648-649
 }
 
+size_t LidarSLAM::TransformCloud(void* points, size_t n, size_t stride_bytes, const Transformd& T, std::vector<uint8_t>& keep) {
+  ensure_context();
+  const double Tw[7] = {T.pos.x(), T.pos.y(), T.pos.z(), T.rot.x(), T.rot.y(), T.rot.z(), T.rot.w()};
+  keep.resize(n);
+  size_t kept = 0;
+  if (so_icp_transform_cloud(gpu_, points, n, stride_bytes, Tw, keep.data(), &kept) < 0)
+    throw std::runtime_error(std::string("so_icp_transform_cloud: ") + so_icp_last_error(gpu_));
+  return kept;
+}
+
 void LidarSLAM::LocalizationPrefiltered(bool initialization, PredictionSource, Transformd position, const void* d_planner_xyz, size_t n_planner,
                                         int32_t n_edge_points, double timeLaserOdometry) {
   ensure_context();

@@ -10,6 +10,7 @@
 //               LocalizationICPMaxIter, OptSet.*, Visual_confidence_factor, localization_mode, init_*, map_dir (:103-120)
 #pragma once
 #include <string>
+#include <vector>
 
 #include "so_icp.h"
 
@@ -76,6 +77,9 @@ class LidarSLAM {
   // feeds LocalizationPrefiltered -- the filtered cloud never visits the host.  xyz may point into a PointCloud2 payload.
   void PrefilterSurf(const float* xyz, size_t n, size_t stride_bytes, bool auto_voxel_size, float line_res, float plane_res,
                      so_icp_prefilter_info* info, const void** d_filtered, size_t* n_filtered);
+  // utils::pointAssociateToMap over a cloud (the registered scan of laserMapping::publishTopic, laserMapping.cpp:464-493) on the
+  // device: records with float x y z at 0 4 8 rewritten in place, keep[i] = the node publishes point i
+  size_t TransformCloud(void* points, size_t n, size_t stride_bytes, const Transformd& T, std::vector<uint8_t>& keep);
   void LocalizationPrefiltered(bool initialization, PredictionSource predictodom, Transformd T_w_lidar_in, const void* d_planner_xyz,
                                size_t n_planner, int32_t n_edge_points, double timeLaserOdometry);
 

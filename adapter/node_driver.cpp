@@ -72,8 +72,15 @@ int main(int argc, char** argv) {
       node.laserFeatureInfoHandler(bag[k].data(), bag[k].size());  // the subscription callback ...
       while (node.processOnce()) {}                                // ... and the process() loop
       if (k) busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      else for (double& v : node.phase_seconds) v = 0;  // (the first frame allocates the device buffers)
     }
-    if (n_msgs > 1) fprintf(stderr, "node_driver: %d frames, %.3f ms per frame (deserialise + guess + prefilter + Localization + publish)\n", n_msgs - 1, 1e3 * busy / (n_msgs - 1));
+    if (n_msgs > 1) {
+      fprintf(stderr, "node_driver: %d frames, %.3f ms per frame (deserialise + guess + prefilter + Localization + publish)", n_msgs - 1, 1e3 * busy / (n_msgs - 1));
+      const char* names[5] = {"extract", "guess", "adjustVoxelSize", "Localization", "publish"};
+      fprintf(stderr, " | of which");
+      for (int k = 0; k < 5; ++k) fprintf(stderr, " %s %.3f", names[k], 1e3 * node.phase_seconds[k] / (n_msgs - 1));
+      fprintf(stderr, "\n");
+    }
     wr<uint32_t>(rec.f, 0xFFFFFFFFu); wr<int32_t>(rec.f, node.frames_failed); wr_blob(rec.f, node.last_error.data(), node.last_error.size());
     fclose(in); fclose(rec.f);
   } catch (const std::exception& e) {

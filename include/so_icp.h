@@ -287,6 +287,14 @@ int so_icp_deskew_scan_dev(so_icp_ctx *ctx, void *d_points, size_t n, size_t str
                            double lidar_start_time, const so_icp_stamped_pose *poses, size_t n_poses, int poses_are_imu,
                            const double T_i_l[7], so_icp_deskew_info *info);
 
+/* -------- one step after Seam A: the registered scan laserMapping::publishTopic builds
+ * (src/LaserMapping/laserMapping.cpp:464-493 with utils::pointAssociateToMap, src/utils/superodom_utils.cpp:148-158).
+ * Records with float x y z at byte 0 4 8, rewritten in place: a point within 0.1 m of the sensor (x*x + y*y + z*z < 0.01 in
+ * float) stays as it is, every other point becomes q * p + t (fp64, rounded to float).  keep[i] (nullable) = 1 when the
+ * result lies farther than 0.1 m from the world origin -- the node publishes only those; *n_kept (nullable) = their number. */
+int so_icp_transform_cloud(so_icp_ctx *ctx, void *points /* host, rewritten in place */, size_t n, size_t stride_bytes,
+                           const double T_w_lidar[7], uint8_t *keep, size_t *n_kept);
+
 /* -------- multi-GPU: one process per GPU; the map is sharded by brick-hash of the voxel grid and the 45 fp64 sums of every
  * evaluation are summed over the ranks: by RCCL (below), by an in-process group, or by the solve launches themselves
  * (peer exchange, further below) -------------------------------------------------------------------------------------- */

@@ -84,7 +84,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
-            "so_icp_deskew_scan", "so_icp_deskew_scan_dev"]
+            "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud"]
 
 _lib = None
 
@@ -139,6 +139,7 @@ def load():
     for fn in (L.so_icp_deskew_scan, L.so_icp_deskew_scan_dev):
         fn.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(C.c_double), C.c_size_t, C.c_int, C.POINTER(C.c_double),
                        C.POINTER(DeskewInfo)]
+    L.so_icp_transform_cloud.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_size_t)]
     L.so_icp_prefilter_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_float, C.c_float, C.POINTER(vp),
                                         C.POINTER(C.c_size_t), C.POINTER(PrefilterInfo)]
     L.so_icp_debug_knn_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
@@ -370,6 +371,16 @@ class LidarSlamGpu:
                                               float(lidar_start_time), _p(poses, C.c_double), len(poses), int(bool(poses_are_imu)),
                                               None if til is None else _p(til, C.c_double), C.byref(info)))
         return rec, info
+
+    def transform_cloud(self, records, T_w_lidar):
+        """the node's registered scan (pointAssociateToMap over a cloud): records uint8 [n, stride], float x y z at 0 4 8.
+        Returns (rewritten records, keep flags [n] uint8, number kept)."""
+        rec = np.ascontiguousarray(records, np.uint8).copy()
+        T = np.ascontiguousarray(T_w_lidar, np.float64)
+        keep = np.zeros(len(rec), np.uint8); nk = C.c_size_t(0)
+        self._check(self.L.so_icp_transform_cloud(self.h, rec.ctypes.data_as(C.c_void_p), rec.shape[0], rec.shape[1], _p(T, C.c_double),
+                                                  _p(keep, C.c_uint8), C.byref(nk)))
+        return rec, keep, nk.value
 
     def deskew_scan_dev(self, d_records, n, stride, time_off, lidar_start_time, poses, poses_are_imu, T_i_l=None):
         """the same on records resident in HBM (d_records: device address), rewritten there; returns DeskewInfo"""

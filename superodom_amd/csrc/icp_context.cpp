@@ -1448,6 +1448,32 @@ int so_icp_deskew_scan(so_icp_ctx* c, void* points, size_t n, size_t stride, siz
   return SO_ICP_OK;
 }
 
+// laserMapping::publishTopic's registered scan, laserMapping.cpp:464-493 (kernel: map_kernels.hip transform_cloud_kernel)
+int so_icp_transform_cloud(so_icp_ctx* c, void* points, size_t n, size_t stride, const double T[7], uint8_t* keep, size_t* n_kept) {
+  if (!c || (!points && n) || !T) return SO_ICP_E_INVALID;
+  if (stride < 12 || stride % 4) return fail(c, SO_ICP_E_INVALID, "records: float x y z at 0 4 8, stride a multiple of 4");
+  if (n >= ((size_t)1 << 31)) return fail(c, SO_ICP_E_UNSUPPORTED, "too many points");
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  if (n_kept) *n_kept = 0;
+  if (!n) return SO_ICP_OK;
+  hipStream_t s = c->stream;
+  HIP_TRY(c, c->pf_in.reserve(n * stride + 64));
+  HIP_TRY(c, c->pf_flags.reserve(n + 64));
+  HIP_TRY(c, c->pf_small.reserve(256));
+  HIP_TRY(c, hipMemcpyAsync(c->pf_in.p, points, n * stride, hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemsetAsync(c->pf_small.p, 0, 8, s));
+  launch_transform_cloud(c->pf_in.as<uint8_t>(), (uint32_t)n, (uint32_t)stride, pose_from_array(T), c->pf_flags.as<uint8_t>(), c->pf_small.as<uint32_t>(), s);
+  HIP_TRY(c, hipGetLastError());
+  uint32_t kept = 0;
+  HIP_TRY(c, hipMemcpyAsync(points, c->pf_in.p, n * stride, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(&kept, c->pf_small.p, 4, hipMemcpyDeviceToHost, s));
+  if (keep) HIP_TRY(c, hipMemcpyAsync(keep, c->pf_flags.p, n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (n_kept) *n_kept = kept;
+  return SO_ICP_OK;
+}
+
 int so_icp_download_scan(so_icp_ctx* c, const void* d_scan, size_t n, float* out_xyz) {
   if (!c || (!d_scan && n) || (!out_xyz && n)) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);

@@ -65,6 +65,8 @@ void launch_transform_scan(const float* d_scan, uint32_t n, const Pose& pose, fl
 void launch_map_insert(const MapInsertArgs& a, hipStream_t s);
 void launch_map_retable(const MapInsertArgs& a, hipStream_t s);  // resolution change: new cell tables over the resident points
 void launch_gather_export(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, float* d_out, hipStream_t s);
+// pointAssociateToMap over a cloud (registered scan of the node): records rewritten in place, keep flags, number kept
+void launch_transform_cloud(uint8_t* d_pts, uint32_t n, uint32_t stride, const Pose& pose, uint8_t* d_keep, uint32_t* d_n_kept /* zeroed */, hipStream_t s);
 // removePointDistortion: records of `stride` bytes (float x y z at 0 4 8, float time at time_off), rewritten in place
 struct DeskewFrames;
 void launch_deskew(uint8_t* d_pts, uint32_t n, uint32_t stride, uint32_t time_off, double t0, const double* d_poses /* n_poses x 8 */,

@@ -1119,6 +1119,34 @@ void launch_deskew(uint8_t* d_pts, uint32_t n, uint32_t stride, uint32_t time_of
   else deskew_kernel<false><<<blocks, 256, 0, s>>>(d_pts, n, stride, time_off, t0, d_poses, n_poses, f, d_n_clamped);
 }
 
+// utils::pointAssociateToMap over a cloud as laserMapping::publishTopic applies it to the full-resolution scan
+// (laserMapping.cpp:464-493, superodom_utils.cpp:148-158): a point within 0.1 m of the sensor stays as it is, every other
+// point becomes q * p + t (Eigen's quaternion * vector in fp64, rounded to float); keep[i] = the result lies farther
+// than 0.1 m from the world origin (the node drops the others from the published cloud).
+__global__ __launch_bounds__(256) void transform_cloud_kernel(uint8_t* __restrict__ pts, uint32_t n, uint32_t stride, Pose pose, uint8_t* __restrict__ keep,
+                                                              uint32_t* __restrict__ n_kept) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool k = false;
+  if (i < n) {
+    float* xyz = reinterpret_cast<float*>(pts + (size_t)i * stride);
+    float x = xyz[0], y = xyz[1], z = xyz[2];
+    if (!(x * x + y * y + z * z < 0.01)) {  // (float products and sums compared with the double 0.01, as the node writes it)
+      double wx, wy, wz;
+      quat_rotate<double>(pose.q, (double)x, (double)y, (double)z, wx, wy, wz);
+      x = (float)(wx + pose.t[0]); y = (float)(wy + pose.t[1]); z = (float)(wz + pose.t[2]);
+      xyz[0] = x; xyz[1] = y; xyz[2] = z;
+    }
+    k = x * x + y * y + z * z > 0.01;
+    keep[i] = k ? 1 : 0;
+  }
+  const unsigned long long m = __ballot(k);
+  if (m && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) atomicAdd(n_kept, (uint32_t)__popcll(m));
+}
+void launch_transform_cloud(uint8_t* d_pts, uint32_t n, uint32_t stride, const Pose& pose, uint8_t* d_keep, uint32_t* d_n_kept, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(transform_cloud_kernel, grid_for(n, 256), dim3(256), 0, s, d_pts, n, stride, pose, d_keep, d_n_kept);
+}
+
 void launch_gather_export(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, float* d_out, hipStream_t s) {
   if (!count) return;
   hipLaunchKernelGGL(gather_export_kernel, grid_for(count, 256), dim3(256), 0, s, pool, cap, slot, count, d_out);

@@ -97,3 +97,30 @@ def test_deskew_on_records_resident_in_hbm(gpu_slam_factory, oracle):
     want, _, _ = oracle.deskew(rec, 20, T0, poses, False, None)
     frac, worst = close_in_ulps(dd.xyz_of(got), dd.xyz_of(want))
     assert frac > 0.999 and worst <= 1.0
+
+
+def test_transform_cloud_is_the_nodes_registered_scan_bit_for_bit(gpu_slam_factory):
+    """so_icp_transform_cloud against the arithmetic laserMapping::publishTopic runs on the host (Eigen's quaternion * vector in
+    fp64: uv = 2 u x v, v + w uv + u x uv; then + t, rounded to float; near-sensor points untouched; keep = farther than 0.1 m
+    from the world origin) -- the same IEEE operations in the same order, so the result is bit-identical."""
+    slam = gpu_slam_factory()
+    rng = np.random.default_rng(5)
+    n = 100000
+    rec = np.zeros((n, 8), np.float32)
+    rec[:, :3] = rng.normal(0, 20, (n, 3)); rec[:, 3] = 1.0; rec[:, 4] = rng.uniform(0, 255, n)
+    T = np.concatenate([[3.0, -4.0, 0.5], R.from_rotvec([0.02, -0.03, 0.8]).as_quat()])
+    rec[::1000, :3] = rng.uniform(-0.05, 0.05, (len(rec[::1000]), 3))                           # within 0.1 m of the sensor: untouched
+    back = R.from_quat(T[3:]).inv().apply(rng.uniform(-0.05, 0.05, (len(rec[5::1000]), 3)) - T[:3])
+    rec[5::1000, :3] = back.astype(np.float32)                                                 # land within 0.1 m of the world origin: dropped
+    got, keep, nk = slam.transform_cloud(rec.view(np.uint8).reshape(n, 32), T)
+    got = got.view(np.float32).reshape(n, 8)
+    x, y, z = (rec[:, k].astype(np.float64) for k in range(3))
+    qx, qy, qz, qw = T[3:]
+    ux, uy, uz = qy * z - qz * y, qz * x - qx * z, qx * y - qy * x
+    ux, uy, uz = ux + ux, uy + uy, uz + uz
+    wx = (x + qw * ux + (qy * uz - qz * uy)) + T[0]; wy = (y + qw * uy + (qz * ux - qx * uz)) + T[1]; wz = (z + qw * uz + (qx * uy - qy * ux)) + T[2]
+    near = (rec[:, 0] * rec[:, 0] + rec[:, 1] * rec[:, 1] + rec[:, 2] * rec[:, 2]).astype(np.float64) < 0.01
+    want = np.where(near[:, None], rec[:, :3], np.stack([wx, wy, wz], 1).astype(np.float32))
+    assert np.array_equal(got[:, :3].view(np.uint32), want.view(np.uint32)) and np.array_equal(got[:, 3:], rec[:, 3:])
+    wkeep = (want[:, 0] * want[:, 0] + want[:, 1] * want[:, 1] + want[:, 2] * want[:, 2]).astype(np.float64) > 0.01
+    assert np.array_equal(keep.astype(bool), wkeep) and nk == wkeep.sum() and near.sum() >= 100 and (~wkeep).sum() >= 150

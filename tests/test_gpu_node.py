@@ -45,7 +45,7 @@ def make_frames(sc, n_frames, with_imu=True):
     return frames
 
 
-def run_node(tmp_path, frames, plane_res, line_res, max_it, msf, auto_voxel=0, debug_view=0, params=None, prior=None):
+def run_node(tmp_path, frames, plane_res, line_res, max_it, msf, auto_voxel=0, debug_view=0, params=None, prior=None, env=None):
     assert os.path.exists(DRIVER), "adapter/node_driver not built: run python __graft_entry__.py"
     fin, fout = tmp_path / "bag.bin", tmp_path / "out.bin"
     with open(fin, "wb") as f:
@@ -53,7 +53,8 @@ def run_node(tmp_path, frames, plane_res, line_res, max_it, msf, auto_voxel=0, d
         for fr in frames:
             raw = cdr_py.encode("LaserFeature", fr["msg"])
             f.write(struct.pack("<I", len(raw))); f.write(raw)
-    r = subprocess.run([DRIVER, str(fin), str(fout)] + ([str(params)] if params else []) + ([str(prior)] if prior else []), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([DRIVER, str(fin), str(fout)] + ([str(params)] if params else []) + ([str(prior)] if prior else []), capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr
     raw = open(fout, "rb").read()
     at, pubs = 0, []
@@ -98,6 +99,10 @@ def test_node_shell_replay_against_the_mirror_the_oracle_and_ground_truth(gpu_sl
     pubs, failed, err = run_node(tmp_path, frames, sc.plane_res, line_res, max_it, -1)
     assert failed == 0, err
     msgs, order = by_frame(pubs, n_frames)
+    # the registered scan through the device (so_icp_transform_cloud, the path of clouds >= 32 k points) publishes the same bytes
+    pubs_dev, failed_dev, err = run_node(tmp_path, frames, sc.plane_res, line_res, max_it, -1, env={"SOICP_NODE_DEVICE_TRANSFORM_MIN": "1"})
+    assert failed_dev == 0, err
+    assert [(f, t, c) for f, t, _, c in pubs_dev if t.endswith("/registered_scan")] == [(f, t, c) for f, t, _, c in pubs if t.endswith("/registered_scan")]
 
     # (d) what is published, and in which order (laserMapping.cpp:415-597; LidarSlam.cpp:965-966 for the uncertainty topics)
     tail = [P + "/prediction_source", P + "/registered_scan", P + "/aft_mapped_to_init_incremental", P + "/laser_odometry", P + "/laser_odom_path", P + "/super_odometry_stats"]
