@@ -264,8 +264,10 @@ class Scene:
             self.map_points = np.load(path)
         else:
             self.map_points = sample_map(self.world, cfg["plane_res"], cfg["map_points"], seed=2)
-            try:
-                os.makedirs(cache_dir, exist_ok=True); np.save(path, self.map_points)
+            try:  # several ranks may build the same scene at once: write aside, then rename (atomic), so that nobody loads half a file
+                os.makedirs(cache_dir, exist_ok=True)
+                tmp = f"{path}.{os.getpid()}.tmp.npy"
+                np.save(tmp, self.map_points); os.replace(tmp, path)
             except OSError:
                 pass
 
