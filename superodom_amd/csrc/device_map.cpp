@@ -329,6 +329,7 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     for (int t = tt.n; t <= kMaxTouched; ++t) tt.old_prefix[t] = n_old;
     for (int t = tt.n; t < kMaxTouched; ++t) tt.slot[t] = 0;
     if (ensure_work((size_t)n_old + n, err)) return -2;
+    tt.inv_leaf_watch = inv_leaf; tt.dirty = d_small_ + 7;  // (cleared with d_small_ below)
     a.rank = rank_; a.world = world_; a.d_owned = world_ > 1 ? d_small_ + 64 : nullptr;
     if (world_ > 1) DM_TRY(hipMemsetAsync(d_small_ + 64, 0, kMaxTouched * sizeof(uint32_t), stream_));
     DM_TRY(hipMemcpyAsync(d_touched_id_, tid.data(), kMapNum, hipMemcpyHostToDevice, stream_));
@@ -378,7 +379,9 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
       const uint32_t cnt = h_small_[8 + t];
       if (cnt > kCapPerSlot) { err = "DeviceMap: a 50 m cube exceeds the per-cube capacity of 1M points"; return -1; }
       slot_count_[tt.slot[t]] = cnt;
-      slot_res_[tt.slot[t]] = plane_res_;  // the whole cube has just been filtered at this leaf size
+      // the whole cube has just been filtered at this leaf size -- unless one of its centroids drifted out of its leaf
+      // (MapTouched::dirty): then two points may share a leaf and the next insert must not use the pass-through
+      slot_res_[tt.slot[t]] = ((h_small_[7] >> t) & 1u) ? 0.f : plane_res_;
       if (world_ > 1) slot_owned_[tt.slot[t]] = h_small_[64 + t];
     }
   }

@@ -19,6 +19,13 @@ struct MapTouched {
   int32_t leaf_lo[kMaxTouched][3];       // floor(cube_min * inv_leaf) - 1: common leaf offset of the cube
   int32_t wcube[kMaxTouched][3];         // WORLD id of the cube (shard ownership hashes it: stable under shiftMap)
   double cube_min[kMaxTouched][3];       // world coordinates of the cube's min corner
+  // Invariant watch: the hash grouping of an insert lets an old point pass through when no new point shares its leaf, which
+  // is only right while every cube holds at most one point per leaf.  A centroid summed in float from tens of thousands of
+  // points can drift out of its own leaf (pcl::VoxelGrid has the same arithmetic); bit t of *dirty is raised when a centroid
+  // of touched cube t does not lie in the leaf it was built from -- the next insert that touches the cube then re-filters
+  // all of it through the sort, as the reference does with every touched block.
+  float inv_leaf_watch;
+  uint32_t* dirty;
 };
 
 struct MapInsertArgs {

@@ -190,6 +190,9 @@ __device__ __forceinline__ void emit_centroid(uint32_t o, uint32_t key, float s0
   }
   keys2[o] = ((uint32_t)t << 18) | (uint32_t)((g[2] * nc + g[1]) * nc + g[0]);  // linear cell index, as in the cube's table
   if (vals2) vals2[o] = o;  // (only the sort-based second stage reads it)
+  // (a lone point is its own centroid and lies in its leaf by construction; see MapTouched::dirty)
+  if (count > 1u && tt.dirty && leaf_key(cx, cy, cz, tt.inv_leaf_watch, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t) != key)
+    atomicOr(tt.dirty, 1u << t);
 }
 
 // leaf-sorted working set made contiguous (spts[i] = wpts[vals[i]]) + first index of every leaf (heads[ordinal]; the

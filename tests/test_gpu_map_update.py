@@ -168,3 +168,30 @@ def test_leaf_group_sizes_of_every_code_path(oracle, gpu_slam_factory, monkeypat
             assert _same_points(slam.export_map(), om.export()), (mode, step)
         results.append(slam.export_map())
     assert np.array_equal(results[0], results[1]), "both first stages leave the same map in the same canonical order"
+
+
+def test_centroids_that_drift_out_of_their_leaf_are_refiltered_like_pcl_does(oracle, gpu_slam_factory):
+    """pcl::VoxelGrid sums a leaf's points in float: with tens of thousands of points at |x| ~ 200 m the addends are rounded to
+    the sum's 0.25 / 0.5 m spacing and the centroid lands OUTSIDE its leaf -- here next to the neighbouring leaf's centroid,
+    so that the block holds two points in one leaf until its next filter merges them.  The hash grouping's pass-through of
+    lone old points must not survive that: the cube is flagged (MapTouched::dirty) and the next insert re-filters it whole."""
+    rng = np.random.default_rng(7)
+    centre = np.array([-205.8, -183.9, 6.5])
+    dense = (rng.normal(0, 0.02, (40000, 3)) * [1, 0.3, 0.3] + centre).astype(np.float32)   # straddles the leaf boundary x = -205.8
+    sparse = (rng.uniform(-20, 20, (500, 3)) * [1, 1, 0.1] + centre + [0, 0, 3.0]).astype(np.float32)  # same cube, other leaves
+    slam = gpu_slam_factory(plane_res=0.2)
+    om = oracle.OracleMap(plane_res=0.2)
+    for m in (slam, om):
+        m.set_origin(centre)
+    slam.shift_map(centre); om.shift(centre)
+    assert slam.add_surf_point_cloud(dense) == om.add_surf(dense)
+    a = slam.export_map()
+    assert _same_points(a, om.export())
+    leaves = np.floor(a * np.float32(5.0)).astype(np.int64)
+    assert len(a) == 2 and (leaves[0] == leaves[1]).all(), "the precondition of this test: two centroids in one leaf"
+    assert slam.add_surf_point_cloud(sparse) == om.add_surf(sparse)
+    b = slam.export_map()
+    assert _same_points(b, om.export()), "the next insert merges the two points (no new point falls into their leaf)"
+    assert len(b) == len(np.unique(np.floor(b * np.float32(5.0)).astype(np.int64), axis=0))
+    assert slam.add_surf_point_cloud(sparse + np.float32(0.05)) == om.add_surf(sparse + np.float32(0.05))  # back on the fast path
+    assert _same_points(slam.export_map(), om.export())
