@@ -9,7 +9,11 @@ sys.path.insert(0, ROOT)
 from superodom_amd import binding  # noqa: E402
 
 ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60.0); ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--oracle", action="store_true", help="also insert into the CPU oracle's LocalMap and compare the point sets")
 a = ap.parse_args()
+if a.oracle:
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
 rng = np.random.default_rng(a.seed)
 
 
@@ -45,19 +49,31 @@ while time.time() < t_end:
     centre = rng.uniform(-300, 300, 3) * [1, 1, 0.05]
     for m in (x, y):
         m.set_origin(centre); m.shift_map(centre)
+    om = None
+    if a.oracle:
+        om = oracle_py.OracleMap(plane_res=res, line_res=res / 2); om.set_origin(centre); om.shift(centre)
     ops = [("origin", centre.copy(), res)]
+    mixed_res = False  # after a resolution change old points share leaves: the order of their float sum is unspecified upstream (tests compare to rounding there)
     for step in range(int(rng.integers(2, 9))):
         if rng.random() < 0.2:
             centre = centre + rng.uniform(-120, 120, 3) * [1, 1, 0.02]
             assert list(x.shift_map(centre)) == list(y.shift_map(centre))
+            if om: assert list(om.shift(centre)) == list(x.shift_map(centre))
             ops.append(("shift", centre.copy(), res))
         if rng.random() < 0.1:
             res = float(rng.choice([0.1, 0.2, 0.4, 0.8]))
             x.set_resolution(res / 2, res); y.set_resolution(res / 2, res)
-            ops.append(("res", centre.copy(), res))
+            if om: om.set_resolution(res / 2, res)
+            ops.append(("res", centre.copy(), res)); mixed_res = True
         pts = cloud(centre)
         assert x.add_surf_point_cloud(pts) == y.add_surf_point_cloud(pts)
         ops.append(("add", pts, res))
+        if om:
+            assert om.add_surf(pts) >= 0
+            eo, eg = om.export(), x.export_map()
+            same = eo.shape == eg.shape and np.array_equal(eo[np.lexsort(eo.T)].view(np.uint32), eg[np.lexsort(eg.T)].view(np.uint32))
+            if not same and not mixed_res:
+                print("ORACLE MISMATCH", (a.seed, rounds, step, len(pts), res), eo.shape, eg.shape); sys.exit(1)
         ex, ey = x.export_map(), y.export_map()
         if not (ex.shape == ey.shape and np.array_equal(ex.view(np.uint32), ey.view(np.uint32))):
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
