@@ -39,14 +39,27 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 N_SIMD = 1024          # 256 CUs x 4 SIMDs
 
 
-def _load_json(name):
+def _kernels_sha():
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "superodom_amd", "csrc", "kernels.hip"), "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+def _load_counters(name):
+    """A PMC result file under profiles/ (written by tools/pmc_*.sh on a GPU box) -- quoted ONLY when it was collected on the
+    kernel source that is being timed now (kernels_hip_sha256); returns (json or None, reason when None)."""
     path = os.path.join(ROOT, "profiles", name)
-    if os.path.exists(path):
-        try:
-            return json.load(open(path))
-        except Exception:
-            return None
-    return None
+    if not os.path.exists(path):
+        return None, f"profiles/{name} absent"
+    try:
+        j = json.load(open(path))
+    except Exception as e:  # noqa: BLE001
+        return None, f"profiles/{name} unreadable: {e}"
+    if j.get("kernels_hip_sha256") != _kernels_sha():
+        return None, f"profiles/{name} was collected on another kernels.hip (sha256 {str(j.get('kernels_hip_sha256'))[:12]} != {str(_kernels_sha())[:12]}): stale, not quoted"
+    return j, None
 
 
 def main():
@@ -280,7 +293,8 @@ def main():
         batch = {"value": 64 * reps / t_b, "unit": "registrations/s", "hypotheses_per_scan": 64, "scans": reps,
                  "hypotheses_per_rank": len(mine), "ms_per_batch": 1e3 * t_b / reps, "returned_ok": ok, "within_2cm_of_ground_truth": good,
                  "outer_iterations_per_hypothesis": outer_b / (64.0 * reps),
-                 "parallelism": f"map replicated on {world} GPU(s), hypotheses split over the ranks, up to 16 concurrent lanes per GPU, no collective",
+                 "parallelism": f"map replicated on {world} GPU(s), hypotheses split over the ranks; on a GPU the hypotheses advance together in batched kernels "
+                                "(one binning / k-NN / persistent solve launch per round over all of them, a workgroup group + LM controller per hypothesis), no collective",
                  "scaling": "strong"}
         if world > 1:
             full.close()
@@ -311,16 +325,20 @@ def main():
     b_knn = 12.0 * q_per_launch + 12.0 * m_per_launch + 24.0 * q_per_launch
     b_knn_whole_map = 36.0 * q_per_launch + 12.0 * tm.knn_map_points / max(tm.knn_launches, 1)
     achieved = b_knn / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0
-    tr = _load_json("knn_traffic.json")     # PMC pass results (per launch), see profiles/README.md
+    tr, tr_why = _load_counters("knn_traffic.json")     # PMC pass results (per launch), see profiles/README.md
     traffic = tr.get("hbm_bytes_per_launch") if tr else None
-    ctr = _load_json("knn_counters.json")
-    valu = None
+    ctr, ctr_why = _load_counters("knn_counters.json")
+    valu = {"unavailable": ctr_why} if ctr is None else None
     if ctr and ctr.get("valu_wave_insts_per_launch") and knn_ms > 0:
         clk = float(ctr.get("shader_clock_ghz", 2.07))
         insts = float(ctr["valu_wave_insts_per_launch"])
-        # a wave-instruction occupies its SIMD's VALU for 4 cycles (64 lanes on 16): issue-bound time = insts * 4 / 1024 SIMDs / clock
-        valu = {"valu_wave_insts_per_launch": insts, "shader_clock_ghz": clk, "issue_bound_ms": insts * 4 / N_SIMD / (clk * 1e9) * 1e3,
-                "valu_issue_frac": insts * 4 / N_SIMD / (clk * 1e9) / (knn_ms * 1e-3), "source": ctr.get("source")}
+        # Issue floor of the sweep = VALU wave-instructions x cycles each / 1024 SIMDs / clock.  gfx950's SIMDs are 32 lanes
+        # wide (MI355X_MICROARCH.md: v_fma_f32 on a wavefront = 2 cycles; packed fp32 and fp64 = 4): the kernel's mix is mostly
+        # 32-bit integer / fp32 with packed-fp32 distance arithmetic, so the floor lies between the two figures below.
+        t2 = insts * 2 / N_SIMD / (clk * 1e9)
+        valu = {"valu_wave_insts_per_launch": insts, "shader_clock_ghz": clk, "issue_bound_ms_at_2_cycles": t2 * 1e3, "issue_bound_ms_at_4_cycles": 2e3 * t2,
+                "valu_issue_frac_at_2_cycles": t2 / (knn_ms * 1e-3), "valu_issue_frac_at_4_cycles": 2 * t2 / (knn_ms * 1e-3),
+                "kernels_hip_sha256": ctr.get("kernels_hip_sha256"), "source": ctr.get("source"), "solve_kernel": ctr.get("solve_kernel")}
     ms_per_step = 1e3 * t_max / args.steps
 
     errs = [synth.pose_error(poses[i], sc.gt_pose(i)) for i in range(len(poses))]
@@ -349,14 +367,15 @@ def main():
         "entry_points": {"note": "registrations/s; 'staged' and 'host' include the scan's H2D copy (1.5 MB), 'resident' does not",
                          args.entry: value, **secondary},
         "roofline": {"bound": "hbm", "kernel": "knn_plane_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": tr_why or tr.get("source"),
                      "algorithmic_bytes_per_launch": b_knn, "avg_launch_ms": knn_ms, "launches": int(tm.knn_launches),
                      "timing": "HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL) on the context's stream, inside the timed region, "
                                "on every 3rd registration (every launch with --time-all-kernels); no-op launches after convergence excluded",
                      "queries_per_launch": q_per_launch, "map_points_in_touched_cubes": m_per_launch,
                      "valu_issue": valu,
                      "note": "B = 36*Q + 12*M_t (SURVEY 8d); with M_t = whole map (BASELINE.md table) B would be %.0f and frac %.4f; "
-                             "the kernel is VALU-issue bound, not HBM bound: see valu_issue (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / clock / time)"
+                             "measured traffic = algorithmic bytes (no re-read waste): the sweep is bounded by instruction issue and by its slowest "
+                             "wavefronts, not by HBM -- see valu_issue"
                              % (b_knn_whole_map, (b_knn_whole_map / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if knn_ms > 0 else 0.0)},
         "host": {"c_abi_ms_per_step": tm.host_ms_total / max(tm.registrations, 1),
                  "note": "wall time inside the registration core (enqueue + wait + post-processing); ms_per_step - this = scan hand-over + Python/ctypes overhead"},
@@ -385,12 +404,21 @@ def main():
         t0 = time.perf_counter()
         worst = (0.0, 0.0)
         oposes = []
+        stats_equal = True  # executed iteration counts, termination codes, 7 + 9 bin histograms of every outer iteration (SURVEY 8d "Parity check")
         for i in range(n_cpu):
             orc, opose, ost, _ = om.register(scans[i % args.scans], guesses[i % args.scans], cfg_a)
             oposes.append(opose)
             if i < len(poses):
                 e = synth.pose_error(poses[i], opose)
                 worst = (max(worst[0], e[0]), max(worst[1], e[1]))
+                g = step_stats[i]
+                same = orc == 0 and g.n_iterations == ost.n_iterations
+                for it in range(min(g.n_iterations, ost.n_iterations)):
+                    a_, b_ = g.iterations[it], ost.iters[it]
+                    same = same and (a_.lm_iterations, a_.num_successful_steps, a_.termination, a_.num_surf_from_scan) == \
+                        (b_.lm_iterations, b_.num_successful_steps, b_.termination, b_.num_surf)
+                    same = same and list(a_.reject_hist) == list(b_.reject_hist) and list(a_.obs_hist) == list(b_.obs_hist)
+                stats_equal = stats_equal and bool(same)
         t_cpu = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": n_cpu / t_cpu, "unit": "registrations/s", "cores": 1, "kind": "port",
                                "sample": f"{n_cpu} registration(s) of the same {Q}-pt scans vs the same map, oracle/liboracle.so = Oracle-A "
@@ -435,6 +463,7 @@ def main():
         except Exception as e:  # the number of record is the 1-thread baseline above
             out["cpu_baseline_all_cores"] = {"error": str(e)}
         out["parity_vs_oracle_m_rad"] = [worst[0], worst[1]]
+        out["parity_iteration_counts_and_histograms_equal"] = stats_equal
         out["parity_scans_checked"] = min(n_cpu, len(poses))
         out["speedup_vs_cpu_1thread"] = value * t_cpu / n_cpu
     print(json.dumps(out))

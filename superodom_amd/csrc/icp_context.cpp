@@ -152,7 +152,7 @@ struct so_icp_ctx {
   DevBuf d_mpts, d_cell_start, d_cube_slot;
   DevMapView view{};
   // scan / correspondence buffers
-  DevBuf d_scan_own, d_keys0, d_keys1, d_vals0, d_vals1, d_chunks, d_sort_tmp, d_spx, d_spy, d_spz, d_nd, d_coeff, d_status, d_nbr5;
+  DevBuf d_scan_own, d_keys0, d_vals0, d_vals1, d_chunks, d_spx, d_spy, d_spz, d_nd, d_coeff, d_status, d_nbr5;
   DevBuf d_kdbg;   // profiling only
   DevBuf d_counts; // sharded device map: per-cube counters on their way through the all-reduce
   DevBuf d_small;  // hist[16] int32 | ticket | n_kept | fb_count | LmSums | partials
@@ -165,7 +165,6 @@ struct so_icp_ctx {
   bool direct_readback = true; unsigned long long reg_counter = 0;
   bool persistent_solve = true;  // SOICP_PERSISTENT=0: one launch per evaluation
   unsigned long long solve_launches = 0;  // persistent solve launches so far (EvalParams::epoch_base)
-  bool use_binning = true;       // SOICP_BINNING=sort: rocPRIM sort of (key, index) pairs + run-based chunk list
   DevBuf d_bin_key, d_bin_cnt, d_bin_off; uint32_t bin_log2 = 0; bool bin_dirty = true;
   int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
   int sync_per_outer = 1;  // 1: read back reg_done after every outer iteration and stop enqueuing (eager mode)
@@ -180,6 +179,21 @@ struct so_icp_ctx {
   // so_icp_register_batch: worker contexts register hypotheses concurrently against the PARENT's resident map
   struct Borrow { bool on = false; DevMapView view{}; float plane_res = 0; int pos[3] = {0, 0, 0}; int count_5x5 = 0; } borrow;
   std::vector<so_icp_ctx*> workers;
+  // so_icp_register_batch, batched kernels: one set of per-registration arrays per hypothesis (common element stride bs)
+  struct BatchBufs {
+    uint32_t cap_hyp = 0, bs = 0, table_log2 = 0;
+    bool tables_clean = false;
+    DevBuf states, begin, active, qslot, qrank, perm, spx, spy, spz, chunks, status, nbr5, nd, coeff, bin_key, bin_cnt, bin_off, partials, sync, hist;
+    DevState* h_states = nullptr; RegBeginArgs* h_begin = nullptr; uint32_t* h_active = nullptr;  // pinned
+    void release() {
+      for (DevBuf* b : {&states, &begin, &active, &qslot, &qrank, &perm, &spx, &spy, &spz, &chunks, &status, &nbr5, &nd, &coeff, &bin_key, &bin_cnt,
+                        &bin_off, &partials, &sync, &hist}) b->release();
+      if (h_states) (void)hipHostFree(h_states);
+      if (h_begin) (void)hipHostFree(h_begin);
+      if (h_active) (void)hipHostFree(h_active);
+      h_states = nullptr; h_begin = nullptr; h_active = nullptr; cap_hyp = 0; bs = 0; table_log2 = 0; tables_clean = false;
+    }
+  } batch;
   bool no_map_shift_once = false;  // retry of a registration: keep the window of the first attempt
   int n_cus = 256;            // compute units of the device: upper bound of the persistent solve launch's workgroups
   int ablate = 0;             // SOICP_ABLATE (profiling / test switches), read at creation
@@ -332,9 +346,8 @@ int upload_map(so_icp_ctx* c) {
 
 int reserve_scan_buffers(so_icp_ctx* c, size_t n) {
   const size_t m = n + 256;
-  HIP_TRY(c, c->d_keys0.reserve(m * 4)); HIP_TRY(c, c->d_keys1.reserve(m * 4));
+  HIP_TRY(c, c->d_keys0.reserve(m * 4));
   HIP_TRY(c, c->d_vals0.reserve(m * 4)); HIP_TRY(c, c->d_vals1.reserve(m * 4)); HIP_TRY(c, c->d_chunks.reserve(m * 4));
-  HIP_TRY(c, c->d_sort_tmp.reserve(sort_temp_bytes(m) + 256));
   HIP_TRY(c, c->d_spx.reserve(m * 4)); HIP_TRY(c, c->d_spy.reserve(m * 4)); HIP_TRY(c, c->d_spz.reserve(m * 4));
   HIP_TRY(c, c->d_nd.reserve(m * 32)); HIP_TRY(c, c->d_coeff.reserve(m * 8)); HIP_TRY(c, c->d_status.reserve(m));
   HIP_TRY(c, c->d_nbr5.reserve(m * 20));
@@ -348,7 +361,6 @@ MatchParams match_params(float plane_res, int ablate) {
   mp.max_point_dist = (double)plane_res / 2.0; // LidarSlam.cpp:820
   mp.ablate = ablate;  // SOICP_ABLATE, read when the context is created (a getenv per registration is a walk over environ)
   mp.kdbg = nullptr;
-  mp.packed_counts = 0;
   return mp;
 }
 EvalParams eval_params(float plane_res, int variant, int ablate) {
@@ -407,6 +419,35 @@ void yaw_correction(double T[7], const double last[7], double yaw_ratio) {
   for (int i = 0; i < 4; ++i) T[3 + i] = q[i] / n;
 }
 
+// The registration's results out of the state block the device published: pose (LidarSlam.cpp:135-136), per-iteration
+// statistics (:242-251), final normal equations, post-processing (:155-157, 198-210).
+void fill_result(so_icp_ctx* c, const DevState& H, const double pose_in[7], so_icp_stats* st, double pose_out[7], bool update_tracker) {
+  double T[7];
+  std::memcpy(T, H.T, sizeof(T));
+  st->n_iterations = H.n_iterations;
+  for (int it = 0; it < H.n_iterations && it < SO_ICP_MAX_OUTER; ++it) {
+    so_icp_iter_stats& is = st->iterations[it];
+    const DevIterStats& d = H.iters[it];
+    is.translation_norm = d.translation_norm; is.rotation_norm = d.rotation_norm;
+    is.num_surf_from_scan = d.num_surf; is.lm_iterations = d.lm_iterations; is.num_successful_steps = d.num_successful;
+    is.termination = d.termination; is.initial_cost = d.initial_cost; is.final_cost = d.final_cost;
+    std::memcpy(is.reject_hist, d.reject_hist, sizeof(is.reject_hist));
+    std::memcpy(is.obs_hist, d.obs_hist, sizeof(is.obs_hist));
+    std::memcpy(is.pose_after, d.pose_after, sizeof(is.pose_after));
+  }
+  if (H.n_iterations > 0 && update_tracker) {
+    std::memcpy(c->prev_obs_hist, H.iters[H.n_iterations - 1].obs_hist, sizeof(c->prev_obs_hist));
+    c->have_hist = true;
+  }
+  std::memcpy(st->JtJ, H.JtJ, sizeof(st->JtJ));
+  std::memcpy(st->Jtr, H.Jtr, sizeof(st->Jtr));
+  yaw_correction(T, pose_in, c->cfg.yaw_ratio);  // performPostOptimizationProcessing, :155-157 (last_T_w_lidar = the guess, :53-57)
+  relative_motion(pose_in, T, st->total_translation, st->total_rotation);
+  relative_motion(pose_in, T, st->translation_from_last, st->rotation_from_last);
+  st->prediction_source = 0;
+  std::memcpy(pose_out, T, sizeof(T));
+}
+
 // LidarSLAM::performLocalizationAndMapping (LidarSlam.cpp:107-152) with the loop state resident on the device:
 // the host enqueues, per outer iteration, the STATIC sequence
 //     clear histograms -> knn_plane -> [ eval(slot) -> (all-reduce) -> lm_step(slot) ] x (1 + lm_max)
@@ -422,10 +463,10 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // (kernels.hip: bin_offsets_kernel / knn_plane_kernel)
   if (n >= ((size_t)1 << 21)) return fail(c, SO_ICP_E_UNSUPPORTED, "scan of 2^21 points or more: the work-list counters hold 21 bits each (chunk descriptors 26)");
   st->flags = (c->retried ? SO_ICP_FLAG_RETRIED : 0u) | (!c->dmap && !c->borrow.on ? SO_ICP_FLAG_HOST_MAP : 0u) |
-              (c->use_binning ? 0u : SO_ICP_FLAG_SORT_BINNING) | (c->cfg.world_size > 1 ? SO_ICP_FLAG_SHARDED : 0u) |
+              (c->cfg.world_size > 1 ? SO_ICP_FLAG_SHARDED : 0u) |
               (c->scan_staged ? SO_ICP_FLAG_STAGED_SCAN : 0u) | (c->direct_readback ? 0u : SO_ICP_FLAG_COPY_READBACK);
-  double T[7], T_init[7], T_last[7];
-  std::memcpy(T, pose_in, sizeof(T)); std::memcpy(T_init, pose_in, sizeof(T)); std::memcpy(T_last, pose_in, sizeof(T));  // LidarSlam.cpp:53-57
+  double T[7];
+  std::memcpy(T, pose_in, sizeof(T));  // LidarSlam.cpp:53-57 (T_w_initial_guess = last_T_w_lidar = T_w_lidar = the guess)
   std::memcpy(pose_out, pose_in, sizeof(T));
   if (c->have_hist) uncertainty_from_hist(c->prev_obs_hist, st->uncertainty);  // LidarSlam.cpp:47
   int pos[3];
@@ -452,7 +493,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // ---- once per registration: prologue (the guess and the loop bounds travel as kernel arguments, no H2D copy),
   //      sampling rule, spatial sort (locality survives the small pose updates), chunk list + gather
   span_begin(c, 2, (uint32_t)n);
-  if (c->use_binning && n) {
+  BinTable bt{nullptr, nullptr, nullptr, 0};
+  if (n) {
     // hash binning: keys + per-key counts (scan_keys), bucket offsets + chunk list (bin_offsets), placement (bin_place).
     // The table has >= 2 slots per query; bin_offsets leaves it empty again.
     uint32_t lg = 16;
@@ -464,30 +506,23 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
       HIP_TRY(c, hipMemsetAsync(c->d_bin_cnt.p, 0, T * 4, s));
       c->bin_log2 = lg;
     }
-    const BinTable bt{c->d_bin_key.as<uint32_t>(), c->d_bin_cnt.as<uint32_t>(), c->d_bin_off.as<uint32_t>(), lg};
+    bt = BinTable{c->d_bin_key.as<uint32_t>(), c->d_bin_cnt.as<uint32_t>(), c->d_bin_off.as<uint32_t>(), lg};
     c->bin_dirty = true;  // until bin_offsets has been enqueued behind scan_keys
     launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
-                     c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), &bt, s);
+                     c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), bt, s);
     launch_bin_offsets(bt, c->d_chunks.as<uint32_t>(), (uint32_t)(c->d_chunks.cap / 4), ds, s);
     c->bin_dirty = false;
     launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(),
                      c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
   } else {
-    launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
-                     c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), nullptr, s);
-    if (n) {
-      launch_sort_pairs(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->d_keys0.as<uint32_t>(), c->d_keys1.as<uint32_t>(),
-                        c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, key_bits(c->view.n_slots), s);
-      launch_chunk_heads(c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_chunks.as<uint32_t>(), ds, d_scan,
-                         c->d_vals1.as<uint32_t>(), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
-    }
+    launch_scan_keys(d_scan, 0, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
+                     c->cfg.world_size, nullptr, nullptr, nullptr, bt, s);  // (empty scan: the prologue alone)
   }
   span_end(c);
   HIP_TRY(c, hipGetLastError());  // a refused launch would otherwise surface as a 50 ms wait or "state was not published"
   const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
   MatchParams mp = match_params(plane_res_now, c->ablate);
   mp.chunk_cap = (uint32_t)(c->d_chunks.cap / 4);
-  mp.packed_counts = (c->use_binning && n) ? 1 : 0;
   if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
     HIP_TRY(c, c->d_kdbg.reserve((size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemsetAsync(c->d_kdbg.p, 0, (size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long), s));
@@ -547,21 +582,11 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     if (it > 0 && c->cfg.world_size > 1 && n) {
       // sharded map: ownership follows the query's cell under the CURRENT pose, so the scan is re-binned at the start of
       // every outer iteration (a 1 degree correction at 50 m moves a point by more than the one-cell halo of a shard)
-      if (c->use_binning) {
-        const BinTable bt{c->d_bin_key.as<uint32_t>(), c->d_bin_cnt.as<uint32_t>(), c->d_bin_off.as<uint32_t>(), c->bin_log2};
-        launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
-                         c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), &bt, s, true);
-        launch_bin_offsets(bt, c->d_chunks.as<uint32_t>(), (uint32_t)(c->d_chunks.cap / 4), ds, s);
-        launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(),
-                         c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s, ds);
-      } else {
-        launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
-                         c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), nullptr, s, true);
-        launch_sort_pairs(c->d_sort_tmp.p, c->d_sort_tmp.cap, c->d_keys0.as<uint32_t>(), c->d_keys1.as<uint32_t>(),
-                          c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(), (uint32_t)n, key_bits(c->view.n_slots), s);
-        launch_chunk_heads(c->d_keys1.as<uint32_t>(), (uint32_t)n, key_dropped(c->view.n_slots), c->d_chunks.as<uint32_t>(), ds, d_scan,
-                           c->d_vals1.as<uint32_t>(), c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
-      }
+      launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
+                       c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), bt, s, true);
+      launch_bin_offsets(bt, c->d_chunks.as<uint32_t>(), (uint32_t)(c->d_chunks.cap / 4), ds, s);
+      launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(),
+                       c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s, ds);
     }
     // processPlannerFeatures: every kept query in parallel (LidarSlam.cpp:323-344)
     knn_span_of_outer.push_back(c->spans.size());
@@ -668,30 +693,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   }
   c->h_state = c->h_ring[last & 1];
   const DevState& H = *c->h_state;
-  std::memcpy(T, H.T, sizeof(T));  // LidarSlam.cpp:135-136
-  st->n_iterations = H.n_iterations;
-  for (int it = 0; it < H.n_iterations && it < SO_ICP_MAX_OUTER; ++it) {
-    so_icp_iter_stats& is = st->iterations[it];
-    const DevIterStats& d = H.iters[it];
-    is.translation_norm = d.translation_norm; is.rotation_norm = d.rotation_norm;
-    is.num_surf_from_scan = d.num_surf; is.lm_iterations = d.lm_iterations; is.num_successful_steps = d.num_successful;
-    is.termination = d.termination; is.initial_cost = d.initial_cost; is.final_cost = d.final_cost;
-    std::memcpy(is.reject_hist, d.reject_hist, sizeof(is.reject_hist));
-    std::memcpy(is.obs_hist, d.obs_hist, sizeof(is.obs_hist));
-    std::memcpy(is.pose_after, d.pose_after, sizeof(is.pose_after));
-  }
-  if (H.n_iterations > 0 && !c->batch_mode) {
-    std::memcpy(c->prev_obs_hist, H.iters[H.n_iterations - 1].obs_hist, sizeof(c->prev_obs_hist));
-    c->have_hist = true;
-  }
-  std::memcpy(st->JtJ, H.JtJ, sizeof(st->JtJ));
-  std::memcpy(st->Jtr, H.Jtr, sizeof(st->Jtr));
-  yaw_correction(T, T_last, c->cfg.yaw_ratio);  // performPostOptimizationProcessing, :155-157
+  fill_result(c, H, pose_in, st, pose_out, !c->batch_mode);
   st->time_elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_icp).count();  // :199-200
-  relative_motion(T_init, T, st->total_translation, st->total_rotation);
-  relative_motion(T_last, T, st->translation_from_last, st->rotation_from_last);
-  st->prediction_source = 0;
-  std::memcpy(pose_out, T, sizeof(T));
   if (timed) {  // keep only the launches that did real work (no-op launches after convergence are excluded)
     std::vector<EventSpan> real;
     for (size_t i = 0; i < c->spans.size(); ++i) {
@@ -703,7 +706,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
         if (sp.kind == 1 && it < (int)eval_span_first.size() && i >= eval_span_first[it] &&
             i < eval_span_first[it] + (persistent ? 1 : 1 + (size_t)std::max(H.iters[it].lm_iterations, 0))) keep = true;
       }
-      if (keep) { EventSpan r = sp; r.units = mp.packed_counts ? (uint32_t)(H.bin_packed & 0x1FFFFFull) : H.n_kept; real.push_back(r); }
+      if (keep) { EventSpan r = sp; r.units = (uint32_t)(H.bin_packed & 0x1FFFFFull); real.push_back(r); }
     }
     c->spans.swap(real);
     // profiling mode brackets the solve launches too: the last one has published its result but its stop event may not
@@ -853,6 +856,144 @@ int resolve_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes,
   return rc;
 }
 
+
+// ---- so_icp_register_batch: B hypotheses of one scan in the same launches ------------------------------------------
+// One binning launch sequence over (queries x hypotheses), then rounds of { one k-NN launch over the chunks of every
+// hypothesis still iterating, one persistent solve launch in which every such hypothesis owns a group of workgroups
+// and runs its own LM controller (kernels.hip: solve_kernel<BATCH>) , one read-back of the state blocks }.  A hypothesis
+// is an independent registration: it leaves the rounds when its own termination rule fires (LidarSlam.cpp:141), and the
+// workgroups it held go to the others in the next round.  Results are bit-identical to so_icp_register per hypothesis.
+constexpr int kBatchMaxConcurrent = 64;
+int batch_reserve(so_icp_ctx* c, uint32_t B, size_t n, uint32_t lg) {
+  so_icp_ctx::BatchBufs& b = c->batch;
+  const uint32_t bs = (uint32_t)(((n + 256 + 63) / 64) * 64);
+  const size_t T = (size_t)1 << lg;
+  const size_t partial_bytes = (size_t)kFitBlocksMax * kRecordChunksMax * 16;
+  if (B > b.cap_hyp || bs > b.bs || lg != b.table_log2) {
+    const uint32_t cap = std::max(B, b.cap_hyp), nbs = std::max(bs, b.bs);
+    b.release();
+    HIP_TRY(c, b.states.reserve((size_t)cap * sizeof(DevState))); HIP_TRY(c, b.begin.reserve((size_t)cap * sizeof(RegBeginArgs)));
+    HIP_TRY(c, b.active.reserve((size_t)cap * 4));
+    for (DevBuf* d : {&b.qslot, &b.qrank, &b.perm, &b.spx, &b.spy, &b.spz, &b.chunks}) HIP_TRY(c, d->reserve((size_t)cap * nbs * 4));
+    HIP_TRY(c, b.status.reserve((size_t)cap * nbs)); HIP_TRY(c, b.nbr5.reserve((size_t)cap * nbs * 20));
+    HIP_TRY(c, b.nd.reserve((size_t)cap * nbs * 32)); HIP_TRY(c, b.coeff.reserve((size_t)cap * nbs * 8));
+    for (DevBuf* d : {&b.bin_key, &b.bin_cnt, &b.bin_off}) HIP_TRY(c, d->reserve((size_t)cap * T * 4));
+    HIP_TRY(c, b.partials.reserve((size_t)cap * partial_bytes)); HIP_TRY(c, b.sync.reserve((size_t)cap * kSyncBytes));
+    HIP_TRY(c, b.hist.reserve((size_t)cap * kHistReplicas * kHistStride * 4));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&b.h_states), (size_t)cap * sizeof(DevState)));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&b.h_begin), (size_t)cap * sizeof(RegBeginArgs)));
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&b.h_active), (size_t)cap * 4));
+    // tags / epochs of the record tables and hand-off blocks count up from zero; the state blocks start cleared
+    HIP_TRY(c, hipMemsetAsync(b.partials.p, 0, (size_t)cap * partial_bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(b.sync.p, 0, (size_t)cap * kSyncBytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(b.states.p, 0, (size_t)cap * sizeof(DevState), c->stream));
+    HIP_TRY(c, hipMemsetAsync(b.hist.p, 0, (size_t)cap * kHistReplicas * kHistStride * 4, c->stream));
+    b.cap_hyp = cap; b.bs = nbs; b.table_log2 = lg; b.tables_clean = false;
+  }
+  if (!b.tables_clean) {  // (bin_offsets leaves the tables empty again)
+    HIP_TRY(c, hipMemsetAsync(b.bin_key.p, 0xFF, (size_t)b.cap_hyp * T * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(b.bin_cnt.p, 0, (size_t)b.cap_hyp * T * 4, c->stream));
+  }
+  return SO_ICP_OK;
+}
+
+int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const double* poses_in, int B, double* poses_out, so_icp_stats* stats,
+                         int32_t* hyp_rc, const int pos[3], int count_5x5) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  std::vector<so_icp_stats> local;
+  if (!stats) { local.resize((size_t)B); stats = local.data(); }
+  for (int h = 0; h < B; ++h) {
+    so_icp_stats* st = stats + h;
+    std::memset(st, 0, sizeof(*st));
+    st->flags = (!c->dmap ? SO_ICP_FLAG_HOST_MAP : 0u) | (c->direct_readback ? 0u : SO_ICP_FLAG_COPY_READBACK);
+    std::memcpy(poses_out + 7 * (size_t)h, poses_in + 7 * (size_t)h, 7 * sizeof(double));
+    if (c->have_hist) uncertainty_from_hist(c->prev_obs_hist, st->uncertainty);
+    st->pos_in_localmap[0] = pos[0]; st->pos_in_localmap[1] = pos[1]; st->pos_in_localmap[2] = pos[2];
+    st->laser_cloud_surf_from_map_num = count_5x5; st->laser_cloud_surf_stack_num = (int32_t)n; st->startup_count = c->startup_count;
+    hyp_rc[h] = SO_ICP_OK;
+  }
+  if (!(count_5x5 > 50)) { for (int h = 0; h < B; ++h) hyp_rc[h] = SO_ICP_NOT_ENOUGH_MAP_FEATURES; return SO_ICP_OK; }  // LidarSlam.cpp:113-116
+  if (n >= ((size_t)1 << 21)) return fail(c, SO_ICP_E_UNSUPPORTED, "scan of 2^21 points or more: the work-list counters hold 21 bits each (chunk descriptors 26)");
+  const int max_outer = std::min(c->cfg.max_iterations > 0 ? c->cfg.max_iterations : 4, SO_ICP_MAX_OUTER);
+  const int lm_max = std::min(c->cfg.lm_max_iterations > 0 ? c->cfg.lm_max_iterations : 4, 16);
+  uint32_t lg = 16;
+  while ((1ull << lg) < 2 * (unsigned long long)n) ++lg;
+  int rc = batch_reserve(c, (uint32_t)B, n, lg);
+  if (rc) return rc;
+  so_icp_ctx::BatchBufs& b = c->batch;
+  hipStream_t s = c->stream;
+  for (int h = 0; h < B; ++h) {
+    std::memcpy(b.h_begin[h].pose, poses_in + 7 * (size_t)h, 7 * sizeof(double));
+    b.h_begin[h].max_outer = max_outer; b.h_begin[h].lm_max = lm_max;
+    b.h_active[h] = (uint32_t)h;
+  }
+  HIP_TRY(c, hipMemcpyAsync(b.begin.p, b.h_begin, (size_t)B * sizeof(RegBeginArgs), hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemcpyAsync(b.active.p, b.h_active, (size_t)B * 4, hipMemcpyHostToDevice, s));
+  const float plane_res_now = map_plane_res(c);
+  MatchParams mp = match_params(plane_res_now, c->ablate);
+  mp.chunk_cap = b.bs;
+  mp.hring[0] = mp.hring[1] = nullptr; mp.seq_base = 0; mp.publish_prev = 0;
+  EvalParams ep = eval_params(plane_res_now, c->cfg.tukey_variant, c->ablate);
+  ep.n_queries = (uint32_t)n; ep.q_stride = 3;
+  ep.timeout_ticks = 20000000ull;  // 200 ms: a pass of one hypothesis on a few workgroups lasts up to a millisecond
+  const uint32_t v_grid = solve_grid((uint32_t)n, (uint32_t)c->n_cus);
+  static const int wg_per_cu_env = std::getenv("SOICP_BATCH_WG_PER_CU") ? std::atoi(std::getenv("SOICP_BATCH_WG_PER_CU")) : 0;
+  const uint32_t resident = solve_batch_resident_blocks((uint32_t)c->n_cus, wg_per_cu_env);
+  if (resident < (uint32_t)B) return fail(c, SO_ICP_E_HIP, "so_icp_register_batch: fewer resident solve workgroups than hypotheses");
+  BatchView bv{b.active.as<uint32_t>(), b.begin.as<RegBeginArgs>(), b.bs, (uint32_t)((size_t)1 << lg),
+               (uint32_t)((size_t)kFitBlocksMax * kRecordChunksMax * 2), (uint32_t)(kSyncBytes / 4), 1u, v_grid};
+  const BinTable bt{b.bin_key.as<uint32_t>(), b.bin_cnt.as<uint32_t>(), b.bin_off.as<uint32_t>(), lg};
+  DevState* ds = b.states.as<DevState>();
+  CorrBuffers corr{b.nd.as<double4>(), b.coeff.as<double>(), b.status.as<uint8_t>()};
+  // ---- binning of the scan under every hypothesis' pose: (queries x hypotheses) in three launches
+  b.tables_clean = false;
+  const double zero_pose[7] = {0, 0, 0, 0, 0, 0, 1};
+  launch_scan_keys(d_scan, (uint32_t)n, ds, zero_pose, max_outer, lm_max, b.hist.as<int32_t>(), c->view, c->cfg.max_surface_features, 0, 1,
+                   b.qslot.as<uint32_t>(), b.qrank.as<uint32_t>(), b.status.as<uint8_t>(), bt, s, false, &bv, (uint32_t)B);
+  launch_bin_offsets(bt, b.chunks.as<uint32_t>(), b.bs, ds, s, &bv, (uint32_t)B);
+  b.tables_clean = true;
+  launch_bin_place(bt, d_scan, (uint32_t)n, b.qslot.as<uint32_t>(), b.qrank.as<uint32_t>(), b.perm.as<uint32_t>(), b.spx.as<float>(),
+                   b.spy.as<float>(), b.spz.as<float>(), s, nullptr, &bv, (uint32_t)B);
+  HIP_TRY(c, hipGetLastError());
+  std::vector<uint32_t> act((size_t)B);
+  for (int h = 0; h < B; ++h) act[(size_t)h] = (uint32_t)h;
+  for (int it = 0; it < max_outer && !act.empty(); ++it) {
+    const uint32_t n_act = (uint32_t)act.size();
+    if (it > 0) {  // (round 0 uses the identity list uploaded with the poses; the stream was synchronised by the last read-back)
+      for (uint32_t k = 0; k < n_act; ++k) b.h_active[k] = act[k];
+      HIP_TRY(c, hipMemcpyAsync(b.active.p, b.h_active, (size_t)n_act * 4, hipMemcpyHostToDevice, s));
+    }
+    // workgroups per hypothesis: the resident grid split evenly (a power of two, never more than the grid they stand in for)
+    uint32_t G = 1;
+    while (2u * G * n_act <= resident && 2u * G <= v_grid) G *= 2u;
+    bv.wg_per_hyp = G;
+    launch_knn_plane(b.spx.as<float>(), b.spy.as<float>(), b.spz.as<float>(), b.perm.as<uint32_t>(), b.chunks.as<uint32_t>(), ds, c->view, mp, corr,
+                     b.nbr5.as<uint32_t>(), b.hist.as<int32_t>(), s, nullptr, nullptr, &bv, n_act);
+    EvalParams ep_it = ep;
+    ep_it.epoch_base = (++c->solve_launches) << 5;
+    launch_solve_batch(lm_max, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep_it, b.partials.as<double>(), b.sync.as<uint32_t>(), b.hist.as<int32_t>(),
+                       c->view, b.nbr5.as<uint32_t>(), mp, bv, n_act, s);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(b.h_states, ds, (size_t)B * sizeof(DevState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    std::vector<uint32_t> next;
+    for (uint32_t h : act) {
+      const DevState& H = b.h_states[h];
+      if (H.outer_iter != it + 1)  // the hypothesis' solve did not finish (a wait inside the launch gave up)
+        return fail(c, SO_ICP_E_HIP, "so_icp_register_batch: the solve of hypothesis " + std::to_string(h) + " did not complete in round " + std::to_string(it) +
+                                         " (workgroups not co-resident?)");
+      if (!H.reg_done && it + 1 < max_outer) next.push_back(h);
+    }
+    act.swap(next);
+  }
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  for (int h = 0; h < B; ++h) {
+    fill_result(c, b.h_states[h], poses_in + 7 * (size_t)h, stats + h, poses_out + 7 * (size_t)h, false);
+    stats[h].time_elapsed_ms = ms;  // (of the whole group: the hypotheses advance together)
+  }
+  return SO_ICP_OK;
+}
+
 }  // namespace
 
 so_icp_ctx::~so_icp_ctx() {
@@ -873,9 +1014,10 @@ so_icp_ctx::~so_icp_ctx() {
   if (peer_own) (void)hipFree(peer_own);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
   for (so_icp_ctx* w : workers) delete w;
+  batch.release();
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
-  for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_keys1, &d_vals0, &d_vals1, &d_chunks,
-                    &d_sort_tmp, &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
+  for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_vals0, &d_vals1, &d_chunks,
+                    &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist, &d_kdbg, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
                     &pf_heads, &pf_temp, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_counts})
     b->release();
@@ -985,7 +1127,6 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_NO_DEFER")) c->no_defer = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("SOICP_BINNING")) c->use_binning = std::string(ev) != "sort";
   const bool want_dmap = !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
   if (want_dmap) {  // world_size > 1: this rank's shard of the map, resident and updated on the device like the whole map is
     c->dmap = std::make_unique<DeviceMap>(c->stream, cfg->rank, cfg->world_size);
@@ -1196,6 +1337,22 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
   std::memcpy(c->last_pos, pos, sizeof(pos));
   int rc = upload_map(c);
   if (rc) return rc;
+  static const bool lanes_mode = std::getenv("SOICP_BATCH_MODE") && std::string(std::getenv("SOICP_BATCH_MODE")) == "lanes";
+  if (!lanes_mode && n > 0) {
+    // batched kernels: groups of up to kBatchMaxConcurrent hypotheses advance together (kernels.hip, BatchView)
+    const int count = map_count_5x5(c, pos);
+    std::vector<int32_t> hrc((size_t)n_hyp, 0);
+    for (int base = 0; base < n_hyp; base += kBatchMaxConcurrent) {
+      const int B = std::min(kBatchMaxConcurrent, n_hyp - base);
+      rc = register_batch_group(c, scan, n, poses_in + 7 * (size_t)base, B, poses_out + 7 * (size_t)base, stats ? stats + base : nullptr,
+                                hrc.data() + base, pos, count);
+      if (rc < 0) return rc;
+    }
+    int ok = 0;
+    for (int h = 0; h < n_hyp; ++h) { if (rc_out) rc_out[h] = hrc[(size_t)h]; if (hrc[(size_t)h] == SO_ICP_OK) ++ok; }
+    return ok;
+  }
+  // SOICP_BATCH_MODE=lanes (and empty scans): the hypotheses as concurrent sequential registrations on worker contexts
   static const int want_lanes = std::getenv("SOICP_BATCH_LANES") ? std::atoi(std::getenv("SOICP_BATCH_LANES")) : 16;
   const int lanes = std::max(1, std::min({want_lanes, n_hyp, 64}));
   // worker contexts: own stream / buffers / device state, no map of their own (they borrow this context's resident map)

@@ -27,9 +27,9 @@ struct MatchParams {
   float plane_res;        // localMap.planeRes_ (float member, LocalMap.h:761)
   float sq_max_dist_f;    // 3 * planeRes evaluated in float (LidarSlam.cpp:526)
   double max_point_dist;  // planeRes / 2.0 (LidarSlam.cpp:820)
-  int32_t ablate;         // profiling only (env SOICP_ABLATE): bit0 skip plane fit, bit1 skip scan, bit2 skip re-rank
+  int32_t ablate;         // profiling / test switches (env SOICP_ABLATE), read only by the PROF instantiations of the kernels,
+                          // which are launched when it is non-zero: bit0 skip plane fit, bit1 skip scan, bit2 skip re-rank, ...
   unsigned long long* kdbg;  // profiling only (SOICP_ABLATE bit 7): 2 sweeps x 4*kKnnBlocks wavefront records of 16 stamps, else nullptr
-  int32_t packed_counts;  // 1: the work-list counters are in DevState::bin_packed (hash binning), 0: n_kept / n_chunks / n_light (sort path)
   uint32_t chunk_cap;     // entries of the chunk list buffer: LIGHT chunks (<= 16 queries) are listed from its top downwards
   // deferred report: when the solve of outer iteration i-1 left the publication of its state block to the k-NN launch of
   // iteration i (EvalParams::defer_publish), that launch's first workgroup writes it to hring[(i-1) & 1] (see EvalParams)
@@ -41,7 +41,7 @@ struct MatchParams {
 struct EvalParams {
   double a2;       // TukeyLoss a^2 with a = (double)sqrtf(3*planeRes)  (LidarSlam.cpp:271)
   int32_t variant; // 0: Ceres 2.0.0, 1: Ceres >= 2.1
-  int32_t ablate;  // profiling only (env SOICP_ABLATE): bit5 skip the LM controller, bit6 skip the point loop
+  int32_t ablate;  // profiling / test switches (env SOICP_ABLATE; PROF instantiations only): bit5 skip the LM controller, bit6 skip the point loop
   // the evaluation kernels walk the queries in ORIGINAL scan order (deterministic sums whatever the spatial binning did):
   // spx/spy/spz = scan, scan+1, scan+2 with q_stride 3; correspondence records are indexed by the original query index
   uint32_t n_queries, q_stride;
@@ -93,9 +93,9 @@ struct DevState {
   int32_t max_outer, lm_max, pad0, pad1;
   // device-side control
   int32_t outer_iter, reg_done, lm_more, n_iterations;
-  uint32_t n_kept, n_chunks /* normal chunks */, n_light /* chunks of <= 16 queries, listed separately */, pad3;
-  // hash binning: the same three counters in ONE word (kept | normal << 21 | light << 42), so that a workgroup of
-  // bin_offsets_kernel reserves its three ranges with one atomic round trip instead of three (MatchParams::packed_counts)
+  uint32_t pad2[4];
+  // work-list counters of the hash binning in ONE word (kept queries | normal chunks << 21 | light chunks (<= 16 queries,
+  // listed separately) << 42), so that a workgroup of bin_offsets_kernel reserves its three ranges with one atomic round trip
   unsigned long long bin_packed;
   double T[7];          // pose of the current outer iteration (T_w_lidar)
   double eval_pose[7];  // pose the next LM evaluation is requested at
@@ -123,18 +123,23 @@ constexpr int kArriveCounters = 16, kArriveStrideWords = 32, kHandoffWordOffset 
 constexpr int kSyncBytes = kHandoffWordOffset * 4 + 8 * 16;
 constexpr int kSumsStride = 48;      // doubles per partial record (45 used)
 constexpr int kRecordChunksMax = 40; // 16-byte chunks per workgroup record of the persistent solve (29 sums + 8 histogram pairs)
-// sort key = (cube slot << 21) | Morton(half-cell: 7 bits per axis, low 3 bits = octant inside the map cell).  Two
-// special "slots" sort behind every real cube:
-//   n_slots     : processed query whose cube is outside the window / has no tree (NOT_ENOUGH_NEIGHBORS)
-//   n_slots + 1 : query not sampled / not owned by this rank (dropped)
-// so that only 21 + log2(n_slots + 2) key bits take part in the sort.
-// (With more than 2046 occupied cubes the slot does not fit above 21 cell bits: the key falls back to whole cells.)
-inline int key_cell_bits(uint32_t n_slots) { return (n_slots + 2u <= 2048u) ? 21 : 18; }
-inline uint32_t key_nocube(uint32_t n_slots) { return n_slots << key_cell_bits(n_slots); }
-inline uint32_t key_dropped(uint32_t n_slots) { return (n_slots + 1u) << key_cell_bits(n_slots); }
-inline int key_bits(uint32_t n_slots) { int b = 0; while ((1u << b) <= n_slots + 1u) ++b; return key_cell_bits(n_slots) + b; }
+// registration prologue arguments (the guess and the loop bounds travel as kernel arguments; a batch reads them from memory)
+struct RegBeginArgs { double pose[7]; int32_t max_outer, lm_max; };
 
-size_t sort_temp_bytes(size_t n);
+// so_icp_register_batch: B hypotheses (initial poses) of ONE scan advance in the same launches.  Every per-registration
+// array exists once per hypothesis with a common element stride; a launch serves the hypotheses listed in `active`
+// (blockIdx.y for the binning and k-NN kernels, blockIdx.x / wg_per_hyp for the solve launch).
+struct BatchView {
+  const uint32_t* active;     // [hypotheses of this launch] index of the hypothesis (device memory)
+  const RegBeginArgs* begin;  // [B] prologue arguments (device memory; scan_keys)
+  uint32_t bs;                // elements per hypothesis of the per-query arrays (table slot / rank, perm, binned SoA scan, status,
+                              // plane records) and of the chunk list (= its capacity); the neighbour lists hold 5 bs
+  uint32_t table_stride;      // bin table entries per hypothesis
+  uint32_t partial_stride;    // doubles per hypothesis in the record table of the solve launch
+  uint32_t sync_stride;       // 32-bit words per hypothesis in the hand-off block
+  uint32_t wg_per_hyp;        // solve: real workgroups per hypothesis
+  uint32_t v_grid;            // solve: workgroups of the single-registration launch they stand in for
+};
 
 void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* d_hist, hipStream_t s);
 // Spatial binning of the scan without a sort: an open-addressing table keyed by the sort key (cube slot | half-cell Morton
@@ -148,26 +153,26 @@ struct BinTable {
   uint32_t log2_size;
 };
 // per query: table slot (0xFFFFFFFF = dropped) and rank inside its bucket
-void launch_bin_offsets(const BinTable& bt, uint32_t* d_chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s);
+// (bv / n_hyp: batched launch over the hypotheses bv->active[0 .. n_hyp), see BatchView; nullptr / 0 = one registration)
+void launch_bin_offsets(const BinTable& bt, uint32_t* d_chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s,
+                        const BatchView* bv = nullptr, uint32_t n_hyp = 0);
 void launch_bin_place(const BinTable& bt, const float* d_scan_xyz, uint32_t n, const uint32_t* d_qslot, const uint32_t* d_qrank,
-                      uint32_t* d_perm, float* spx, float* spy, float* spz, hipStream_t s, const DevState* st_if_rebin = nullptr);
+                      uint32_t* d_perm, float* spx, float* spy, float* spz, hipStream_t s, const DevState* st_if_rebin = nullptr,
+                      const BatchView* bv = nullptr, uint32_t n_hyp = 0);
 
 // scan_keys also runs the registration prologue (reg_begin) in its first workgroup; n == 0 launches the prologue alone
 void launch_scan_keys(const float* d_scan_xyz, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max,
                       int32_t* d_hist, const DevMapView& map, int max_surface_features, int rank, int world, uint32_t* d_keys,
                       uint32_t* d_vals, uint8_t* d_status /* SO_MATCH_DROPPED for queries that are not processed */,
-                      const BinTable* bin /* non-null: d_keys / d_vals receive table slot / rank instead of key / index */, hipStream_t s,
-                      bool rebin = false /* sharded map, outer iteration >= 1: keys under the CURRENT device-resident pose, no prologue */);
-void launch_sort_pairs(void* d_temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                       const uint32_t* vals_in, uint32_t* vals_out, uint32_t n, int end_bit, hipStream_t s);
-// chunk work list + gather of the scan into sorted SoA order
-void launch_chunk_heads(const uint32_t* d_keys_sorted, uint32_t n, uint32_t dropped_key, uint32_t* d_chunk_start, DevState* st,
-                        const float* d_scan_xyz, const uint32_t* d_perm, float* spx, float* spy, float* spz, hipStream_t s);
-void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* d_keys_sorted,
+                      const BinTable& bin /* d_keys / d_vals receive the query's table slot / rank inside its bucket */, hipStream_t s,
+                      bool rebin = false /* sharded map, outer iteration >= 1: keys under the CURRENT device-resident pose, no prologue */,
+                      const BatchView* bv = nullptr, uint32_t n_hyp = 0);
+void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* d_perm,
                       const uint32_t* d_chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
                       CorrBuffers corr, uint32_t* d_nbr5 /*5 canonical indices per query*/,
                       int32_t* d_hist /*kHistReplicas*kHistStride*/, hipStream_t s, hipEvent_t ev_start = nullptr,
-                      hipEvent_t ev_stop = nullptr /* timing events attached to the dispatch itself */);
+                      hipEvent_t ev_stop = nullptr /* timing events attached to the dispatch itself */,
+                      const BatchView* bv = nullptr, uint32_t n_hyp = 0);
 void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr,
                  DevState* st, const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist,
                  LmSums* d_sums, const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper,
@@ -176,6 +181,15 @@ void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, con
 void launch_solve(int lm_max, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, DevState* st,
                   const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist, LmSums* d_sums,
                   const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper, uint32_t max_blocks, hipStream_t s);
+// workgroups of the single-registration solve launch for a scan of n_upper queries (the grid a batch stands in for)
+uint32_t solve_grid(uint32_t n_upper, uint32_t max_blocks);
+// workgroups of the batched solve launch that are certainly resident together on n_cus compute units (occupancy query of the
+// BATCH instantiation, at most two per compute unit; wg_per_cu > 0 overrides the per-CU number downwards)
+uint32_t solve_batch_resident_blocks(uint32_t n_cus, int wg_per_cu);
+// the solves of the hypotheses bv.active[0 .. n_hyp) in one launch of n_hyp * bv.wg_per_hyp workgroups (all resident)
+void launch_solve_batch(int lm_max, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, DevState* st,
+                        const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist, const DevMapView& map,
+                        const uint32_t* d_nbr5, const MatchParams& mp, const BatchView& bv, uint32_t n_hyp, hipStream_t s);
 void launch_lm_step(int slot, DevState* st, const LmSums* d_sums, int32_t* d_hist, const EvalParams& ep, hipStream_t s);
 // peer exchange self-test: every rank writes a tagged chunk into every inbox and waits (<= 2 s) for all of them in its own; *d_ok = 1 on success
 void launch_peer_selftest(void* const inbox[8], int rank, int world, uint32_t tag, int32_t* d_ok, hipStream_t s);

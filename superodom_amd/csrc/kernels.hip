@@ -3,7 +3,6 @@
 //   scan_keys_kernel    registration prologue, sampling rule, world transform, spatial key (cube | half-cell octant) and
 //                       the hash-binning count of every query                     (LidarSlam.cpp:346-359, 397-398)
 //   bin_offsets_kernel  bucket offsets + the k-NN work lists (normal / light chunks); bin_place_kernel: binned SoA scan
-//                       (SOICP_BINNING=sort: rocPRIM sort + chunk_heads_kernel instead)
 //   knn_plane_kernel    one wavefront per chunk: cube-restricted exact 5-NN over the hashed-voxel cell grid (LDS-staged
 //                       candidate tiles, selection network, exact re-rank + certification), distance gate
 //                                                                                  (LocalMap.h:481-525, LidarSlam.cpp:720-747)
@@ -25,9 +24,7 @@
 
 #include <cstddef>
 #include <cstdlib>
-#include <cstring>  // rocprim/iterator/texture_cache_iterator.hpp calls ::memset on the host path
-
-#include <rocprim/rocprim.hpp>
+#include <cstring>
 
 #ifdef SO_LM_STAMPS  // profiling build: device clock at the phases of the LM controller (tools/eval_stamps.py prints them)
 #define SO_LM_STAMP(dbg, i) do { if (dbg) (dbg)[i] = wall_clock64(); } while (0)
@@ -90,14 +87,17 @@ __device__ __forceinline__ CellRef locate(const DevMapView& m, float qx, float q
 // ------------------------------------------------------------------------------------------------
 // scan preparation
 // ------------------------------------------------------------------------------------------------
+// BATCH instantiations (so_icp_register_batch: B hypotheses of ONE scan in the same launches): blockIdx.y picks the
+// hypothesis h = active[blockIdx.y]; every per-registration array is laid out with the common element stride bv.bs
+// (kernels.h: BatchView).  The single-registration instantiations compile to the code they were before.
+
 // registration prologue: pose <- host-provided guess (kernel arguments: no H2D copy), counters and histograms cleared
-struct RegBeginArgs { double pose[7]; int32_t max_outer, lm_max; };
 __device__ __forceinline__ void reg_begin_state(DevState* st, const RegBeginArgs& a, int tid) {
   if (tid < 7) { st->pose_in[tid] = a.pose[tid]; st->T[tid] = a.pose[tid]; st->eval_pose[tid] = a.pose[tid]; }
   if (tid == 0) {
     st->max_outer = a.max_outer; st->lm_max = a.lm_max;
     st->outer_iter = 0; st->reg_done = 0; st->lm_more = 0; st->n_iterations = 0;
-    st->n_kept = 0; st->n_chunks = 0; st->n_light = 0; st->bin_packed = 0ull;
+    st->bin_packed = 0ull;
   }
 }
 // stand-alone prologue (empty scan: scan_keys_kernel, which normally carries it, is not launched)
@@ -108,26 +108,38 @@ __global__ __launch_bounds__(512) void reg_begin_kernel(DevState* st, RegBeginAr
 static_assert(kHistReplicas * kHistStride == 512, "reg_begin_kernel clears one histogram word per thread");
 
 // (workgroup 0 also runs the registration prologue: one launch less per registration)
+template <bool BATCH>
 __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict__ scan, uint32_t n,
                                                         DevState* __restrict__ st, RegBeginArgs a, int32_t* __restrict__ hist,
                                                         DevMapView map,
                                                         int max_surface_features, int rank, int world,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint8_t* __restrict__ status, BinTable bt, int rebin) {
+                                                        uint8_t* __restrict__ status, BinTable bt, int rebin, BatchView bv) {
+  if (BATCH) {
+    const uint32_t h = bv.active[blockIdx.y];
+    st += h; hist += (size_t)h * (kHistReplicas * kHistStride);
+    keys += (size_t)h * bv.bs; vals += (size_t)h * bv.bs; status += (size_t)h * bv.bs;
+    bt.key += (size_t)h * bv.table_stride; bt.cnt += (size_t)h * bv.table_stride;
+  }
+  const RegBeginArgs* ab = BATCH ? bv.begin + bv.active[blockIdx.y] : nullptr;  // (a batch reads its prologue arguments from memory)
   // rebin (sharded map, outer iteration >= 1): ownership and binning are re-derived under the CURRENT pose -- a query that
   // the pose update carried out of its owner's halo (1 degree at 50 m is more than a cell) is handed to its new owner, so
   // every rank searches only queries whose whole gate ball lies inside its shard.  No prologue; a no-op once converged.
   if (rebin) {
     if (st->reg_done) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { st->n_kept = 0; st->n_chunks = 0; st->n_light = 0; st->bin_packed = 0ull; }  // (bin_offsets / chunk_heads of this round add to them)
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->bin_packed = 0ull;  // (bin_offsets of this round adds to it)
   } else if (blockIdx.x == 0) {
     hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
-    reg_begin_state(st, a, threadIdx.x);
+    if (BATCH) reg_begin_state(st, *ab, threadIdx.x); else reg_begin_state(st, a, threadIdx.x);
   }
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Pose pose = pose_from_array(rebin ? st->T : a.pose);
-  const int cell_bits = (map.n_slots + 2u <= 2048u) ? 21 : 18;  // == key_cell_bits()
+  const Pose pose = pose_from_array(rebin ? st->T : (BATCH ? ab->pose : a.pose));
+  // key = (cube slot << 21) | Morton(half-cell: 7 bits per axis, low 3 bits = octant inside the map cell).  Two special
+  // "slots" follow the real cubes: n_slots = processed query whose cube is outside the window / has no tree
+  // (NOT_ENOUGH_NEIGHBORS), n_slots + 1 = query not sampled / not owned by this rank (dropped).  With more than 2046
+  // occupied cubes the slot does not fit above 21 cell bits: the key falls back to whole cells.
+  const int cell_bits = (map.n_slots + 2u <= 2048u) ? 21 : 18;
   const uint32_t kDropped = (map.n_slots + 1u) << cell_bits, kNoCube = map.n_slots << cell_bits;
   uint32_t key = kDropped;
   bool process = true;
@@ -163,12 +175,7 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
     }
   }
   if (key == kDropped) status[i] = SO_MATCH_DROPPED;  // every other query gets its status from the k-NN sweep
-  if (!bt.key) {  // sort path: (key, index) pairs for the radix / merge sort
-    keys[i] = key;
-    vals[i] = i;
-    return;
-  }
-  // ---- binning path: claim / find the key's table slot, then count the query in (one atomic per distinct key of the
+  // ---- hash binning: claim / find the key's table slot, then count the query in (one atomic per distinct key of the
   //      wavefront: consecutive scan points are neighbours in space, a wavefront holds a handful of keys)
   const bool kept = key != kDropped;
   const int lane = threadIdx.x & 63;
@@ -208,9 +215,15 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
 // A bucket is cut every 64 queries; a last piece of <= 16 queries is a LIGHT chunk (the k-NN wavefront scans its
 // candidates with four parts of its lanes: about half the time of a full chunk) and goes to the second list, which
 // grows from the top of the buffer downwards -- the k-NN kernel pairs light chunks so that all chunks run in one round.
+template <bool BATCH>
 __global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t* __restrict__ chunk_start, uint32_t chunk_cap,
-                                                           DevState* __restrict__ st) {
+                                                           DevState* __restrict__ st, BatchView bv) {
   __shared__ uint32_t wq[16], wc[16], wl[16], base_q, base_c, base_l;
+  if (BATCH) {
+    const uint32_t h = bv.active[blockIdx.y];
+    st += h; chunk_start += (size_t)h * bv.bs;
+    bt.key += (size_t)h * bv.table_stride; bt.cnt += (size_t)h * bv.table_stride; bt.off += (size_t)h * bv.table_stride;
+  }
   const uint32_t t4 = blockIdx.x * blockDim.x + threadIdx.x;  // slots 4*t4 .. 4*t4+3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint4 c4 = reinterpret_cast<const uint4*>(bt.cnt)[t4];
@@ -264,10 +277,16 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t
 }
 
 // queries into their binned positions (SoA) + the position -> query index map the k-NN kernel files its results with
+template <bool BATCH>
 __global__ __launch_bounds__(256) void bin_place_kernel(BinTable bt, const float* __restrict__ scan, uint32_t n,
                                                         const uint32_t* __restrict__ qslot, const uint32_t* __restrict__ qrank,
                                                         uint32_t* __restrict__ perm, float* __restrict__ spx, float* __restrict__ spy,
-                                                        float* __restrict__ spz, const DevState* __restrict__ st_if_rebin) {
+                                                        float* __restrict__ spz, const DevState* __restrict__ st_if_rebin, BatchView bv) {
+  if (BATCH) {
+    const size_t h = bv.active[blockIdx.y];
+    bt.off += h * bv.table_stride; qslot += h * bv.bs; qrank += h * bv.bs; perm += h * bv.bs;
+    spx += h * bv.bs; spy += h * bv.bs; spz += h * bv.bs;
+  }
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (st_if_rebin && st_if_rebin->reg_done) return;  // re-binning round of a registration that has converged: nothing to place
@@ -277,61 +296,6 @@ __global__ __launch_bounds__(256) void bin_place_kernel(BinTable bt, const float
   __builtin_nontemporal_store(i, &perm[pos]);
   __builtin_nontemporal_store(scan[3 * i], &spx[pos]); __builtin_nontemporal_store(scan[3 * i + 1], &spy[pos]);
   __builtin_nontemporal_store(scan[3 * i + 2], &spz[pos]);
-}
-
-// Work list of the k-NN kernel: a CHUNK = up to 64 consecutive sorted queries with the same key (one half-cell octant
-// of the map grid), handled by one wavefront.  Runs longer than 64 are cut every 64 queries counted from the START OF
-// THE RUN (not at 64-aligned positions of the array: alignment would cut almost every run once more and cost ~25%
-// more chunks).  A chunk's lanes therefore share one small union block of map cells and the cost of a wave is ~ one
-// candidate set whatever the query density.  Descriptor = start | (count-1) << 26.
-// (Measured before: merging several cells into one chunk halves the wave count and DOUBLES the kernel time.)
-// The same launch gathers the scan into sorted SoA order (spx/spy/spz) for the k-NN kernel.  (SOICP_BINNING=sort path;
-// the default is the hash binning of scan_keys_kernel / bin_offsets_kernel / bin_place_kernel.)
-__global__ __launch_bounds__(1024) void chunk_heads_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t kKeyDropped,
-                                                           uint32_t* __restrict__ chunk_start, DevState* __restrict__ st,
-                                                           const float* __restrict__ scan, const uint32_t* __restrict__ perm,
-                                                           float* __restrict__ spx, float* __restrict__ spy, float* __restrict__ spz) {
-  __shared__ uint32_t wave_cnt[16];
-  __shared__ uint32_t block_base;
-  if (st->reg_done) return;  // (re-binning round after convergence)
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t key = i < n ? keys[i] : kKeyDropped;
-  const bool kept = key != kKeyDropped;
-  if (kept) { const uint32_t o = perm[i]; spx[i] = scan[3 * o]; spy[i] = scan[3 * o + 1]; spz[i] = scan[3 * o + 2]; }
-  // keys are sorted and the dropped key is the largest value: the kept queries are the prefix [0, n_kept)
-  if (kept && (i + 1 == n || keys[i + 1] == kKeyDropped)) st->n_kept = i + 1;
-  bool head = false;
-  uint32_t count = 0;
-  if (kept) {
-    if (i == 0 || keys[i - 1] != key) {
-      head = true;  // first query of a run
-    } else if (i >= 64 && keys[i - 64] == key) {  // inside a long run: every 64th query counted from the run's start
-      uint32_t lo = 0, hi = i - 64;               // lower_bound(key) in [0, i-64]
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
-      head = ((i - lo) & 63u) == 0;
-    }
-  }
-  if (head) {  // end of the chunk: 64 queries or the end of the run
-    if (i + 63 < n && keys[i + 63] == key) {
-      count = 64;
-    } else {
-      uint32_t lo = i + 1, hi = (i + 63 < n) ? i + 63 : n;  // first index in (i, hi] whose key differs (hi if none)
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] == key) lo = mid + 1; else hi = mid; }
-      count = lo - i;
-    }
-  }
-  const unsigned long long m = __ballot(head);
-  if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = 0;
-    for (int w = 0; w < 16; ++w) { const uint32_t c = wave_cnt[w]; wave_cnt[w] = tot; tot += c; }
-    block_base = tot ? atomicAdd(&st->n_chunks, tot) : 0u;  // one atomic per 1024 queries
-  }
-  __syncthreads();
-  if (head)
-    chunk_start[block_base + wave_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i | ((count - 1u) << 26);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -611,7 +575,7 @@ __device__ __forceinline__ void observability(const double pw[3], const double e
 
 // ComputePlaneDistanceParameters after the neighbour search (LidarSlam.cpp:533-571)
 __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const double pw[3], const Pose& pose,
-                                                     const MatchParams& mp, double nd[4], double& coeff, int obs[3]) {
+                                                     const MatchParams& mp, double nd[4], double& coeff, int obs[3], bool jacobi_eig = false) {
   // PCA (LidarSlam.cpp:756-775, utils/superodom_utils.h:143-151)
   double mx = 0, my = 0, mz = 0;
 #pragma unroll
@@ -624,7 +588,7 @@ __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const d
     s00 += a * a; s01 += a * b; s02 += a * c; s11 += b * b; s12 += b * c; s22 += c * c;
   }
   double ev[3], nrm[3];
-  if (mp.ablate & 512) eig3_sym(s00, s01, s02, s11, s12, s22, ev, nrm);  // profiling switch: the iterative reference solver
+  if (jacobi_eig) eig3_sym(s00, s01, s02, s11, s12, s22, ev, nrm);  // test switch (SOICP_ABLATE=512, PROF instantiation): the iterative reference solver
   else eig3_sym_direct(s00, s01, s02, s11, s12, s22, ev, nrm);
   if (ev[0] < 1e-6 || fdiv(ev[1], ev[2]) < 0.1) return SO_MATCH_BAD_PCA;  // LidarSlam.cpp:772
   double x[3];
@@ -739,6 +703,10 @@ __device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz
 
 __device__ __forceinline__ void publish_state_to(DevState* dst, const DevState* st, unsigned long long seq, int tid, int nthreads);  // below
 
+// PROF : the profiling / test-hook instantiation (per-wavefront stamps, SOICP_ABLATE switches, kernel statistics); the
+//        production instantiation carries none of it (the sweep is instruction-issue bound).
+// BATCH: so_icp_register_batch -- blockIdx.y picks the hypothesis, see BatchView.
+template <bool PROF, bool BATCH>
 __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
                                                         const float* __restrict__ spz,
                                                         const uint32_t* __restrict__ perm /* binned position -> query index */,
@@ -747,28 +715,33 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
                                                         const float4* __restrict__ mpts,
                                                         const uint32_t* __restrict__ mcell_start, DevMapView map,
                                                         MatchParams mp, CorrBuffers corr, uint32_t* __restrict__ nbr5,
-                                                        int32_t* __restrict__ hist) {
+                                                        int32_t* __restrict__ hist, BatchView bv) {
   __shared__ int32_t lh[20];
   __shared__ __attribute__((aligned(16))) float tiles[4][4][kTileCand + 16];  // per wavefront: x[], y[], z[], |c|^2 (block-local)
   __shared__ uint32_t tcanon[4][kTileCand + 16];  // per wavefront: canonical map index of the staged candidate
   __shared__ uint32_t rowtab[4][2][36];  // per wavefront: exclusive candidate offsets [33] and first canonical index [32] of the block's x-runs
+  if (BATCH) {
+    const size_t h = bv.active[blockIdx.y];
+    st += h; spx += h * bv.bs; spy += h * bv.bs; spz += h * bv.bs; perm += h * bv.bs; chunk_start += h * bv.bs;
+    corr.status += h * bv.bs; nbr5 += h * 5 * bv.bs; hist += h * (kHistReplicas * kHistStride);
+  }
   if (st->reg_done) return;  // the registration already converged: this launch is a no-op
   // the report of the previous outer iteration, left to this launch by its solve (MatchParams::publish_prev)
-  if (mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
+  if (!BATCH && mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
     publish_state_to(mp.hring[(st->outer_iter - 1) & 1], st, mp.seq_base | (unsigned long long)st->outer_iter, (int)threadIdx.x, 256);
-  uint32_t n_kept = st->n_kept, n_normal = st->n_chunks, n_light = st->n_light;
-  if (mp.packed_counts) {
-    const unsigned long long pk = st->bin_packed;
-    n_kept = (uint32_t)(pk & 0x1FFFFFull); n_normal = (uint32_t)((pk >> 21) & 0x1FFFFFull); n_light = (uint32_t)(pk >> 42);
-  }
+  // the work-list counters of bin_offsets_kernel: kept queries | normal chunks << 21 | light chunks << 42
+  const unsigned long long pk = st->bin_packed;
+  const uint32_t n_kept = (uint32_t)(pk & 0x1FFFFFull), n_normal = (uint32_t)((pk >> 21) & 0x1FFFFFull), n_light = (uint32_t)(pk >> 42);
   // Logical order of the work list: [first half of the light chunks][normal chunks][second half of the light chunks].
   // Wavefront w takes positions w, w + 4096, ...: with up to 8 192 chunks the wavefronts that get a second chunk are the
   // ones whose first chunk is light, and their second chunk is light too -- two light chunks cost about as much as one
   // full chunk, so the whole sweep runs in ONE round of resident wavefronts (a second round ran on a mostly empty chip).
   const uint32_t n_chunks = n_normal + n_light, n_light1 = (n_light + 1u) >> 1;
   const Pose pose = pose_from_array(st->T);
-  if (threadIdx.x < 20) lh[threadIdx.x] = 0;
-  __syncthreads();
+  if (PROF) {  // kernel statistics (group passes, fallback lanes, candidates scanned): profiling instantiation only
+    if (threadIdx.x < 20) lh[threadIdx.x] = 0;
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   float* tx = tiles[wv][0];
@@ -778,7 +751,8 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   uint32_t* ti = tcanon[wv];
   uint32_t* rowoff = rowtab[wv][0];
   uint32_t* rowbeg = rowtab[wv][1];
-  const bool stamp = (mp.ablate & 128) != 0 && mp.kdbg != nullptr;
+  const int abl = PROF ? mp.ablate : 0;  // profiling / test switches exist only in the PROF instantiation (launched when SOICP_ABLATE is set)
+  const bool stamp = PROF && (abl & 128) != 0 && mp.kdbg != nullptr;
   unsigned long long ts[4] = {0, 0, 0, 0}, acc[5] = {0, 0, 0, 0, 0}, t_first = 0, n_mine = 0, t_maxchunk = 0;
   unsigned long long n_cand_total = 0, n_q_total = 0, n_groups_total = 0, n_pass2 = 0, max_info = 0, n_fb_total = 0;
   unsigned long long c_first = 0;
@@ -793,7 +767,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   // sqrt(3*planeRes) (LidarSlam.cpp:526,741), where "not found inside the gate ball" is a certain TOO_FAR.
   const float r_gate = sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f;
   const float r_near = 0.5f * cell;
-  const int first_pass = (r_near < 0.8f * r_gate && !(mp.ablate & 256)) ? 0 : 1;
+  const int first_pass = (r_near < 0.8f * r_gate && !(abl & 256)) ? 0 : 1;
   // one wavefront per chunk of the work list (a second / further chunk when the list is longer than the grid)
   for (uint32_t chunk = blockIdx.x * 4 + wv; chunk < n_chunks; chunk += gridDim.x * 4) {
   if (stamp) ts[0] = wall_clock64();
@@ -807,8 +781,8 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
                          : (chunk < n_light1 + n_normal ? chunk - n_light1 : mp.chunk_cap - 1u - (chunk - n_normal));
     const uint32_t desc = __builtin_amdgcn_readfirstlane(chunk_start[entry]);
     const uint32_t start = desc & 0x03FFFFFFu, count = (desc >> 26) + 1u;
-    split = count <= 32u && !(mp.ablate & 1024);
-    split4 = count <= 16u && split && !(mp.ablate & 2048);
+    split = count <= 32u && !(abl & 1024);
+    split4 = count <= 16u && split && !(abl & 2048);
     const int ql = split4 ? (lane & 15) : (split ? (lane & 31) : lane);
     j = start + (uint32_t)ql;
     valid_q = (ql < (int)count) && (j < n_kept);
@@ -847,7 +821,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   for (int pass = first_pass; pass < 2; ++pass) {
   bool pending = !resolved && !need_exact;
   unsigned long long todo = __ballot(pending);
-  if (mp.ablate & 2) todo = 0;
+  if (abl & 2) todo = 0;
   if (!todo) break;
   if (stamp && pass == 1) ++n_pass2;
   const float r_cover = pass == 0 ? r_near : r_gate;
@@ -946,7 +920,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
       // stage with coalesced 16-byte loads (position -> row by a 5-step binary search over the row offsets)
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (!(mp.ablate & 16))
+      if (!(abl & 16))
       for (uint32_t t = lane; t < cnt + 16; t += 64) {
         float lx = 0.f, ly = 0.f, lz = 0.f, lc = 3.0e38f;  // padding entries lose against every real candidate
         uint32_t canon = 0xFFFFFFFFu;
@@ -964,7 +938,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (!(mp.ablate & 8) && split) {
+      if (!(abl & 8) && split) {
         // two quads per trip, one per half of the wavefront (two LDS addresses per read)
         for (uint32_t jl = 0; jl < cnt; jl += sstep) {
           const uint32_t a = jl + hoff;
@@ -978,7 +952,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
           net.push(make_key_v(d23.x, e + 2, keep));
           net.push(make_key_v(d23.y, e + 3, keep));
         }
-      } else if (!(mp.ablate & 8)) {
+      } else if (!(abl & 8)) {
         // uniform addresses: four broadcast ds_read_b128 feed four candidates; the next quad is fetched while this one
         // runs through the selection network (software pipeline, no wait between LDS issue and use)
         float4 X = *reinterpret_cast<const float4*>(tx), Y = *reinterpret_cast<const float4*>(ty);
@@ -1051,7 +1025,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
     if (stamp) { ts[1] = wall_clock64(); acc[3] += ts[1] - ts[3]; }
   }
   // exact re-rank of the survivors + certification
-  if (scanned && !need_exact && !(mp.ablate & 4)) {
+  if (scanned && !need_exact && !(abl & 4)) {
     // First the five best approximate keys only.  Every candidate that is NOT re-ranked has exact d2 >= R2:
     //   in-block outsiders: approximate d2 >= L (the first key left out, index bits cleared), exact >= L - kApproxAbsErr;
     //   points of the cube outside the block: farther than the block boundary (cov2).
@@ -1099,13 +1073,13 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
     } else if (pass == 1) {
       need_exact = true;
     }
-  } else if (scanned && (mp.ablate & 4)) {
+  } else if (scanned && (abl & 4)) {
     resolved = true;
   }
   }  // pass loop
   if (stamp) ts[2] = wall_clock64();
   __builtin_amdgcn_s_setprio(0);
-  if (lane == 0) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
+  if (PROF && lane == 0) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
 
   if (valid_q && (!split || lane < (split4 ? 16 : 32))) {
     int status;
@@ -1113,13 +1087,13 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
       status = SO_MATCH_NOT_ENOUGH;  // LidarSlam.cpp:736-739
     } else {
       if (need_exact || !resolved) {  // rare: exact per-lane scan of the 27 cells
-        atomicAdd(&lh[17], 1);
+        if (PROF) atomicAdd(&lh[17], 1);
         top.init();
         too_far_certain = false;
         knn27(map, c, qx, qy, qz, top);
       }
       const float d2_4 = __uint_as_float((uint32_t)(top.b4 >> 32));
-      if ((mp.ablate & 1) || too_far_certain || top.b4 == ~0ull || (double)d2_4 > (double)mp.sq_max_dist_f) {
+      if ((abl & 1) || too_far_certain || top.b4 == ~0ull || (double)d2_4 > (double)mp.sq_max_dist_f) {
         status = SO_MATCH_TOO_FAR;   // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
       } else {
         status = SO_MATCH_PENDING;   // five neighbours inside the gate: the plane fit runs in plane_eval_kernel
@@ -1148,9 +1122,11 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
     d[7] = n_mine; d[8] = t_maxchunk; d[9] = n_cand_total; d[10] = n_q_total; d[11] = n_groups_total; d[12] = n_pass2; d[13] = max_info;
     d[14] = n_fb_total | ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 48);  // + HW_ID[15:0] (wave, simd, cu, se), XCC_ID: where the wavefront ran
   }
-  __syncthreads();
-  if (threadIdx.x >= 16 && threadIdx.x < 20 && lh[threadIdx.x])  // kernel statistics only; the histograms are built by plane_eval_kernel
-    atomicAdd(&hist[(blockIdx.x % kHistReplicas) * kHistStride + threadIdx.x], lh[threadIdx.x]);
+  if (PROF) {
+    __syncthreads();
+    if (threadIdx.x >= 16 && threadIdx.x < 20 && lh[threadIdx.x])  // kernel statistics only; the histograms are built by the fit pass
+      atomicAdd(&hist[(blockIdx.x % kHistReplicas) * kHistStride + threadIdx.x], lh[threadIdx.x]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1360,7 +1336,14 @@ enum { kPassNotLast = 0, kPassMore = 1, kPassDone = 2, kPassSums = 3 };
 // workgroup but the one that arrives last; that one reduces the partial records and (fuse_lm) runs the LM controller:
 // kPassMore = another evaluation is requested at sh.S.cand, kPassDone = the solve ended (state published),
 // kPassSums = !fuse_lm, the sums are in `out` for the all-reduce.
-template <bool FIT, bool PERSIST = false>
+// PROF  : profiling / test-hook instantiation (phase stamps, SOICP_ABLATE switches), launched only when SOICP_ABLATE is set.
+// BATCH : so_icp_register_batch.  The real workgroup stands in for the VIRTUAL workgroups [span.vb0, span.vb1) of the grid of
+//         span.V workgroups a single registration of the same scan launches: it walks their query sets one after the other,
+//         reduces each through LDS exactly like a workgroup of that grid would and pushes one record per virtual workgroup,
+//         so the controller's workgroup adds the same numbers in the same order -- the sums, and with them every decision
+//         and the pose, are bit-identical to the single registration, whatever the number of real workgroups.
+struct WgSpan { uint32_t vb0, vb1, V; bool ctl; };
+template <bool FIT, bool PERSIST = false, bool PROF = false, bool BATCH = false>
 __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose, const float* __restrict__ spx,
                                          const float* __restrict__ spy, const float* __restrict__ spz,
                                          const CorrBuffers& corr, DevState* __restrict__ st, const EvalParams& ep,
@@ -1368,7 +1351,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
                                          int32_t* __restrict__ hist, LmSums* __restrict__ out,
                                          const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
                                          const MatchParams& mp, EvalShared& sh, unsigned long long pass_tag = 0,
-                                         CorrCache* cc = nullptr, u4v* hand = nullptr, unsigned long long want = 0) {
+                                         CorrCache* cc = nullptr, u4v* hand = nullptr, unsigned long long want = 0,
+                                         const WgSpan span = WgSpan{0, 0, 0, false}) {
   // PERSIST (solve_kernel): workgroup 0 is the finisher of every pass of the launch, so the controller state stays in
   // its LDS from pass to pass and goes to memory only when the solve ends; the workgroup records are PUSHED (tagged
   // 16-byte chunks, see below) instead of stored + counted
@@ -1382,18 +1366,21 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   int32_t* lh = sh.lh;
   bool& is_last = sh.is_last;
   const int tid = threadIdx.x;
-  const bool stamp = (ep.ablate & 128) != 0;
+  static_assert(!BATCH || PERSIST, "batched hypotheses run in the persistent solve launch");
+  const int abl = PROF ? ep.ablate : 0;
+  const bool stamp = PROF && (abl & 128) != 0;
+  const uint32_t V = BATCH ? span.V : gridDim.x;                    // workgroups of the (virtual) grid
+  const uint32_t vb_begin = BATCH ? span.vb0 : blockIdx.x, vb_end = BATCH ? span.vb1 : blockIdx.x + 1u;
+  const bool is_ctl = BATCH ? span.ctl : (blockIdx.x == 0);         // this workgroup collects the records and runs the controller
   unsigned long long t_begin = 0, t_loop = 0, t_red = 0, t_ticket = 0, t_loaded = 0, t_sums = 0, t_lm = 0;
   if (stamp) t_begin = wall_clock64();
   if (FIT) {
     if (tid < 16) lh[tid] = 0;
     __syncthreads();
   }
-  const uint32_t n_kept = (ep.ablate & 64) ? 0u : ep.n_queries;  // every query of the scan, original order
+  const uint32_t n_kept = (abl & 64) ? 0u : ep.n_queries;  // every query of the scan, original order
   const uint32_t qs = ep.q_stride;
   double acc[kNAcc];
-#pragma unroll
-  for (int a = 0; a < kNAcc; ++a) acc[a] = 0;
   // R(q) as Eigen::Quaternion::toRotationMatrix (lidarOptimization.cpp:70)
   const double qx = pose.q[0], qy = pose.q[1], qz = pose.q[2], qw = pose.q[3];
   const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
@@ -1449,14 +1436,14 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     double c;
     double4 nd;
     if (FIT) {
-      if (PERSIST && trip >= 0) {  // (the coordinates go to the cache before the fit: three registers less to carry through it)
+      if (PERSIST && !BATCH && trip >= 0) {  // (the coordinates go to the cache before the fit: three registers less to carry through it)
         cc->px[trip][tid] = fx; cc->py[trip][tid] = fy; cc->pz[trip][tid] = fz;
       }
       double fnd[4] = {0, 0, 0, 0}, fc = 0;
       int obs[3] = {0, 0, 0};
       if (status == SO_MATCH_PENDING) {
         const double pw[3] = {wx, wy, wz};
-        status = plane_from_neighbours(nb, pw, pose, mp, fnd, fc, obs);
+        status = plane_from_neighbours(nb, pw, pose, mp, fnd, fc, obs, PROF && (mp.ablate & 512));
       }
       if (status != SO_MATCH_SUCCESS) { fc = 0; fnd[0] = fnd[1] = fnd[2] = fnd[3] = 0; }
       nd = make_double4(fnd[0], fnd[1], fnd[2], fnd[3]);
@@ -1469,7 +1456,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       atomicAdd(&lh[status], 1);                                          // MatchRejectionHistogramPlane, LidarSlam.cpp:341
       if (status == SO_MATCH_SUCCESS) { atomicAdd(&lh[7 + obs[0]], 1); atomicAdd(&lh[7 + obs[1]], 1); atomicAdd(&lh[7 + obs[2]], 1); }
       if (status != SO_MATCH_SUCCESS) return;
-      if (PERSIST && trip >= 0) {
+      if (PERSIST && !BATCH && trip >= 0) {
         cc->nx[trip][tid] = nd.x; cc->ny[trip][tid] = nd.y; cc->nz[trip][tid] = nd.z; cc->nw[trip][tid] = nd.w;
         cc->c[trip][tid] = c;  // >= 0 marks the entry as an accepted correspondence
       }
@@ -1479,14 +1466,38 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     }
     tail(px, py, pz, wx, wy, wz, nd, c);
   };
-  const uint32_t jstride = gridDim.x * blockDim.x;
+  const uint32_t jstride = V * blockDim.x;
+  double mine = 0;
+  u4v* rec = reinterpret_cast<u4v*>(partials);        // PERSIST: the record table of the pushed workgroup records
+  const unsigned int tag = (unsigned int)pass_tag;
+  for (uint32_t vb = vb_begin, trip_ = 0; BATCH ? (vb < vb_end) : (trip_ < 1u); ++vb, ++trip_) {  // (exactly one trip unless BATCH)
+#pragma unroll
+  for (int a = 0; a < kNAcc; ++a) acc[a] = 0;
   if (FIT) {
-    if (PERSIST) { cc->c[0][tid] = -1.0; cc->c[1][tid] = -1.0; }  // (each thread touches only its own column: no barrier)
+    if (PERSIST && !BATCH) { cc->c[0][tid] = -1.0; cc->c[1][tid] = -1.0; }  // (each thread touches only its own column: no barrier)
     // Two queries per trip with their gathers issued together: status + neighbour indices of both (one round trip),
     // then the ten neighbour points (one round trip), then the two fits.  With one wavefront per SIMD nothing else
     // hides the latency of the dependent index -> point loads (measured: 3 us of a 12 us pass).
     bool first = true;
-    for (uint32_t jA = blockIdx.x * blockDim.x + tid; jA < n_kept; jA += 2 * jstride) {
+    if (BATCH) {
+      // one query per trip (same order of accumulation): half the live registers, so that two workgroups fit a compute unit
+      // and their wavefronts hide each other's gather and fp64 latencies -- a batch has the parallelism the single
+      // registration lacks
+      for (uint32_t j = vb * blockDim.x + tid; j < n_kept; j += jstride) {
+        const int stq = corr.status[j];
+        uint32_t iq[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) iq[t] = nbr5[(size_t)5 * j + t];
+        float nbq[15];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          const float4 a = mpts[stq == SO_MATCH_PENDING ? iq[t] : 0u];
+          nbq[3 * t] = a.x; nbq[3 * t + 1] = a.y; nbq[3 * t + 2] = a.z;
+        }
+        body(j, stq, nbq, -1);
+      }
+    } else
+    for (uint32_t jA = vb * blockDim.x + tid; jA < n_kept; jA += 2 * jstride) {
       const uint32_t jB = jA + jstride;
       const bool hasB = jB < n_kept;
       const uint32_t jBs = hasB ? jB : jA;
@@ -1506,7 +1517,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       if (hasB) body(jB, stB, nbB, first ? 1 : -1);
       first = false;
     }
-  } else if (PERSIST) {
+  } else if (PERSIST && !BATCH) {
     // the two queries this thread fitted first: out of the LDS cache (no memory round trip on the pass's critical path)
 #pragma unroll
     for (int trip = 0; trip < 2; ++trip) {
@@ -1520,16 +1531,16 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
         tail(px, py, pz, wx, wy, wz, nd, c);
       }
     }
-    for (uint32_t j = blockIdx.x * blockDim.x + tid + 2 * jstride; j < n_kept; j += jstride) body(j, corr.status[j], nullptr, -1);
+    for (uint32_t j = vb * blockDim.x + tid + 2 * jstride; j < n_kept; j += jstride) body(j, corr.status[j], nullptr, -1);
   } else {
-    for (uint32_t j = blockIdx.x * blockDim.x + tid; j < n_kept; j += jstride) body(j, corr.status[j], nullptr, -1);
+    for (uint32_t j = vb * blockDim.x + tid; j < n_kept; j += jstride) body(j, corr.status[j], nullptr, -1);
   }
   if (stamp) t_loop = wall_clock64();
   // workgroup reduction through LDS (transposed: no serial shuffle chains), fixed order
 #pragma unroll
   for (int a = 0; a < kNAcc; ++a) red[tid][a] = acc[a];
   __syncthreads();
-  const double mine = reduce_records(red, part, tid);
+  mine = reduce_records(red, part, tid);
   if (PERSIST) {
     // Push model: the record of this workgroup for this pass is kNAcc chunks of 16 bytes {value (8), pass tag (4), one
     // histogram counter of the fit pass (4)}, each written with ONE sc1 dwordx4 store -- fire and forget: no drain, no
@@ -1541,25 +1552,29 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     // A stale chunk is always the previous pass's (every pass rewrites every chunk), so a 32-bit tag suffices.
     static_assert(SO_SOLVE_BLOCKS == 256, "record table: 8 groups of 32 workgroups");
     static_assert(kNAcc <= kRecordChunksMax, "record table");
-    u4v* rec = reinterpret_cast<u4v*>(partials);
-    const unsigned int tag = (unsigned int)pass_tag;
     // The correspondence stores of the fit loop are long on their way (the LDS reduction came in between); retiring
     // them HERE, in the compiler's scoreboard too, keeps it from placing its own vmcnt waits between the hand-written
     // polling loads below (which it cannot see), where each would cost a full memory round trip.
     if (FIT) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
     if (tid < kNAcc) {
       const unsigned long long b = (unsigned long long)__double_as_longlong(mine);
-      const unsigned int extra = (FIT && tid < 16) ? (unsigned int)lh[tid] : 0u;  // MatchRejectionHistogramPlane + observability bins
+      // MatchRejectionHistogramPlane + observability bins (BATCH: lh counts every virtual workgroup of this real one: they
+      // travel with the record of the last -- integer sums, any split gives the same totals)
+      const unsigned int extra = (FIT && tid < 16 && (!BATCH || vb + 1u == vb_end)) ? (unsigned int)lh[tid] : 0u;
       const u4v v = {(unsigned int)b, (unsigned int)(b >> 32), tag, extra};
-      const uint32_t w = blockIdx.x;
+      const uint32_t w = vb;
       store16_sc1(rec + ((w & 31u) * 8u + (w >> 5)) * kNAcc + tid, v);
     }
+  }
+  }  // virtual workgroups
+  if (PERSIST) {
     if (stamp) t_red = wall_clock64();
-    if (blockIdx.x != 0) return kPassNotLast;
+    if (!is_ctl) return kPassNotLast;
     constexpr int kPoll = 8 * kNAcc;  // 232 polling threads
     const bool poller = tid < kPoll;
     const int g = poller ? tid / kNAcc : 0, a = poller ? tid - g * kNAcc : 0;
     const u4v* base = rec + (poller ? tid : 0);
+    if (!BATCH) {
     u4v r[32];
     const unsigned long long t0 = wall_clock64();
     bool ok;
@@ -1576,9 +1591,9 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       asm volatile("" : "+v"(r[29]), "+v"(r[30]), "+v"(r[31]) :: "memory");
       ok = true;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) ok = ok && (r[i].z == tag || (uint32_t)(32 * g + i) >= gridDim.x);
+      for (int i = 0; i < 32; ++i) ok = ok && (r[i].z == tag || (uint32_t)(32 * g + i) >= V);
       ok = ok || !poller;
-      if (ep.ablate & 8192) { ok = false; break; }  // test hook: behave as if the records never arrived (the launch is abandoned)
+      if (abl & 8192) { ok = false; break; }  // test hook: behave as if the records never arrived (the launch is abandoned)
       if (__ballot(!ok) == 0ull) break;
       if (wall_clock64() - t0 > ep.timeout_ticks) break;  // give up instead of hanging the device (EvalParams::timeout_ticks)
     }
@@ -1589,10 +1604,47 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       int hsum = 0;
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        const bool have = (uint32_t)(32 * g + i) < gridDim.x;
+        const bool have = (uint32_t)(32 * g + i) < V;
         sum += have ? __longlong_as_double((long long)(((unsigned long long)r[i].y << 32) | r[i].x)) : 0.0;
         if (FIT) hsum += have ? (int)r[i].w : 0;
       }
+      if (poller) {
+        part[g][a] = sum;
+        if (FIT && a < 16) sh.hpart[g][a] = hsum;
+      }
+    }
+    } else {
+      // BATCH: the same sums in the same order, eight records at a time (a quarter of the registers -- two workgroups fit a
+      // compute unit -- and a pass lasts tens of microseconds here: the four round trips do not matter, polling gently does)
+      double sum = 0;
+      int hsum = 0;
+      bool ok = true;
+      const unsigned long long t0 = wall_clock64();
+      for (int i0 = 0; i0 < 32; i0 += 8) {
+        u4v r[8];
+        for (;;) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r[k]) : "v"(base + (size_t)(i0 + k) * kPoll) : "memory");
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) :: "memory");
+          bool good = true;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) good = good && (r[k].z == tag || (uint32_t)(32 * g + i0 + k) >= V);
+          good = good || !poller;
+          if (abl & 8192) good = false;  // test hook: behave as if the records never arrived
+          if (__ballot(!good) == 0ull) break;
+          if ((abl & 8192) || wall_clock64() - t0 > ep.timeout_ticks) { ok = ok && good; break; }  // give up (EvalParams::timeout_ticks)
+          __builtin_amdgcn_s_sleep(32);
+        }
+        if (__ballot(!ok) != 0ull) break;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const bool have = (uint32_t)(32 * g + i0 + k) < V;
+          sum += have ? __longlong_as_double((long long)(((unsigned long long)r[k].y << 32) | r[k].x)) : 0.0;
+          if (FIT) hsum += have ? (int)r[k].w : 0;
+        }
+      }
+      if (!__syncthreads_and(ok ? 1 : 0)) return kPassNotLast;  // timeout: the solve of this hypothesis is abandoned, the host reports it
       if (poller) {
         part[g][a] = sum;
         if (FIT && a < 16) sh.hpart[g][a] = hsum;
@@ -1654,6 +1706,21 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       __syncthreads();
     }
     if (stamp) t_sums = wall_clock64();
+    if (BATCH) {  // (not latency-critical here: the controller works on the LDS copy of its state, no register staging)
+      if (tid == 0) {
+        int rd = 0;
+        const int more_ = lm_control_regs(slot, st, sh_S, sh_sums, sh_ctl, true, &rd);
+        sh.reg_done = rd;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned long long val = (k < 7) ? (unsigned long long)__double_as_longlong(sh_S.cand[k < 7 ? k : 0]) : (unsigned long long)more_;
+          const u4v v = {(unsigned int)val, (unsigned int)(val >> 32), (unsigned int)want, (unsigned int)(want >> 32)};
+          store16_sc1(hand + k, v);
+        }
+        for (int k = 0; k < 7; ++k) sh.pose[k] = sh_S.cand[k];
+        sh_more = more_;
+      }
+    } else
     if (tid == 0) sh_more = lm_control(slot, st, sh_S, sh_sums, sh_ctl, true, hand, want, sh.pose, &sh.reg_done);  // (publishes the hand-off)
     __syncthreads();
     unsigned long long t_ctl = 0;
@@ -1759,7 +1826,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   copy_words(reinterpret_cast<double*>(out), o, (int)(sizeof(LmSums) / 8), tid, 256);
   if (stamp) t_sums = wall_clock64();
   if (!fuse_lm) return kPassSums;  // sharded map: the sums are all-reduced first, lm_step_kernel runs the controller
-  if (tid == 0) sh_more = (ep.ablate & 32) ? 1 : lm_control(slot, st, sh_S, sh_sums, sh_ctl);  // sh_S / sh_ctl arrived with the partials
+  if (tid == 0) sh_more = (abl & 32) ? 1 : lm_control(slot, st, sh_S, sh_sums, sh_ctl);  // sh_S / sh_ctl arrived with the partials
   __syncthreads();
   unsigned long long t_ctl = 0;
   if (stamp) t_ctl = wall_clock64();
@@ -1783,7 +1850,7 @@ static_assert(sizeof(LmState) / 8 <= 256, "controller state is moved one word pe
 //              plane, inlier gate, coefficient, observability labels -> correspondence record + histograms), then
 //              the first evaluation at the outer pose.
 // FIT = false: evaluations at the poses requested by the LM controller.
-template <bool FIT>
+template <bool FIT, bool PROF>
 __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void eval_kernel(int slot, int fuse_lm, const float* __restrict__ spx,
                                                    const float* __restrict__ spy, const float* __restrict__ spz,
                                                    CorrBuffers corr, DevState* __restrict__ st, EvalParams ep,
@@ -1794,7 +1861,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void eval_kernel(int sl
   __shared__ EvalShared sh;
   if (!eval_slot_active(st, slot)) return;
   const Pose pose = pose_from_array(slot == 0 ? st->T : st->eval_pose);
-  (void)eval_pass<FIT>(slot, fuse_lm, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh);
+  (void)eval_pass<FIT, false, PROF>(slot, fuse_lm, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh);
 }
 
 // The whole solve of one outer iteration in ONE launch (single device): slot 0 = plane fit + first evaluation, then up
@@ -1803,14 +1870,31 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void eval_kernel(int sl
 // -- the XCDs' L2s are not coherent with each other, so nothing that crosses workgroups inside this launch goes
 // through plain loads.  Requires every workgroup to be resident (<= 256 workgroups of 256 threads, 60 KB LDS each: two
 // fit on a CU); a wait that exceeds 50 ms gives up (the host then reports the missing publication).
-__global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int lm_max, const float* __restrict__ spx, const float* __restrict__ spy,
+// BATCH (so_icp_register_batch): bv.wg_per_hyp consecutive workgroups serve hypothesis active[blockIdx.x / wg_per_hyp] --
+// its own state block, correspondence records, record table and hand-off record; the first of them is its controller.
+// Each stands in for an equal share of the bv.v_grid workgroups of the single-registration launch (eval_pass, WgSpan), so
+// the hypotheses advance independently of each other inside the one launch and every one of them reproduces the single
+// registration bit for bit.  The grid never exceeds the compute units (every workgroup resident).
+template <bool PROF, bool BATCH>
+__global__ __launch_bounds__(256, BATCH ? 2 : 1) void solve_kernel(int lm_max, const float* __restrict__ spx, const float* __restrict__ spy,
                                                     const float* __restrict__ spz, CorrBuffers corr, DevState* __restrict__ st,
                                                     EvalParams ep, double* __restrict__ partials, uint32_t* __restrict__ ticket,
                                                     int32_t* __restrict__ hist, LmSums* __restrict__ out,
                                                     const float4* __restrict__ mpts, const uint32_t* __restrict__ nbr5,
-                                                    MatchParams mp) {
+                                                    MatchParams mp, BatchView bv) {
   __shared__ EvalShared sh;
   __shared__ CorrCache cache;  // 26 KB next to the 64 KB of EvalShared: gfx950 has 160 KB of LDS per CU, one workgroup each here
+  WgSpan span{0, 0, 0, false};
+  if (BATCH) {
+    const uint32_t G = bv.wg_per_hyp, hi = blockIdx.x / G, sub = blockIdx.x - hi * G;
+    const size_t h = bv.active[hi];
+    st += h; corr.nd += h * bv.bs; corr.coeff += h * bv.bs; corr.status += h * bv.bs; nbr5 += h * 5 * bv.bs;
+    partials += h * bv.partial_stride; ticket += h * bv.sync_stride; hist += h * (kHistReplicas * kHistStride);
+    span.V = bv.v_grid;
+    span.vb0 = (uint32_t)(((unsigned long long)sub * bv.v_grid) / G);
+    span.vb1 = (uint32_t)(((unsigned long long)(sub + 1u) * bv.v_grid) / G);
+    span.ctl = sub == 0;
+  }
   if (st->reg_done) return;
   const int tid = threadIdx.x;
   // hand-off record: 8 chunks of 16 bytes {value, epoch}, each written / read with ONE sc1 dwordx4 access (atomic as a
@@ -1828,7 +1912,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
     sh.ctl.lm_max = st->lm_max; sh.ctl.outer_iter = st->outer_iter; sh.ctl.max_outer = st->max_outer;
   }
   const unsigned long long tag0 = (e0 + 1ull) << 5;  // pass tags: unique over launches (every launch advances the epoch) and passes (slot <= 16)
-  int code = eval_pass<true, true>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0, &cache, hand, e0 + 1ull);
+  int code = eval_pass<true, true, PROF, BATCH>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0, &cache, hand, e0 + 1ull, span);
   for (int slot = 1; slot <= lm_max; ++slot) {
     __syncthreads();
     const unsigned long long want = e0 + (unsigned long long)slot;
@@ -1858,7 +1942,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void solve_kernel(int l
     if (sh.more != 1) return;  // solve ended (or timeout)
     pose = pose_from_array(sh.pose);
     __syncthreads();
-    code = eval_pass<false, true>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0 + (unsigned long long)slot, &cache, hand, want + 1ull);
+    code = eval_pass<false, true, PROF, BATCH>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0 + (unsigned long long)slot, &cache, hand, want + 1ull, span);
   }
 }
 
@@ -1971,117 +2055,109 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
-// rocPRIM picks block sort + merge passes for ~131 k pairs (measured 58 us per registration); forcing Onesweep
-// (merge_sort_limit = 0) was measured SLOWER (120 us: look-back state memsets + 8-bit passes).
-// SOICP_SORT_CFG selects a merge-sort tuning (experiment switch).
-using SortConfig = rocprim::default_config;
-using MergeCfg1 = rocprim::merge_sort_config<512, 256, 16, 128, 128, 4, 0>;
-using MergeCfg2 = rocprim::merge_sort_config<512, 512, 8, 128, 256, 8, 0>;
-using MergeCfg3 = rocprim::merge_sort_config<256, 256, 8, 128, 128, 8, 0>;
-using MergeCfg4 = rocprim::merge_sort_config<512, 256, 16, 128, 128, 4, (1u << 30)>;
-using MergeCfg5 = rocprim::merge_sort_config<512, 256, 8, 128, 128, 4, (1u << 30)>;
-using MergeCfg6 = rocprim::merge_sort_config<512, 512, 4, 128, 128, 4, (1u << 30)>;
-using MergeCfg7 = rocprim::merge_sort_config<1024, 512, 4, 128, 128, 4, (1u << 30)>;
-using MergeCfg8 = rocprim::merge_sort_config<256, 256, 8, 128, 128, 4, (1u << 30)>;
-using MergeCfg9 = rocprim::merge_sort_config<1024, 256, 8, 128, 128, 4, (1u << 30)>;
-// default 6: stable merge sort, 2048-item block sort + odd-even merges (61 us against 68 us for rocPRIM's own choice)
-static int sort_cfg() { static const int v = std::getenv("SOICP_SORT_CFG") ? std::atoi(std::getenv("SOICP_SORT_CFG")) : 6; return v; }
-template <class Cfg>
-static hipError_t merge_pairs(void* tmp, size_t& bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo, size_t n,
-                              hipStream_t s) {
-  return rocprim::merge_sort<Cfg>(tmp, bytes, ki, ko, vi, vo, n, rocprim::less<uint32_t>(), s);
-}
-static hipError_t sort_dispatch(void* tmp, size_t& bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo, size_t n,
-                                unsigned end_bit, hipStream_t s) {
-  switch (sort_cfg()) {
-    case 1: return merge_pairs<MergeCfg1>(tmp, bytes, ki, ko, vi, vo, n, s);
-    case 2: return merge_pairs<MergeCfg2>(tmp, bytes, ki, ko, vi, vo, n, s);
-    case 3: return merge_pairs<MergeCfg3>(tmp, bytes, ki, ko, vi, vo, n, s);
-    case 4: return merge_pairs<MergeCfg4>(tmp, bytes, ki, ko, vi, vo, n, s);
-    case 5: return merge_pairs<MergeCfg5>(tmp, bytes, ki, ko, vi, vo, n, s);
-    case 6: return merge_pairs<MergeCfg6>(tmp, bytes, ki, ko, vi, vo, n, s);
-    case 7: return merge_pairs<MergeCfg7>(tmp, bytes, ki, ko, vi, vo, n, s);
-    case 8: return merge_pairs<MergeCfg8>(tmp, bytes, ki, ko, vi, vo, n, s);
-    case 9: return merge_pairs<MergeCfg9>(tmp, bytes, ki, ko, vi, vo, n, s);
-    default: return rocprim::radix_sort_pairs<SortConfig>(tmp, bytes, ki, ko, vi, vo, n, 0, end_bit, s);
-  }
-}
-size_t sort_temp_bytes(size_t n) {
-  size_t bytes = 0;
-  (void)sort_dispatch(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 32,
-                      (hipStream_t)0);
-  return bytes;
-}
-
 void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist, hipStream_t s) {
   RegBeginArgs a;
   for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
   a.max_outer = max_outer; a.lm_max = lm_max;
   hipLaunchKernelGGL(reg_begin_kernel, dim3(1), dim3(512), 0, s, st, a, hist);
 }
+static const BatchView kNoBatch{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
 void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist,
                       const DevMapView& map, int max_sf, int rank, int world, uint32_t* keys, uint32_t* vals, uint8_t* status,
-                      const BinTable* bin, hipStream_t s, bool rebin) {
+                      const BinTable& bin, hipStream_t s, bool rebin, const BatchView* bv, uint32_t n_hyp) {
+  RegBeginArgs a{};
+  if (bv) {  // (the hypotheses' prologue arguments are in bv->begin)
+    if (!n || !n_hyp) return;
+    hipLaunchKernelGGL(scan_keys_kernel<true>, dim3((n + 255u) / 256u, n_hyp), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world,
+                       keys, vals, status, bin, 0, *bv);
+    return;
+  }
   if (!n) { if (!rebin) launch_reg_begin(st, pose, max_outer, lm_max, hist, s); return; }
-  RegBeginArgs a;
   for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
   a.max_outer = max_outer; a.lm_max = lm_max;
-  hipLaunchKernelGGL(scan_keys_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals, status,
-                     bin ? *bin : BinTable{nullptr, nullptr, nullptr, 0}, rebin ? 1 : 0);
+  hipLaunchKernelGGL(scan_keys_kernel<false>, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals, status,
+                     bin, rebin ? 1 : 0, kNoBatch);
 }
-void launch_bin_offsets(const BinTable& bt, uint32_t* chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s) {
-  hipLaunchKernelGGL(bin_offsets_kernel, dim3((1u << bt.log2_size) / 4096u), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st);
+void launch_bin_offsets(const BinTable& bt, uint32_t* chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s, const BatchView* bv,
+                        uint32_t n_hyp) {
+  const uint32_t gx = (1u << bt.log2_size) / 4096u;
+  if (bv) { if (n_hyp) hipLaunchKernelGGL(bin_offsets_kernel<true>, dim3(gx, n_hyp), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st, *bv); }
+  else hipLaunchKernelGGL(bin_offsets_kernel<false>, dim3(gx), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st, kNoBatch);
 }
 void launch_bin_place(const BinTable& bt, const float* d_scan, uint32_t n, const uint32_t* qslot, const uint32_t* qrank, uint32_t* perm,
-                      float* spx, float* spy, float* spz, hipStream_t s, const DevState* st_if_rebin) {
+                      float* spx, float* spy, float* spz, hipStream_t s, const DevState* st_if_rebin, const BatchView* bv, uint32_t n_hyp) {
   if (!n) return;
-  hipLaunchKernelGGL(bin_place_kernel, grid_for(n, 256), dim3(256), 0, s, bt, d_scan, n, qslot, qrank, perm, spx, spy, spz, st_if_rebin);
+  if (bv) { if (n_hyp) hipLaunchKernelGGL(bin_place_kernel<true>, dim3((n + 255u) / 256u, n_hyp), dim3(256), 0, s, bt, d_scan, n, qslot, qrank, perm, spx, spy, spz, nullptr, *bv); }
+  else hipLaunchKernelGGL(bin_place_kernel<false>, grid_for(n, 256), dim3(256), 0, s, bt, d_scan, n, qslot, qrank, perm, spx, spy, spz, st_if_rebin, kNoBatch);
 }
-void launch_sort_pairs(void* tmp, size_t tmp_bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo,
-                       uint32_t n, int end_bit, hipStream_t s) {
-  if (!n) return;
-  (void)sort_dispatch(tmp, tmp_bytes, ki, ko, vi, vo, (size_t)n, (unsigned)end_bit, s);
-}
-void launch_chunk_heads(const uint32_t* keys_sorted, uint32_t n, uint32_t dropped_key, uint32_t* chunk_start, DevState* st,
-                        const float* d_scan, const uint32_t* perm, float* spx, float* spy, float* spz, hipStream_t s) {
-  if (!n) return;
-  hipLaunchKernelGGL(chunk_heads_kernel, grid_for(n, 1024), dim3(1024), 0, s, keys_sorted, n, dropped_key, chunk_start, st, d_scan, perm,
-                     spx, spy, spz);
-}
-void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* keys_sorted,
+void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* perm,
                       const uint32_t* chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
-                      CorrBuffers corr, uint32_t* nbr5, int32_t* hist, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
-  // timing events ride on the kernel's own dispatch packet (no marker packets: separate hipEventRecord calls cost
+                      CorrBuffers corr, uint32_t* nbr5, int32_t* hist, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop,
+                      const BatchView* bv, uint32_t n_hyp) {
+  if (bv) {
+    // B x ~4 800 chunks: 256 workgroups per hypothesis, every wavefront walks ~5 chunks (no tail to hide with 64 hypotheses in
+    // flight, and a quarter of the workgroup prologues of the one-round grid of the single registration)
+    if (!n_hyp) return;
+    if (mp.ablate) hipLaunchKernelGGL((knn_plane_kernel<true, true>), dim3(kKnnBlocks / 4, n_hyp), dim3(256), 0, s, spx, spy, spz, perm, chunk_start, st,
+                                      map.pts, map.cell_start, map, mp, corr, nbr5, hist, *bv);
+    else hipLaunchKernelGGL((knn_plane_kernel<false, true>), dim3(kKnnBlocks / 4, n_hyp), dim3(256), 0, s, spx, spy, spz, perm, chunk_start, st,
+                            map.pts, map.cell_start, map, mp, corr, nbr5, hist, *bv);
+    return;
+  }
+  // The production instantiation carries no profiling code; SOICP_ABLATE != 0 selects the instrumented one.
+  // Timing events ride on the kernel's own dispatch packet (no marker packets: separate hipEventRecord calls cost
   // ~3.7 us of stream time each, 8 % of a registration when every sweep is timed)
+  auto* k = mp.ablate ? knn_plane_kernel<true, false> : knn_plane_kernel<false, false>;
   if (ev_start && ev_stop)
-    hipExtLaunchKernelGGL(knn_plane_kernel, dim3(kKnnBlocks), dim3(256), 0, s, ev_start, ev_stop, 0, spx, spy, spz, keys_sorted,
-                          chunk_start, st, map.pts, map.cell_start, map, mp, corr, nbr5, hist);
+    hipExtLaunchKernelGGL(k, dim3(kKnnBlocks), dim3(256), 0, s, ev_start, ev_stop, 0, spx, spy, spz, perm,
+                          chunk_start, st, map.pts, map.cell_start, map, mp, corr, nbr5, hist, kNoBatch);
   else
-    hipLaunchKernelGGL(knn_plane_kernel, dim3(kKnnBlocks), dim3(256), 0, s, spx, spy, spz, keys_sorted, chunk_start, st, map.pts,
-                       map.cell_start, map, mp, corr, nbr5, hist);
+    hipLaunchKernelGGL(k, dim3(kKnnBlocks), dim3(256), 0, s, spx, spy, spz, perm, chunk_start, st, map.pts,
+                       map.cell_start, map, mp, corr, nbr5, hist, kNoBatch);
+}
+uint32_t solve_grid(uint32_t n_upper, uint32_t max_blocks) {
+  uint32_t blocks = (n_upper + 255u) / 256u;
+  blocks = blocks < 1 ? 1 : (blocks > (uint32_t)kFitBlocksMax ? (uint32_t)kFitBlocksMax : blocks);
+  if (max_blocks >= 1 && blocks > max_blocks) blocks = max_blocks;
+  return blocks;
 }
 void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr,
                  DevState* st, const EvalParams& ep, double* partials, uint32_t* ticket, int32_t* hist, LmSums* sums,
                  const DevMapView& map, const uint32_t* nbr5, const MatchParams& mp, uint32_t n_upper, hipStream_t s) {
+  const bool prof = ep.ablate != 0 || mp.ablate != 0;
   if (slot == 0) {  // plane fit + first evaluation, dense over the queries
-    uint32_t blocks = (n_upper + 255u) / 256u;
-    blocks = blocks < 1 ? 1 : (blocks > (uint32_t)kFitBlocksMax ? (uint32_t)kFitBlocksMax : blocks);
-    hipLaunchKernelGGL(eval_kernel<true>, dim3(blocks), dim3(256), 0, s, slot, fuse_lm ? 1 : 0, spx, spy, spz, corr, st, ep, partials,
-                       ticket, hist, sums, map.pts, nbr5, mp);
+    const uint32_t blocks = solve_grid(n_upper, 0);
+    auto* k = prof ? eval_kernel<true, true> : eval_kernel<true, false>;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, s, slot, fuse_lm ? 1 : 0, spx, spy, spz, corr, st, ep, partials, ticket, hist, sums, map.pts, nbr5, mp);
   } else {
-    hipLaunchKernelGGL(eval_kernel<false>, dim3(kEvalBlocks), dim3(256), 0, s, slot, fuse_lm ? 1 : 0, spx, spy, spz, corr, st, ep,
-                       partials, ticket, hist, sums, map.pts, nbr5, mp);
+    auto* k = prof ? eval_kernel<false, true> : eval_kernel<false, false>;
+    hipLaunchKernelGGL(k, dim3(kEvalBlocks), dim3(256), 0, s, slot, fuse_lm ? 1 : 0, spx, spy, spz, corr, st, ep, partials, ticket, hist, sums, map.pts, nbr5, mp);
   }
 }
 void launch_solve(int lm_max, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, DevState* st,
                   const EvalParams& ep, double* partials, uint32_t* ticket, int32_t* hist, LmSums* sums, const DevMapView& map,
                   const uint32_t* nbr5, const MatchParams& mp, uint32_t n_upper, uint32_t max_blocks, hipStream_t s) {
   // every workgroup must be resident for the whole launch (94 KB of LDS: one per compute unit)
-  uint32_t blocks = (n_upper + 255u) / 256u;
-  blocks = blocks < 1 ? 1 : (blocks > (uint32_t)kFitBlocksMax ? (uint32_t)kFitBlocksMax : blocks);
-  if (max_blocks >= 1 && blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(solve_kernel, dim3(blocks), dim3(256), 0, s, lm_max, spx, spy, spz, corr, st, ep, partials, ticket, hist, sums,
-                     map.pts, nbr5, mp);
+  const uint32_t blocks = solve_grid(n_upper, max_blocks);
+  const bool prof = ep.ablate != 0 || mp.ablate != 0;
+  auto* k = prof ? solve_kernel<true, false> : solve_kernel<false, false>;
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, s, lm_max, spx, spy, spz, corr, st, ep, partials, ticket, hist, sums, map.pts, nbr5, mp, kNoBatch);
+}
+uint32_t solve_batch_resident_blocks(uint32_t n_cus, int wg_per_cu) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, solve_kernel<false, true>, 256, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+  if (nb > 2) nb = 2;  // (registers: two wavefronts per SIMD; LDS: two 66 KB workgroups)
+  if (wg_per_cu >= 1 && wg_per_cu < nb) nb = wg_per_cu;
+  return (uint32_t)nb * n_cus;
+}
+void launch_solve_batch(int lm_max, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr, DevState* st,
+                        const EvalParams& ep, double* partials, uint32_t* ticket, int32_t* hist, const DevMapView& map,
+                        const uint32_t* nbr5, const MatchParams& mp, const BatchView& bv, uint32_t n_hyp, hipStream_t s) {
+  if (!n_hyp) return;
+  const bool prof = ep.ablate != 0 || mp.ablate != 0;
+  auto* k = prof ? solve_kernel<true, true> : solve_kernel<false, true>;
+  hipLaunchKernelGGL(k, dim3(n_hyp * bv.wg_per_hyp), dim3(256), 0, s, lm_max, spx, spy, spz, corr, st, ep, partials, ticket, hist, (LmSums*)nullptr, map.pts,
+                     nbr5, mp, bv);
 }
 void launch_lm_step(int slot, DevState* st, const LmSums* sums, int32_t* hist, const EvalParams& ep, hipStream_t s) {
   hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(64), 0, s, slot, st, sums, hist, ep);

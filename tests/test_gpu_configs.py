@@ -100,9 +100,60 @@ def test_batch64_full_size_with_the_survey_seeds(oracle, gpu_slam_factory):
             _assert_registration_equal(sts[h], ost, out[h], opose, ("batch64", h))
     finally:
         oracle.set_num_threads(1)
-    # the batch is B independent registrations: hypothesis 7 alone gives the same bits
-    rc, p7, s7 = slam.register_dev(d, n, poses[7])
-    assert rc == 0 and np.array_equal(p7, out[7])
+    # the batch is B independent registrations: EVERY hypothesis alone gives the same bits (pose, final normal equations,
+    # every per-iteration statistic) -- the batched kernels reproduce the single registration's summation tree
+    for h in range(64):
+        rc, ph, sh = slam.register_dev(d, n, poses[h])
+        assert rc == 0 and np.array_equal(ph, out[h]), h
+        _assert_same_bits(sts[h], sh, ("batch64 vs single", h))
+
+
+def _assert_same_bits(a, b, tag):
+    assert a.n_iterations == b.n_iterations, tag
+    assert np.array_equal(np.array(a.JtJ), np.array(b.JtJ)) and np.array_equal(np.array(a.Jtr), np.array(b.Jtr)), tag
+    for it in range(a.n_iterations):
+        x, y = a.iterations[it], b.iterations[it]
+        assert (x.lm_iterations, x.num_successful_steps, x.termination, x.num_surf_from_scan) == \
+               (y.lm_iterations, y.num_successful_steps, y.termination, y.num_surf_from_scan), (tag, it)
+        assert list(x.reject_hist) == list(y.reject_hist) and list(x.obs_hist) == list(y.obs_hist), (tag, it)
+        assert (x.initial_cost, x.final_cost) == (y.initial_cost, y.final_cost), (tag, it)
+        assert np.array_equal(np.array(x.pose_after), np.array(y.pose_after)), (tag, it)
+
+
+@pytest.mark.parametrize("scene,n_hyp,sub", [("tiny", 5, None), ("tiny", 70, None), ("small", 33, None), ("small", 9, 1500)])
+def test_batched_hypotheses_equal_single_registrations_bit_for_bit(oracle, gpu_slam_factory, scene, n_hyp, sub):
+    """so_icp_register_batch on the batched kernels: odd hypothesis counts (workgroups per hypothesis that do not divide the
+    grid they stand in for), more hypotheses than one group holds (70 > 64), scans whose single-registration grid is small
+    (tiny: 16 workgroups), a sub-sampled scan (max_surface_features), hypotheses that converge in different rounds and
+    hypotheses that start far away.  Every hypothesis must equal its single registration bit for bit; a sample is compared
+    with the oracle in full."""
+    sc, slam, om = _setup(scene, oracle, gpu_slam_factory, max_iterations=5)
+    if sub:
+        slam.set_max_surface_features(sub)
+    i = 2
+    scan = sc.scan(i)
+    poses = np.stack([synth.perturb_pose(sc.gt_pose(i), 7000 + 64 * i + h, 0.02 + 0.5 * (h % 7) / 6.0, 0.2 + 5.0 * (h % 5) / 4.0) for h in range(n_hyp)])
+    d, n = slam.upload_scan(scan)
+    ok, rcs, out, sts = slam.register_batch(None, poses, d_scan=d, n=n)
+    assert ok == n_hyp and (rcs == 0).all()
+    outer = set()
+    for h in range(n_hyp):
+        rc, ph, sh = slam.register_dev(d, n, poses[h])
+        assert rc == 0 and np.array_equal(ph, out[h]), (scene, h)
+        _assert_same_bits(sts[h], sh, (scene, h))
+        outer.add(sh.n_iterations)
+    if n_hyp >= 33:
+        assert len(outer) >= 2, "the hypotheses should leave the rounds at different times"
+    cfg = oracle.default_config(max_iterations=5, max_surface_features=sub if sub else -1)
+    for h in (0, n_hyp // 2, n_hyp - 1):
+        orc, opose, ost, _ = om.register(scan, poses[h], cfg)
+        assert orc == 0
+        _assert_registration_equal(sts[h], ost, out[h], opose, (scene, "batch", h))
+    # a host scan buffer instead of a resident one; and a batch of one
+    ok2, _, out2, _ = slam.register_batch(scan, poses[:3])
+    assert ok2 == 3 and np.array_equal(out2, out[:3])
+    ok1, _, out1, _ = slam.register_batch(None, poses[4:5], d_scan=d, n=n)
+    assert ok1 == 1 and np.array_equal(out1[0], out[4])
 
 
 def test_staged_scan_is_the_same_registration(oracle, gpu_slam_factory, soicp):
@@ -160,7 +211,7 @@ def test_stats_flags_name_the_degraded_modes(oracle, gpu_slam_factory, soicp, mo
     scan, guess = sc.scan(0), sc.guess(0)
     rc, _, st = slam.register(scan, guess)
     assert rc == 0 and st.flags == 0, hex(st.flags)
-    for env, flag in (({"SOICP_PERSISTENT": "0"}, soicp.FLAG_PER_EVAL_LAUNCHES), ({"SOICP_BINNING": "sort"}, soicp.FLAG_SORT_BINNING),
+    for env, flag in (({"SOICP_PERSISTENT": "0"}, soicp.FLAG_PER_EVAL_LAUNCHES),
                       ({"SOICP_HOST_MAP": "1"}, soicp.FLAG_HOST_MAP), ({"SOICP_READBACK": "copy"}, soicp.FLAG_COPY_READBACK)):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -224,8 +275,7 @@ def test_resolution_change_keeps_the_points_until_their_cube_is_touched(oracle, 
     assert np.allclose(a, b, rtol=0, atol=2e-5), float(np.abs(a - b).max())
 
 
-@pytest.mark.parametrize("binning", ["hash", "sort"])
-def test_two_shard_ranks_follow_the_queries_across_outer_iterations(oracle, gpu_slam_factory, monkeypatch, binning):
+def test_two_shard_ranks_follow_the_queries_across_outer_iterations(oracle, gpu_slam_factory):
     """N = 2 with max_iterations = 5 and a 3 degree / 0.4 m initial error: between outer iterations the pose update moves far
     queries by more than a map cell (1.5 m at 30 m), i.e. out of the one-cell halo of the shard that owned them under the
     initial pose.  Ownership is therefore re-derived under the current pose at the start of every outer iteration
@@ -233,11 +283,9 @@ def test_two_shard_ranks_follow_the_queries_across_outer_iterations(oracle, gpu_
     group (the sums take the place of the RCCL all-reduce): every iteration's histograms, iteration counts and termination
     codes must equal the single-context registration and the oracle; the poses agree to the last bits."""
     import threading
-    if binning == "sort":
-        monkeypatch.setenv("SOICP_BINNING", "sort")
     sc, full, om = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
     shards = []
-    key = 0x5151 + (1 if binning == "sort" else 0)
+    key = 0x5151
     for rank in (0, 1):
         sh = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5, rank=rank, world_size=2)
         sh.add_surf_point_cloud(sc.map_points)

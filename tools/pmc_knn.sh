@@ -11,8 +11,10 @@ for a in ${1:-0}; do
   SOICP_ABLATE=$a rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES --kernel-trace --output-format csv -d /tmp/pmc_$a -- \
     python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile-pass --no-secondary --entry resident > /tmp/pmc_$a.log 2>&1
   python - "$a" /tmp/pmc_$a $OUT > $OUT/ablate_$a.txt <<'PY'
-import sys, glob, csv, collections, json
+import sys, glob, csv, collections, json, hashlib, os
 a, d, out = sys.argv[1], sys.argv[2], sys.argv[3]
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sha = hashlib.sha256(open(R + "/superodom_amd/csrc/kernels.hip", "rb").read()).hexdigest()  # bench.py quotes the counters only for the same kernel source
 vals = collections.defaultdict(list)
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
@@ -29,11 +31,11 @@ for (k, c), v in sorted(vals.items()):
     print(f"{k:42s} {c:22s} launches {len(v):4d} real {len(keep):4d} mean(real) {real[(k, c)]:14.1f}")
 if a == "0":
     kk = [k for (k, c) in real if "knn_plane" in k][0]
-    j = {"kernel": "soicp::knn_plane_kernel", "round": 2,
+    j = {"kernel": "soicp::knn_plane_kernel", "round": 3, "kernels_hip_sha256": sha,
          "source": "tools/pmc_knn.sh: rocprofv3 --pmc SQ_INSTS_VALU ... --kernel-trace (own pass, no other trace domain), bench.py --steps 4 --warmup 1 --entry resident; no-op launches excluded",
          "valu_wave_insts_per_launch": real[(kk, "SQ_INSTS_VALU")], "salu_wave_insts_per_launch": real[(kk, "SQ_INSTS_SALU")],
          "lds_wave_insts_per_launch": real[(kk, "SQ_INSTS_LDS")], "waves_per_launch": real[(kk, "SQ_WAVES")],
-         "wave_cycles_per_launch_x4": real[(kk, "SQ_WAVE_CYCLES")], "shader_clock_ghz": 2.15}
+         "wave_cycles_per_launch_x4": real[(kk, "SQ_WAVE_CYCLES")], "active_inst_valu_x4": real[(kk, "SQ_ACTIVE_INST_VALU")], "shader_clock_ghz": 2.15}
     ks = [k for (k, c) in real if "solve_kernel" in k]
     if ks:
         j["solve_kernel"] = {"valu_wave_insts_per_launch": real[(ks[0], "SQ_INSTS_VALU")], "active_inst_valu_x4": real[(ks[0], "SQ_ACTIVE_INST_VALU")],

@@ -14,8 +14,10 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile-pass --no-secondary --entry resident > /tmp/pmc_$ctr.log 2>&1
 done
 python - $OUT <<'PY'
-import sys, glob, csv, collections, json
+import sys, glob, csv, collections, json, hashlib, os
 out = sys.argv[1]
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sha = hashlib.sha256(open(R + "/superodom_amd/csrc/kernels.hip", "rb").read()).hexdigest()  # bench.py quotes the traffic only for the same kernel source
 res = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
@@ -32,12 +34,17 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     real = [x for x in v if x > 0.2 * max(v)] if v else []
     res[ctr] = (sum(real) / len(real)) if real else None
     res[ctr + "_launches"] = len(real)
-j = {"kernel": "soicp::knn_plane_kernel", "round": 2,
+    v = [x for k, vs in acc.items() if "solve_kernel" in k for x in vs]
+    real = [x for x in v if x > 0.2 * max(v)] if v else []
+    res["solve_" + ctr] = (sum(real) / len(real)) if real else None
+j = {"kernel": "soicp::knn_plane_kernel", "round": 3, "kernels_hip_sha256": sha,
      "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, bench.py --steps 4 --warmup 1); no-op launches excluded",
      "FETCH_SIZE_KB_per_launch": res["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": res["WRITE_SIZE"],
      "launches": [res["FETCH_SIZE_launches"], res["WRITE_SIZE_launches"]],
      "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> read bytes = 2 * FETCH_SIZE * 1024",
-     "hbm_bytes_per_launch": int(2 * res["FETCH_SIZE"] * 1024 + res["WRITE_SIZE"] * 1024) if res["FETCH_SIZE"] and res["WRITE_SIZE"] else None}
+     "hbm_bytes_per_launch": int(2 * res["FETCH_SIZE"] * 1024 + res["WRITE_SIZE"] * 1024) if res["FETCH_SIZE"] and res["WRITE_SIZE"] else None,
+     "solve_kernel": {"FETCH_SIZE_KB_per_launch": res["solve_FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": res["solve_WRITE_SIZE"],
+                      "hbm_bytes_per_launch": int(2 * res["solve_FETCH_SIZE"] * 1024 + res["solve_WRITE_SIZE"] * 1024) if res["solve_FETCH_SIZE"] and res["solve_WRITE_SIZE"] else None}}
 json.dump(j, open(f"{out}/knn_traffic.json", "w"), indent=1)
 print(json.dumps(j))
 PY
