@@ -42,6 +42,7 @@ extern "C" {
 #define SO_ICP_OK 0
 #define SO_ICP_NOT_ENOUGH_MAP_FEATURES 1 /* LS.cpp:113-116: surf_from_map_num <= 50, pose = guess */
 #define SO_ICP_MAP_SEEDED 2              /* Localization(initialization=false): LS.cpp:45-46, 83-94 */
+#define SO_ICP_STAGE_DECLINED 3          /* so_icp_stage_scan: both staging slots hold scans that are still needed; not staged (soft) */
 #define SO_ICP_E_INVALID (-1)
 #define SO_ICP_E_HIP (-2)
 #define SO_ICP_E_NOMEM (-3)
@@ -128,7 +129,7 @@ typedef struct {
 #define SO_ICP_FLAG_RETRIED 0x2u             /* THIS registration was repeated after an abandoned persistent solve launch */
 #define SO_ICP_FLAG_HOST_MAP 0x4u            /* LocalMap lives on the host and is re-uploaded after every insert (planeRes < 0.1
                                                  or SOICP_HOST_MAP=1) */
-#define SO_ICP_FLAG_SORT_BINNING 0x8u        /* scan binned by the rocPRIM sort path (SOICP_BINNING=sort) */
+#define SO_ICP_FLAG_SORT_BINNING 0x8u        /* reserved (the sort-binning path of ABI v2 rounds 1-2 no longer exists; never set) */
 #define SO_ICP_FLAG_SHARDED 0x10u            /* world_size > 1: map shard + collective per evaluation */
 #define SO_ICP_FLAG_STAGED_SCAN 0x20u        /* the scan came from so_icp_stage_scan (upload overlapped with earlier work) */
 #define SO_ICP_FLAG_COPY_READBACK 0x40u      /* state read back with hipMemcpyAsync (SOICP_READBACK=copy) */
@@ -194,8 +195,11 @@ int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t str
  * so_icp_localization with the SAME (scan_xyz, n, stride_bytes) consumes the staged copy instead of uploading again
  * (so_icp_stats::flags carries SO_ICP_FLAG_STAGED_SCAN); any other call simply ignores it.  The caller's buffer must stay
  * valid and unchanged until that call (or the next so_icp_stage_scan) returns.  Two slots: one scan may be staged while
- * the previous one is being registered.  Unlike the other entry points this one may be called from ANOTHER thread than
- * the registration calls (the node's feature callback, lmap.cpp:21-25). */
+ * the previous one is being registered; while a registration reads one slot and the other holds the scan to be registered
+ * next, a further announcement returns SO_ICP_STAGE_DECLINED (soft: that scan is uploaded by its own registration call).
+ * A staged copy is also dropped by a map-seeding so_icp_localization(initialization = 0) on the same buffer.  Unlike the
+ * other entry points this one may be called from ANOTHER thread than the registration calls (the node's feature callback,
+ * lmap.cpp:21-25). */
 int so_icp_stage_scan(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes);
 /* same, scan already resident in HBM as packed float xyz (n*3 floats, device pointer) */
 int so_icp_register_dev(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n,

@@ -95,42 +95,57 @@ struct EventSpan { int kind; hipEvent_t a, b; uint32_t units; };  // kind 0 knn,
 struct InprocGroup {
   std::mutex mu; std::condition_variable cv;
   int world = 0, arrived = 0, members = 0; unsigned long long generation = 0;
+  // A round is identified by (kind, size): members that disagree about what is being summed -- one in the LmSums reduce, another
+  // in the per-cube counts after a failed insert -- must not be paired silently; a member that returns early (a failed HIP call
+  // before the exchange) or never arrives makes the round fail on every member instead of blocking the others for ever.
+  int round_kind = -1; size_t round_size = 0; bool aborted = false;
+  static constexpr int kWaitSeconds = 60;
   std::vector<LmSums> slot; LmSums total{};
-  void allreduce(int rank, LmSums* io) {
+  std::vector<std::vector<int32_t>> islot; std::vector<int32_t> itotal;
+  void abort_all() { std::lock_guard<std::mutex> lk(mu); aborted = true; cv.notify_all(); }
+  // returns false when the round failed (mismatch, abort, or a member missing for kWaitSeconds): the group is unusable afterwards
+  template <class Publish, class Combine>
+  bool round(int kind, size_t size, Publish&& publish, Combine&& combine) {
     std::unique_lock<std::mutex> lk(mu);
-    slot[(size_t)rank] = *io;
+    if (aborted) return false;
+    if (arrived == 0) { round_kind = kind; round_size = size; }
+    else if (round_kind != kind || round_size != size) { aborted = true; cv.notify_all(); return false; }
+    publish();
     if (++arrived == world) {
+      combine();
+      arrived = 0; ++generation;
+      cv.notify_all();
+      return true;
+    }
+    const unsigned long long g = generation;
+    const bool done = cv.wait_for(lk, std::chrono::seconds(kWaitSeconds), [&] { return generation != g || aborted; });
+    if (!done || aborted) { aborted = true; cv.notify_all(); return false; }
+    return true;
+  }
+  bool allreduce(int rank, LmSums* io) {
+    const bool ok = round(0, sizeof(LmSums), [&] { slot[(size_t)rank] = *io; }, [&] {
       double* t = reinterpret_cast<double*>(&total);
       for (size_t k = 0; k < sizeof(LmSums) / sizeof(double); ++k) {
         double acc = 0;
-        for (int r = 0; r < world; ++r) acc += reinterpret_cast<const double*>(&slot[(size_t)r])[k];
+        for (int r = 0; r < world; ++r) acc += reinterpret_cast<const double*>(&slot[(size_t)r])[k];  // fixed order: rank 0, 1, ...
         t[k] = acc;
       }
-      arrived = 0; ++generation;
-      cv.notify_all();
-    } else {
-      const unsigned long long g = generation;
-      cv.wait(lk, [&] { return generation != g; });
-    }
-    *io = total;
+    });
+    if (ok) { std::lock_guard<std::mutex> lk(mu); *io = total; }
+    return ok;
   }
   // same for a vector of counters (per-cube point counts after a map insert)
-  std::vector<std::vector<int32_t>> islot; std::vector<int32_t> itotal;
-  void allreduce_i32(int rank, std::vector<int32_t>& io) {
-    std::unique_lock<std::mutex> lk(mu);
-    if (islot.size() != (size_t)world) islot.resize((size_t)world);
-    islot[(size_t)rank] = io;
-    if (++arrived == world) {
+  bool allreduce_i32(int rank, std::vector<int32_t>& io) {
+    const bool ok = round(1, io.size(), [&] {
+      if (islot.size() != (size_t)world) islot.resize((size_t)world);
+      islot[(size_t)rank] = io;
+    }, [&] {
       itotal.assign(io.size(), 0);
       for (int r = 0; r < world; ++r)
         for (size_t k = 0; k < io.size() && k < islot[(size_t)r].size(); ++k) itotal[k] += islot[(size_t)r][k];
-      arrived = 0; ++generation;
-      cv.notify_all();
-    } else {
-      const unsigned long long g = generation;
-      cv.wait(lk, [&] { return generation != g; });
-    }
-    io = itotal;
+    });
+    if (ok) { std::lock_guard<std::mutex> lk(mu); io = itotal; }
+    return ok;
   }
 };
 std::mutex g_groups_mu;
@@ -217,6 +232,7 @@ struct so_icp_ctx {
   void* peer_inbox[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool peer_opened[8] = {false, false, false, false, false, false, false, false};  // mapped with hipIpcOpenMemHandle (to be closed)
   bool peer_connected = false, peer_on = false;
+  unsigned peer_connects = 0;  // handshakes so far (tag of the self-test chunks)
   // so_icp_stage_scan: a copy thread + copy stream bring the NEXT scan to HBM while the current registration runs
   struct StageSlot {
     const float* src = nullptr; size_t n = 0, stride = 0;  // identity of the staged host buffer
@@ -299,7 +315,8 @@ int exchange_map_counts(so_icp_ctx* c) {
   std::vector<int32_t> v;
   c->dmap->owned_counts(v);
   if (c->group) {
-    c->group->allreduce_i32(c->cfg.rank, v);
+    if (!c->group->allreduce_i32(c->cfg.rank, v))
+      return fail(c, SO_ICP_E_RCCL, "in-process group: the map-count exchange failed (a member returned early, is in another exchange, or did not arrive)");
   } else if (c->comm) {
     HIP_TRY(c, c->d_counts.reserve(v.size() * sizeof(int32_t)));
     HIP_TRY(c, hipMemcpyAsync(c->d_counts.p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -568,7 +585,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     if (!fuse_lm && c->group) {  // in-process group: through host memory (every member calls this the same number of times)
       HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(LmSums), hipMemcpyDeviceToHost, s));
       HIP_TRY(c, hipStreamSynchronize(s));
-      c->group->allreduce(c->cfg.rank, c->h_sums);
+      if (!c->group->allreduce(c->cfg.rank, c->h_sums))
+        return fail(c, SO_ICP_E_RCCL, "in-process group: the exchange of the normal-equation sums failed (a member returned early or did not arrive)");
       HIP_TRY(c, hipMemcpyAsync(c->d_sums, c->h_sums, sizeof(LmSums), hipMemcpyHostToDevice, s));
       launch_lm_step(slot, ds, c->d_sums, c->d_hist, ep, s);
     } else if (!fuse_lm) {  // per-evaluation collective: 45 fp64 summed over the shards (xGMI, latency-bound), then the controller
@@ -643,9 +661,15 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
         if (*seq == want) break;
         HIP_TRY(c, hipStreamSynchronize(s));
         if (*seq == want) break;
-        if (persistent && peer)
+        if (persistent && peer) {
+          // The ranks' pass counters (DevState::peer_seq) and inboxes can no longer be assumed equal: chunks of the failed attempt
+          // still carry tags the next registration would reuse.  The peer path is left until the caller repeats the collective
+          // handshake (so_icp_peer_export clears the inbox and the counter, _connect, _enable).
+          c->peer_on = false; c->peer_connected = false;
           return fail(c, SO_ICP_E_HIP, "peer exchange: a solve launch was abandoned (a rank's records did not arrive within SOICP_PEER_TIMEOUT_MS, or the "
-                                       "workgroups were not co-resident); every rank must run the same registrations");
+                                       "workgroups were not co-resident); the peer exchange is now disabled on this rank until so_icp_peer_export / "
+                                       "_connect / _enable are repeated on every rank");
+        }
         if (persistent) {
           // The persistent solve launch needs all of its workgroups resident at once.  If the device could not provide that
           // (compute units held by another process, a partitioned device, ...) its waits gave up after 50 ms: fall back to
@@ -735,6 +759,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     c->retried = false;
     if (rc == kRetryWithoutPersistentSolve) rc = fail(c, SO_ICP_E_HIP, "registration state was not published by the device");
   }
+  if (rc < 0 && c->group) c->group->abort_all();  // the other members of an in-process group must not wait for this one's next exchange
   return rc;
 }
 
@@ -773,7 +798,11 @@ void stage_worker(so_icp_ctx* c) {
       bool got = false;
       while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(400)) {
         if (c->stage_pending.load(std::memory_order_acquire) > 0) { got = true; break; }
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
       }
       lk.lock();
       if (!got) {
@@ -837,6 +866,17 @@ const float* take_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t strid
     return nullptr;
   }
   return nullptr;
+}
+// A call that reads (xyz, n, stride) itself -- map seeding -- without consuming a staged copy of it: the copy is dropped, so that
+// a later frame whose buffer happens to have the same address and size is never served the old contents.
+void drop_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes) {
+  std::unique_lock<std::mutex> lk(c->stage_mu);
+  if (!c->stage_started) return;
+  for (so_icp_ctx::StageSlot& sl : c->stage) {
+    if (sl.state == 0 || sl.state == 3 || sl.src != xyz || sl.n != n || sl.stride != stride_bytes) continue;
+    c->stage_cv.wait(lk, [&] { return sl.state != 1; });
+    sl.src = nullptr; sl.state = 0;
+  }
 }
 void release_staged(so_icp_ctx* c) {
   if (!c->stage_in_use) return;
@@ -1183,7 +1223,7 @@ int so_icp_map_add_surf(so_icp_ctx* c, const float* xyz, size_t n, size_t stride
   if (c->dmap) {  // bin + VoxelGrid + index rebuild on the device (map_kernels.hip)
     HIP_TRY(c, hipSetDevice(c->cfg.device_id));
     const int r = c->dmap->add_surf_host(xyz, n, stride_bytes / 4, c->err);
-    if (r < 0) return r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP;
+    if (r < 0) { if (c->group) c->group->abort_all(); return r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP; }
     const int xr = exchange_map_counts(c);
     return xr ? xr : r;
   }
@@ -1302,10 +1342,14 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
       c->stage_thread = std::thread(stage_worker, c);
       c->stage_started = true;
     }
-    // the slot after the last one used, unless the registration in flight is reading it: then the other one (an older staged
-    // scan that was never registered is dropped)
+    // An empty slot if there is one.  Otherwise, while a registration is reading one slot the other holds the scan that is
+    // registered NEXT: it stays, this announcement is declined (SO_ICP_STAGE_DECLINED: the scan will be uploaded by its own
+    // registration call) -- the slot in use becomes free when that registration returns.  With nothing in flight and two
+    // announced scans waiting, the older one gives way (a caller that announces scans it never registers cannot block the slots).
     int k = c->stage_next;
-    if (c->stage[k].state == 3) k ^= 1;
+    if (c->stage[0].state == 0 || c->stage[0].state == -1) k = 0;
+    else if (c->stage[1].state == 0 || c->stage[1].state == -1) k = 1;
+    else if (c->stage[0].state == 3 || c->stage[1].state == 3) return SO_ICP_STAGE_DECLINED;
     so_icp_ctx::StageSlot& sl = c->stage[k];
     c->stage_next = k ^ 1;
     c->stage_cv.wait(lk, [&] { return sl.state != 1; });  // (a slot still being copied: the caller staged three scans in a row)
@@ -1503,6 +1547,7 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   if (!initialization) {  // initializeMapping, LidarSlam.cpp:83-94
     std::memcpy(pose_out, T_in, 7 * sizeof(double));
     if (st) std::memset(st, 0, sizeof(*st));
+    if (!c->host_only) drop_staged(c, xyz, n, stride_bytes);
     if (c->dmap) c->dmap->set_origin(T_in); else c->map.set_origin(T_in);
     const int r = transform_and_add(T_in);
     if (r) return r;
@@ -1824,8 +1869,14 @@ int so_icp_peer_export(so_icp_ctx* c, uint8_t handle[SO_ICP_PEER_HANDLE_BYTES]) 
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&c->peer_own, kPeerInboxBytes, hipDeviceMallocFinegrained); }
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&c->peer_own, kPeerInboxBytes); }
     if (e != hipSuccess) { c->peer_own = nullptr; return fail(c, SO_ICP_E_HIP, std::string("peer exchange: inbox allocation: ") + hipGetErrorString(e)); }
-    HIP_TRY(c, hipMemset(c->peer_own, 0, kPeerInboxBytes));
   }
+  // A (new) handshake starts from an empty inbox -- stale pass records and self-test chunks of an earlier connection must not
+  // satisfy the polls of this one -- and from pass number zero on every rank.  The exchange of the handles that follows
+  // is the barrier between these clears and the first remote store.
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemset(c->peer_own, 0, kPeerInboxBytes));
+  HIP_TRY(c, hipMemset(&c->d_state->peer_seq, 0, sizeof(unsigned long long)));
+  c->peer_on = false; c->peer_connected = false;
   if (hipIpcGetMemHandle(&h.ipc, c->peer_own) != hipSuccess) {
     (void)hipGetLastError();  // contexts of ONE process need no IPC handle (pid + pointer below); across processes connect() will refuse
     std::memset(&h.ipc, 0, sizeof(h.ipc));
@@ -1856,7 +1907,7 @@ int so_icp_peer_connect(so_icp_ctx* c, const uint8_t* handles, int* self_test_ok
   // self-test with the very stores / loads of the solve's exchange (every rank runs it; waits up to 2 s for the others)
   int32_t* d_ok = reinterpret_cast<int32_t*>(c->d_fbcount);
   HIP_TRY(c, hipMemsetAsync(d_ok, 0, 4, c->stream));
-  launch_peer_selftest(c->peer_inbox, c->cfg.rank, world, 0x7E57u, d_ok, c->stream);
+  launch_peer_selftest(c->peer_inbox, c->cfg.rank, world, 0x7E570000u + (++c->peer_connects & 0xFFFFu), d_ok, c->stream);  // (every rank connects equally often)
   HIP_TRY(c, hipMemcpyAsync(c->h_u32, d_ok, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   *self_test_ok = c->h_u32[0] == 1 ? 1 : 0;
