@@ -98,7 +98,9 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import datetime
+        # (every wait of the control plane is bounded: a rank that died must end the run, not hang it)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
 
     # ---------------- synthetic workload (seeded) ----------------
     sc = synth.Scene(args.workload)
@@ -340,6 +342,14 @@ def main():
                 "valu_issue_frac_at_2_cycles": t2 / (knn_ms * 1e-3), "valu_issue_frac_at_4_cycles": 2 * t2 / (knn_ms * 1e-3),
                 "kernels_hip_sha256": ctr.get("kernels_hip_sha256"), "source": ctr.get("source"), "solve_kernel": ctr.get("solve_kernel")}
     ms_per_step = 1e3 * t_max / args.steps
+    shard_info = None
+    if world > 1:  # how the queries of the bench scans fall to the ranks under their initial poses (ownership rule of the sharded map)
+        hists = np.stack([binding.shard_histogram(scans[i], guesses[i], slam.origin(), sc.plane_res, world) for i in range(args.scans)])
+        mean_owned = hists.mean(axis=0)
+        shard_info = {"queries_owned_per_rank_mean": [float(v) for v in mean_owned],
+                      "imbalance_max_over_mean_per_scan": [float(h.max() / h.mean()) for h in hists],
+                      "note": "brick-hash ownership (4 x 4 x 4 cells): the dense near-field floor under the sensor is one or two bricks, so the "
+                              "busiest rank sets the sweep and fit times; what sharding can gain is bounded by the step's serial chains (DESIGN section 5)"}
 
     errs = [synth.pose_error(poses[i], sc.gt_pose(i)) for i in range(len(poses))]
     entry_text = {"staged": "so_icp_register on HOST scan buffers, the next scan announced with so_icp_stage_scan (copy thread + copy stream): "
@@ -359,6 +369,9 @@ def main():
                                     f"45-double records through hipIpc-mapped inboxes over xGMI (peer exchange)" if peer else
                                     f"map sharded by brick-hash x{world}, ownership re-derived every outer iteration, 45-fp64 RCCL all-reduce per evaluation")),
                    "peer_exchange": bool(peer),
+                   "transport": (None if world == 1 else ("peer exchange: tagged 16-byte chunks pushed into hipIpc-mapped inboxes by the persistent solve launches"
+                                                          if peer else "RCCL all-reduce of 45 fp64 per evaluation + controller launch")),
+                   "shards": shard_info,
                    "distinct_scans": args.scans},
         "executed": {"outer_iterations_per_step": iters_outer / args.steps, "lm_iterations_per_step": iters_lm / args.steps,
                      "accepted_correspondences": accepted / args.steps, "stats_flags": int(flags),

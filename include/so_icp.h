@@ -331,6 +331,10 @@ int so_icp_peer_enable(so_icp_ctx *ctx, int on);
 /* brick-hash ownership of the shard (host logic, testable without a GPU) */
 int so_icp_shard_owner_of_point(const float p[3], const int origin[3], float plane_res, int world_size);
 int so_icp_cells_per_cube(float plane_res, double *cell_size);
+/* how a scan's queries fall to the ranks under `pose` (the ownership rule of the sharded registration; host arithmetic):
+ * counts[r] = queries whose map cell rank r owns (queries outside the window count for rank 0, like in the kernels) */
+int so_icp_shard_histogram(const float *scan_xyz, size_t n, size_t stride_bytes, const double pose[7], const int origin[3],
+                           float plane_res, int world_size, int64_t *counts /* world_size */);
 
 /* -------- host-side Levenberg-Marquardt state machine (the Ceres restatement the device path is
  * driven by; exposed so it can be tested without a GPU) ------------------------------------------ */

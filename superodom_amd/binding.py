@@ -84,7 +84,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
-            "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud"]
+            "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram"]
 
 _lib = None
 
@@ -125,6 +125,7 @@ def load():
     L.so_icp_comm_init.argtypes = [vp, u8p]
     L.so_icp_shard_owner_of_point.argtypes = [f32p, i32p, C.c_float, C.c_int]
     L.so_icp_cells_per_cube.argtypes = [C.c_float, f64p]
+    L.so_icp_shard_histogram.argtypes = [f32p, C.c_size_t, C.c_size_t, f64p, i32p, C.c_float, C.c_int, C.POINTER(C.c_int64)]
     L.so_icp_lm_begin.argtypes = [C.POINTER(LmState), f64p, C.POINTER(Sums), C.c_int, f64p]
     L.so_icp_lm_feed.argtypes = [C.POINTER(LmState), C.POINTER(Sums), f64p]
     L.so_icp_lm_result.argtypes = [C.POINTER(LmState), f64p, C.POINTER(IterStats)]
@@ -467,6 +468,17 @@ def cells_per_cube(plane_res):
     cell = C.c_double()
     nc = load().so_icp_cells_per_cube(float(plane_res), C.byref(cell))
     return nc, cell.value
+
+
+def shard_histogram(scan, pose, origin, plane_res, world_size):
+    """Queries of `scan` (sensor frame) that fall to each rank under `pose` (so_icp_shard_histogram)."""
+    scan = _f32(scan).reshape(-1, 3); pose = np.ascontiguousarray(pose, dtype=np.float64); o = np.ascontiguousarray(origin, dtype=np.int32)
+    out = np.zeros(int(world_size), np.int64)
+    rc = load().so_icp_shard_histogram(_p(scan, C.c_float), len(scan), 12, _p(pose, C.c_double), _p(o, C.c_int32), float(plane_res), int(world_size),
+                                       _p(out, C.c_int64))
+    if rc:
+        raise SoIcpError(f"so_icp_shard_histogram: {rc}")
+    return out
 
 
 def shard_owner_of_point(p, origin, plane_res, world_size):

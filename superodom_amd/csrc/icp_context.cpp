@@ -209,6 +209,7 @@ struct so_icp_ctx {
       h_states = nullptr; h_begin = nullptr; h_active = nullptr; cap_hyp = 0; bs = 0; table_log2 = 0; tables_clean = false;
     }
   } batch;
+  int batch_degrade = 0;  // 0: two solve workgroups per compute unit, 1: one (after a batched solve that was not co-resident), 2: lanes
   bool no_map_shift_once = false;  // retry of a registration: keep the window of the first attempt
   int n_cus = 256;            // compute units of the device: upper bound of the persistent solve launch's workgroups
   int ablate = 0;             // SOICP_ABLATE (profiling / test switches), read at creation
@@ -978,7 +979,7 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
   ep.timeout_ticks = 20000000ull;  // 200 ms: a pass of one hypothesis on a few workgroups lasts up to a millisecond
   const uint32_t v_grid = solve_grid((uint32_t)n, (uint32_t)c->n_cus);
   static const int wg_per_cu_env = std::getenv("SOICP_BATCH_WG_PER_CU") ? std::atoi(std::getenv("SOICP_BATCH_WG_PER_CU")) : 0;
-  const uint32_t resident = solve_batch_resident_blocks((uint32_t)c->n_cus, wg_per_cu_env);
+  const uint32_t resident = solve_batch_resident_blocks((uint32_t)c->n_cus, c->batch_degrade >= 1 ? 1 : wg_per_cu_env);
   if (resident < (uint32_t)B) return fail(c, SO_ICP_E_HIP, "so_icp_register_batch: fewer resident solve workgroups than hypotheses");
   BatchView bv{b.active.as<uint32_t>(), b.begin.as<RegBeginArgs>(), b.bs, (uint32_t)((size_t)1 << lg),
                (uint32_t)((size_t)kFitBlocksMax * kRecordChunksMax * 2), (uint32_t)(kSyncBytes / 4), 1u, v_grid};
@@ -1019,9 +1020,11 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
     std::vector<uint32_t> next;
     for (uint32_t h : act) {
       const DevState& H = b.h_states[h];
-      if (H.outer_iter != it + 1)  // the hypothesis' solve did not finish (a wait inside the launch gave up)
-        return fail(c, SO_ICP_E_HIP, "so_icp_register_batch: the solve of hypothesis " + std::to_string(h) + " did not complete in round " + std::to_string(it) +
-                                         " (workgroups not co-resident?)");
+      if (H.outer_iter != it + 1) {  // the hypothesis' solve did not finish (a wait inside the launch gave up)
+        c->err = "so_icp_register_batch: the solve of hypothesis " + std::to_string(h) + " did not complete in round " + std::to_string(it) +
+                 " (workgroups not co-resident: compute units held by another process?)";
+        return kRetryWithoutPersistentSolve;
+      }
       if (!H.reg_done && it + 1 < max_outer) next.push_back(h);
     }
     act.swap(next);
@@ -1382,7 +1385,7 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
   int rc = upload_map(c);
   if (rc) return rc;
   static const bool lanes_mode = std::getenv("SOICP_BATCH_MODE") && std::string(std::getenv("SOICP_BATCH_MODE")) == "lanes";
-  if (!lanes_mode && n > 0) {
+  if (!lanes_mode && n > 0 && c->batch_degrade < 2) {
     // batched kernels: groups of up to kBatchMaxConcurrent hypotheses advance together (kernels.hip, BatchView)
     const int count = map_count_5x5(c, pos);
     std::vector<int32_t> hrc((size_t)n_hyp, 0);
@@ -1390,13 +1393,25 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
       const int B = std::min(kBatchMaxConcurrent, n_hyp - base);
       rc = register_batch_group(c, scan, n, poses_in + 7 * (size_t)base, B, poses_out + 7 * (size_t)base, stats ? stats + base : nullptr,
                                 hrc.data() + base, pos, count);
+      // A batched solve launch needs its workgroups resident together.  If the device could not provide that (shared with another
+      // process), the group is repeated with one workgroup per compute unit; if that fails too the context falls back to
+      // concurrent sequential registrations (below) for the rest of its life.  so_icp_last_error keeps the notice.
+      if (rc == kRetryWithoutPersistentSolve) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->batch.tables_clean = false;
+        if (++c->batch_degrade <= 1) { base -= kBatchMaxConcurrent; continue; }
+        break;
+      }
       if (rc < 0) return rc;
     }
-    int ok = 0;
-    for (int h = 0; h < n_hyp; ++h) { if (rc_out) rc_out[h] = hrc[(size_t)h]; if (hrc[(size_t)h] == SO_ICP_OK) ++ok; }
-    return ok;
+    if (c->batch_degrade < 2) {
+      int ok = 0;
+      for (int h = 0; h < n_hyp; ++h) { if (rc_out) rc_out[h] = hrc[(size_t)h]; if (hrc[(size_t)h] == SO_ICP_OK) ++ok; }
+      return ok;
+    }
   }
-  // SOICP_BATCH_MODE=lanes (and empty scans): the hypotheses as concurrent sequential registrations on worker contexts
+  // SOICP_BATCH_MODE=lanes, empty scans, and a device that cannot keep the batched solve resident: the hypotheses as concurrent
+  // sequential registrations on worker contexts (own stream / buffers / state each, one launch per evaluation)
   static const int want_lanes = std::getenv("SOICP_BATCH_LANES") ? std::atoi(std::getenv("SOICP_BATCH_LANES")) : 16;
   const int lanes = std::max(1, std::min({want_lanes, n_hyp, 64}));
   // worker contexts: own stream / buffers / device state, no map of their own (they borrow this context's resident map)
@@ -1938,6 +1953,22 @@ int so_icp_shard_owner_of_point(const float p[3], const int origin[3], float pla
     g[a] = v < 0 ? 0 : (v >= nc ? nc - 1 : v);
   }
   return shard_owner_of_cell(w[0], w[1], w[2], g[0], g[1], g[2], world_size);
+}
+
+int so_icp_shard_histogram(const float* scan_xyz, size_t n, size_t stride_bytes, const double pose[7], const int origin[3], float plane_res,
+                           int world_size, int64_t* counts) {
+  if ((!scan_xyz && n) || !pose || !origin || !counts || world_size < 1) return SO_ICP_E_INVALID;
+  if (stride_bytes == 0) stride_bytes = 12;
+  if (stride_bytes % 4) return SO_ICP_E_INVALID;
+  const size_t sf = stride_bytes / 4;
+  for (int r = 0; r < world_size; ++r) counts[r] = 0;
+  for (size_t i = 0; i < n; ++i) {  // the queries' world positions exactly as scan_keys_kernel forms them (LidarSlam.cpp:397-398, 728-731)
+    double wx, wy, wz;
+    quat_rotate<double>(pose + 3, (double)scan_xyz[i * sf], (double)scan_xyz[i * sf + 1], (double)scan_xyz[i * sf + 2], wx, wy, wz);
+    const float q[3] = {(float)(wx + pose[0]), (float)(wy + pose[1]), (float)(wz + pose[2])};
+    counts[so_icp_shard_owner_of_point(q, origin, plane_res, world_size)]++;
+  }
+  return SO_ICP_OK;
 }
 
 int so_icp_lm_begin(so_icp_lm_state* s, const double x0[7], const so_icp_sums* sums, int max_iterations, double next_pose[7]) {

@@ -100,6 +100,11 @@ def test_shard_ownership_is_a_partition_and_roughly_balanced(soicp):
         if W == 2:  # brick-hash ownership: query density is very non-uniform (near-field floor), so only a loose bound
             assert frac.min() > 0.2, frac
     assert soicp.shard_owner_of_point(world_pts[0], origin, 0.2, 1) == 0
+    # so_icp_shard_histogram (the N > 1 bench line's per-rank query counts): the same rule applied to a sensor-frame scan under a pose
+    for W in (2, 8):
+        h = soicp.shard_histogram(sc.scan(0), gt, origin, 0.2, W)
+        owners = np.array([soicp.shard_owner_of_point(p, origin, 0.2, W) for p in world_pts])
+        assert h.sum() == len(world_pts) and np.array_equal(h, np.bincount(owners, minlength=W))
     # outside the window -> rank 0 counts it
     assert soicp.shard_owner_of_point(np.array([1e5, 0, 0], np.float32), origin, 0.2, 8) == 0
 
