@@ -182,7 +182,6 @@ struct so_icp_ctx {
   unsigned long long solve_launches = 0;  // persistent solve launches so far (EvalParams::epoch_base)
   DevBuf d_bin_key, d_bin_cnt, d_bin_off; uint32_t bin_log2 = 0; bool bin_dirty = true;
   int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
-  int sync_per_outer = 1;  // 1: read back reg_done after every outer iteration and stop enqueuing (eager mode)
   std::vector<DevBuf> resident_scans;  // so_icp_upload_scan
   DevBuf pf_in, pf_out, pf_small, pf_w, pf_s, pf_k0, pf_k1, pf_v0, pf_v1, pf_flags, pf_pos, pf_heads, pf_temp;  // so_icp_prefilter_scan
   // Seam B scratch
@@ -209,11 +208,11 @@ struct so_icp_ctx {
       h_states = nullptr; h_begin = nullptr; h_active = nullptr; cap_hyp = 0; bs = 0; table_log2 = 0; tables_clean = false;
     }
   } batch;
-  int batch_degrade = 0;  // 0: two solve workgroups per compute unit, 1: one (after a batched solve that was not co-resident), 2: lanes
+  int batch_degrade = 0;  // 0: two solve workgroups per compute unit, 1: one (after a batched solve that was not co-resident, or
+                          // SOICP_BATCH_WG_PER_CU=1), 2: lanes = concurrent sequential registrations (SOICP_BATCH_MODE=lanes)
   bool no_map_shift_once = false;  // retry of a registration: keep the window of the first attempt
   int n_cus = 256;            // compute units of the device: upper bound of the persistent solve launch's workgroups
   int ablate = 0;             // SOICP_ABLATE (profiling / test switches), read at creation
-  bool no_defer = false;      // SOICP_NO_DEFER=1
   bool speculate = true;      // enqueue outer iteration i+1 before the report of i is in (SOICP_SPECULATE=0: wait first)
   bool batch_mode = false;    // no kernel timing, tracker state read-only
   bool batch_single = false;  // batch on ONE lane: nothing runs next to it, the persistent solve launch is safe
@@ -470,8 +469,8 @@ void fill_result(so_icp_ctx* c, const DevState& H, const double pose_in[7], so_i
 // the host enqueues, per outer iteration, the STATIC sequence
 //     clear histograms -> knn_plane -> [ eval(slot) -> (all-reduce) -> lm_step(slot) ] x (1 + lm_max)
 // and every kernel consults DevState (reg_done / lm_more) to turn itself into a no-op once the controller has
-// finished -- no host round trip per evaluation.  One small read-back per outer iteration (or one per
-// registration with SOICP_SYNC_PER_OUTER=0) tells the host when to stop enqueuing.
+// finished -- no host round trip per evaluation.  One small read-back per outer iteration tells the host when to stop
+// enqueuing.
 constexpr int kRetryWithoutPersistentSolve = -1000;  // internal: never leaves register_core
 int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const double pose_in[7], double pose_out[7], so_icp_stats* st) {
   const auto t_begin = std::chrono::steady_clock::now();
@@ -575,7 +574,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   if (!persistent) st->flags |= SO_ICP_FLAG_PER_EVAL_LAUNCHES;
   // deferred report (see EvalParams::defer_publish): possible when the host always has the next k-NN launch in the queue
   // before it waits for a report
-  const bool defer_reports = persistent && direct_rb && c->speculate && c->sync_per_outer && !c->no_defer;
+  const bool defer_reports = persistent && direct_rb && c->speculate;
   mp.publish_prev = defer_reports ? 1 : 0;
   auto enqueue_eval = [&](int slot) -> int {
     span_begin(c, 1, (uint32_t)n);
@@ -616,10 +615,6 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     }
     launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->d_vals1.as<uint32_t>(),
                      c->d_chunks.as<uint32_t>(), ds, c->view, mp, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s, ka, kb);
-    static const int repeat_knn = std::getenv("SOICP_REPEAT_KNN") ? std::atoi(std::getenv("SOICP_REPEAT_KNN")) : 0;
-    for (int rep = 0; rep < repeat_knn; ++rep)  // profiling aid: identical relaunch (results are idempotent)
-      launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->d_vals1.as<uint32_t>(),
-                       c->d_chunks.as<uint32_t>(), ds, c->view, mp, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s);
     if (c->cfg.time_kernels >= 2)  // kernel statistics of this sweep (profiling mode only)
       HIP_TRY(c, hipMemcpyAsync(c->h_hist + (size_t)it * kHistReplicas * kHistStride, c->d_hist,
                                 kHistReplicas * kHistStride * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -690,31 +685,17 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // part B (the solve launch / the remaining evaluations) follows as soon as the report says "not converged" -- the device
   // is then busy with part A for tens of microseconds.  If iteration it did converge, the speculated launch is a no-op
   // (every kernel consults DevState::reg_done) that drains while the host post-processes.
-  // SOICP_SYNC_PER_OUTER=0 enqueues all max_outer iterations up front instead, SOICP_SPECULATE=0 nothing ahead.
+  // (SOICP_SPECULATE=0 enqueues nothing ahead: every launch of a profiled run is then a real one.)
   int last = 0;
-  if (c->sync_per_outer) {
-    if ((rc = enqueue_outer_a(0)) || (rc = enqueue_outer_b(0))) return rc;
-    for (int it = 0;; ++it) {
-      if (c->speculate && it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
-      if (defer_reports && it + 1 < max_outer) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));  // behind the launch that reports it
-      if ((rc = await_outer(it))) return rc;
-      last = it;
-      if (c->h_ring[it & 1]->reg_done || it + 1 >= max_outer) break;
-      if (!c->speculate && (rc = enqueue_outer_a(it + 1))) return rc;  // SOICP_SPECULATE=0: no launch that could turn out a no-op
-      if ((rc = enqueue_outer_b(it + 1))) return rc;
-    }
-  } else {
-    for (int it = 0; it < max_outer; ++it)
-      if ((rc = enqueue_outer_a(it)) || (rc = enqueue_outer_b(it))) return rc;
-    // all iterations were enqueued: the one that converges publishes last (later ones are no-ops), so wait for the stream
-    HIP_TRY(c, hipStreamSynchronize(s));
-    last = 0;
-    if (direct_rb) {
-      for (int it = 0; it < max_outer; ++it)
-        if (c->h_ring[it & 1]->seq == (seq_base | (unsigned long long)(it + 1))) last = it;
-    } else {
-      last = max_outer - 1;
-    }
+  if ((rc = enqueue_outer_a(0)) || (rc = enqueue_outer_b(0))) return rc;
+  for (int it = 0;; ++it) {
+    if (c->speculate && it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
+    if (defer_reports && it + 1 < max_outer) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));  // behind the launch that reports it
+    if ((rc = await_outer(it))) return rc;
+    last = it;
+    if (c->h_ring[it & 1]->reg_done || it + 1 >= max_outer) break;
+    if (!c->speculate && (rc = enqueue_outer_a(it + 1))) return rc;  // SOICP_SPECULATE=0: no launch that could turn out a no-op
+    if ((rc = enqueue_outer_b(it + 1))) return rc;
   }
   c->h_state = c->h_ring[last & 1];
   const DevState& H = *c->h_state;
@@ -978,8 +959,7 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
   ep.n_queries = (uint32_t)n; ep.q_stride = 3;
   ep.timeout_ticks = 20000000ull;  // 200 ms: a pass of one hypothesis on a few workgroups lasts up to a millisecond
   const uint32_t v_grid = solve_grid((uint32_t)n, (uint32_t)c->n_cus);
-  static const int wg_per_cu_env = std::getenv("SOICP_BATCH_WG_PER_CU") ? std::atoi(std::getenv("SOICP_BATCH_WG_PER_CU")) : 0;
-  const uint32_t resident = solve_batch_resident_blocks((uint32_t)c->n_cus, c->batch_degrade >= 1 ? 1 : wg_per_cu_env);
+  const uint32_t resident = solve_batch_resident_blocks((uint32_t)c->n_cus, c->batch_degrade >= 1 ? 1 : 0);
   if (resident < (uint32_t)B) return fail(c, SO_ICP_E_HIP, "so_icp_register_batch: fewer resident solve workgroups than hypotheses");
   BatchView bv{b.active.as<uint32_t>(), b.begin.as<RegBeginArgs>(), b.bs, (uint32_t)((size_t)1 << lg),
                (uint32_t)((size_t)kFitBlocksMax * kRecordChunksMax * 2), (uint32_t)(kSyncBytes / 4), 1u, v_grid};
@@ -1163,13 +1143,13 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   c->h_state = c->h_ring[0];
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_hist), (size_t)SO_ICP_MAX_OUTER * kHistReplicas * kHistStride * sizeof(int32_t))) != hipSuccess)
     return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
-  if (const char* ev = std::getenv("SOICP_SYNC_PER_OUTER")) c->sync_per_outer = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_READBACK")) c->direct_readback = std::string(ev) != "copy";
   if (const char* ev = std::getenv("SOICP_SPECULATE")) c->speculate = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_ABLATE")) c->ablate = std::atoi(ev);
-  if (const char* ev = std::getenv("SOICP_NO_DEFER")) c->no_defer = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_BATCH_WG_PER_CU")) { if (std::atoi(ev) == 1) c->batch_degrade = 1; }  // (several processes on one device)
+  if (const char* ev = std::getenv("SOICP_BATCH_MODE")) { if (std::string(ev) == "lanes") c->batch_degrade = 2; }
   const bool want_dmap = !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
   if (want_dmap) {  // world_size > 1: this rank's shard of the map, resident and updated on the device like the whole map is
     c->dmap = std::make_unique<DeviceMap>(c->stream, cfg->rank, cfg->world_size);
@@ -1384,8 +1364,7 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
   std::memcpy(c->last_pos, pos, sizeof(pos));
   int rc = upload_map(c);
   if (rc) return rc;
-  static const bool lanes_mode = std::getenv("SOICP_BATCH_MODE") && std::string(std::getenv("SOICP_BATCH_MODE")) == "lanes";
-  if (!lanes_mode && n > 0 && c->batch_degrade < 2) {
+  if (n > 0 && c->batch_degrade < 2) {
     // batched kernels: groups of up to kBatchMaxConcurrent hypotheses advance together (kernels.hip, BatchView)
     const int count = map_count_5x5(c, pos);
     std::vector<int32_t> hrc((size_t)n_hyp, 0);
@@ -1412,8 +1391,7 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
   }
   // SOICP_BATCH_MODE=lanes, empty scans, and a device that cannot keep the batched solve resident: the hypotheses as concurrent
   // sequential registrations on worker contexts (own stream / buffers / state each, one launch per evaluation)
-  static const int want_lanes = std::getenv("SOICP_BATCH_LANES") ? std::atoi(std::getenv("SOICP_BATCH_LANES")) : 16;
-  const int lanes = std::max(1, std::min({want_lanes, n_hyp, 64}));
+  const int lanes = std::max(1, std::min(16, n_hyp));
   // worker contexts: own stream / buffers / device state, no map of their own (they borrow this context's resident map)
   while ((int)c->workers.size() < lanes - 1) {
     so_icp_config wc = c->cfg;

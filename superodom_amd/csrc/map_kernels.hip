@@ -905,24 +905,12 @@ __global__ __launch_bounds__(256) void vg_centroid_long_kernel(const uint32_t* _
   }
 }
 
-// Stable (key, index) sort of the working set.  rocPRIM's default switches from merge sort to Onesweep at 1 M items;
-// SOICP_MAP_SORT=onesweep lowers the switch to 200 k (experiment switch).
-using OnesweepEarly = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 200000>;
-static bool map_sort_onesweep() {
-  static const bool v = [] { const char* e = std::getenv("SOICP_MAP_SORT"); return e && std::strcmp(e, "onesweep") == 0; }();
-  return v;
-}
+// Stable (key, index) sort of the working set: merge sort with 2048-item block sorts and odd-even merges (measured against
+// rocPRIM's own choice, its Onesweep radix sort and two other merge configurations in rounds 1-2: the fastest at these sizes).
 static hipError_t map_sort(void* tmp, size_t& bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo, size_t n,
-                           unsigned end_bit, hipStream_t s) {
-  if (map_sort_onesweep()) return rocprim::radix_sort_pairs<OnesweepEarly>(tmp, bytes, ki, ko, vi, vo, n, 0, end_bit, s);
-  static const int cfg = std::getenv("SOICP_MAP_SORT_CFG") ? std::atoi(std::getenv("SOICP_MAP_SORT_CFG")) : 1;  // measured: 0.66 vs 0.71 ms per Localization()
-  using M1 = rocprim::merge_sort_config<512, 512, 4, 128, 128, 4, (1u << 30)>;   // 2048-item block sort, odd-even merges
-  using M2 = rocprim::merge_sort_config<512, 512, 4, 128, 128, 4, 0>;            // 2048-item block sort, merge-path merges
-  using M3 = rocprim::merge_sort_config<512, 256, 16, 128, 256, 8, 0>;           // 4096-item block sort, merge-path merges
-  if (cfg == 1) return rocprim::merge_sort<M1>(tmp, bytes, ki, ko, vi, vo, n, rocprim::less<uint32_t>(), s);
-  if (cfg == 2) return rocprim::merge_sort<M2>(tmp, bytes, ki, ko, vi, vo, n, rocprim::less<uint32_t>(), s);
-  if (cfg == 3) return rocprim::merge_sort<M3>(tmp, bytes, ki, ko, vi, vo, n, rocprim::less<uint32_t>(), s);
-  return rocprim::radix_sort_pairs(tmp, bytes, ki, ko, vi, vo, n, 0, end_bit, s);
+                           unsigned /*end_bit*/, hipStream_t s) {
+  using M1 = rocprim::merge_sort_config<512, 512, 4, 128, 128, 4, (1u << 30)>;
+  return rocprim::merge_sort<M1>(tmp, bytes, ki, ko, vi, vo, n, rocprim::less<uint32_t>(), s);
 }
 
 size_t map_sort_temp_bytes(size_t n) {

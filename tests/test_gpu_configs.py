@@ -156,6 +156,25 @@ def test_batched_hypotheses_equal_single_registrations_bit_for_bit(oracle, gpu_s
     assert ok1 == 1 and np.array_equal(out1[0], out[4])
 
 
+@pytest.mark.parametrize("env", [{"SOICP_BATCH_MODE": "lanes"}, {"SOICP_BATCH_WG_PER_CU": "1"}])
+def test_batch_fallback_paths_give_the_same_bits(oracle, gpu_slam_factory, monkeypatch, env):
+    """The degraded forms of so_icp_register_batch -- one solve workgroup per compute unit, and concurrent sequential
+    registrations on worker contexts (what a device that cannot keep the batched solve resident falls back to) -- return the
+    poses of the batched kernels bit for bit."""
+    sc, slam, _ = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
+    scan = sc.scan(6)
+    poses = np.stack([synth.perturb_pose(sc.gt_pose(6), 9000 + h, 0.05 + 0.4 * (h % 5) / 4.0, 0.5 + 4.0 * (h % 3) / 2.0) for h in range(19)])
+    ok, rcs, out, sts = slam.register_batch(scan, poses)
+    assert ok == 19
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)  # read by so_icp_create
+    _, alt, _ = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
+    ok2, rcs2, out2, sts2 = alt.register_batch(scan, poses)
+    assert ok2 == 19 and np.array_equal(out2, out)
+    for h in range(19):
+        _assert_same_bits(sts[h], sts2[h], (env, h))
+
+
 def test_staged_scan_is_the_same_registration(oracle, gpu_slam_factory, soicp):
     """so_icp_stage_scan + so_icp_register: the copy thread's upload feeds the same kernels -- bit-identical results, the
     stats say which path ran; a staged scan that is never consumed, a re-staged one and strided input are handled."""

@@ -152,9 +152,8 @@ def test_determinism_bitwise(gpu_slam_factory, oracle):
     assert np.array_equal(p1, p2), "fixed-order reductions: repeated registrations must agree bit for bit"
 
 
-@pytest.mark.parametrize("env", [{"SOICP_PERSISTENT": "0"}, {"SOICP_READBACK": "copy"}, {"SOICP_SYNC_PER_OUTER": "0"},
-                                 {"SOICP_SPECULATE": "0"}, {"SOICP_SPECULATE": "0", "SOICP_PERSISTENT": "0"}, {"SOICP_NO_DEFER": "1"},
-                                 {"SOICP_PERSISTENT": "0", "SOICP_READBACK": "copy", "SOICP_SYNC_PER_OUTER": "0"}])
+@pytest.mark.parametrize("env", [{"SOICP_PERSISTENT": "0"}, {"SOICP_READBACK": "copy"}, {"SOICP_SPECULATE": "0"},
+                                 {"SOICP_SPECULATE": "0", "SOICP_PERSISTENT": "0"}, {"SOICP_PERSISTENT": "0", "SOICP_READBACK": "copy"}])
 def test_control_flow_variants_are_bit_identical(oracle, gpu_slam_factory, monkeypatch, env):
     """The same kernels under every host-side schedule: persistent solve launch vs one launch per evaluation, state
     published by the device vs hipMemcpyAsync read-back, speculative per-iteration enqueue vs everything up front."""
