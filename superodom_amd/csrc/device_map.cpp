@@ -210,10 +210,13 @@ int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err)
   std::vector<int> occupied;
   for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) occupied.push_back((int)s);
   const float inv_leaf = 1.0f / finest_res_;  // the points' leaf keys are distinct on the finest grid they were filtered on
-  for (size_t r0 = 0; r0 < occupied.size(); r0 += kMaxTouched) {
+  const uint32_t lbits = leaf_bits(finest_res_);
+  const size_t per_round = max_touched(lbits);
+  for (size_t r0 = 0; r0 < occupied.size(); r0 += per_round) {
     MapInsertArgs a{};
     MapTouched& tt = a.tt;
-    tt.n = (int)std::min<size_t>(kMaxTouched, occupied.size() - r0);
+    tt.lbits = lbits;
+    tt.n = (int)std::min<size_t>(per_round, occupied.size() - r0);
     uint32_t n_old = 0;
     for (int t = 0; t < tt.n; ++t) {
       const int s = occupied[r0 + t], cube = slot_cube_[s];
@@ -304,11 +307,14 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
   if (ensure_pool((int)slot_cube_.size(), err)) return -2;
   const float inv_leaf = 1.0f / plane_res_;
   std::vector<int8_t> tid(kMapNum);
-  // 2. rounds of at most kMaxTouched cubes
-  for (size_t r0 = 0; r0 < touched.size(); r0 += kMaxTouched) {
+  // 2. rounds of at most kMaxTouched cubes (4 when the leaf coordinates need 10 key bits: planeRes < 0.1)
+  const uint32_t lbits = leaf_bits(plane_res_);
+  const size_t per_round = max_touched(lbits);
+  for (size_t r0 = 0; r0 < touched.size(); r0 += per_round) {
     MapInsertArgs a{};
     MapTouched& tt = a.tt;
-    tt.n = (int)std::min<size_t>(kMaxTouched, touched.size() - r0);
+    tt.lbits = lbits;
+    tt.n = (int)std::min<size_t>(per_round, touched.size() - r0);
     std::fill(tid.begin(), tid.end(), (int8_t)-1);
     uint32_t n_old = 0;
     for (int t = 0; t < tt.n; ++t) {

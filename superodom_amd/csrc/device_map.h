@@ -50,7 +50,10 @@ class DeviceMap {
   int add_surf_host(const float* xyz, size_t n, size_t stride_floats, std::string& err);
   size_t export_points(float* xyz, size_t cap, bool only_5x5, const int pos[3], std::string& err);
   bool view(DevMapView& v, std::string& err);  // refreshes the device cube_slot table when the bookkeeping changed
-  bool supported_resolution(float plane_res) const { return plane_res >= 0.0999f; }
+  // leaf keys hold 9 or 10 bits per axis (50 / planeRes + 4 leaves per cube axis must fit): planeRes >= 0.05
+  bool supported_resolution(float plane_res) const { return plane_res >= 0.0499f; }
+  static uint32_t leaf_bits(float leaf) { return (50.0f / leaf + 6.0f < 512.0f) ? 9u : 10u; }
+  static size_t max_touched(uint32_t lbits) { return lbits == 9u ? (size_t)kMaxTouched : (size_t)4; }
 
  private:
   int ensure_pool(int slots_needed, std::string& err);

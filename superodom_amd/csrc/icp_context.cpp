@@ -1169,7 +1169,7 @@ void so_icp_destroy(so_icp_ctx* ctx) {
 
 int so_icp_set_resolution(so_icp_ctx* c, float line_res, float plane_res) {
   if (!c || !(plane_res > 0) || !(line_res > 0)) return SO_ICP_E_INVALID;
-  if (c->dmap && !c->dmap->supported_resolution(plane_res)) return fail(c, SO_ICP_E_UNSUPPORTED, "device map needs plane_res >= 0.1");
+  if (c->dmap && !c->dmap->supported_resolution(plane_res)) return fail(c, SO_ICP_E_UNSUPPORTED, "device map needs plane_res >= 0.05 (leaf coordinates of the grouping keys hold 10 bits)");
   if (c->dmap) {
     NEED_DEVICE(c);
     HIP_TRY(c, hipSetDevice(c->cfg.device_id));

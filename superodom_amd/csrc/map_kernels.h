@@ -9,7 +9,7 @@
 
 namespace soicp {
 
-constexpr int kMaxTouched = 32;  // cubes handled by one insert round (5 key bits)
+constexpr int kMaxTouched = 32;  // cubes handled by one insert round (5 key bits above 3 x 9 leaf bits; 4 cubes with 10-bit leaves)
 
 // the cubes one insert round touches (passed by value to the kernels)
 struct MapTouched {
@@ -26,6 +26,7 @@ struct MapTouched {
   // all of it through the sort, as the reference does with every touched block.
   float inv_leaf_watch;
   uint32_t* dirty;
+  uint32_t lbits;  // bits per leaf coordinate in the keys (9: up to kMaxTouched cubes per round, 10: up to 4; map_kernels.hip leaf_key)
 };
 
 struct MapInsertArgs {

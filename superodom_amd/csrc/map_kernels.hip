@@ -78,9 +78,12 @@ __global__ __launch_bounds__(256) void transform_scan_kernel(const float* __rest
 
 // leaf coordinate = floor(v * inv_leaf) evaluated in FLOAT exactly like pcl::VoxelGrid; an arbitrary common offset per
 // cube keeps the lexicographic (z, y, x) order, which is all VoxelGrid's linear leaf index is used for.
-__device__ __forceinline__ uint32_t leaf_key(float x, float y, float z, float inv_leaf, int lo0, int lo1, int lo2, uint32_t tid) {
+// Key = touched-cube id above three leaf coordinates of `lbits` bits each: 9 bits (<= 508 leaves per axis of a 50 m cube, i.e.
+// planeRes >= 0.1, and 32 cubes per round) or 10 bits (planeRes down to 0.05, 4 cubes per round) -- MapTouched::lbits.
+__device__ __forceinline__ uint32_t leaf_key(float x, float y, float z, float inv_leaf, int lo0, int lo1, int lo2, uint32_t tid, uint32_t lbits) {
   const int l0 = (int)floorf(x * inv_leaf) - lo0, l1 = (int)floorf(y * inv_leaf) - lo1, l2 = (int)floorf(z * inv_leaf) - lo2;
-  return (tid << 27) | ((uint32_t)(l2 & 511) << 18) | ((uint32_t)(l1 & 511) << 9) | (uint32_t)(l0 & 511);
+  const uint32_t m = (1u << lbits) - 1u;
+  return (tid << (3u * lbits)) | (((uint32_t)l2 & m) << (2u * lbits)) | (((uint32_t)l1 & m) << lbits) | ((uint32_t)l0 & m);
 }
 
 __global__ __launch_bounds__(256) void gather_old_kernel(MapTouched tt, const float4* __restrict__ pool, uint32_t cap, float inv_leaf,
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void gather_old_kernel(MapTouched tt, const fl
   for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
   const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
   wpts[e] = p;
-  keys[e] = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t);
+  keys[e] = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
   vals[e] = e;
 }
 
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void append_new_kernel(const float* __restrict
   const int t = touched_id[cube];
   if (t < 0) { keys[e] = 0xFFFFFFFFu; return; }     // a cube handled by another round of this insert
   if (world > 1 && !shard_keeps_leaf(p[0], p[1], p[2], inv_leaf, tt, t, nc, inv_cell, rank, world)) { keys[e] = 0xFFFFFFFFu; return; }  // another rank's leaf
-  keys[e] = leaf_key(p[0], p[1], p[2], inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t);
+  keys[e] = leaf_key(p[0], p[1], p[2], inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
 }
 
 // sharded map: number of the cube's points whose OWN cell lies in a brick of this rank (every point of the full map is
@@ -180,7 +183,7 @@ __device__ __forceinline__ void emit_centroid(uint32_t o, uint32_t key, float s0
   const float cnt = (float)count;
   const float cx = s0 / cnt, cy = s1 / cnt, cz = s2 / cnt;
   cent[o] = make_float4(cx, cy, cz, 0.f);
-  const int t = (int)(key >> 27);
+  const int t = (int)(key >> (3u * tt.lbits));
   int g[3];
   const float c3[3] = {cx, cy, cz};
 #pragma unroll
@@ -191,7 +194,7 @@ __device__ __forceinline__ void emit_centroid(uint32_t o, uint32_t key, float s0
   keys2[o] = ((uint32_t)t << 18) | (uint32_t)((g[2] * nc + g[1]) * nc + g[0]);  // linear cell index, as in the cube's table
   if (vals2) vals2[o] = o;  // (only the sort-based second stage reads it)
   // (a lone point is its own centroid and lies in its leaf by construction; see MapTouched::dirty)
-  if (count > 1u && tt.dirty && leaf_key(cx, cy, cz, tt.inv_leaf_watch, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t) != key)
+  if (count > 1u && tt.dirty && leaf_key(cx, cy, cz, tt.inv_leaf_watch, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits) != key)
     atomicOr(tt.dirty, 1u << t);
 }
 
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) void leafhash_insert_new_kernel(const float* _
     const int cube = cube_of[i];
     const int t = cube < 0 ? -1 : (int)touched_id[cube];  // outside the 21x21x11 window (LocalMap.h:605) / a cube of another round: dropped
     if (t >= 0 && !(world > 1 && !shard_keeps_leaf(p[0], p[1], p[2], inv_leaf, tt, t, nc, inv_cell, rank, world)))
-      key = leaf_key(p[0], p[1], p[2], inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t);
+      key = leaf_key(p[0], p[1], p[2], inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
     keys[e] = key;
   }
   const bool kept = key != kLeafEmpty;
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void leafhash_match_old_kernel(const float4* _
 #pragma unroll
   for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
   const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
-  const uint32_t key = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t);
+  const uint32_t key = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
   wpts[e] = p; keys[e] = key;
   const uint32_t mask = (1u << ht.log2_size) - 1u;
   uint32_t h = leaf_hash(key, ht.log2_size), slot = kLeafEmpty;
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(256) void cell_place_kernel(const uint32_t* __restr
   const float4 v = cent[o];
   const uint32_t at = grid_scan[(size_t)t * ncell1 + (k & 0x3FFFFu)] + rank[o];  // global position over all touched cubes
   tmp[at] = v;
-  tmpk[at] = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t);  // (the ranking pass reads 4 bytes per comparison)
+  tmpk[at] = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t, tt.lbits);  // (the ranking pass reads 4 bytes per comparison)
 }
 // pass 2: final position inside the cell = number of the cell's centroids with a smaller leaf key (one centroid per leaf:
 // the keys are distinct), i.e. ascending leaf order -- what the stable sort by (cell, leaf) produced
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(256) void cell_rank_kernel(const uint32_t* __restri
   const size_t gi = (size_t)t * ncell1 + (k & 0x3FFFFu);
   const uint32_t beg = grid_scan[gi], cnt = grid[gi];
   const float4 v = cent[o];
-  const uint32_t kv = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t);
+  const uint32_t kv = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t, tt.lbits);
   const uint32_t mine = rank[o];
   uint32_t r = 0;
   for (uint32_t j = 0; j < cnt; ++j) {

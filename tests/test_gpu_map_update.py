@@ -50,6 +50,41 @@ def test_incremental_inserts_and_window_roll_match_oracle(oracle, gpu_slam_facto
     assert slam.map_size() == om.size() == 0
 
 
+def test_fine_resolution_stays_on_the_device(oracle, gpu_slam_factory, soicp):
+    """planeRes below 0.1 (10-bit leaf coordinates in the grouping keys, four cubes per insert round): the map lives on the device
+    like at any other resolution -- no SO_ICP_FLAG_HOST_MAP -- and repeated inserts over 3 x 3 cubes reproduce addSurfPointCloud
+    point for point; Seam B and a registration agree with the oracle (LocalMap.h:591-645 has no resolution cliff)."""
+    rng = np.random.default_rng(5)
+    res = 0.05
+    slam = gpu_slam_factory(plane_res=res, line_res=res / 2, max_surface_features=-1, max_iterations=4)
+    om = oracle.OracleMap(plane_res=res, line_res=res / 2)
+    for step in range(3):  # 9 cubes touched: three rounds of <= 4 cubes
+        pts = np.concatenate([noisy_planes_cloud(9000, rng, offset=(dx, dy, 0)) for dx in (-50, 0, 50) for dy in (-50, 0, 50)])
+        assert slam.add_surf_point_cloud(pts) == om.add_surf(pts)
+        assert slam.map_size() == om.size()
+        assert _same_points(slam.export_map(), om.export()), f"insert {step} at planeRes {res}"
+    sc = synth.Scene("tiny", plane_res=res, map_points=150_000)
+    s2 = gpu_slam_factory(plane_res=res, line_res=res / 2, max_surface_features=-1, max_iterations=4)
+    assert s2.add_surf_point_cloud(sc.map_points) == s2.map_size()
+    o2 = oracle.OracleMap(plane_res=res, line_res=res / 2)
+    o2.add_surf(s2.export_map(), raw=True)
+    rc, pose, st = s2.register(sc.scan(1), sc.guess(1))
+    orc, opose, ost, _ = o2.register(sc.scan(1), sc.guess(1), oracle.default_config(max_iterations=4))
+    assert rc == orc and not (st.flags & soicp.FLAG_HOST_MAP)
+    if rc == 0:
+        assert st.n_iterations == ost.n_iterations
+        for it in range(st.n_iterations):
+            assert list(st.iterations[it].reject_hist) == list(ost.iters[it].reject_hist)
+            assert list(st.iterations[it].obs_hist) == list(ost.iters[it].obs_hist)
+        assert np.allclose(pose, opose, atol=1e-8)
+    gt = sc.gt_pose(0)
+    q = (sc.scan(0) @ synth.quat_to_R(gt[3:]).T + gt[:3]).astype(np.float32)[::9]
+    found, nbr, d2, _ = s2.nearest_k_search_surf(q, 5)
+    of, on, od = o2.knn(q, 5)[:3]
+    f = found.astype(bool)
+    assert np.array_equal(found.astype(bool), np.asarray(of).astype(bool)) and np.array_equal(d2[f].view(np.uint32), np.asarray(od)[f].view(np.uint32))
+
+
 def test_many_touched_cubes_and_points_outside_window(oracle, gpu_slam_factory):
     rng = np.random.default_rng(2)
     slam = gpu_slam_factory(plane_res=0.2)
