@@ -334,12 +334,13 @@ def main():
     if ctr and ctr.get("valu_wave_insts_per_launch") and knn_ms > 0:
         clk = float(ctr.get("shader_clock_ghz", 2.07))
         insts = float(ctr["valu_wave_insts_per_launch"])
-        # Issue floor of the sweep = VALU wave-instructions x cycles each / 1024 SIMDs / clock.  gfx950's SIMDs are 32 lanes
-        # wide (MI355X_MICROARCH.md: v_fma_f32 on a wavefront = 2 cycles; packed fp32 and fp64 = 4): the kernel's mix is mostly
-        # 32-bit integer / fp32 with packed-fp32 distance arithmetic, so the floor lies between the two figures below.
-        t2 = insts * 2 / N_SIMD / (clk * 1e9)
-        valu = {"valu_wave_insts_per_launch": insts, "shader_clock_ghz": clk, "issue_bound_ms_at_2_cycles": t2 * 1e3, "issue_bound_ms_at_4_cycles": 2e3 * t2,
-                "valu_issue_frac_at_2_cycles": t2 / (knn_ms * 1e-3), "valu_issue_frac_at_4_cycles": 2 * t2 / (knn_ms * 1e-3),
+        # Issue floor of the sweep: the SQ counts the quad-cycles its VALUs were busy (SQ_ACTIVE_INST_VALU) -- 1.01 per VALU wave-
+        # instruction in this kernel, i.e. 4 cycles each -- so floor = busy quad-cycles x 4 / 1024 SIMDs / shader clock: the time the
+        # sweep would take if every SIMD issued VALU work back to back and all SIMDs carried the same load.
+        busy = float(ctr.get("active_inst_valu_x4") or insts)
+        t_busy = busy * 4 / N_SIMD / (clk * 1e9)
+        valu = {"valu_wave_insts_per_launch": insts, "valu_busy_quad_cycles_per_launch": busy, "salu_wave_insts_per_launch": ctr.get("salu_wave_insts_per_launch"),
+                "shader_clock_ghz": clk, "issue_bound_ms": t_busy * 1e3, "valu_issue_frac": t_busy / (knn_ms * 1e-3),
                 "kernels_hip_sha256": ctr.get("kernels_hip_sha256"), "source": ctr.get("source"), "solve_kernel": ctr.get("solve_kernel")}
     ms_per_step = 1e3 * t_max / args.steps
     shard_info = None
