@@ -703,6 +703,20 @@ __device__ __forceinline__ int32_t approx_key(float m2qx, float m2qy, float m2qz
 
 __device__ __forceinline__ void publish_state_to(DevState* dst, const DevState* st, unsigned long long seq, int tid, int nthreads);  // below
 
+#ifndef SO_KNN_FILTER
+#define SO_KNN_FILTER 1  // stage only the candidates within the search radius of the group's bounding box (see knn_plane_kernel)
+#endif
+// wave-wide minimum of v over the DPP network (row_shr 1, 2, 4, 8 inside the rows of 16, row_bcast:15 / :31 across rows): no LDS,
+// the result is wave-uniform (read from lane 63).  Lanes that must not take part pass +inf.
+__device__ __forceinline__ float wave_min_f32(float v) {
+  const int inf = 0x7F800000;
+#define SO_DPP_MIN(ctrl, rows) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), ctrl, rows, 0xF, false)))
+  SO_DPP_MIN(0x111, 0xF); SO_DPP_MIN(0x112, 0xF); SO_DPP_MIN(0x114, 0xF); SO_DPP_MIN(0x118, 0xF);
+  SO_DPP_MIN(0x142, 0xA); SO_DPP_MIN(0x143, 0xC);
+#undef SO_DPP_MIN
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // PROF : the profiling / test-hook instantiation (per-wavefront stamps, SOICP_ABLATE switches, kernel statistics); the
 //        production instantiation carries none of it (the sweep is instruction-issue bound).
 // BATCH: so_icp_register_batch -- blockIdx.y picks the hypothesis, see BatchView.
@@ -913,13 +927,68 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
     const float2v pqx = {m2qx, m2qx}, pqy = {m2qy, m2qy}, pqz = {m2qz, m2qz}, pqq = {qq, qq};
     Net8 net;
     net.init();
+    // Candidate FILTER: the block is whole cells, the lanes sit in one corner of it, so
+    // most of its points are farther from EVERY lane than the radius this pass can certify anyway (r_cover: half a cell in
+    // the near pass, the gate radius in the full pass).  A candidate is staged only if it lies within r_cover (+ margin) of
+    // the bounding box of the group's queries -- about half of the block's points on a surface map -- and the selection
+    // network runs over the kept ones only.  Exactness: a dropped point is farther than r_cover from every query of the
+    // group, so "every point that was not re-ranked has exact d2 >= R2" holds with R2 <= r_cover^2 (cov2 below).
+    bool filt = SO_KNN_FILTER != 0;
+    float bl0 = 0.f, bl1 = 0.f, bl2 = 0.f, bh0 = 0.f, bh1 = 0.f, bh2 = 0.f;
+    if (filt) {
+      const float pinf = __int_as_float(0x7F800000);
+      bl0 = wave_min_f32(mine ? lqx : pinf); bl1 = wave_min_f32(mine ? lqy : pinf); bl2 = wave_min_f32(mine ? lqz : pinf);
+      bh0 = -wave_min_f32(mine ? -lqx : pinf); bh1 = -wave_min_f32(mine ? -lqy : pinf); bh2 = -wave_min_f32(mine ? -lqz : pinf);
+    }
+    const float dk = r_cover + 2e-4f, dk2 = dk * dk;  // (block-local fp32 coordinates: errors ~1e-6 m, the margin covers them a hundredfold)
+    uint32_t total_eff = total;
+    if (filt) {
+      // the WHOLE enumeration is filtered into the one tile; a group whose kept candidates do not fit it (dense cells in the
+      // full pass) falls back to the unfiltered stream of pieces below
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      uint32_t w = 0;  // kept candidates so far (wave-uniform)
+      for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+        const uint32_t t = t0 + (uint32_t)lane;
+        bool kp = false;
+        float lx = 0.f, ly = 0.f, lz = 0.f, lc = 0.f;
+        uint32_t canon = 0xFFFFFFFFu;
+        if (t < total) {
+          int r = 0;
+#pragma unroll
+          for (int step = 16; step >= 1; step >>= 1) r = (r + step < 32 && rowoff[r + step] <= t) ? r + step : r;
+          canon = rowbeg[r] + (t - rowoff[r]);
+          const float4 p = mpts[canon];
+          lx = (float)((double)p.x - ox); ly = (float)((double)p.y - oy); lz = (float)((double)p.z - oz);
+          lc = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+          const float ex = fmaxf(fmaxf(bl0 - lx, lx - bh0), 0.f), ey = fmaxf(fmaxf(bl1 - ly, ly - bh1), 0.f), ez = fmaxf(fmaxf(bl2 - lz, lz - bh2), 0.f);
+          kp = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) <= dk2;
+        }
+        const unsigned long long m = __ballot(kp);
+        const uint32_t nk = (uint32_t)__popcll(m);
+        if (w + nk > kTileCand) { filt = false; break; }
+        if (kp) {
+          const uint32_t pos = w + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          tx[pos] = lx; ty[pos] = ly; tz[pos] = lz; tc[pos] = lc; ti[pos] = canon;
+        }
+        w += nk;
+      }
+      if (filt) {
+        if (lane < 16) { tx[w + lane] = 0.f; ty[w + lane] = 0.f; tz[w + lane] = 0.f; tc[w + lane] = 3.0e38f; ti[w + lane] = 0xFFFFFFFFu; }  // padding entries lose
+        total_eff = w;
+      }
+    }
+    const uint32_t n_enum = filt ? total_eff : total;  // what the scan below walks: the kept candidates in the tile, or the raw enumeration
     // The group's candidate enumeration [0, total) is streamed through the LDS tile in pieces of kTileCand; the
     // selection network simply continues across pieces (keys carry the position in the whole enumeration).
-    for (uint32_t base = 0; base < total; base += kTileCand) {
-      const uint32_t cnt = (total - base < kTileCand) ? total - base : kTileCand;
+    for (uint32_t base = 0; base < n_enum; base += kTileCand) {
+      const uint32_t cnt = (n_enum - base < kTileCand) ? n_enum - base : kTileCand;
       // stage with coalesced 16-byte loads (position -> row by a 5-step binary search over the row offsets)
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      if (filt) {
+        // (the tile already holds the kept candidates)
+      } else
       if (!(abl & 16))
       for (uint32_t t = lane; t < cnt + 16; t += 64) {
         float lx = 0.f, ly = 0.f, lz = 0.f, lc = 3.0e38f;  // padding entries lose against every real candidate
@@ -987,11 +1056,11 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
     // group still has its candidates' indices in LDS; a streamed one goes back through the row table.
     const int32_t ks[8] = {net.a0, net.a1, net.a2, net.a3, net.a4, net.a5, net.a6, net.a7};
     uint32_t gi[8];
-    if (total <= kTileCand) {
+    if (filt || total <= kTileCand) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const uint32_t jl = (uint32_t)ks[t] & kKeyIdxMask;
-        gi[t] = (ks[t] == kKeyEmpty || jl >= total) ? 0xFFFFFFFFu : ti[jl < kTileCand ? jl : 0];
+        gi[t] = (ks[t] == kKeyEmpty || jl >= total_eff) ? 0xFFFFFFFFu : ti[jl < kTileCand ? jl : 0];
       }
     } else {
 #pragma unroll
@@ -1021,6 +1090,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
         cv = fmaxf(cv - 1e-4f, 0.f);  // cell membership of a map point is decided in fp64 on its own coordinates: keep a margin
         cov2 = cv * cv;
       }
+      if (filt) cov2 = fminf(cov2, r_cover * r_cover);  // (candidates beyond r_cover of every lane of the group were not staged)
     }
     if (stamp) { ts[1] = wall_clock64(); acc[3] += ts[1] - ts[3]; }
   }
