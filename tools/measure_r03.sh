@@ -15,7 +15,7 @@ print("kernels", {k: round(v, 4) for k, v in d["kernels"].items() if isinstance(
 print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline_oracle_b"].get("value"), d["cpu_baseline_all_cores"].get("value"), d["parity_vs_oracle_m_rad"], d["parity_iteration_counts_and_histograms_equal"])
 PY
 bash tools/prof_stats.sh $TAG 2>&1 | tail -24 | tee $O/prof_stats.txt
-cp gpurun_out/prof_$TAG/*.csv gpurun_out/prof_$TAG/*.json $O/ 2>/dev/null
+cp gpurun_out/prof_$TAG/*.csv $O/ 2>/dev/null; cp gpurun_out/prof_$TAG/bench_line.json $O/bench_line_under_rocprofv3.json; cp gpurun_out/prof_$TAG/bench_line_no_speculation.json $O/bench_line_under_rocprofv3_no_speculation.json
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_batch_$TAG && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_batch_$TAG -- python $R/tools/batch_rate.py --scans 3 > /tmp/prof_batch_$TAG.log 2>&1
   f=$(find /tmp/prof_batch_$TAG -name "*kernel_stats.csv" | head -1); cp $f $R/$O/batch_kernel_stats.csv; grep "batch mode" /tmp/prof_batch_$TAG.log ) | tee $O/batch_under_rocprofv3.txt
 python tools/batch_rate.py 2>&1 | grep "batch mode" | tee $O/batch_rate.txt
