@@ -347,11 +347,8 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     a.wpts = d_wpts_; a.cent = d_cent_; a.spts = d_spts_; a.heads = d_heads_;
     a.keys0 = d_k0_; a.keys1 = d_k1_; a.vals0 = d_v0_; a.vals1 = d_v1_; a.flags = d_flags_; a.pos = d_pos_;
     a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
-    static const bool use_grid = !(std::getenv("SOICP_MAP_STAGE2") && std::string(std::getenv("SOICP_MAP_STAGE2")) == "sort");
-    if (use_grid) {
-      if (ensure_grid((size_t)tt.n * ncell1_ + 1024, err)) return -2;
-      a.grid = d_grid_; a.grid_scan = d_grid_scan_;
-    }
+    if (ensure_grid((size_t)tt.n * ncell1_ + 1024, err)) return -2;
+    a.grid = d_grid_; a.grid_scan = d_grid_scan_;
     a.temp = d_temp_; a.temp_bytes = temp_bytes_;
     // first stage: leaf grouping through a hash table (default) or the stable radix sort of the whole working set
     // (the hash grouping lets an old point that shares its leaf with no NEW point pass through: valid when the cube holds one
@@ -359,7 +356,7 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     //  insert that touches a cube re-filters all of it, LocalMap.h:617-641 -- through the sort)
     bool one_point_per_leaf = true;
     for (int t = 0; t < tt.n; ++t) one_point_per_leaf = one_point_per_leaf && (slot_count_[tt.slot[t]] == 0 || slot_res_[tt.slot[t]] == plane_res_);
-    if (hash_grouping_ && use_grid && one_point_per_leaf) {
+    if (hash_grouping_ && one_point_per_leaf) {
       if (ensure_leaf_table(n, err)) return -2;
       a.ht_key = d_ht_key_; a.ht_cnt = d_ht_cnt_; a.ht_off = d_ht_off_;
       a.ht_log2 = 12;  // this round's share of the (all-empty) table: the kernels hash into / scan the first 2^ht_log2 slots only

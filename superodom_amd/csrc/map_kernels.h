@@ -49,7 +49,7 @@ struct MapInsertArgs {
   // own cell it owns (d_owned: summed over the ranks = the cube's full point count, LocalMap.h:292-318)
   int32_t rank, world;
   uint32_t* d_owned;                       // [kMaxTouched], zeroed by the caller; nullptr when world == 1
-  uint32_t *grid, *grid_scan;              // [tt.n * ncell1] each, or nullptr: second stage by sort + binary-search table
+  uint32_t *grid, *grid_scan;              // [tt.n * ncell1] each: per-cube cell grids of the second stage
   void* temp; size_t temp_bytes;
 };
 

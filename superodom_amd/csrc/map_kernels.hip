@@ -660,48 +660,6 @@ __global__ __launch_bounds__(kGiantThreads) void leafhash_giant_kernel(const uin
   }
 }
 
-__global__ __launch_bounds__(256) void pad_keys_kernel(uint32_t* __restrict__ keys2, uint32_t* __restrict__ vals2,
-                                                       const uint32_t* __restrict__ n_cent, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || i < *n_cent) return;
-  keys2[i] = 0xFFFFFFFFu; vals2[i] = i;
-}
-
-__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t key) {
-  uint32_t lo = 0, hi = n;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (a[mid] < key) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-
-__global__ __launch_bounds__(256) void scatter_kernel(const uint32_t* __restrict__ keys2s, const uint32_t* __restrict__ vals2s,
-                                                      const uint32_t* __restrict__ n_cent, const float4* __restrict__ cent,
-                                                      MapTouched tt, uint32_t cap, float4* __restrict__ pool,
-                                                      uint32_t* __restrict__ counts /*[32]*/) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t m = *n_cent;
-  if (i >= m) return;
-  const uint32_t t = keys2s[i] >> 18;
-  const uint32_t beg = lower_bound_u32(keys2s, m, t << 18);
-  const uint32_t local = i - beg;
-  if (local < cap) pool[(size_t)tt.slot[t] * cap + local] = cent[vals2s[i]];
-  if (i + 1 == m || (keys2s[i + 1] >> 18) != t) counts[t] = local + 1;  // last point of this cube
-}
-
-// cell_start[slot][c] = canonical index of the first point whose cell >= c (c = nc^3: one past the cube's last point)
-__global__ __launch_bounds__(256) void table_kernel(const uint32_t* __restrict__ keys2s, const uint32_t* __restrict__ n_cent,
-                                                    MapTouched tt, uint32_t cap, uint32_t ncell1, uint32_t* __restrict__ cell_start) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t t = blockIdx.y;
-  if (c >= ncell1) return;
-  const uint32_t m = *n_cent;
-  const uint32_t beg = lower_bound_u32(keys2s, m, t << 18);
-  const uint32_t at = (c == ncell1 - 1) ? lower_bound_u32(keys2s, m, (t + 1) << 18) : lower_bound_u32(keys2s, m, (t << 18) | c);
-  cell_start[(size_t)tt.slot[t] * ncell1 + c] = tt.slot[t] * cap + (at - beg);
-}
-
 __global__ __launch_bounds__(256) void gather_export_kernel(const float4* __restrict__ pool, uint32_t cap, uint32_t slot, uint32_t count,
                                                             float* __restrict__ out_xyz) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -985,7 +943,7 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(leaf_centroid_long_kernel, dim3(kMaxLongLeaves / 4), dim3(256), 0, s, a.keys1, a.heads, a.spts, a.tt, a.nc, a.inv_cell,
                        a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
   }
-  if (a.grid) {  // second stage by counting into the cell grids (no sort)
+  {  // second stage by counting into the cell grids (no sort)
     const size_t gn = (size_t)a.tt.n * a.ncell1;
     const uint32_t* halt = a.d_n_cent + 5;  // raised by leafhash_giant_kernel: the round is repeated with the sort-based first stage
     (void)hipMemsetAsync(a.grid, 0, gn * sizeof(uint32_t), s);
@@ -1003,14 +961,6 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
                          a.rank, a.world, a.d_owned);
     return;
   }
-  hipLaunchKernelGGL(pad_keys_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals0, a.d_n_cent, total);
-  tb = a.temp_bytes;
-  (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable: leaf order inside a cell
-  hipLaunchKernelGGL(scatter_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.d_n_cent, a.cent, a.tt, a.cap, a.pool, a.d_counts);
-  hipLaunchKernelGGL(table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.keys1, a.d_n_cent, a.tt, a.cap, a.ncell1, a.cell_start);
-  if (a.world > 1 && a.d_owned)
-    hipLaunchKernelGGL(count_owned_kernel, dim3((total + 255) / 256, a.tt.n), dim3(256), 0, s, a.pool, a.cap, a.tt, a.d_counts, a.nc, a.inv_cell, a.rank,
-                       a.world, a.d_owned);
 }
 // Resolution change (localMap.planeRes_ is pushed every frame, laserMapping.cpp:648-649): the points of a cube stay as they
 // are -- the reference re-filters a block only when the next insert touches it (LocalMap.h:617-641) -- only the cell
