@@ -205,11 +205,14 @@ int so_icp_stage_scan(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t s
 int so_icp_register_dev(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n,
                         const double pose_in[7], double pose_out[7], so_icp_stats *stats);
 /* Batched hypotheses (BASELINE.json configs[4], the "degeneracy / alignment-risk" use): the SAME scan registered from
- * n_hyp initial poses (poses_in = n_hyp x 7).  Every hypothesis is an independent so_icp_register (own sort, own
+ * n_hyp initial poses (poses_in = n_hyp x 7).  Every hypothesis is an independent so_icp_register (own binning, own
  * correspondences, own LM solves); the map window is shifted once, for hypothesis 0 (LS.cpp:363), and the context's
- * scan-to-scan state (previous observability histogram, startup counter) is left as it was.  Up to 16 hypotheses
- * (SOICP_BATCH_LANES, at most 64) run concurrently: worker contexts with their own stream and buffers borrow this context's
- * resident map; results are bit-identical to one so_icp_register per hypothesis.  d_scan_xyz != NULL
+ * scan-to-scan state (previous observability histogram, startup counter) is left as it was.  Groups of up to 64
+ * hypotheses go through batched kernels -- one binning / k-NN / persistent-solve launch per outer iteration over all
+ * hypotheses still running, a group of workgroups and an LM controller per hypothesis -- whose sums follow the summation
+ * tree of the single registration: results are bit-identical to one so_icp_register per hypothesis.  A device that cannot
+ * keep the batched solve resident falls back by itself (one workgroup per compute unit, then concurrent sequential
+ * registrations on worker contexts that borrow this context's resident map); same bits.  d_scan_xyz != NULL
  * takes a scan already resident in HBM (so_icp_upload_scan), else scan_xyz is uploaded once.  Returns the number of
  * hypotheses that returned SO_ICP_OK (>= 0), or a negative error; rc_out[h] (nullable) = status of hypothesis h. */
 int so_icp_register_batch(so_icp_ctx *ctx, const float *scan_xyz, const void *d_scan_xyz, size_t n, size_t stride_bytes,

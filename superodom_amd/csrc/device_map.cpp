@@ -374,7 +374,6 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
       if (world_ > 1) DM_TRY(hipMemsetAsync(d_small_ + 64, 0, kMaxTouched * sizeof(uint32_t), stream_));
       launch_map_insert(a, stream_);
       DM_TRY(hipGetLastError());
-    DM_TRY(hipGetLastError());  // a refused launch must not pass for an insert
       DM_TRY(hipMemcpyAsync(h_small_, d_small_, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
       DM_TRY(hipStreamSynchronize(stream_));
     }

@@ -156,6 +156,44 @@ def test_batched_hypotheses_equal_single_registrations_bit_for_bit(oracle, gpu_s
     assert ok1 == 1 and np.array_equal(out1[0], out[4])
 
 
+def test_batch_with_hypotheses_that_fail_and_degenerate_inputs(oracle, gpu_slam_factory, soicp):
+    """Hypotheses that leave the rounds for other reasons than convergence: a guess lifted 8 m above the scene (same map
+    window, a fraction of the matches, no convergence to the truth), a guess turned by 90 degrees (matches, but few),
+    duplicates of one guess, next to ordinary ones -- each must carry the status, the pose and the statistics of its single
+    registration.  Then an EMPTY map (every hypothesis SO_ICP_NOT_ENOUGH_MAP_FEATURES, pose = guess, LS.cpp:113-116), a
+    batch of zero hypotheses and an empty scan."""
+    sc, slam, _ = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
+    i = 4
+    scan = sc.scan(i)
+    gt = sc.gt_pose(i)
+    far = gt.copy(); far[2] += 8.0
+    turned = gt.copy()
+    turned[3:] = synth.quat_mul(gt[3:], synth.quat_from_rotvec(np.array([0.0, 0.0, np.pi / 2])))
+    near = [synth.perturb_pose(gt, 8100 + h, 0.1, 1.0) for h in range(3)]
+    poses = np.stack([near[0], far, near[1], turned, near[0], far, near[2]])
+    d, n = slam.upload_scan(scan)
+    ok, rcs, out, sts = slam.register_batch(None, poses, d_scan=d, n=n)
+    singles = [slam.register_dev(d, n, p) for p in poses]
+    assert [int(r) for r in rcs] == [r[0] for r in singles]
+    assert sts[1].iterations[0].num_surf_from_scan < sts[0].iterations[0].num_surf_from_scan / 2, "far fewer matches from 8 m above"
+    assert ok == sum(1 for r in singles if r[0] == 0) >= 4
+    for h, (rc, ph, sh) in enumerate(singles):
+        assert np.array_equal(out[h], ph), h
+        _assert_same_bits(sts[h], sh, ("mixed batch", h))
+    assert np.array_equal(out[0], out[4])
+    # empty map
+    empty = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5)
+    ok, rcs, out, _ = empty.register_batch(scan, poses)
+    assert ok == 0 and (rcs == soicp.NOT_ENOUGH_MAP_FEATURES).all() and np.array_equal(out, poses)
+    empty.close()
+    # no hypotheses / no points
+    ok, rcs, out, _ = slam.register_batch(None, np.zeros((0, 7)), d_scan=d, n=n)
+    assert ok == 0 and len(rcs) == 0
+    none = np.zeros((0, 3), np.float32)
+    ok, rcs, out, _ = slam.register_batch(none, poses[:3])
+    assert [int(r) for r in rcs] == [slam.register(none, p)[0] for p in poses[:3]] and ok == int((rcs == 0).sum())
+
+
 @pytest.mark.parametrize("env", [{"SOICP_BATCH_MODE": "lanes"}, {"SOICP_BATCH_WG_PER_CU": "1"}])
 def test_batch_fallback_paths_give_the_same_bits(oracle, gpu_slam_factory, monkeypatch, env):
     """The degraded forms of so_icp_register_batch -- one solve workgroup per compute unit, and concurrent sequential
