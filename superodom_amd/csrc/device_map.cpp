@@ -3,6 +3,7 @@
 #include "device_map.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -22,11 +23,10 @@ static inline int cidx(int i, int j, int k) { return i + kMapW * j + kMapW * kMa
 
 DeviceMap::~DeviceMap() {
   for (void* p : {(void*)d_pool_, (void*)d_cell_start_, (void*)d_cube_slot_, (void*)d_wpts_, (void*)d_cent_, (void*)d_k0_, (void*)d_k1_,
-                  (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, (void*)d_spts_, (void*)d_heads_, (void*)d_grid_, (void*)d_grid_scan_, d_temp_, (void*)d_cube_of_, (void*)d_touched_,
-                  (void*)d_touched_id_, (void*)d_small_, (void*)d_stage_, (void*)d_ht_key_, (void*)d_ht_cnt_, (void*)d_ht_off_})
+                  (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, (void*)d_spts_, (void*)d_heads_, (void*)d_grid_, (void*)d_grid_scan_, d_temp_, (void*)d_cube_of_,
+                  (void*)d_small_, (void*)d_stage_, (void*)d_ht_key_, (void*)d_ht_cnt_, (void*)d_ht_off_})
     if (p) (void)hipFree(p);
-  if (h_touched_) (void)hipHostFree(h_touched_);
-  if (h_small_) (void)hipHostFree(h_small_);
+  if (h_small_) (void)hipHostFree(h_small_);  // (the touched flags live in the same blocks)
 }
 
 void DeviceMap::clear() {
@@ -148,12 +148,14 @@ int DeviceMap::ensure_leaf_table(size_t n_new, std::string& err) {
 }
 
 int DeviceMap::ensure_work(size_t total, std::string& err) {
-  if (!d_touched_) {
-    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_touched_), kMapNum));
-    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_touched_id_), kMapNum));
-    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_small_), 128 * sizeof(uint32_t)));
-    DM_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_touched_), kMapNum));
-    DM_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small_), 128 * sizeof(uint32_t)));
+  // the counters and the touched-cube flags share one block on either side: one fill, one copy back per insert
+  if (!h_small_) {
+    DM_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_small_), kSmallWords * sizeof(uint32_t) + kMapNum));
+    h_touched_ = reinterpret_cast<uint8_t*>(h_small_ + kSmallWords);
+  }
+  if (!d_small_) {
+    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_small_), kSmallWords * sizeof(uint32_t) + kMapNum));
+    d_touched_ = reinterpret_cast<uint8_t*>(d_small_ + kSmallWords);
   }
   if (total <= work_cap_) return 0;
   const size_t cap = total + total / 4 + 1024;
@@ -234,6 +236,7 @@ int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err)
     for (int t = tt.n; t < kMaxTouched; ++t) tt.slot[t] = 0;
     if (ensure_work(n_old, err)) return -2;
     if (ensure_grid((size_t)tt.n * ncell1_ + 1024, err)) return -2;
+    block_clean_ = false;
     DM_TRY(hipMemsetAsync(d_small_, 0, 48 * sizeof(uint32_t), stream_));
     a.n_old = n_old; a.inv_leaf = inv_leaf;
     a.nc = nc_; a.ncell1 = ncell1_; a.inv_cell = 1.0 / cell_;
@@ -243,6 +246,11 @@ int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err)
     a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
     a.grid = d_grid_; a.grid_scan = d_grid_scan_;
     a.temp = d_temp_; a.temp_bytes = temp_bytes_;
+    {
+      const size_t need = (size_t)tt.n * ncell1_ + 1;
+      a.grid_is_clean = need <= grid_zero_upto_;
+      grid_zero_upto_ = std::max(grid_zero_upto_, need);
+    }
     launch_map_retable(a, stream_);
     DM_TRY(hipGetLastError());
     DM_TRY(hipStreamSynchronize(stream_));  // `a` travels by value, but the next round reuses the work buffers
@@ -254,7 +262,7 @@ int DeviceMap::ensure_grid(size_t gn, std::string& err) {
   if (gn > grid_cap_) {
     if (d_grid_) (void)hipFree(d_grid_);
     if (d_grid_scan_) (void)hipFree(d_grid_scan_);
-    d_grid_ = d_grid_scan_ = nullptr; grid_cap_ = 0;
+    d_grid_ = d_grid_scan_ = nullptr; grid_cap_ = 0; grid_zero_upto_ = 0;
     DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_grid_), gn * sizeof(uint32_t)));
     DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_grid_scan_), gn * sizeof(uint32_t)));
     grid_cap_ = gn;
@@ -293,34 +301,26 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     new_cap_ = n + 1024;
   }
   // 1. cube of every new point + touched flags (one small read-back)
-  DM_TRY(hipMemsetAsync(d_touched_, 0, kMapNum, stream_));
-  DM_TRY(hipMemsetAsync(d_small_ + 48, 0, sizeof(uint32_t), stream_));
+  // (ONE fill clears the counters of the first round below, the per-rank counts and the flags -- enqueued behind the
+  //  PREVIOUS insert, when the host has nothing else to do, see the end of this function)
+  if (!block_clean_) DM_TRY(hipMemsetAsync(d_small_, 0, kSmallWords * sizeof(uint32_t) + kMapNum, stream_));
+  block_clean_ = false;
   launch_world_cube(d_xyz, (uint32_t)n, (uint32_t)stride_floats, origin_, d_cube_of_, d_touched_, d_small_ + 48, stream_);
-  DM_TRY(hipMemcpyAsync(h_touched_, d_touched_, kMapNum, hipMemcpyDeviceToHost, stream_));
-  DM_TRY(hipMemcpyAsync(h_small_ + 48, d_small_ + 48, sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-  DM_TRY(hipStreamSynchronize(stream_));
-  const int inserted_total = (int)h_small_[48];  // points inside the 21x21x11 window (LocalMap.h:605)
-  std::vector<int> touched;
-  for (int cube = 0; cube < kMapNum; ++cube) if (h_touched_[cube]) touched.push_back(cube);
-  if (touched.empty()) return 0;
-  for (int cube : touched) if (cube_slot_[cube] < 0) alloc_slot(cube);
-  if (ensure_pool((int)slot_cube_.size(), err)) return -2;
+  DM_TRY(hipMemcpyAsync(h_small_ + 48, d_small_ + 48, (kSmallWords - 48) * sizeof(uint32_t) + kMapNum, hipMemcpyDeviceToHost, stream_));
   const float inv_leaf = 1.0f / plane_res_;
-  std::vector<int8_t> tid(kMapNum);
-  // 2. rounds of at most kMaxTouched cubes (4 when the leaf coordinates need 10 key bits: planeRes < 0.1)
   const uint32_t lbits = leaf_bits(plane_res_);
-  const size_t per_round = max_touched(lbits);
-  for (size_t r0 = 0; r0 < touched.size(); r0 += per_round) {
+  const size_t per_round = max_touched(lbits);  // at most kMaxTouched cubes (4 when the leaf coordinates need 10 key bits: planeRes < 0.1)
+  // 2. one round: the cubes `cubes[0..count)` are re-filtered with the new points that fall into them
+  auto run_round = [&](const int* cubes, int count, bool clear_counters) -> int {
     MapInsertArgs a{};
     MapTouched& tt = a.tt;
     tt.lbits = lbits;
-    tt.n = (int)std::min<size_t>(per_round, touched.size() - r0);
-    std::fill(tid.begin(), tid.end(), (int8_t)-1);
+    tt.n = count;
     uint32_t n_old = 0;
     for (int t = 0; t < tt.n; ++t) {
-      const int cube = touched[r0 + t];
+      const int cube = cubes[t];
       const int s = cube_slot_[cube];
-      tid[cube] = (int8_t)t;
+      tt.cube[t] = cube;  // (ascending: the lists below are built in block order)
       tt.slot[t] = (uint32_t)s;
       tt.old_prefix[t] = n_old;
       n_old += slot_count_[s];
@@ -333,15 +333,16 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
       }
     }
     for (int t = tt.n; t <= kMaxTouched; ++t) tt.old_prefix[t] = n_old;
-    for (int t = tt.n; t < kMaxTouched; ++t) tt.slot[t] = 0;
+    for (int t = tt.n; t < kMaxTouched; ++t) { tt.slot[t] = 0; tt.cube[t] = INT32_MAX; }
     if (ensure_work((size_t)n_old + n, err)) return -2;
-    tt.inv_leaf_watch = inv_leaf; tt.dirty = d_small_ + 7;  // (cleared with d_small_ below)
+    tt.inv_leaf_watch = inv_leaf; tt.dirty = d_small_ + 7;  // (cleared with the counters)
     a.rank = rank_; a.world = world_; a.d_owned = world_ > 1 ? d_small_ + 64 : nullptr;
-    if (world_ > 1) DM_TRY(hipMemsetAsync(d_small_ + 64, 0, kMaxTouched * sizeof(uint32_t), stream_));
-    DM_TRY(hipMemcpyAsync(d_touched_id_, tid.data(), kMapNum, hipMemcpyHostToDevice, stream_));
-    DM_TRY(hipMemsetAsync(d_small_, 0, 48 * sizeof(uint32_t), stream_));
+    if (clear_counters) {  // (the first round's counters were cleared together with the flags)
+      if (world_ > 1) DM_TRY(hipMemsetAsync(d_small_ + 64, 0, kMaxTouched * sizeof(uint32_t), stream_));
+      DM_TRY(hipMemsetAsync(d_small_, 0, 48 * sizeof(uint32_t), stream_));
+    }
     a.d_xyz = d_xyz; a.n_new = (uint32_t)n; a.stride_floats = (uint32_t)stride_floats; a.n_old = n_old;
-    a.d_cube_of = d_cube_of_; a.d_touched_id = d_touched_id_; a.inv_leaf = inv_leaf;
+    a.d_cube_of = d_cube_of_; a.inv_leaf = inv_leaf;
     a.nc = nc_; a.ncell1 = ncell1_; a.inv_cell = 1.0 / cell_;
     a.pool = d_pool_; a.cap = kCapPerSlot; a.cell_start = d_cell_start_;
     a.wpts = d_wpts_; a.cent = d_cent_; a.spts = d_spts_; a.heads = d_heads_;
@@ -349,13 +350,24 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
     if (ensure_grid((size_t)tt.n * ncell1_ + 1024, err)) return -2;
     a.grid = d_grid_; a.grid_scan = d_grid_scan_;
+    {  // the round leaves the counters it used at zero again (cell_table_kernel): fill only what no round has cleared yet
+      const size_t need = (size_t)tt.n * ncell1_ + 1;
+      a.grid_is_clean = need <= grid_zero_upto_;
+      grid_zero_upto_ = std::max(grid_zero_upto_, need);
+    }
     a.temp = d_temp_; a.temp_bytes = temp_bytes_;
     // first stage: leaf grouping through a hash table (default) or the stable radix sort of the whole working set
     // (the hash grouping lets an old point that shares its leaf with no NEW point pass through: valid when the cube holds one
     //  point per leaf of the CURRENT grid, i.e. it was last filtered at this planeRes; after a resolution change the first
     //  insert that touches a cube re-filters all of it, LocalMap.h:617-641 -- through the sort)
     bool one_point_per_leaf = true;
-    for (int t = 0; t < tt.n; ++t) one_point_per_leaf = one_point_per_leaf && (slot_count_[tt.slot[t]] == 0 || slot_res_[tt.slot[t]] == plane_res_);
+    for (int t = 0; t < tt.n; ++t) {
+      const uint32_t sl = tt.slot[t];
+      one_point_per_leaf = one_point_per_leaf && (slot_count_[sl] == 0 || slot_res_[sl] == plane_res_);
+      // a cube last filtered on another grid (or marked by the drift watch: negative) goes in in the order of THAT grid's leaves
+      a.old_inv_leaf[t] = (slot_count_[sl] > 0 && slot_res_[sl] != 0.f && slot_res_[sl] != plane_res_) ? 1.0f / std::fabs(slot_res_[sl]) : 0.f;
+      a.reorder_old = a.reorder_old || a.old_inv_leaf[t] > 0.f;
+    }
     if (hash_grouping_ && one_point_per_leaf) {
       if (ensure_leaf_table(n, err)) return -2;
       a.ht_key = d_ht_key_; a.ht_cnt = d_ht_cnt_; a.ht_off = d_ht_off_;
@@ -364,8 +376,8 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     }
     launch_map_insert(a, stream_);
     DM_TRY(hipGetLastError());  // a refused launch must not pass for an insert
-    DM_TRY(hipMemcpyAsync(h_small_, d_small_, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
-    DM_TRY(hipStreamSynchronize(stream_));  // also keeps `tid` / the staging buffer alive long enough
+    DM_TRY(hipMemcpyAsync(h_small_, d_small_, kSmallWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+    DM_TRY(hipStreamSynchronize(stream_));  // also keeps the staging buffer alive long enough
     if (a.ht_key && h_small_[5]) {
       // a leaf with more members than the grouping kernels sort in LDS: the second stage stood still (nothing of the map was
       // rewritten); the round is repeated with the sort-based first stage
@@ -374,7 +386,8 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
       if (world_ > 1) DM_TRY(hipMemsetAsync(d_small_ + 64, 0, kMaxTouched * sizeof(uint32_t), stream_));
       launch_map_insert(a, stream_);
       DM_TRY(hipGetLastError());
-      DM_TRY(hipMemcpyAsync(h_small_, d_small_, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+      DM_TRY(hipMemcpyAsync(h_small_, d_small_, 48 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+      if (world_ > 1) DM_TRY(hipMemcpyAsync(h_small_ + 64, d_small_ + 64, kMaxTouched * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
       DM_TRY(hipStreamSynchronize(stream_));
     }
     for (int t = 0; t < tt.n; ++t) {
@@ -383,10 +396,25 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
       slot_count_[tt.slot[t]] = cnt;
       // the whole cube has just been filtered at this leaf size -- unless one of its centroids drifted out of its leaf
       // (MapTouched::dirty): then two points may share a leaf and the next insert must not use the pass-through
-      slot_res_[tt.slot[t]] = ((h_small_[7] >> t) & 1u) ? 0.f : plane_res_;
+      slot_res_[tt.slot[t]] = ((h_small_[7] >> t) & 1u) ? -plane_res_ : plane_res_;
       if (world_ > 1) slot_owned_[tt.slot[t]] = h_small_[64 + t];
     }
+    return 0;
+  };
+  DM_TRY(hipStreamSynchronize(stream_));
+  const int inserted_total = (int)h_small_[48];  // points inside the 21x21x11 window (LocalMap.h:605)
+  std::vector<int> touched;
+  for (int cube = 0; cube < kMapNum; ++cube) if (h_touched_[cube]) touched.push_back(cube);
+  // the next insert's fill, now: the stream is idle and the host is about to return
+  auto clear_for_next = [&]() { if (hipMemsetAsync(d_small_, 0, kSmallWords * sizeof(uint32_t) + kMapNum, stream_) == hipSuccess) block_clean_ = true; else (void)hipGetLastError(); };
+  if (touched.empty()) { clear_for_next(); return 0; }
+  for (int cube : touched) if (cube_slot_[cube] < 0) alloc_slot(cube);
+  if (ensure_pool((int)slot_cube_.size(), err)) return -2;
+  for (size_t r0 = 0; r0 < touched.size(); r0 += per_round) {  // (block order: MapTouched::cube ascends)
+    const int rc = run_round(touched.data() + r0, (int)std::min<size_t>(per_round, touched.size() - r0), r0 > 0);
+    if (rc) return rc;
   }
+  clear_for_next();
   return inserted_total;
 }
 

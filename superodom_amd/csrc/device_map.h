@@ -69,7 +69,8 @@ class DeviceMap {
   std::vector<int32_t> cube_slot_;   // kMapNum: slot or -1
   std::vector<int32_t> slot_cube_;   // slot -> cube or -1 (free)
   std::vector<uint32_t> slot_count_;
-  std::vector<float> slot_res_;      // planeRes the slot's cube was last filtered with (0: empty)
+  std::vector<float> slot_res_;      // planeRes the slot's cube was last filtered with (0: empty; negative: filtered with -value, but a
+                                     // centroid drifted out of its leaf -- the pass-through grouping is off for the cube)
   bool slot_table_dirty_ = true;
   bool hash_grouping_ = true;
   // device
@@ -82,9 +83,12 @@ class DeviceMap {
   uint32_t *d_ht_key_ = nullptr, *d_ht_cnt_ = nullptr, *d_ht_off_ = nullptr; uint32_t ht_log2_ = 0;  // leaf hash table of the first stage (map_kernels.hip)
   int ensure_leaf_table(size_t n_new, std::string& err);
   void* d_temp_ = nullptr; size_t temp_bytes_ = 0;
-  int32_t* d_cube_of_ = nullptr; uint8_t* d_touched_ = nullptr; int8_t* d_touched_id_ = nullptr; uint32_t* d_small_ = nullptr;
+  int32_t* d_cube_of_ = nullptr; uint8_t* d_touched_ = nullptr; uint32_t* d_small_ = nullptr;
   float* d_stage_ = nullptr; size_t stage_cap_ = 0;  // host->device staging of new points / export
-  uint8_t* h_touched_ = nullptr; uint32_t* h_small_ = nullptr;  // pinned
+  uint8_t* h_touched_ = nullptr; uint32_t* h_small_ = nullptr;  // pinned; {counters[kSmallWords], touched flags[kMapNum]} in one block, like d_small_ / d_touched_
+  static constexpr size_t kSmallWords = 128;
+  size_t grid_zero_upto_ = 0;          // d_grid_[0 .. this) is all zero between inserts (a round cleans up after itself)
+  bool block_clean_ = false;           // d_small_ / d_touched_ were cleared behind the previous insert
 };
 
 }  // namespace soicp

@@ -14,6 +14,7 @@ constexpr int kMaxTouched = 32;  // cubes handled by one insert round (5 key bit
 // the cubes one insert round touches (passed by value to the kernels)
 struct MapTouched {
   int32_t n;
+  int32_t cube[kMaxTouched];             // block index of touched cube t, ASCENDING; unused entries INT32_MAX (touched_index)
   uint32_t slot[kMaxTouched];            // pool slot of touched cube t
   uint32_t old_prefix[kMaxTouched + 1];  // exclusive prefix of the cubes' current point counts
   int32_t leaf_lo[kMaxTouched][3];       // floor(cube_min * inv_leaf) - 1: common leaf offset of the cube
@@ -34,7 +35,6 @@ struct MapInsertArgs {
   const float* d_xyz;        // new world-frame points (device)
   uint32_t n_new, stride_floats, n_old;
   const int32_t* d_cube_of;  // per new point: cube index or -1
-  const int8_t* d_touched_id;  // cube -> t of THIS round, -1 otherwise
   float inv_leaf;
   int32_t nc; uint32_t ncell1; double inv_cell;
   float4* pool; uint32_t cap; uint32_t* cell_start;
@@ -49,7 +49,13 @@ struct MapInsertArgs {
   // own cell it owns (d_owned: summed over the ranks = the cube's full point count, LocalMap.h:292-318)
   int32_t rank, world;
   uint32_t* d_owned;                       // [kMaxTouched], zeroed by the caller; nullptr when world == 1
-  uint32_t *grid, *grid_scan;              // [tt.n * ncell1] each: per-cube cell grids of the second stage
+  uint32_t *grid, *grid_scan;              // [tt.n * ncell1 + 1] each: per-cube cell grids of the second stage (+ the total behind them)
+  // Sort path only: a cube that was last filtered on ANOTHER leaf grid (old_inv_leaf[t] = 1 / that planeRes, 0 = keep the pool
+  // order) enters the working set in the order the reference stores it -- ascending leaf index of that grid (the output order
+  // of its last VoxelGrid, LocalMap.h:621-627) -- because several of its points now share a leaf and are summed in that order.
+  float old_inv_leaf[kMaxTouched];
+  bool reorder_old;
+  bool grid_is_clean;                      // grid[0 .. tt.n * ncell1] is all zero (left so by the previous round): no fill needed
   void* temp; size_t temp_bytes;
 };
 

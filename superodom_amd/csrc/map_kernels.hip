@@ -100,6 +100,46 @@ __global__ __launch_bounds__(256) void gather_old_kernel(MapTouched tt, const fl
   vals[e] = e;
 }
 
+// Re-filtering a cube on a new leaf grid (first insert that touches it after a planeRes change): the reference's block
+// cloud is still in the output order of its LAST VoxelGrid -- ascending leaf index of the old grid -- and the new, coarser
+// leaves sum their several old points in that order.  The pool is in (cell, leaf) order, which is the same order only
+// inside one cell; a leaf that straddles two cells would add its points in another order (1 ulp in the centroid).  So:
+// key every old point by its leaf on the OLD grid of its cube (10 bits per axis, no cube id: the main sort groups by cube
+// and is stable), sort, and gather the working set's head in that order.
+struct OldGrids { float inv_leaf[kMaxTouched]; };
+__global__ __launch_bounds__(256) void old_order_key_kernel(MapTouched tt, OldGrids og, const float4* __restrict__ pool, uint32_t cap, uint32_t n_old,
+                                                            uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_old) return;
+  int t = 0;
+#pragma unroll
+  for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
+  const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
+  const float il = og.inv_leaf[t];
+  uint32_t k = 0u;  // (0: a cube whose points keep the pool order -- equal keys, stable sort)
+  if (il > 0.f) {
+    const int lo0 = (int)floorf((float)tt.cube_min[t][0] * il) - 2, lo1 = (int)floorf((float)tt.cube_min[t][1] * il) - 2,
+              lo2 = (int)floorf((float)tt.cube_min[t][2] * il) - 2;
+    k = leaf_key(p.x, p.y, p.z, il, lo0, lo1, lo2, 0u, 10u);
+  }
+  keys[e] = k;
+  vals[e] = e;
+}
+__global__ __launch_bounds__(256) void gather_old_ordered_kernel(MapTouched tt, const float4* __restrict__ pool, uint32_t cap, float inv_leaf,
+                                                                 uint32_t n_old, const uint32_t* __restrict__ order, float4* __restrict__ wpts,
+                                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_old) return;
+  const uint32_t e = order[i];
+  int t = 0;
+#pragma unroll
+  for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
+  const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
+  wpts[i] = p;
+  keys[i] = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
+  vals[i] = i;
+}
+
 // Sharded map: does rank `rank` keep the leaf that the point (x, y, z) of touched cube t falls into?  The decision is a
 // function of the LEAF (its float index per axis, exactly as pcl::VoxelGrid computes it), so all the points of a leaf share
 // it and every kept centroid is the centroid of the whole leaf -- bit-identical to the unsharded map.  A leaf is kept when
@@ -126,8 +166,17 @@ __device__ __forceinline__ bool shard_keeps_leaf(float x, float y, float z, floa
   return false;
 }
 
+// cube -> t of THIS round (binary search in the ascending list the launch carries), -1: a cube of another round
+__device__ __forceinline__ int touched_index(const MapTouched& tt, int cube) {
+  static_assert(kMaxTouched == 32, "five halving steps");
+  int t = 0;
+#pragma unroll
+  for (int step = 16; step >= 1; step >>= 1) t = tt.cube[t + step] <= cube ? t + step : t;
+  return tt.cube[t] == cube ? t : -1;
+}
+
 __global__ __launch_bounds__(256) void append_new_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats,
-                                                         const int32_t* __restrict__ cube_of, const int8_t* __restrict__ touched_id,
+                                                         const int32_t* __restrict__ cube_of,
                                                          MapTouched tt, float inv_leaf, uint32_t n_old, float4* __restrict__ wpts,
                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int nc, double inv_cell,
                                                          int rank, int world) {
@@ -139,7 +188,7 @@ __global__ __launch_bounds__(256) void append_new_kernel(const float* __restrict
   wpts[e] = make_float4(p[0], p[1], p[2], 0.f);
   vals[e] = e;
   if (cube < 0) { keys[e] = 0xFFFFFFFFu; return; }  // outside the 21x21x11 window: dropped (LocalMap.h:605)
-  const int t = touched_id[cube];
+  const int t = touched_index(tt, cube);
   if (t < 0) { keys[e] = 0xFFFFFFFFu; return; }     // a cube handled by another round of this insert
   if (world > 1 && !shard_keeps_leaf(p[0], p[1], p[2], inv_leaf, tt, t, nc, inv_cell, rank, world)) { keys[e] = 0xFFFFFFFFu; return; }  // another rank's leaf
   keys[e] = leaf_key(p[0], p[1], p[2], inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
@@ -306,7 +355,7 @@ __device__ __forceinline__ uint32_t leaf_hash(uint32_t key, uint32_t log2_size) 
 
 // (the new points' part of the working set -- append_new_kernel's job on the sort path -- is produced here as well: one launch less)
 __global__ __launch_bounds__(256) void leafhash_insert_new_kernel(const float* __restrict__ xyz, uint32_t n_new, uint32_t stride_floats,
-                                                                  const int32_t* __restrict__ cube_of, const int8_t* __restrict__ touched_id,
+                                                                  const int32_t* __restrict__ cube_of,
                                                                   MapTouched tt, float inv_leaf, int nc, double inv_cell, int rank, int world,
                                                                   float4* __restrict__ wpts, uint32_t* __restrict__ keys, uint32_t n_old, LeafTable ht,
                                                                   uint32_t* __restrict__ mslot, uint32_t* __restrict__ mrank) {
@@ -317,7 +366,7 @@ __global__ __launch_bounds__(256) void leafhash_insert_new_kernel(const float* _
     const float* p = xyz + (size_t)i * stride_floats;
     wpts[e] = make_float4(p[0], p[1], p[2], 0.f);
     const int cube = cube_of[i];
-    const int t = cube < 0 ? -1 : (int)touched_id[cube];  // outside the 21x21x11 window (LocalMap.h:605) / a cube of another round: dropped
+    const int t = cube < 0 ? -1 : touched_index(tt, cube);  // outside the 21x21x11 window (LocalMap.h:605) / a cube of another round: dropped
     if (t >= 0 && !(world > 1 && !shard_keeps_leaf(p[0], p[1], p[2], inv_leaf, tt, t, nc, inv_cell, rank, world)))
       key = leaf_key(p[0], p[1], p[2], inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
     keys[e] = key;
@@ -703,14 +752,17 @@ __global__ __launch_bounds__(256) void cell_count_kernel(const uint32_t* __restr
   base = (uint32_t)__shfl((int)base, lead, 64);
   if (kept) rank[o] = base + my_idx;
 }
-// grid_scan = exclusive scan of grid over all touched cubes; per cube: table entry = slot*cap + (scan - scan at the cube's
-// first cell); the entry behind the last cell = the cube's new point count
+// grid_scan = exclusive scan of grid over all touched cubes (one entry more than cells: the total); per cube: table entry =
+// slot*cap + (scan - scan at the cube's first cell); the entry behind the last cell = the cube's new point count.
+// The counters have done their work once they are scanned: this launch, one thread per cell, puts them back to zero, so
+// that the next insert finds the grids clean (a 12 MB fill per insert otherwise).
 __global__ __launch_bounds__(256) void cell_table_kernel(const uint32_t* __restrict__ grid_scan, MapTouched tt, uint32_t cap, uint32_t ncell1,
                                                          uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts,
-                                                         const uint32_t* __restrict__ halt) {
+                                                         const uint32_t* __restrict__ halt, uint32_t* __restrict__ grid) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t t = blockIdx.y;
-  if (c >= ncell1 || *halt) return;
+  if (c >= ncell1 || *halt) return;  // (halted before the counting: the grids are still clean)
+  grid[(size_t)t * ncell1 + c] = 0u;
   const uint32_t local = grid_scan[(size_t)t * ncell1 + c] - grid_scan[(size_t)t * ncell1];
   cell_start[(size_t)tt.slot[t] * ncell1 + c] = tt.slot[t] * cap + local;
   if (c == ncell1 - 1) counts[t] = local;
@@ -736,7 +788,7 @@ __global__ __launch_bounds__(256) void cell_place_kernel(const uint32_t* __restr
 //  points can share a leaf key: the order then falls back on the coordinates' bit patterns and, for bitwise equal points,
 //  on the placement rank, so that every point keeps a position of its own.)
 __global__ __launch_bounds__(256) void cell_rank_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ n_cent,
-                                                        const uint32_t* __restrict__ grid, const uint32_t* __restrict__ grid_scan,
+                                                        const uint32_t* __restrict__ grid_scan,
                                                         const float4* __restrict__ cent, const float4* __restrict__ tmp,
                                                         const uint32_t* __restrict__ tmpk, MapTouched tt,
                                                         uint32_t cap, uint32_t ncell1, float inv_leaf, float4* __restrict__ pool,
@@ -746,7 +798,7 @@ __global__ __launch_bounds__(256) void cell_rank_kernel(const uint32_t* __restri
   const uint32_t k = keys2[o], t = k >> 18;
   if (k == 0xFFFFFFFFu) return;
   const size_t gi = (size_t)t * ncell1 + (k & 0x3FFFFu);
-  const uint32_t beg = grid_scan[gi], cnt = grid[gi];
+  const uint32_t beg = grid_scan[gi], cnt = grid_scan[gi + 1] - beg;  // (the scan has one entry behind the last cell)
   const float4 v = cent[o];
   const uint32_t kv = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t, tt.lbits);
   const uint32_t mine = rank[o];
@@ -897,10 +949,18 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
   size_t tb = a.temp_bytes;
   const bool hashed = a.ht_key != nullptr && a.grid != nullptr;
   if (!hashed) {  // (the hash grouping's first two kernels build the working set themselves)
-    if (a.n_old)
+    if (a.n_old && a.reorder_old) {
+      OldGrids og;
+      for (int t = 0; t < kMaxTouched; ++t) og.inv_leaf[t] = a.old_inv_leaf[t];
+      hipLaunchKernelGGL(old_order_key_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.tt, og, a.pool, a.cap, a.n_old, a.keys0, a.vals0);
+      (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)a.n_old, 30, s);  // stable
+      tb = a.temp_bytes;
+      hipLaunchKernelGGL(gather_old_ordered_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, a.inv_leaf, a.n_old, a.vals1, a.wpts,
+                         a.keys0, a.vals0);
+    } else if (a.n_old)
       hipLaunchKernelGGL(gather_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0);
     if (a.n_new)
-      hipLaunchKernelGGL(append_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of, a.d_touched_id,
+      hipLaunchKernelGGL(append_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of,
                          a.tt, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0, a.nc, a.inv_cell, a.rank, a.world);
   }
   uint32_t* keys2 = a.keys0;  // cell key per centroid, input of the second stage
@@ -912,7 +972,7 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
     keys2 = a.vals0;
     if (a.n_new)
       hipLaunchKernelGGL(leafhash_insert_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of,
-                         a.d_touched_id, a.tt, a.inv_leaf, a.nc, a.inv_cell, a.rank, a.world, a.wpts, a.keys0, a.n_old, ht, a.keys1, a.vals1);
+                         a.tt, a.inv_leaf, a.nc, a.inv_cell, a.rank, a.world, a.wpts, a.keys0, a.n_old, ht, a.keys1, a.vals1);
     if (a.n_old)
       hipLaunchKernelGGL(leafhash_match_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.pool, a.cap, a.inv_leaf, a.keys0, a.n_old, a.wpts, ht,
                          a.keys1, a.vals1, a.tt, a.nc, a.inv_cell, a.cent, keys2);
@@ -946,15 +1006,15 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
   {  // second stage by counting into the cell grids (no sort)
     const size_t gn = (size_t)a.tt.n * a.ncell1;
     const uint32_t* halt = a.d_n_cent + 5;  // raised by leafhash_giant_kernel: the round is repeated with the sort-based first stage
-    (void)hipMemsetAsync(a.grid, 0, gn * sizeof(uint32_t), s);
+    if (!a.grid_is_clean) (void)hipMemsetAsync(a.grid, 0, (gn + 1) * sizeof(uint32_t), s);  // (else: cleaned by the previous round's cell_table_kernel)
     hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.ncell1, a.grid, a.vals1, halt);
     tb = a.temp_bytes;
-    (void)rocprim::exclusive_scan(a.temp, tb, a.grid, a.grid_scan, 0u, gn, rocprim::plus<uint32_t>(), s);
+    (void)rocprim::exclusive_scan(a.temp, tb, a.grid, a.grid_scan, 0u, gn + 1, rocprim::plus<uint32_t>(), s);
     hipLaunchKernelGGL(cell_table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.grid_scan, a.tt, a.cap, a.ncell1, a.cell_start,
-                       a.d_counts, halt);
+                       a.d_counts, halt, a.grid);
     hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.tt, a.ncell1,
                        a.inv_leaf, a.spts, a.flags, halt);  // spts / flags (first-stage scratch) are free after the centroids
-    hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.grid, a.grid_scan, a.cent, a.spts, a.flags, a.tt,
+    hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.grid_scan, a.cent, a.spts, a.flags, a.tt,
                        a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1, halt);
     if (a.world > 1 && a.d_owned)
       hipLaunchKernelGGL(count_owned_kernel, dim3((total + 255) / 256, a.tt.n), dim3(256), 0, s, a.pool, a.cap, a.tt, a.d_counts, a.nc, a.inv_cell,
@@ -993,15 +1053,15 @@ void launch_map_retable(const MapInsertArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(retable_gather_kernel, grid_for(total, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, total, a.nc, a.inv_cell, a.cent, a.keys0,
                      a.d_n_cent);
   const size_t gn = (size_t)a.tt.n * a.ncell1;
-  (void)hipMemsetAsync(a.grid, 0, gn * sizeof(uint32_t), s);
+  if (!a.grid_is_clean) (void)hipMemsetAsync(a.grid, 0, (gn + 1) * sizeof(uint32_t), s);
   hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.ncell1, a.grid, a.vals1, a.d_n_cent + 5);
   size_t tb = a.temp_bytes;
-  (void)rocprim::exclusive_scan(a.temp, tb, a.grid, a.grid_scan, 0u, gn, rocprim::plus<uint32_t>(), s);
+  (void)rocprim::exclusive_scan(a.temp, tb, a.grid, a.grid_scan, 0u, gn + 1, rocprim::plus<uint32_t>(), s);
   hipLaunchKernelGGL(cell_table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.grid_scan, a.tt, a.cap, a.ncell1, a.cell_start,
-                     a.d_counts, a.d_n_cent + 5);
+                     a.d_counts, a.d_n_cent + 5, a.grid);
   hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.tt, a.ncell1,
                      a.inv_leaf, a.spts, a.flags, a.d_n_cent + 5);
-  hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid, a.grid_scan, a.cent, a.spts, a.flags, a.tt,
+  hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid_scan, a.cent, a.spts, a.flags, a.tt,
                      a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1, a.d_n_cent + 5);
 }
 void launch_vg_stats(const float* d_xyz, uint32_t n, uint32_t stride_floats, double* d_part, int blocks, hipStream_t s) {

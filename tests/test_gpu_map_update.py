@@ -230,3 +230,34 @@ def test_centroids_that_drift_out_of_their_leaf_are_refiltered_like_pcl_does(ora
     assert len(b) == len(np.unique(np.floor(b * np.float32(5.0)).astype(np.int64), axis=0))
     assert slam.add_surf_point_cloud(sparse + np.float32(0.05)) == om.add_surf(sparse + np.float32(0.05))  # back on the fast path
     assert _same_points(slam.export_map(), om.export())
+
+
+def test_trajectory_that_gains_and_loses_cubes_matches_the_oracle(oracle, gpu_slam_factory, monkeypatch):
+    """A trajectory of inserts that gains cubes, loses cubes, jumps to an untouched area and rolls the window: after every
+    insert the map equals the oracle's point set, and the sort-based first stage (SOICP_MAP_GROUPING=sort) leaves the same
+    points in the same canonical order.  (The rounds reuse what the previous insert left behind: the cell grids a round
+    cleans up after itself, the counter block cleared behind the previous insert, the cube list in the launch arguments.)"""
+    rng = np.random.default_rng(21)
+    centres = [(0, 0), (20, 5), (48, 10), (52, 10), (80, 30), (80, 30), (20, 5), (300, -200), (300, -190), (0, 0)]
+    clouds = [np.concatenate([noisy_planes_cloud(9000, rng, offset=(cx + dx, cy + dy, 0)) for dx, dy in ((-12, -12), (14, 9))]) for cx, cy in centres]
+    exports = []
+    for mode in ("hash", "sort"):
+        monkeypatch.setenv("SOICP_MAP_GROUPING", mode)
+        slam = gpu_slam_factory(plane_res=0.2)
+        om = oracle.OracleMap(plane_res=0.2)
+        out = []
+        for step, pts in enumerate(clouds):
+            if step == 7:  # the jump: roll the window first, like Localization does (LidarSlam.cpp:363)
+                t = np.array([300.0, -200.0, 0.0])
+                assert list(slam.shift_map(t)) == list(om.shift(t))
+            if step == 5:  # a resolution change in between: the cell tables are rebuilt, the next insert re-filters what it touches
+                slam.set_resolution(0.15, 0.3); om.set_resolution(0.15, 0.3)
+            assert slam.add_surf_point_cloud(pts) == om.add_surf(pts), (mode, step)
+            e = slam.export_map()
+            assert slam.map_size() == om.size() == len(e)
+            assert _same_points(e, om.export()), (mode, step)
+            out.append(e)
+        exports.append(out)
+        slam.close()
+    for step, (a, b) in enumerate(zip(*exports)):
+        assert np.array_equal(a, b), f"insert {step}: the two first stages left different maps (or orders)"

@@ -53,7 +53,6 @@ while time.time() < t_end:
     if a.oracle:
         om = oracle_py.OracleMap(plane_res=res, line_res=res / 2); om.set_origin(centre); om.shift(centre)
     ops = [("origin", centre.copy(), res)]
-    mixed_res = False  # after a resolution change old points share leaves: the order of their float sum is unspecified upstream (tests compare to rounding there)
     for step in range(int(rng.integers(2, 9))):
         if rng.random() < 0.2:
             centre = centre + rng.uniform(-120, 120, 3) * [1, 1, 0.02]
@@ -64,7 +63,7 @@ while time.time() < t_end:
             res = float(rng.choice([0.1, 0.2, 0.4, 0.8]))
             x.set_resolution(res / 2, res); y.set_resolution(res / 2, res)
             if om: om.set_resolution(res / 2, res)
-            ops.append(("res", centre.copy(), res)); mixed_res = True
+            ops.append(("res", centre.copy(), res))
         pts = cloud(centre)
         assert x.add_surf_point_cloud(pts) == y.add_surf_point_cloud(pts)
         ops.append(("add", pts, res))
@@ -72,7 +71,7 @@ while time.time() < t_end:
             assert om.add_surf(pts) >= 0
             eo, eg = om.export(), x.export_map()
             same = eo.shape == eg.shape and np.array_equal(eo[np.lexsort(eo.T)].view(np.uint32), eg[np.lexsort(eg.T)].view(np.uint32))
-            if not same and not mixed_res:
+            if not same:  # (also after resolution changes: a re-filtered cube sums its old points in the order of its previous leaf grid)
                 print("ORACLE MISMATCH", (a.seed, rounds, step, len(pts), res), eo.shape, eg.shape); sys.exit(1)
         ex, ey = x.export_map(), y.export_map()
         if not (ex.shape == ey.shape and np.array_equal(ex.view(np.uint32), ey.view(np.uint32))):
