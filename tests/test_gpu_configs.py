@@ -323,13 +323,13 @@ def test_resolution_change_keeps_the_points_until_their_cube_is_touched(oracle, 
     w = (sc.scan(2) @ synth.quat_to_R(gt[3:]).T + gt[:3]).astype(np.float32)
     assert slam.add_surf_point_cloud(w) == om.add_surf(w)
     a, b = slam.export_map(), om.export()
-    # Several OLD points now share one 0.8 m leaf: their centroid is a float sum whose order is the block's storage order --
-    # unspecified upstream (PCL sorts the leaf indices with std::sort) and different here (canonical cell order) -- so the
-    # merged centroids agree to float rounding, not to the bit; leaf membership (the count) is exact.
+    # Several OLD points now share one 0.8 m leaf: their centroid is a float sum in the block's storage order -- the output
+    # order of the cube's previous VoxelGrid (ascending leaf index of the grid it was last filtered on).  The product keeps
+    # its pool in (cell, leaf) order and restores that order for the re-filter (map_kernels.hip: old_order_key_kernel), so
+    # the merged centroids equal the oracle's to the bit.  (Inside one leaf PCL's std::sort leaves the order of the points
+    # unspecified; the oracle -- the contract -- sums in input order)
     assert len(a) == len(b)
-    ka, kb = np.floor(a * np.float32(1.25)).astype(np.int64), np.floor(b * np.float32(1.25)).astype(np.int64)
-    a, b = a[np.lexsort(ka.T)], b[np.lexsort(kb.T)]
-    assert np.allclose(a, b, rtol=0, atol=2e-5), float(np.abs(a - b).max())
+    assert np.array_equal(a[np.lexsort(a.T)].view(np.uint32), b[np.lexsort(b.T)].view(np.uint32))
 
 
 def test_two_shard_ranks_follow_the_queries_across_outer_iterations(oracle, gpu_slam_factory):
