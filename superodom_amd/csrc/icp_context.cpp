@@ -1170,6 +1170,13 @@ void so_icp_destroy(so_icp_ctx* ctx) {
 int so_icp_set_resolution(so_icp_ctx* c, float line_res, float plane_res) {
   if (!c || !(plane_res > 0) || !(line_res > 0)) return SO_ICP_E_INVALID;
   if (c->dmap && !c->dmap->supported_resolution(plane_res)) return fail(c, SO_ICP_E_UNSUPPORTED, "device map needs plane_res >= 0.05 (leaf coordinates of the grouping keys hold 10 bits)");
+  if (c->cfg.world_size > 1 && plane_res != map_plane_res(c) && (c->dmap ? c->dmap->size_local() : c->map.size()) > 0)
+    // A shard holds the leaves within one CELL of the bricks it owns, and cell size and bricks follow planeRes: after a
+    // change the resident subset would no longer cover the gate balls of the rank's queries (wrong neighbours, silently).
+    // Re-sharding needs the other ranks' points; until that exchange exists the call is refused -- clear the map first,
+    // or keep planeRes fixed (auto_voxel_size off) on sharded contexts.
+    return fail(c, SO_ICP_E_UNSUPPORTED, "so_icp_set_resolution: planeRes cannot change under a sharded, non-empty map (world_size > 1): "
+                                          "the shards are cut along the cell grid that follows planeRes");
   if (c->dmap) {
     NEED_DEVICE(c);
     HIP_TRY(c, hipSetDevice(c->cfg.device_id));

@@ -332,6 +332,24 @@ def test_resolution_change_keeps_the_points_until_their_cube_is_touched(oracle, 
     assert np.array_equal(a[np.lexsort(a.T)].view(np.uint32), b[np.lexsort(b.T)].view(np.uint32))
 
 
+def test_plane_res_change_is_refused_on_a_sharded_map(gpu_slam_factory, soicp):
+    """The shards are cut along the cell grid, which follows planeRes: after a change a shard would no longer hold the points
+    its queries need (tools/soak_shards.py found wrong neighbours there).  so_icp_set_resolution refuses the change while the
+    sharded map holds points -- loudly -- and accepts it on an empty map and when nothing changes."""
+    sc = synth.Scene("tiny")
+    sh = gpu_slam_factory(plane_res=0.2, line_res=0.1, rank=0, world_size=2)
+    sh.set_resolution(0.2, 0.4)                      # empty map: fine
+    sh.set_resolution(0.1, 0.2)
+    sh.add_surf_point_cloud(sc.map_points)
+    sh.set_resolution(0.1, 0.2)                      # unchanged (the node pushes it every frame, lmap.cpp:648-649): fine
+    with pytest.raises(Exception, match="sharded"):
+        sh.set_resolution(0.2, 0.4)
+    assert sh.plane_res() == pytest.approx(0.2) if hasattr(sh, "plane_res") else True
+    sh.clear_map()
+    sh.set_resolution(0.2, 0.4)
+    sh.close()
+
+
 def test_two_shard_ranks_follow_the_queries_across_outer_iterations(oracle, gpu_slam_factory):
     """N = 2 with max_iterations = 5 and a 3 degree / 0.4 m initial error: between outer iterations the pose update moves far
     queries by more than a map cell (1.5 m at 30 m), i.e. out of the one-cell halo of the shard that owned them under the
