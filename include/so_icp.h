@@ -156,9 +156,10 @@ int so_icp_device_available(void);
 
 /* -------- per-frame knobs (public fields the node writes, lmap.cpp:648-649, 703-711) ---------- */
 /* planeRes may change between frames (auto_voxel_size, lmap.cpp:604-649): the resident points stay as they are, the index
- * follows, the next insert re-filters the cubes it touches (LM.h:617-641).  world_size > 1: a CHANGE of planeRes over a
- * non-empty map is refused with SO_ICP_E_UNSUPPORTED -- the shards are cut along the cell grid that follows planeRes, and
- * re-cutting them needs points of other ranks; clear the map first or keep planeRes fixed on sharded contexts. */
+ * follows, the next insert re-filters the cubes it touches (LM.h:617-641).  world_size > 1: the shards are cut along the
+ * cell grid, which follows planeRes, so a CHANGE of planeRes over a non-empty map re-cuts them from every rank's points --
+ * a COLLECTIVE step over the communicator (every rank makes the same call; all-gather of the owned points, a few MB);
+ * without a communicator the change is refused with SO_ICP_E_UNSUPPORTED. */
 int so_icp_set_resolution(so_icp_ctx *ctx, float line_res, float plane_res);
 int so_icp_set_max_surface_features(so_icp_ctx *ctx, int max_surface_features);
 int so_icp_set_max_iterations(so_icp_ctx *ctx, int max_iterations);

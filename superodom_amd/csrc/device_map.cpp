@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 
 namespace soicp {
 
@@ -416,6 +417,112 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
   }
   clear_for_next();
   return inserted_total;
+}
+
+// ---- sharded map, planeRes change: re-cut of the shards -----------------------------------------------------------
+// The shards are cut along the cell grid (a rank keeps the leaves within one cell of its bricks), and cells and bricks
+// follow planeRes.  export_owned() hands out this rank's share of the FULL map -- the points whose own cell (current
+// grid) lies in one of its bricks: every point of the map is owned by exactly one rank -- cube by cube, with the
+// planeRes the cube was last filtered with (the re-filter order needs it).  The caller all-gathers the blobs;
+// reshard() then keeps, of all points, those whose leaf on the NEW grid this rank would keep at an insert, and rebuilds
+// the index.  Record: int32 cube, float res (negative: the drift watch had marked the cube), uint32 n, n x 3 floats.
+int DeviceMap::export_owned(std::vector<uint8_t>& blob, std::string& err) {
+  blob.clear();
+  std::vector<float> tmp;
+  const double inv_cell = 1.0 / cell_;
+  for (int cube = 0; cube < kMapNum; ++cube) {
+    const int s = cube_slot_[cube];
+    if (s < 0 || slot_count_[s] == 0) continue;
+    const uint32_t cnt = slot_count_[s];
+    if ((size_t)cnt * 3 > stage_cap_) {
+      if (d_stage_) (void)hipFree(d_stage_);
+      d_stage_ = nullptr; stage_cap_ = 0;
+      DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_stage_), ((size_t)cnt * 3 + 1024) * sizeof(float)));
+      stage_cap_ = (size_t)cnt * 3 + 1024;
+    }
+    tmp.resize((size_t)cnt * 3);
+    launch_gather_export(d_pool_, kCapPerSlot, (uint32_t)s, cnt, d_stage_, stream_);
+    DM_TRY(hipMemcpyAsync(tmp.data(), d_stage_, (size_t)cnt * 12, hipMemcpyDeviceToHost, stream_));
+    DM_TRY(hipStreamSynchronize(stream_));
+    const int ci = cube % kMapW, cj = (cube / kMapW) % kMapH, ck = cube / (kMapW * kMapH);
+    const int w[3] = {ci - origin_[0], cj - origin_[1], ck - origin_[2]};
+    std::vector<float> mine;
+    for (uint32_t i = 0; i < cnt; ++i) {
+      int g[3];
+      for (int a = 0; a < 3; ++a) {  // count_owned_kernel's arithmetic
+        const int v = (int)std::floor(((double)tmp[3 * (size_t)i + a] - (double)(w[a] * kCube - kHalfCube)) * inv_cell);
+        g[a] = v < 0 ? 0 : (v >= nc_ ? nc_ - 1 : v);
+      }
+      if ((int)(brick_hash(w[0], w[1], w[2], g[0] / kBrickCells, g[1] / kBrickCells, g[2] / kBrickCells) % (uint32_t)world_) == rank_)
+        mine.insert(mine.end(), tmp.begin() + 3 * (size_t)i, tmp.begin() + 3 * (size_t)i + 3);
+    }
+    if (mine.empty()) continue;
+    const int32_t c32 = cube; const float res = slot_res_[s]; const uint32_t n = (uint32_t)(mine.size() / 3);
+    const size_t at = blob.size();
+    blob.resize(at + 12 + mine.size() * sizeof(float));
+    std::memcpy(&blob[at], &c32, 4); std::memcpy(&blob[at + 4], &res, 4); std::memcpy(&blob[at + 8], &n, 4);
+    std::memcpy(&blob[at + 12], mine.data(), mine.size() * sizeof(float));
+  }
+  return 0;
+}
+
+int DeviceMap::reshard(const std::vector<std::vector<uint8_t>>& blobs, float line_res, float plane_res, std::string& err) {
+  struct CubeSet { float res = 0.f; std::vector<float> xyz; };
+  std::map<int, CubeSet> cubes;  // ascending block index
+  for (const std::vector<uint8_t>& b : blobs) {
+    size_t at = 0;
+    while (at + 12 <= b.size()) {
+      int32_t cube; float res; uint32_t n;
+      std::memcpy(&cube, &b[at], 4); std::memcpy(&res, &b[at + 4], 4); std::memcpy(&n, &b[at + 8], 4);
+      at += 12;
+      if (cube < 0 || cube >= kMapNum || at + (size_t)n * 12 > b.size()) { err = "DeviceMap::reshard: malformed record"; return -2; }
+      CubeSet& cs = cubes[cube];
+      if (cs.res != 0.f && std::fabs(cs.res) != std::fabs(res)) { err = "DeviceMap::reshard: the ranks disagree about a cube's filter resolution"; return -2; }
+      cs.res = (cs.res < 0.f || res < 0.f) ? -std::fabs(res) : res;  // (marked by the drift watch on any rank: marked)
+      const size_t k = cs.xyz.size();
+      cs.xyz.resize(k + (size_t)n * 3);
+      std::memcpy(cs.xyz.data() + k, &b[at], (size_t)n * 12);
+      at += (size_t)n * 12;
+    }
+    if (at != b.size()) { err = "DeviceMap::reshard: trailing bytes in a record stream"; return -2; }
+  }
+  double cell_new;
+  const int nc_new = cells_per_cube(plane_res, &cell_new);
+  const float inv_leaf_new = 1.0f / plane_res;
+  if (ensure_work(1, err)) return -2;
+  for (size_t s = 0; s < slot_cube_.size(); ++s) { slot_count_[s] = 0; slot_owned_[s] = 0; slot_full_[s] = 0; }
+  for (const auto& kv : cubes) if (cube_slot_[kv.first] < 0) alloc_slot(kv.first);
+  if (ensure_pool((int)slot_cube_.size(), err)) return -2;
+  block_clean_ = false;
+  for (const auto& kv : cubes) {
+    const int cube = kv.first;
+    const CubeSet& cs = kv.second;
+    const uint32_t n = (uint32_t)(cs.xyz.size() / 3);
+    if (!n) continue;
+    if (n > kCapPerSlot) { err = "DeviceMap: a 50 m cube exceeds the per-cube capacity of 1M points"; return -1; }
+    const int s = cube_slot_[cube];
+    if ((size_t)n * 3 > stage_cap_) {
+      if (d_stage_) (void)hipFree(d_stage_);
+      d_stage_ = nullptr; stage_cap_ = 0;
+      DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_stage_), ((size_t)n * 3 + 1024) * sizeof(float)));
+      stage_cap_ = (size_t)n * 3 + 1024;
+    }
+    MapTouched tt{};
+    tt.n = 1;
+    const int ci = cube % kMapW, cj = (cube / kMapW) % kMapH, ck = cube / (kMapW * kMapH);
+    const int w[3] = {ci - origin_[0], cj - origin_[1], ck - origin_[2]};
+    for (int ax = 0; ax < 3; ++ax) { tt.cube_min[0][ax] = w[ax] * kCube - kHalfCube; tt.wcube[0][ax] = w[ax]; }
+    DM_TRY(hipMemcpyAsync(d_stage_, cs.xyz.data(), (size_t)n * 12, hipMemcpyHostToDevice, stream_));
+    DM_TRY(hipMemsetAsync(d_small_, 0, 2 * sizeof(uint32_t), stream_));
+    launch_shard_select(d_stage_, n, tt, inv_leaf_new, nc_new, 1.0 / cell_new, rank_, world_, d_pool_ + (size_t)s * kCapPerSlot, kCapPerSlot, d_small_, stream_);
+    DM_TRY(hipGetLastError());
+    DM_TRY(hipMemcpyAsync(h_small_, d_small_, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+    DM_TRY(hipStreamSynchronize(stream_));
+    slot_count_[s] = h_small_[0]; slot_owned_[s] = h_small_[1]; slot_full_[s] = n;  // (n = the cube's count in the full map)
+    slot_res_[s] = cs.res;
+  }
+  slot_table_dirty_ = true;
+  return set_resolution(line_res, plane_res, err);  // the index over the new resident set (launch_map_retable)
 }
 
 size_t DeviceMap::export_points(float* xyz, size_t cap, bool only_5x5, const int pos[3], std::string& err) {

@@ -44,6 +44,9 @@ class DeviceMap {
   // sharded map: per cube index, the number of resident points whose own cell this rank owns (sum over ranks = full count)
   void owned_counts(std::vector<int32_t>& out) const;
   void set_full_counts(const std::vector<int32_t>& full);
+  // sharded map, planeRes change: this rank's share of the full map / the re-cut from every rank's share (device_map.cpp)
+  int export_owned(std::vector<uint8_t>& blob, std::string& err);
+  int reshard(const std::vector<std::vector<uint8_t>>& blobs, float line_res, float plane_res, std::string& err);
   void clear();
   // LocalMap::addSurfPointCloud on the device.  d_xyz: device pointer, stride in floats.  Returns #points inside the window or <0.
   int add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, std::string& err);

@@ -147,6 +147,17 @@ struct InprocGroup {
     if (ok) { std::lock_guard<std::mutex> lk(mu); io = itotal; }
     return ok;
   }
+  // all-gather of byte strings of any length (the shards' points at a planeRes change); same discipline as above: the last
+  // member to arrive assembles the result, nobody's slot is read after the round
+  std::vector<std::vector<uint8_t>> bslot, ball;
+  bool allgather_bytes(int rank, const std::vector<uint8_t>& mine, std::vector<std::vector<uint8_t>>& all) {
+    const bool ok = round(2, 0, [&] {
+      if (bslot.size() != (size_t)world) bslot.resize((size_t)world);
+      bslot[(size_t)rank] = mine;
+    }, [&] { ball = bslot; });
+    if (ok) { std::lock_guard<std::mutex> lk(mu); all = ball; }
+    return ok;
+  }
 };
 std::mutex g_groups_mu;
 std::vector<std::pair<uint64_t, std::shared_ptr<InprocGroup>>> g_groups;
@@ -326,6 +337,50 @@ int exchange_map_counts(so_icp_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }  // (a shard context without a communicator -- tests that drive the ranks one by one -- reports its own owned counts)
   c->dmap->set_full_counts(v);
+  return SO_ICP_OK;
+}
+
+// Sharded device map, planeRes change: the shards are cut along the cell grid, which follows planeRes.  Every rank hands out
+// the points it owns, all ranks gather all of them (in-process group, or RCCL all-gather of the padded byte strings), and each
+// re-cuts its shard on the new grid (DeviceMap::reshard).  Collective: every rank must make the same so_icp_set_resolution call.
+int reshard_for_resolution(so_icp_ctx* c, float line_res, float plane_res) {
+  std::vector<uint8_t> mine;
+  if (c->dmap->export_owned(mine, c->err) < 0) return SO_ICP_E_HIP;
+  std::vector<std::vector<uint8_t>> all;
+  if (c->group) {
+    if (!c->group->allgather_bytes(c->cfg.rank, mine, all))
+      return fail(c, SO_ICP_E_RCCL, "in-process group: the exchange of the shards' points failed (a member returned early, is in another exchange, or did not arrive)");
+  } else {
+    const int W = c->cfg.world_size;
+    auto nccl_fail = [&](const char* what, ncclResult_t r) { return fail(c, SO_ICP_E_RCCL, std::string(what) + ": " + (c->rccl.GetErrorString ? c->rccl.GetErrorString(r) : "?")); };
+    // lengths first, then the strings padded to the longest
+    std::vector<unsigned long long> len((size_t)W, 0ull);
+    len[(size_t)c->cfg.rank] = mine.size();
+    HIP_TRY(c, c->d_counts.reserve((size_t)W * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_counts.p, len.data(), (size_t)W * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    ncclResult_t r = c->rccl.AllGather(c->d_counts.as<unsigned long long>() + c->cfg.rank, c->d_counts.p, 1, ncclUint64, c->comm, c->stream);
+    if (r != ncclSuccess) return nccl_fail("ncclAllGather(shard sizes)", r);
+    HIP_TRY(c, hipMemcpyAsync(len.data(), c->d_counts.p, (size_t)W * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    size_t longest = 16;
+    for (unsigned long long v : len) longest = std::max(longest, (size_t)v);
+    longest = (longest + 15) & ~(size_t)15;
+    DevBuf send, recv;
+    HIP_TRY(c, send.reserve(longest)); HIP_TRY(c, recv.reserve(longest * (size_t)W));
+    if (!mine.empty()) HIP_TRY(c, hipMemcpyAsync(send.p, mine.data(), mine.size(), hipMemcpyHostToDevice, c->stream));
+    r = c->rccl.AllGather(send.p, recv.p, longest, ncclUint8, c->comm, c->stream);
+    if (r != ncclSuccess) { send.release(); recv.release(); return nccl_fail("ncclAllGather(shard points)", r); }
+    std::vector<uint8_t> host(longest * (size_t)W);
+    hipError_t e = hipMemcpyAsync(host.data(), recv.p, host.size(), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    send.release(); recv.release();
+    HIP_TRY(c, e);
+    all.resize((size_t)W);
+    for (int k = 0; k < W; ++k) all[(size_t)k].assign(host.begin() + (long)(longest * (size_t)k), host.begin() + (long)(longest * (size_t)k + (size_t)len[(size_t)k]));
+  }
+  const int rc = c->dmap->reshard(all, line_res, plane_res, c->err);
+  if (rc < 0) return rc == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP;
+  c->uploaded_version = 0;
   return SO_ICP_OK;
 }
 
@@ -1170,13 +1225,21 @@ void so_icp_destroy(so_icp_ctx* ctx) {
 int so_icp_set_resolution(so_icp_ctx* c, float line_res, float plane_res) {
   if (!c || !(plane_res > 0) || !(line_res > 0)) return SO_ICP_E_INVALID;
   if (c->dmap && !c->dmap->supported_resolution(plane_res)) return fail(c, SO_ICP_E_UNSUPPORTED, "device map needs plane_res >= 0.05 (leaf coordinates of the grouping keys hold 10 bits)");
-  if (c->cfg.world_size > 1 && plane_res != map_plane_res(c) && (c->dmap ? c->dmap->size_local() : c->map.size()) > 0)
+  if (c->dmap && c->cfg.world_size > 1 && plane_res != map_plane_res(c) && c->dmap->size_local() > 0) {
     // A shard holds the leaves within one CELL of the bricks it owns, and cell size and bricks follow planeRes: after a
     // change the resident subset would no longer cover the gate balls of the rank's queries (wrong neighbours, silently).
-    // Re-sharding needs the other ranks' points; until that exchange exists the call is refused -- clear the map first,
-    // or keep planeRes fixed (auto_voxel_size off) on sharded contexts.
-    return fail(c, SO_ICP_E_UNSUPPORTED, "so_icp_set_resolution: planeRes cannot change under a sharded, non-empty map (world_size > 1): "
-                                          "the shards are cut along the cell grid that follows planeRes");
+    // The shards are re-cut from every rank's points -- a collective step; without a communicator it cannot be done.
+    NEED_DEVICE(c);
+    HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+    if (!c->group && !c->comm)
+      return fail(c, SO_ICP_E_UNSUPPORTED, "so_icp_set_resolution: planeRes cannot change under a sharded, non-empty map without a communicator "
+                                            "(the shards are cut along the cell grid that follows planeRes; re-cutting them needs the other ranks' points)");
+    const int rc = reshard_for_resolution(c, line_res, plane_res);
+    if (rc) return rc;
+    c->map.set_resolution(line_res, plane_res);
+    c->cfg.line_res = line_res; c->cfg.plane_res = plane_res;
+    return SO_ICP_OK;
+  }
   if (c->dmap) {
     NEED_DEVICE(c);
     HIP_TRY(c, hipSetDevice(c->cfg.device_id));

@@ -217,6 +217,48 @@ __global__ __launch_bounds__(256) void count_owned_kernel(const float4* __restri
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(&owned[t], (uint32_t)__popcll(m));
 }
 
+static inline dim3 grid_for_n(uint32_t n) { return dim3((n + 255u) / 256u); }
+// Re-cut of a shard after a planeRes change (DeviceMap::reshard).  The candidates are ALL points of one cube -- every
+// rank's owned points, gathered --; this rank keeps those whose leaf ON THE NEW GRID it would keep at an insert
+// (shard_keeps_leaf with the new leaf size, cell size and bricks), so that the next re-filter finds every old point of
+// every leaf it keeps, and nothing of the others.  Order in the pool: arbitrary (the retable that follows sorts).
+__global__ __launch_bounds__(256) void shard_select_kernel(const float* __restrict__ xyz, uint32_t n, MapTouched tt, float inv_leaf, int nc,
+                                                           double inv_cell, int rank, int world, float4* __restrict__ pool_slot, uint32_t cap,
+                                                           uint32_t* __restrict__ counters /* [0] kept, [1] owned */) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool keep = false, mine = false;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < n) {
+    x = xyz[3 * (size_t)i]; y = xyz[3 * (size_t)i + 1]; z = xyz[3 * (size_t)i + 2];
+    keep = shard_keeps_leaf(x, y, z, inv_leaf, tt, 0, nc, inv_cell, rank, world);
+    const float c3[3] = {x, y, z};
+    int g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int v = (int)floor(((double)c3[a] - tt.cube_min[0][a]) * inv_cell);
+      g[a] = v < 0 ? 0 : (v >= nc ? nc - 1 : v);
+    }
+    mine = (int)(brick_hash(tt.wcube[0][0], tt.wcube[0][1], tt.wcube[0][2], g[0] / kBrickCells, g[1] / kBrickCells, g[2] / kBrickCells) % (uint32_t)world) == rank;
+  }
+  const int lane = threadIdx.x & 63;
+  const unsigned long long mk = __ballot(keep), mo = __ballot(mine);
+  uint32_t base = 0;
+  if (lane == 0) {
+    if (mk) base = atomicAdd(&counters[0], (uint32_t)__popcll(mk));
+    if (mo) atomicAdd(&counters[1], (uint32_t)__popcll(mo));
+  }
+  base = (uint32_t)__shfl((int)base, 0, 64);
+  if (keep) {
+    const uint32_t at = base + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+    if (at < cap) pool_slot[at] = make_float4(x, y, z, 0.f);
+  }
+}
+void launch_shard_select(const float* d_xyz, uint32_t n, const MapTouched& tt, float inv_leaf, int nc, double inv_cell, int rank, int world,
+                         float4* pool_slot, uint32_t cap, uint32_t* d_counters, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(shard_select_kernel, grid_for_n(n), dim3(256), 0, s, d_xyz, n, tt, inv_leaf, nc, inv_cell, rank, world, pool_slot, cap, d_counters);
+}
+
 __global__ __launch_bounds__(256) void leaf_flags_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

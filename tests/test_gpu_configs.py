@@ -332,22 +332,65 @@ def test_resolution_change_keeps_the_points_until_their_cube_is_touched(oracle, 
     assert np.array_equal(a[np.lexsort(a.T)].view(np.uint32), b[np.lexsort(b.T)].view(np.uint32))
 
 
-def test_plane_res_change_is_refused_on_a_sharded_map(gpu_slam_factory, soicp):
-    """The shards are cut along the cell grid, which follows planeRes: after a change a shard would no longer hold the points
-    its queries need (tools/soak_shards.py found wrong neighbours there).  so_icp_set_resolution refuses the change while the
-    sharded map holds points -- loudly -- and accepts it on an empty map and when nothing changes."""
-    sc = synth.Scene("tiny")
-    sh = gpu_slam_factory(plane_res=0.2, line_res=0.1, rank=0, world_size=2)
-    sh.set_resolution(0.2, 0.4)                      # empty map: fine
-    sh.set_resolution(0.1, 0.2)
-    sh.add_surf_point_cloud(sc.map_points)
-    sh.set_resolution(0.1, 0.2)                      # unchanged (the node pushes it every frame, lmap.cpp:648-649): fine
-    with pytest.raises(Exception, match="sharded"):
-        sh.set_resolution(0.2, 0.4)
-    assert sh.plane_res() == pytest.approx(0.2) if hasattr(sh, "plane_res") else True
-    sh.clear_map()
-    sh.set_resolution(0.2, 0.4)
-    sh.close()
+def test_plane_res_change_recuts_the_shards(oracle, gpu_slam_factory, soicp):
+    """The shards are cut along the cell grid, which follows planeRes (tools/soak_shards.py saw wrong neighbours after a
+    change).  so_icp_set_resolution over a sharded, non-empty map is a collective step: every rank hands out the points it
+    owns, all gather all, each re-cuts its shard on the new grid.  Afterwards: every resident point is a point of the
+    unsharded map, the union is the whole map, the full-map counts are right, registrations and the next insert (which
+    re-filters what it touches on the new leaf grid) follow the single context.  Without a communicator: refused, loudly."""
+    sc = synth.Scene("small")
+    mk = dict(plane_res=0.2, line_res=0.1, max_surface_features=-1, max_iterations=4)
+    lone = gpu_slam_factory(rank=0, world_size=2, **mk)
+    lone.set_resolution(0.2, 0.4); lone.set_resolution(0.1, 0.2)   # empty map: nothing to re-cut
+    lone.add_surf_point_cloud(sc.map_points)
+    lone.set_resolution(0.1, 0.2)                                  # unchanged (the node pushes it every frame, lmap.cpp:648-649)
+    with pytest.raises(Exception, match="communicator"):
+        lone.set_resolution(0.2, 0.4)
+    lone.close()
+    one = gpu_slam_factory(**mk)
+    shards = [gpu_slam_factory(rank=r, world_size=3, **mk) for r in range(3)]
+    for sh in shards:
+        sh.comm_init_inprocess(0x4E5)
+    one.add_surf_point_cloud(sc.map_points)
+    _in_threads([lambda sh=sh: sh.add_surf_point_cloud(sc.map_points) for sh in shards])
+    key = lambda a: {tuple(v) for v in a.view(np.uint32).reshape(-1, 3).tolist()}
+    for res in (0.4, 0.2, 0.4):
+        one.set_resolution(res / 2, res)
+        _in_threads([lambda sh=sh: (sh.set_resolution(res / 2, res), True)[1] for sh in shards])
+        full = one.export_map(); kfull = key(full); union = set()
+        for sh in shards:
+            total, mine = sh.map_size(this_rank=True)
+            part = sh.export_map()
+            assert total == len(full) and len(part) == mine < len(full)
+            assert key(part) <= kfull
+            union |= key(part)
+        assert union == kfull
+        for i in (2, 9):
+            scan, guess = sc.scan(i), sc.guess(i, dt=0.3, dth_deg=2.0)
+            rc, pose, st = one.register(scan, guess)
+            out = _in_threads([lambda sh=sh: sh.register(scan, guess) for sh in shards])
+            assert all(r[0] == rc == 0 for r in out) and all(np.array_equal(out[0][1], r[1]) for r in out)
+            for r in out:
+                assert r[2].n_iterations == st.n_iterations
+                for it in range(st.n_iterations):
+                    a, b = r[2].iterations[it], st.iterations[it]
+                    assert (a.lm_iterations, a.termination, a.num_surf_from_scan) == (b.lm_iterations, b.termination, b.num_surf_from_scan), (res, i, it)
+                    assert list(a.reject_hist) == list(b.reject_hist) and list(a.obs_hist) == list(b.obs_hist)
+                ok, dt, dr = pose_close(r[1], pose, 1e-9, 1e-9)
+                assert ok, (res, i, dt, dr)
+        # an insert on the new grid: the touched cubes are re-filtered, shard by shard, like the whole map
+        gt = sc.gt_pose(4)
+        w = (sc.scan(4) @ synth.quat_to_R(gt[3:]).T + gt[:3]).astype(np.float32)
+        n1 = one.add_surf_point_cloud(w)
+        assert [r for r in _in_threads([lambda sh=sh: sh.add_surf_point_cloud(w) for sh in shards])] == [n1] * 3
+        full = one.export_map(); kfull = key(full); union = set()
+        for sh in shards:
+            part = sh.export_map()
+            assert key(part) <= kfull, "every resident centroid is a centroid of the unsharded map, bit for bit"
+            union |= key(part)
+        assert union == kfull and shards[0].map_size() == len(full)
+    for sh in shards:
+        sh.close()
 
 
 def test_two_shard_ranks_follow_the_queries_across_outer_iterations(oracle, gpu_slam_factory):

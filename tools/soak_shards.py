@@ -2,8 +2,8 @@
 """Differential soak of the SHARDED path on one GPU (GPU box): N = 2..4 shard contexts joined by an in-process group (the
 sums take the place of the RCCL all-reduce / peer exchange), each driven from its own thread, against ONE context holding
 the whole map: Localization frame after frame (sharded device-side insert, per-cube counts by collective) with random
-guess errors up to 0.6 m / 6 degrees (queries change owner between outer iterations) and sub-sampled scans.  (planeRes is
-fixed: so_icp_set_resolution refuses a change over a sharded, non-empty map.)
+guess errors up to 0.6 m / 6 degrees (queries change owner between outer iterations), planeRes switches (the shards are
+re-cut: a collective step) and sub-sampled scans.
 Every frame: all ranks return the same bits; status, iteration counts, termination codes, both histograms equal the single
 context's; poses to 1e-9; every resident centroid is a centroid of the unsharded map, the shards' union is the whole map.
 usage: python tools/soak_shards.py [--seconds 120] [--seed 0]"""
@@ -54,6 +54,10 @@ while time.time() < t_end:
     n_seq += 1
     for k in range(1, int(rng.integers(3, 7))):
         if not ok: break
+        if rng.random() < 0.2:
+            res = float(rng.choice([0.2, 0.4]))
+            one.set_resolution(res / 2, res)
+            in_threads([lambda sh=sh: (sh.set_resolution(res / 2, res), True)[1] for sh in shards])
         i = (i0 + k) % 32
         scan = sc.scan(i)
         if rng.random() < 0.3: scan = scan[rng.permutation(len(scan))[: int(rng.integers(500, len(scan)))]]
