@@ -366,12 +366,15 @@ int reshard_for_resolution(so_icp_ctx* c, float line_res, float plane_res) {
     for (unsigned long long v : len) longest = std::max(longest, (size_t)v);
     longest = (longest + 15) & ~(size_t)15;
     DevBuf send, recv;
-    HIP_TRY(c, send.reserve(longest)); HIP_TRY(c, recv.reserve(longest * (size_t)W));
-    if (!mine.empty()) HIP_TRY(c, hipMemcpyAsync(send.p, mine.data(), mine.size(), hipMemcpyHostToDevice, c->stream));
-    r = c->rccl.AllGather(send.p, recv.p, longest, ncclUint8, c->comm, c->stream);
-    if (r != ncclSuccess) { send.release(); recv.release(); return nccl_fail("ncclAllGather(shard points)", r); }
     std::vector<uint8_t> host(longest * (size_t)W);
-    hipError_t e = hipMemcpyAsync(host.data(), recv.p, host.size(), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = send.reserve(longest);
+    if (e == hipSuccess) e = recv.reserve(longest * (size_t)W);
+    if (e == hipSuccess && !mine.empty()) e = hipMemcpyAsync(send.p, mine.data(), mine.size(), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      r = c->rccl.AllGather(send.p, recv.p, longest, ncclUint8, c->comm, c->stream);
+      if (r != ncclSuccess) { send.release(); recv.release(); return nccl_fail("ncclAllGather(shard points)", r); }
+      e = hipMemcpyAsync(host.data(), recv.p, host.size(), hipMemcpyDeviceToHost, c->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     send.release(); recv.release();
     HIP_TRY(c, e);
@@ -1225,7 +1228,10 @@ void so_icp_destroy(so_icp_ctx* ctx) {
 int so_icp_set_resolution(so_icp_ctx* c, float line_res, float plane_res) {
   if (!c || !(plane_res > 0) || !(line_res > 0)) return SO_ICP_E_INVALID;
   if (c->dmap && !c->dmap->supported_resolution(plane_res)) return fail(c, SO_ICP_E_UNSUPPORTED, "device map needs plane_res >= 0.05 (leaf coordinates of the grouping keys hold 10 bits)");
-  if (c->dmap && c->cfg.world_size > 1 && plane_res != map_plane_res(c) && c->dmap->size_local() > 0) {
+  // ("non-empty" must be the same decision on every rank: the FULL map's count, which the ranks share after any insert under the
+  //  communicator -- a rank whose own shard happens to be empty still takes part in the exchange)
+  if (c->dmap && c->cfg.world_size > 1 && plane_res != map_plane_res(c) &&
+      ((c->group || c->comm) ? c->dmap->size() : c->dmap->size_local()) > 0) {
     // A shard holds the leaves within one CELL of the bricks it owns, and cell size and bricks follow planeRes: after a
     // change the resident subset would no longer cover the gate balls of the rank's queries (wrong neighbours, silently).
     // The shards are re-cut from every rank's points -- a collective step; without a communicator it cannot be done.
