@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential soak of the registration (GPU box): random scans, guesses, resolutions and sampling limits on the small
 scenes, the HIP path against the CPU oracle -- iteration counts, LM iterations / termination codes, both histograms, the
-per-query MatchingResult of the last iteration, poses to 1e-8.  usage: python tools/soak_registration.py [--seconds 120] [--seed 0]"""
+per-query MatchingResult of the last iteration, poses to 1e-8.  usage: python tools/soak_registration.py [--seconds 120] [--seed 0] [--scenes tiny,small]"""
 import argparse, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,10 +10,11 @@ import oracle_py as oracle  # noqa: E402
 from superodom_amd import binding, synth  # noqa: E402
 
 ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=120.0); ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--scenes", default="tiny,small", help="comma-separated synth scenes (os1_128_2m = the configuration of record: ~1 s of oracle per registration)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 oracle.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
-scenes = {name: synth.Scene(name) for name in ("tiny", "small")}
+scenes = {name: synth.Scene(name) for name in a.scenes.split(",")}
 t_end, n_reg, n_bad, worst = time.time() + a.seconds, 0, 0, (0.0, 0.0)
 while time.time() < t_end:
     name = str(rng.choice(list(scenes)))
