@@ -14,8 +14,8 @@
 //   second stage (no sort): cell_count_kernel (centroids counted into the dense cell grids of the touched cubes, atomic rank),
 //                         exclusive scan of the grids = the cubes' new cell_start tables (cell_table_kernel), cell_place_kernel
 //                         (into a scratch array, leaf key alongside), cell_rank_kernel (final position inside the cell =
-//                         number of smaller leaf keys: canonical order = cell, then leaf).  SOICP_MAP_STAGE2=sort keeps the
-//                         earlier path (stable sort by cell key, scatter, table by binary search).
+//                         number of smaller leaf keys: canonical order = cell, then leaf); cell_table_kernel also puts the
+//                         counters back to zero, so the next insert needs no fill of the grids.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
