@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--shuffle-scan", action="store_true", help="experiment: random point order inside every scan (worst case for the binning atomics)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the k-NN launches (no roofline)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the kernel-split pass after the timed region (runs under rocprofv3 use it: one registration = one set of launches)")
+    ap.add_argument("--pageable-scans", action="store_true", help="leave the host scan buffers pageable (default: pinned with so_icp_host_register, like a node "
+                                                                  "that keeps its feature clouds in registered buffers): the staged copies then go through the copy thread")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +137,9 @@ def main():
     if args.shuffle_scan:
         scans = [np.ascontiguousarray(s_[np.random.default_rng(77 + i).permutation(len(s_))]) for i, s_ in enumerate(scans)]
     guesses = [sc.guess(i) for i in range(args.scans)]
+    if not args.pageable_scans:  # host scan buffers in registered (pinned) memory: so_icp_stage_scan / so_icp_register copy by DMA straight from them
+        for s_ in scans:
+            slam.host_register(s_)
     d_scans = [slam.upload_scan(s) for s in scans]  # resident copies: the secondary / profiling loops and --entry resident
     Q = len(scans[0])
     map_total, map_rank = slam.map_size(this_rank=True)
@@ -392,7 +397,16 @@ def main():
                              "wavefronts, not by HBM -- see valu_issue"
                              % (b_knn_whole_map, (b_knn_whole_map / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if knn_ms > 0 else 0.0)},
         "host": {"c_abi_ms_per_step": tm.host_ms_total / max(tm.registrations, 1),
-                 "note": "wall time inside the registration core (enqueue + wait + post-processing); ms_per_step - this = scan hand-over + Python/ctypes overhead"},
+                 # what the timed region holds beyond the registration cores: the first scan's copy (nothing hides it), the scan
+                 # hand-overs, the ctypes calls, the final synchronisation -- per step
+                 "fixed_overhead_ms_per_step": ms_per_step - tm.host_ms_total / max(tm.registrations, 1),
+                 "stage_wait_ms_per_step": tm.stage_wait_ms_total / max(tm.registrations, 1),
+                 "staged_by_dma_from_registered_memory": int(tm.staged_direct), "staged_through_copy_thread": int(tm.staged_copied),
+                 "stage_declined": int(tm.stage_declined),
+                 "scan_buffers": "pageable" if args.pageable_scans else "registered host memory (so_icp_host_register)",
+                 "note": "c_abi = wall time inside the registration core (enqueue + wait + post-processing); stage_wait = host time the registrations "
+                         "waited for a staged scan still on its way through the copy thread (0 with registered buffers: the registration's first kernel "
+                         "waits for the DMA on the device)"},
         # ms of one registration by kernel family, from the profiling pass after the timed region (real launches only:
         # no-op launches after convergence excluded).  solve = plane fit + every LM evaluation + controller (one persistent
         # launch per outer iteration on one GPU; eval + all-reduce + controller launches when the map is sharded).

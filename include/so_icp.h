@@ -42,7 +42,7 @@ extern "C" {
 #define SO_ICP_OK 0
 #define SO_ICP_NOT_ENOUGH_MAP_FEATURES 1 /* LS.cpp:113-116: surf_from_map_num <= 50, pose = guess */
 #define SO_ICP_MAP_SEEDED 2              /* Localization(initialization=false): LS.cpp:45-46, 83-94 */
-#define SO_ICP_STAGE_DECLINED 3          /* so_icp_stage_scan: both staging slots hold scans that are still needed; not staged (soft) */
+#define SO_ICP_STAGE_DECLINED 3          /* so_icp_stage_scan: every staging slot holds a scan that is still needed; not staged (soft) */
 #define SO_ICP_E_INVALID (-1)
 #define SO_ICP_E_HIP (-2)
 #define SO_ICP_E_NOMEM (-3)
@@ -143,6 +143,9 @@ typedef struct {
   /* k-NN kernel statistics (time_kernels only): wave group passes, lanes sent to the exact per-lane scan,
    * wave-uniform candidates streamed */
   int64_t knn_group_passes, knn_fallback_lanes, knn_candidates_scanned;
+  /* so_icp_stage_scan: host time registrations spent waiting for a staged scan that was still on its way through the copy
+   * thread; announcements copied by DMA straight from registered host memory / through the copy thread / declined */
+  double stage_wait_ms_total;  int64_t staged_direct, staged_copied, stage_declined;
 } so_icp_timing;
 
 /* -------- lifecycle ------------------------------------------------------------------------ */
@@ -194,18 +197,26 @@ int so_icp_knn_surf(so_icp_ctx *ctx, const float *q_xyz, size_t nq, int k,
  * the scan into the map (so_icp_localization does).  prev uncertainty comes from the previous call. */
 int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes,
                     const double pose_in[7], double pose_out[7], so_icp_stats *stats);
-/* Announce the NEXT scan: the host buffer is copied to a pinned staging slot and on to HBM by the context's copy thread +
- * copy stream while the caller goes on (typically: while the previous so_icp_register is still running -- the node's
- * feature callback, lmap.cpp:21-25, has the cloud long before process() reaches it).  A following so_icp_register /
- * so_icp_localization with the SAME (scan_xyz, n, stride_bytes) consumes the staged copy instead of uploading again
- * (so_icp_stats::flags carries SO_ICP_FLAG_STAGED_SCAN); any other call simply ignores it.  The caller's buffer must stay
- * valid and unchanged until that call (or the next so_icp_stage_scan) returns.  Two slots: one scan may be staged while
- * the previous one is being registered; while a registration reads one slot and the other holds the scan to be registered
- * next, a further announcement returns SO_ICP_STAGE_DECLINED (soft: that scan is uploaded by its own registration call).
- * A staged copy is also dropped by a map-seeding so_icp_localization(initialization = 0) on the same buffer.  Unlike the
- * other entry points this one may be called from ANOTHER thread than the registration calls (the node's feature callback,
- * lmap.cpp:21-25). */
+/* Announce the NEXT scan: the host buffer travels to HBM on the context's copy stream while the caller goes on (typically:
+ * while the previous so_icp_register is still running -- the node's feature callback, lmap.cpp:21-25, has the cloud long
+ * before process() reaches it).  Packed xyz (stride 12) inside a buffer pinned with so_icp_host_register is read by DMA
+ * straight from the caller's memory: this call enqueues the copy and returns, and the registration's first kernel waits for
+ * it on the device.  Anything else (pageable memory, strided pcl::PointXYZI records) is packed into a pinned buffer by the
+ * context's copy thread first.  A following so_icp_register / so_icp_localization with the SAME (scan_xyz, n, stride_bytes)
+ * consumes the staged copy instead of uploading again (so_icp_stats::flags carries SO_ICP_FLAG_STAGED_SCAN); any other call
+ * simply ignores it.  The caller's buffer must stay valid and unchanged until that call (or the next so_icp_stage_scan)
+ * returns.  Three slots: two scans may be announced ahead of the one being registered; a further announcement returns
+ * SO_ICP_STAGE_DECLINED (soft: that scan is uploaded by its own registration call).  Announcing a buffer again supersedes
+ * its earlier copy; a copy announced BEFORE a scan that has been consumed since (a skipped frame) is never served and gives
+ * its slot to the next announcement.  A staged copy is also dropped by a map-seeding so_icp_localization(initialization = 0)
+ * on the same buffer.  Unlike the other entry points this one may be called from ANOTHER thread than the registration calls
+ * (the node's feature callback, lmap.cpp:21-25). */
 int so_icp_stage_scan(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes);
+/* Pin a host buffer the caller keeps its clouds in (hipHostRegister; the node's copy of the message payload into its feature
+ * cloud, pcl::fromROSMsg at lmap.cpp:250-263, then lands in pinned memory): so_icp_stage_scan and so_icp_register copy
+ * packed scans that lie inside it by DMA without an intermediate copy.  Unregister before freeing the buffer. */
+int so_icp_host_register(so_icp_ctx *ctx, const void *ptr, size_t bytes);
+int so_icp_host_unregister(so_icp_ctx *ctx, const void *ptr);
 /* same, scan already resident in HBM as packed float xyz (n*3 floats, device pointer) */
 int so_icp_register_dev(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n,
                         const double pose_in[7], double pose_out[7], so_icp_stats *stats);

@@ -65,7 +65,8 @@ class Timing(C.Structure):
                 ("eval_ms_total", C.c_double), ("eval_launches", C.c_int64), ("eval_points", C.c_int64),
                 ("prep_ms_total", C.c_double), ("prep_launches", C.c_int64),
                 ("host_ms_total", C.c_double), ("registrations", C.c_int64),
-                ("knn_group_passes", C.c_int64), ("knn_fallback_lanes", C.c_int64), ("knn_candidates_scanned", C.c_int64)]
+                ("knn_group_passes", C.c_int64), ("knn_fallback_lanes", C.c_int64), ("knn_candidates_scanned", C.c_int64),
+                ("stage_wait_ms_total", C.c_double), ("staged_direct", C.c_int64), ("staged_copied", C.c_int64), ("stage_declined", C.c_int64)]
 
 
 class Sums(C.Structure):
@@ -84,7 +85,8 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_shard_owner_of_point", "so_icp_cells_per_cube", "so_icp_lm_begin", "so_icp_lm_feed", "so_icp_lm_result",
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
-            "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram"]
+            "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram",
+            "so_icp_host_register", "so_icp_host_unregister"]
 
 _lib = None
 
@@ -146,6 +148,8 @@ def load():
     L.so_icp_debug_knn_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
     L.so_icp_set_time_kernels.argtypes = [vp, C.c_int]
     L.so_icp_stage_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
+    L.so_icp_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.so_icp_host_unregister.argtypes = [vp, vp]
     L.so_icp_debug_match_status.argtypes = [vp, u8p, C.c_size_t]
     L.so_icp_comm_init_inprocess.argtypes = [vp, C.c_uint64]
     L.so_icp_peer_export.argtypes = [vp, u8p]
@@ -274,6 +278,15 @@ class LidarSlamGpu:
         the register call that consumes it)."""
         assert isinstance(scan, np.ndarray) and scan.dtype == np.float32 and scan.flags.c_contiguous
         self._check(self.L.so_icp_stage_scan(self.h, _p(scan, C.c_float), len(scan), 12))
+
+    def host_register(self, arr):
+        """so_icp_host_register: pin the numpy array's memory (it must stay alive until host_unregister / close); packed scans
+        announced from inside it travel to HBM by DMA straight from the array."""
+        assert isinstance(arr, np.ndarray) and arr.flags.c_contiguous
+        self._check(self.L.so_icp_host_register(self.h, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def host_unregister(self, arr):
+        self._check(self.L.so_icp_host_unregister(self.h, arr.ctypes.data_as(C.c_void_p)))
 
     def prepare_stage_scan(self, scan):
         assert isinstance(scan, np.ndarray) and scan.dtype == np.float32 and scan.flags.c_contiguous

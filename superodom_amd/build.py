@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsoicp.so")
 SOURCES = ["kernels.hip", "map_kernels.hip", "icp_context.cpp", "local_map.cpp", "device_map.cpp"]
-HEADERS = ["kernels.h", "map_kernels.h", "device_map.h", "lm_solver.h", "local_map.h", "so_math.h", "deskew_math.h", os.path.join("..", "..", "include", "so_icp.h")]
+HEADERS = ["kernels.h", "map_kernels.h", "device_map.h", "lm_solver.h", "local_map.h", "so_math.h", "deskew_math.h", "plane_fit.h", os.path.join("..", "..", "include", "so_icp.h")]
 ARCH = "gfx950"
 # -ffp-contract=off: the fp64 plane fit / evaluation follow the reference's unfused arithmetic
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]

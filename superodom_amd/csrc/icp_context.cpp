@@ -244,19 +244,28 @@ struct so_icp_ctx {
   bool peer_opened[8] = {false, false, false, false, false, false, false, false};  // mapped with hipIpcOpenMemHandle (to be closed)
   bool peer_connected = false, peer_on = false;
   unsigned peer_connects = 0;  // handshakes so far (tag of the self-test chunks)
-  // so_icp_stage_scan: a copy thread + copy stream bring the NEXT scan to HBM while the current registration runs
+  // so_icp_stage_scan: the NEXT scans travel to HBM while the current registration runs -- straight from the caller's buffer
+  // when that is registered (pinned) host memory (so_icp_host_register: the announcing thread enqueues the DMA on the copy
+  // stream and returns; the registration's first kernel waits for it ON THE DEVICE), else through a copy thread that packs
+  // the cloud into a pinned buffer first.
+  static constexpr int kStageSlots = 3;  // one in use by the registration in flight + two announced ahead
   struct StageSlot {
     const float* src = nullptr; size_t n = 0, stride = 0;  // identity of the staged host buffer
     DevBuf dev; float* pinned = nullptr; size_t pinned_cap = 0;
     int state = 0;  // 0 empty, 1 queued (the copy thread owns it), 2 ready, 3 in use by the registration in flight, -1 failed
+    unsigned long long seq = 0;          // announcement number (newer scans have larger ones)
+    hipEvent_t ev = nullptr;             // direct path: end of the H2D copy on the copy stream
+    bool ev_pending = false;             //   ... which may still be reading the caller's buffer
     std::string err;
-  } stage[2];
+  } stage[kStageSlots];
   StageSlot* stage_in_use = nullptr;  // the slot the current registration reads (released when the call returns)
-  int stage_next = 0;
+  unsigned long long stage_seq = 0, stage_consumed_seq = 0;  // announcements so far / announcement number of the scan consumed last
   bool stage_quit = false, stage_started = false;
   std::atomic<int> stage_pending{0};      // queued slots the copy thread has not picked up yet
   std::atomic<bool> stage_parked{false};  // the copy thread sleeps on stage_cv (it spins for a while after every job first)
   std::thread stage_thread; std::mutex stage_mu; std::condition_variable stage_cv;
+  struct HostRange { const char* p; size_t bytes; };
+  std::vector<HostRange> host_ranges;     // so_icp_host_register (under stage_mu)
   hipStream_t copy_stream = nullptr;
   bool retried = false;       // the current registration is the repeat of an abandoned one
   unsigned long long peer_timeout_ticks = 100000000ull;  // 1 s at 100 MHz: patience of a solve launch with the peer exchange (SOICP_PEER_TIMEOUT_MS)
@@ -803,14 +812,16 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
   return rc;
 }
 
-int upload_scan_impl(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, DevBuf& dst) {
+// wait = false: the caller enqueues the scan's consumers on the same stream and does not return to ITS caller before they
+// have completed (so_icp_register), so the source buffer outlives the copy without a host-side wait here
+int upload_scan_impl(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, DevBuf& dst, bool wait = true) {
   if (stride_bytes == 0) stride_bytes = 12;
   if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
   HIP_TRY(c, dst.reserve((n + 64) * 12));
   if (!n) return SO_ICP_OK;
   if (stride_bytes == 12) {
     HIP_TRY(c, hipMemcpyAsync(dst.p, xyz, n * 12, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (wait) HIP_TRY(c, hipStreamSynchronize(c->stream));
   } else {
     std::vector<float> packed(n * 3);
     const size_t sf = stride_bytes / 4;
@@ -821,15 +832,33 @@ int upload_scan_impl(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_by
   return SO_ICP_OK;
 }
 
-// ---- so_icp_stage_scan: copy thread -----------------------------------------------------------------------------
-// One thread per context, started on first use.  It owns the copy stream: pack (only for strided input) into a pinned
-// buffer, hipMemcpyAsync to the slot's HBM buffer, wait, mark the slot ready.  The registration thread never touches
-// the copy stream; it only waits (on the condition variable) for the slot it is about to consume.
+// ---- so_icp_stage_scan ---------------------------------------------------------------------------------------------
+// Slot life: empty -> (queued, copy thread) -> ready -> in use by the registration that consumes it -> empty.
+// Everything below runs under stage_mu: so_icp_stage_scan may come from another thread than the registration calls.
+bool stage_any_queued(const so_icp_ctx* c) {
+  for (const so_icp_ctx::StageSlot& sl : c->stage) if (sl.state == 1) return true;
+  return false;
+}
+// the copy of a direct slot has left the caller's buffer (host-side wait; a no-op in steady state: the copy was enqueued
+// a registration ago)
+void stage_finish_direct(so_icp_ctx::StageSlot& sl) {
+  if (sl.ev_pending) { (void)hipEventSynchronize(sl.ev); sl.ev_pending = false; }
+}
+bool host_range_registered(const so_icp_ctx* c, const void* p, size_t bytes) {
+  const char* q = static_cast<const char*>(p);
+  for (const so_icp_ctx::HostRange& r : c->host_ranges) if (q >= r.p && q + bytes <= r.p + r.bytes) return true;
+  return false;
+}
+
+// Copy thread: one per context, started on first use, for sources that are NOT registered host memory.  Pack (strided input,
+// e.g. 32-byte pcl::PointXYZI) into the slot's pinned buffer, hipMemcpyAsync to the slot's HBM buffer, wait, mark the slot
+// ready.  A copy from pinned memory runs on an SDMA engine, whereas the runtime may serve a pageable source with a blit
+// kernel that competes for compute units with the persistent solve launch of the registration in flight.
 void stage_worker(so_icp_ctx* c) {
   (void)hipSetDevice(c->cfg.device_id);
   std::unique_lock<std::mutex> lk(c->stage_mu);
   for (;;) {
-    if (!(c->stage_quit || c->stage[0].state == 1 || c->stage[1].state == 1)) {
+    if (!(c->stage_quit || stage_any_queued(c))) {
       // Nothing queued.  A registration stream announces the next scan within a few hundred microseconds: spin that long
       // on the pending counter (no futex wake-up on the announcing thread's path), then park on the condition variable
       // (a 10 Hz node finds the thread parked and pays one notify per frame).
@@ -847,64 +876,89 @@ void stage_worker(so_icp_ctx* c) {
       lk.lock();
       if (!got) {
         c->stage_parked.store(true);
-        c->stage_cv.wait(lk, [&] { return c->stage_quit || c->stage[0].state == 1 || c->stage[1].state == 1; });
+        c->stage_cv.wait(lk, [&] { return c->stage_quit || stage_any_queued(c); });
         c->stage_parked.store(false);
       }
       continue;
     }
     if (c->stage_quit) return;
     c->stage_pending.fetch_sub(1, std::memory_order_acq_rel);
-    so_icp_ctx::StageSlot& sl = c->stage[c->stage[0].state == 1 ? 0 : 1];
-    const float* src = sl.src; const size_t n = sl.n, stride = sl.stride;
+    so_icp_ctx::StageSlot* pick = nullptr;  // oldest queued announcement first
+    for (so_icp_ctx::StageSlot& q : c->stage) if (q.state == 1 && (!pick || q.seq < pick->seq)) pick = &q;
+    so_icp_ctx::StageSlot& sl = *pick;
+    const float* src = sl.src; const size_t n = sl.n, stride = sl.stride; const unsigned long long seq = sl.seq;
     lk.unlock();
     std::string err;
     hipError_t e = sl.dev.reserve((n + 64) * 12);
     if (e == hipSuccess && n) {
-      const float* from = src;
-      {  // always through the slot's pinned buffer (packing strided input, e.g. 32-byte pcl::PointXYZI, on the way): a copy
-         // from pinned memory runs on an SDMA engine, whereas the runtime may serve a pageable source with a blit kernel that
-         // competes for compute units with the persistent solve launch of the registration in flight
-        if (sl.pinned_cap < n * 12) {
-          if (sl.pinned) (void)hipHostFree(sl.pinned);
-          sl.pinned = nullptr; sl.pinned_cap = 0;
-          e = hipHostMalloc(reinterpret_cast<void**>(&sl.pinned), n * 12 + 4096);
-          if (e == hipSuccess) sl.pinned_cap = n * 12 + 4096;
-        }
-        if (e == hipSuccess) {
-          const size_t sf = stride / 4;
-          if (sf == 3) std::memcpy(sl.pinned, src, n * 12);
-          else for (size_t i = 0; i < n; ++i) { sl.pinned[3 * i] = src[i * sf]; sl.pinned[3 * i + 1] = src[i * sf + 1]; sl.pinned[3 * i + 2] = src[i * sf + 2]; }
-          from = sl.pinned;
-        }
+      if (sl.pinned_cap < n * 12) {
+        if (sl.pinned) (void)hipHostFree(sl.pinned);
+        sl.pinned = nullptr; sl.pinned_cap = 0;
+        e = hipHostMalloc(reinterpret_cast<void**>(&sl.pinned), n * 12 + 4096);
+        if (e == hipSuccess) sl.pinned_cap = n * 12 + 4096;
       }
-      if (e == hipSuccess) e = hipMemcpyAsync(sl.dev.p, from, n * 12, hipMemcpyHostToDevice, c->copy_stream);
+      if (e == hipSuccess) {
+        const size_t sf = stride / 4;
+        if (sf == 3) std::memcpy(sl.pinned, src, n * 12);
+        else for (size_t i = 0; i < n; ++i) { sl.pinned[3 * i] = src[i * sf]; sl.pinned[3 * i + 1] = src[i * sf + 1]; sl.pinned[3 * i + 2] = src[i * sf + 2]; }
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(sl.dev.p, sl.pinned, n * 12, hipMemcpyHostToDevice, c->copy_stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
     }
     if (e != hipSuccess) err = std::string("so_icp_stage_scan: ") + hipGetErrorString(e);
     lk.lock();
-    if (sl.src == src && sl.n == n && sl.stride == stride && sl.state == 1) { sl.state = err.empty() ? 2 : -1; sl.err = err; }
+    if (sl.seq == seq && sl.state == 1) { sl.state = err.empty() ? 2 : -1; sl.err = err; }
     c->stage_cv.notify_all();
   }
 }
 
-// The staged copy of (xyz, n, stride), waiting for the copy thread if it is still on its way; nullptr = not staged.
-// A staged copy is consumed by the call that takes it: the caller may refill the same host buffer for a later frame, and a
-// later call without a new so_icp_stage_scan must not see the old contents.  (The HBM buffer itself stays valid until the
-// slot is staged again, i.e. for the whole call that took it.)
+// The staged copy of (xyz, n, stride) -- the NEWEST announcement of that buffer --, waiting for the copy thread if it is still
+// on its way; nullptr = not staged.  A staged copy is consumed by the call that takes it: the caller may refill the same host
+// buffer for a later frame, and a later call without a new so_icp_stage_scan must not see the old contents.  (The HBM buffer
+// itself stays valid until the slot is staged again, i.e. for the whole call that took it.)  A copy that the announcing
+// thread enqueued itself (registered host memory) is awaited by the registration's stream, not by the host.
 const float* take_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, int* rc) {
   *rc = SO_ICP_OK;
   std::unique_lock<std::mutex> lk(c->stage_mu);
   if (!c->stage_started) return nullptr;
+  so_icp_ctx::StageSlot* best = nullptr;
   for (so_icp_ctx::StageSlot& sl : c->stage) {
-    if (sl.state == 0 || sl.src != xyz || sl.n != n || sl.stride != stride_bytes) continue;
-    c->stage_cv.wait(lk, [&] { return sl.state != 1; });
-    const int state = sl.state;
-    sl.src = nullptr;
-    if (state == 2) { sl.state = 3; c->stage_in_use = &sl; return sl.dev.as<float>(); }  // (so_icp_stage_scan -- possibly on another thread -- leaves it alone)
-    sl.state = 0;
-    if (state == -1) { c->err = sl.err; *rc = SO_ICP_E_HIP; }
-    return nullptr;
+    if (sl.state == 0 || sl.state == 3 || sl.src != xyz || sl.n != n || sl.stride != stride_bytes) continue;
+    if (sl.seq < c->stage_consumed_seq) {
+      // announced before a scan that has been consumed since: its frame was skipped, and the caller may have refilled the
+      // buffer meanwhile (allowed once a later so_icp_stage_scan has returned) -- never served
+      c->stage_cv.wait(lk, [&] { return sl.state != 1; });
+      stage_finish_direct(sl);
+      sl.src = nullptr; sl.state = 0;
+      continue;
+    }
+    if (!best || sl.seq > best->seq) best = &sl;
   }
+  if (!best) return nullptr;
+  for (so_icp_ctx::StageSlot& sl : c->stage) {  // older announcements of the same buffer: superseded
+    if (&sl == best || sl.state == 0 || sl.state == 3 || sl.src != xyz || sl.n != n || sl.stride != stride_bytes) continue;
+    c->stage_cv.wait(lk, [&] { return sl.state != 1; });
+    stage_finish_direct(sl);
+    sl.src = nullptr; sl.state = 0;
+  }
+  so_icp_ctx::StageSlot& sl = *best;
+  if (sl.state == 1) {
+    const auto t0 = std::chrono::steady_clock::now();
+    c->stage_cv.wait(lk, [&] { return sl.state != 1; });
+    c->timing.stage_wait_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  const int state = sl.state;
+  sl.src = nullptr;
+  if (state == 2) {
+    if (sl.ev_pending && hipStreamWaitEvent(c->stream, sl.ev, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      stage_finish_direct(sl);  // (cannot order the streams on the device: wait here)
+    }
+    sl.state = 3; c->stage_in_use = &sl; c->stage_consumed_seq = sl.seq;
+    return sl.dev.as<float>();  // (so_icp_stage_scan -- possibly on another thread -- leaves a slot in use alone)
+  }
+  sl.state = 0;
+  if (state == -1) { c->err = sl.err; *rc = SO_ICP_E_HIP; }
   return nullptr;
 }
 // A call that reads (xyz, n, stride) itself -- map seeding -- without consuming a staged copy of it: the copy is dropped, so that
@@ -915,23 +969,26 @@ void drop_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes)
   for (so_icp_ctx::StageSlot& sl : c->stage) {
     if (sl.state == 0 || sl.state == 3 || sl.src != xyz || sl.n != n || sl.stride != stride_bytes) continue;
     c->stage_cv.wait(lk, [&] { return sl.state != 1; });
+    stage_finish_direct(sl);
     sl.src = nullptr; sl.state = 0;
   }
 }
 void release_staged(so_icp_ctx* c) {
   if (!c->stage_in_use) return;
   std::lock_guard<std::mutex> lk(c->stage_mu);
+  c->stage_in_use->ev_pending = false;  // (the registration that read the slot has completed, and the copy before it)
   c->stage_in_use->state = 0;
   c->stage_in_use = nullptr;
 }
 
 // the scan of this call in HBM: the staged copy when the caller announced it, else a plain upload into d_scan_own
+// (enqueued on the registration's own stream in front of its kernels: no host-side wait)
 int resolve_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, const float** d_scan) {
   int rc = SO_ICP_OK;
   c->scan_staged = false;
   if (const float* staged = take_staged(c, xyz, n, stride_bytes ? stride_bytes : 12, &rc)) { c->scan_staged = true; *d_scan = staged; return SO_ICP_OK; }
   if (rc) return rc;
-  rc = upload_scan_impl(c, xyz, n, stride_bytes, c->d_scan_own);
+  rc = upload_scan_impl(c, xyz, n, stride_bytes, c->d_scan_own, /*wait=*/false);
   *d_scan = c->d_scan_own.as<float>();
   return rc;
 }
@@ -1090,7 +1147,9 @@ so_icp_ctx::~so_icp_ctx() {
     stage_cv.notify_all();
     if (stage_thread.joinable()) stage_thread.join();
   }
-  for (StageSlot& sl : stage) { sl.dev.release(); if (sl.pinned) (void)hipHostFree(sl.pinned); }
+  if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+  for (StageSlot& sl : stage) { sl.dev.release(); if (sl.pinned) (void)hipHostFree(sl.pinned); if (sl.ev) (void)hipEventDestroy(sl.ev); }
+  for (const HostRange& r : host_ranges) (void)hipHostUnregister(const_cast<char*>(r.p));
   for (int r = 0; r < 8; ++r) if (peer_opened[r] && peer_inbox[r]) (void)hipIpcCloseMemHandle(peer_inbox[r]);
   if (peer_own) (void)hipFree(peer_own);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -1391,33 +1450,88 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
   NEED_DEVICE(c);
   if (stride_bytes == 0) stride_bytes = 12;
   if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
+  bool queued = false;
   {
     // (this entry point may be called from ANOTHER thread than the registration calls -- the node's feature callback --,
     //  so everything it touches lives under stage_mu)
     std::unique_lock<std::mutex> lk(c->stage_mu);
+    HIP_TRY(c, hipSetDevice(c->cfg.device_id));
     if (!c->stage_started) {
-      HIP_TRY(c, hipSetDevice(c->cfg.device_id));
       HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
       c->stage_thread = std::thread(stage_worker, c);
       c->stage_started = true;
     }
-    // An empty slot if there is one.  Otherwise, while a registration is reading one slot the other holds the scan that is
-    // registered NEXT: it stays, this announcement is declined (SO_ICP_STAGE_DECLINED: the scan will be uploaded by its own
-    // registration call) -- the slot in use becomes free when that registration returns.  With nothing in flight and two
-    // announced scans waiting, the older one gives way (a caller that announces scans it never registers cannot block the slots).
-    int k = c->stage_next;
-    if (c->stage[0].state == 0 || c->stage[0].state == -1) k = 0;
-    else if (c->stage[1].state == 0 || c->stage[1].state == -1) k = 1;
-    else if (c->stage[0].state == 3 || c->stage[1].state == 3) return SO_ICP_STAGE_DECLINED;
-    so_icp_ctx::StageSlot& sl = c->stage[k];
-    c->stage_next = k ^ 1;
-    c->stage_cv.wait(lk, [&] { return sl.state != 1; });  // (a slot still being copied: the caller staged three scans in a row)
-    if (sl.state == 3) return fail(c, SO_ICP_E_INVALID, "so_icp_stage_scan: both staging slots are in use");  // (cannot happen with one registration in flight)
-    sl.src = xyz; sl.n = n; sl.stride = stride_bytes; sl.state = 1; sl.err.clear();
+    // Every earlier announcement has left ITS host buffer when this call returns (the contract of so_icp.h: a staged buffer
+    // stays unchanged until the call that consumes it, or the next so_icp_stage_scan, returns).  In steady state those copies
+    // ended a registration ago and nothing waits here.  The same buffer announced again supersedes its older copy.
+    for (so_icp_ctx::StageSlot& sl : c->stage) {
+      if (sl.state == 1) c->stage_cv.wait(lk, [&] { return sl.state != 1; });
+      if (sl.state == 2 || sl.state == -1) {
+        stage_finish_direct(sl);
+        if (sl.src == xyz || sl.state == -1) { sl.src = nullptr; sl.state = 0; }
+      }
+    }
+    // Slot: an empty one; else a ready copy that was announced BEFORE the scan consumed last (its frame was skipped: it would
+    // never be asked for again), oldest first; else, with no registration in flight, the oldest ready copy gives way (a caller
+    // that announces scans it never registers cannot block the slots).  Otherwise every slot holds a scan that is still
+    // needed -- one being registered, two announced ahead of it: SO_ICP_STAGE_DECLINED (soft: that scan is uploaded by its
+    // own registration call).
+    so_icp_ctx::StageSlot* pick = nullptr;
+    bool in_flight = false;
+    for (so_icp_ctx::StageSlot& sl : c->stage) { if (sl.state == 0 && !pick) pick = &sl; in_flight = in_flight || sl.state == 3; }
+    if (!pick)
+      for (so_icp_ctx::StageSlot& sl : c->stage)
+        if (sl.state == 2 && (sl.seq < c->stage_consumed_seq || !in_flight) && (!pick || sl.seq < pick->seq)) pick = &sl;
+    if (!pick) { c->timing.stage_declined++; return SO_ICP_STAGE_DECLINED; }
+    so_icp_ctx::StageSlot& sl = *pick;
+    sl.src = xyz; sl.n = n; sl.stride = stride_bytes; sl.err.clear(); sl.seq = ++c->stage_seq; sl.ev_pending = false;
+    if (stride_bytes == 12 && n && host_range_registered(c, xyz, n * 12)) {
+      // registered (pinned) host memory, packed xyz: no pack, no copy thread -- the DMA reads the caller's buffer itself
+      sl.state = 0;  // (until the copy is enqueued: an error below leaves the slot empty)
+      HIP_TRY(c, sl.dev.reserve((n + 64) * 12));
+      if (!sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+      HIP_TRY(c, hipMemcpyAsync(sl.dev.p, xyz, n * 12, hipMemcpyHostToDevice, c->copy_stream));
+      HIP_TRY(c, hipEventRecord(sl.ev, c->copy_stream));
+      sl.ev_pending = true; sl.state = 2;
+      c->timing.staged_direct++;
+    } else {
+      sl.state = 1; queued = true;
+      c->timing.staged_copied++;
+    }
   }
-  c->stage_pending.fetch_add(1, std::memory_order_release);
-  if (c->stage_parked.load()) c->stage_cv.notify_all();
+  if (queued) {
+    c->stage_pending.fetch_add(1, std::memory_order_release);
+    if (c->stage_parked.load()) c->stage_cv.notify_all();
+  }
   return SO_ICP_OK;
+}
+
+// Pin a host buffer of the caller (hipHostRegister): scans announced from inside it with stride 12 go to HBM by DMA straight
+// from the buffer.  The node side keeps its feature clouds in a few such buffers.
+int so_icp_host_register(so_icp_ctx* c, const void* ptr, size_t bytes) {
+  if (!c || !ptr || !bytes) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  std::lock_guard<std::mutex> lk(c->stage_mu);
+  if (host_range_registered(c, ptr, bytes)) return SO_ICP_OK;
+  HIP_TRY(c, hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault));
+  c->host_ranges.push_back(so_icp_ctx::HostRange{static_cast<const char*>(ptr), bytes});
+  return SO_ICP_OK;
+}
+int so_icp_host_unregister(so_icp_ctx* c, const void* ptr) {
+  if (!c || !ptr) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  std::unique_lock<std::mutex> lk(c->stage_mu);
+  for (size_t i = 0; i < c->host_ranges.size(); ++i) {
+    if (c->host_ranges[i].p != static_cast<const char*>(ptr)) continue;
+    for (so_icp_ctx::StageSlot& sl : c->stage) stage_finish_direct(sl);  // no copy may still be reading the buffer
+    if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    HIP_TRY(c, hipHostUnregister(const_cast<void*>(ptr)));
+    c->host_ranges.erase(c->host_ranges.begin() + (long)i);
+    return SO_ICP_OK;
+  }
+  return fail(c, SO_ICP_E_INVALID, "so_icp_host_unregister: this pointer was not registered with so_icp_host_register");
 }
 
 int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, size_t n, size_t stride_bytes, const double* poses_in,

@@ -30,6 +30,7 @@
 #define SO_LM_STAMP(dbg, i) do { if (dbg) (dbg)[i] = wall_clock64(); } while (0)
 #endif
 #include "kernels.h"
+#include "plane_fit.h"
 
 namespace soicp {
 
@@ -41,6 +42,8 @@ namespace soicp {
 #define SO_MATCH_MSE 5
 #define SO_MATCH_DROPPED 254  // not sampled / not owned by this rank: never counted, never evaluated
 #define SO_MATCH_PENDING 255  // k-NN done, plane fit not yet (internal hand-off between the two kernels)
+static_assert(SO_FIT_SUCCESS == SO_MATCH_SUCCESS && SO_FIT_BAD_PCA == SO_MATCH_BAD_PCA && SO_FIT_INVALID == SO_MATCH_INVALID && SO_FIT_MSE == SO_MATCH_MSE,
+              "plane_fit.h returns MatchingResult codes");
 
 // ------------------------------------------------------------------------------------------------
 // map addressing
@@ -573,7 +576,10 @@ __device__ __forceinline__ void observability(const double pw[3], const double e
   o0 = b1; o1 = b2; o2 = 6 + t1;
 }
 
-// ComputePlaneDistanceParameters after the neighbour search (LidarSlam.cpp:533-571)
+// ComputePlaneDistanceParameters after the neighbour search (LidarSlam.cpp:533-571) with the reference's own algorithms --
+// column-pivoted Householder for the plane, optionally cyclic Jacobi for the PCA.  Production runs plane_fit5 (plane_fit.h:
+// the closed form of the same least-squares problem); this one is kept behind SOICP_ABLATE = 4096 / 512 (PROF kernels) for A/B
+// runs and for the gate-edge test.
 __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const double pw[3], const Pose& pose,
                                                      const MatchParams& mp, double nd[4], double& coeff, int obs[3], bool jacobi_eig = false) {
   // PCA (LidarSlam.cpp:756-775, utils/superodom_utils.h:143-151)
@@ -1204,6 +1210,24 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 constexpr int kNAcc = 29;  // cost, count, Jtr[6], JtJ[21]
 
+// Which queries a workgroup of the evaluation / solve launches walks: thread `tid` of (virtual) workgroup vb, trip q, grid of V
+// workgroups.  Round 3 gave a workgroup 256 CONSECUTIVE scan points per trip; a sweep's rejected points come in long runs
+// (whole ring segments that see nothing within the gate), so some workgroups fitted 512 planes and others almost none, and
+// the fit pass waited 3.7 us for the slowest (in-kernel stamps).  Now the scan is dealt in SEGMENTS of 64 points (one
+// wavefront's coalesced load): segment (4 q + wave) V + vb -- every workgroup samples the whole sweep evenly.  Every schedule
+// (persistent / per-evaluation launches, batched hypotheses standing in for virtual workgroups) goes through this one
+// function, so their sums stay bit-identical to each other.
+#ifndef SO_QUERY_INTERLEAVE
+#define SO_QUERY_INTERLEAVE 1
+#endif
+__device__ __forceinline__ uint32_t query_of(uint32_t vb, uint32_t V, int tid, uint32_t q) {
+#if SO_QUERY_INTERLEAVE
+  return (((q * 4u + (uint32_t)(tid >> 6)) * V + vb) << 6) + (uint32_t)(tid & 63);
+#else
+  return vb * 256u + (uint32_t)tid + q * V * 256u;
+#endif
+}
+
 // slot 0 evaluates at the outer pose T (lm_begin); slots >= 1 evaluate the candidate requested by the LM
 // controller and are no-ops once the controller has finished (or the registration has converged).
 __device__ __forceinline__ bool eval_slot_active(const DevState* st, int slot) {
@@ -1459,8 +1483,11 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   const double R00 = 1 - (tyy + tzz), R01 = txy - twz, R02 = txz + twy;
   const double R10 = txy + twz, R11 = 1 - (txx + tzz), R12 = tyz - twx;
   const double R20 = txz - twy, R21 = tyz + twx, R22 = 1 - (txx + tyy);
-  // one query: (FIT) plane fit from the prefetched neighbour coordinates, then residual / Jacobian / sums
+  const ObsAxes axes = obs_axes(pose);  // (FIT) sensor axes of the observability analysis: constant over the pass
   // residual, robust weight, Jacobian row and the 29 sums of one accepted correspondence (w* = R p + t)
+  // (s / a^2 as a product with the reciprocal formed once per pass: the IEEE division sequence is ~28 instructions per
+  //  correspondence and evaluation; the quotient feeds the weights only -- the comparison s <= a^2 is on s itself)
+  const double inv_a2 = 1.0 / ep.a2, rho_out = (ep.variant == 0) ? ep.a2 / 6.0 : ep.a2 / 3.0;
   auto tail = [&](double px, double py, double pz, double wx, double wy, double wz, const double4& nd, double c) {
     // (fused multiply-adds from here on: no thresholds downstream, see SO_FMA)
     const double r = SO_FMA(nd.x, wx, SO_FMA(nd.y, wy, SO_FMA(nd.z, wz, nd.w)));  // lidarOptimization.cpp:61
@@ -1468,11 +1495,10 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     const double s = r * r;
     double rho0, rho1;
     if (s <= ep.a2) {
-      const double v = 1.0 - s / ep.a2, v2 = v * v;
-      if (ep.variant == 0) { rho0 = ep.a2 / 6.0 * (1.0 - v2 * v); rho1 = 0.5 * v2; }
-      else { rho0 = ep.a2 / 3.0 * (1.0 - v2 * v); rho1 = v2; }
+      const double v = 1.0 - s * inv_a2, v2 = v * v;
+      rho0 = rho_out * (1.0 - v2 * v); rho1 = (ep.variant == 0) ? 0.5 * v2 : v2;
     } else {
-      rho0 = (ep.variant == 0) ? ep.a2 / 6.0 : ep.a2 / 3.0; rho1 = 0;
+      rho0 = rho_out; rho1 = 0;
     }
     const double w = c * rho1;
     // J = [n^T, -n^T R [p]x] = [n^T, (p x R^T n)^T]  (lidarOptimization.cpp:68-74)
@@ -1513,7 +1539,10 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       int obs[3] = {0, 0, 0};
       if (status == SO_MATCH_PENDING) {
         const double pw[3] = {wx, wy, wz};
-        status = plane_from_neighbours(nb, pw, pose, mp, fnd, fc, obs, PROF && (mp.ablate & 512));
+        // (test switches of the PROF instantiation: 4096 = the reference's column-pivoted Householder factorisation instead of the
+        //  closed form of plane_fit.h, 512 = that plus the cyclic Jacobi eigen-solver)
+        if (PROF && (mp.ablate & (512 | 4096))) status = plane_from_neighbours(nb, pw, pose, mp, fnd, fc, obs, (mp.ablate & 512) != 0);
+        else status = plane_fit5(nb, pw, axes, mp.sq_max_dist_f, mp.max_point_dist, fnd, fc, obs);
       }
       if (status != SO_MATCH_SUCCESS) { fc = 0; fnd[0] = fnd[1] = fnd[2] = fnd[3] = 0; }
       nd = make_double4(fnd[0], fnd[1], fnd[2], fnd[3]);
@@ -1536,7 +1565,6 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     }
     tail(px, py, pz, wx, wy, wz, nd, c);
   };
-  const uint32_t jstride = V * blockDim.x;
   double mine = 0;
   u4v* rec = reinterpret_cast<u4v*>(partials);        // PERSIST: the record table of the pushed workgroup records
   const unsigned int tag = (unsigned int)pass_tag;
@@ -1553,7 +1581,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       // one query per trip (same order of accumulation): half the live registers, so that two workgroups fit a compute unit
       // and their wavefronts hide each other's gather and fp64 latencies -- a batch has the parallelism the single
       // registration lacks
-      for (uint32_t j = vb * blockDim.x + tid; j < n_kept; j += jstride) {
+      for (uint32_t q = 0, j; (j = query_of(vb, V, tid, q)) < n_kept; ++q) {
         const int stq = corr.status[j];
         uint32_t iq[5];
 #pragma unroll
@@ -1567,8 +1595,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
         body(j, stq, nbq, -1);
       }
     } else
-    for (uint32_t jA = vb * blockDim.x + tid; jA < n_kept; jA += 2 * jstride) {
-      const uint32_t jB = jA + jstride;
+    for (uint32_t q = 0, jA; (jA = query_of(vb, V, tid, q)) < n_kept; q += 2) {
+      const uint32_t jB = query_of(vb, V, tid, q + 1u);
       const bool hasB = jB < n_kept;
       const uint32_t jBs = hasB ? jB : jA;
       const int stA = corr.status[jA];
@@ -1601,9 +1629,9 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
         tail(px, py, pz, wx, wy, wz, nd, c);
       }
     }
-    for (uint32_t j = vb * blockDim.x + tid + 2 * jstride; j < n_kept; j += jstride) body(j, corr.status[j], nullptr, -1);
+    for (uint32_t q = 2, j; (j = query_of(vb, V, tid, q)) < n_kept; ++q) body(j, corr.status[j], nullptr, -1);
   } else {
-    for (uint32_t j = vb * blockDim.x + tid; j < n_kept; j += jstride) body(j, corr.status[j], nullptr, -1);
+    for (uint32_t q = 0, j; (j = query_of(vb, V, tid, q)) < n_kept; ++q) body(j, corr.status[j], nullptr, -1);
   }
   if (stamp) t_loop = wall_clock64();
   // workgroup reduction through LDS (transposed: no serial shuffle chains), fixed order
