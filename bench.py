@@ -81,8 +81,10 @@ def main():
     ap.add_argument("--shuffle-scan", action="store_true", help="experiment: random point order inside every scan (worst case for the binning atomics)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the k-NN launches (no roofline)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the kernel-split pass after the timed region (runs under rocprofv3 use it: one registration = one set of launches)")
-    ap.add_argument("--pageable-scans", action="store_true", help="leave the host scan buffers pageable (default: pinned with so_icp_host_register, like a node "
-                                                                  "that keeps its feature clouds in registered buffers): the staged copies then go through the copy thread")
+    ap.add_argument("--scan-buffers", default="pinned", choices=["pinned", "registered", "pageable"],
+                    help="where the HOST scan buffers of the timed loop live: pinned = so_icp_host_alloc (a node that keeps its feature clouds in a pinned "
+                         "pool: DMA straight from them), registered = numpy memory pinned with so_icp_host_register, pageable = plain numpy memory (the "
+                         "staged copies then go through the context's copy thread, which packs them into a pinned buffer first)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,7 +139,9 @@ def main():
     if args.shuffle_scan:
         scans = [np.ascontiguousarray(s_[np.random.default_rng(77 + i).permutation(len(s_))]) for i, s_ in enumerate(scans)]
     guesses = [sc.guess(i) for i in range(args.scans)]
-    if not args.pageable_scans:  # host scan buffers in registered (pinned) memory: so_icp_stage_scan / so_icp_register copy by DMA straight from them
+    if args.scan_buffers == "pinned":      # host scan buffers in pinned memory: so_icp_stage_scan / so_icp_register copy by DMA straight from them
+        scans = [slam.host_alloc_like(s_) for s_ in scans]
+    elif args.scan_buffers == "registered":
         for s_ in scans:
             slam.host_register(s_)
     d_scans = [slam.upload_scan(s) for s in scans]  # resident copies: the secondary / profiling loops and --entry resident
@@ -403,7 +407,8 @@ def main():
                  "stage_wait_ms_per_step": tm.stage_wait_ms_total / max(tm.registrations, 1),
                  "staged_by_dma_from_registered_memory": int(tm.staged_direct), "staged_through_copy_thread": int(tm.staged_copied),
                  "stage_declined": int(tm.stage_declined),
-                 "scan_buffers": "pageable" if args.pageable_scans else "registered host memory (so_icp_host_register)",
+                 "scan_buffers": {"pinned": "pinned host memory (so_icp_host_alloc)", "registered": "registered host memory (so_icp_host_register)",
+                                  "pageable": "pageable"}[args.scan_buffers],
                  "note": "c_abi = wall time inside the registration core (enqueue + wait + post-processing); stage_wait = host time the registrations "
                          "waited for a staged scan still on its way through the copy thread (0 with registered buffers: the registration's first kernel "
                          "waits for the DMA on the device)"},

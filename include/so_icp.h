@@ -83,7 +83,14 @@ typedef struct {
   float line_res, plane_res;    /* localMap.lineRes_/planeRes_ (LM.h:760-761; pushed every frame, lmap.cpp:648-649) */
   double yaw_ratio;             /* OptSet.yaw_ratio (LS.cpp:906) */
   double velocity_failure_threshold; /* OptSet.velocity_failure_threshold (LS.cpp:179) */
+  int32_t shard_mode;           /* world_size > 1: SO_ICP_SHARD_MAP (0) = the map sharded by brick-hash of the voxel grid, queries follow
+                                   their cell's owner (BASELINE configs[3]); SO_ICP_SHARD_QUERIES (1) = the map replicated on every
+                                   rank, the scan's 64-point segments dealt round-robin to the ranks -- equal shares whatever the scene,
+                                   no halo, no re-binning; the same 45-double exchange per evaluation in both */
+  int32_t reserved0;
 } so_icp_config;
+#define SO_ICP_SHARD_MAP 0
+#define SO_ICP_SHARD_QUERIES 1
 
 /* super_odometry_msgs/msg/IterationStats.msg + what LS.cpp:242-251 fills + solver summary */
 typedef struct {
@@ -133,6 +140,7 @@ typedef struct {
 #define SO_ICP_FLAG_SHARDED 0x10u            /* world_size > 1: map shard + collective per evaluation */
 #define SO_ICP_FLAG_STAGED_SCAN 0x20u        /* the scan came from so_icp_stage_scan (upload overlapped with earlier work) */
 #define SO_ICP_FLAG_COPY_READBACK 0x40u      /* state read back with hipMemcpyAsync (SOICP_READBACK=copy) */
+#define SO_ICP_FLAG_QUERY_SPLIT 0x80u        /* world_size > 1 with SO_ICP_SHARD_QUERIES: map replicated, this rank registered its share of the scan */
 
 /* average kernel durations since the last so_icp_reset_timing (HIP events on the context's stream) */
 typedef struct {
@@ -156,6 +164,8 @@ const char *so_icp_last_error(const so_icp_ctx *ctx); /* ctx may be NULL for cre
 int so_icp_abi_version(void);
 /* 1 when a HIP device is usable by this library; the product has NO CPU fallback */
 int so_icp_device_available(void);
+/* HIP devices visible to this process (one process per GPU: device_id = LOCAL_RANK) */
+int so_icp_device_count(void);
 
 /* -------- per-frame knobs (public fields the node writes, lmap.cpp:648-649, 703-711) ---------- */
 /* planeRes may change between frames (auto_voxel_size, lmap.cpp:604-649): the resident points stay as they are, the index
@@ -217,6 +227,10 @@ int so_icp_stage_scan(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t s
  * packed scans that lie inside it by DMA without an intermediate copy.  Unregister before freeing the buffer. */
 int so_icp_host_register(so_icp_ctx *ctx, const void *ptr, size_t bytes);
 int so_icp_host_unregister(so_icp_ctx *ctx, const void *ptr);
+/* Pinned host memory from the HIP runtime's allocator (hipHostMalloc), owned by the context until so_icp_host_free /
+ * so_icp_destroy: a pool for the caller's clouds without a registration call per buffer. */
+int so_icp_host_alloc(so_icp_ctx *ctx, size_t bytes, void **ptr_out);
+int so_icp_host_free(so_icp_ctx *ctx, void *ptr);
 /* same, scan already resident in HBM as packed float xyz (n*3 floats, device pointer) */
 int so_icp_register_dev(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n,
                         const double pose_in[7], double pose_out[7], so_icp_stats *stats);

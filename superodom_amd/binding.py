@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libsoicp.so")
 N_REJECT, N_OBS, MAX_OUTER, UID_BYTES, PEER_HANDLE_BYTES = 7, 9, 16, 128, 80
 
 OK, NOT_ENOUGH_MAP_FEATURES, MAP_SEEDED = 0, 1, 2
+SHARD_MAP, SHARD_QUERIES = 0, 1
 
 
 class Config(C.Structure):
@@ -20,7 +21,7 @@ class Config(C.Structure):
                 ("max_iterations", C.c_int32), ("lm_max_iterations", C.c_int32), ("max_surface_features", C.c_int32),
                 ("k", C.c_int32), ("tukey_variant", C.c_int32), ("time_kernels", C.c_int32),
                 ("line_res", C.c_float), ("plane_res", C.c_float), ("yaw_ratio", C.c_double),
-                ("velocity_failure_threshold", C.c_double)]
+                ("velocity_failure_threshold", C.c_double), ("shard_mode", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class IterStats(C.Structure):
@@ -42,6 +43,7 @@ class Stats(C.Structure):
 
 # so_icp_stats.flags
 FLAG_PER_EVAL_LAUNCHES, FLAG_RETRIED, FLAG_HOST_MAP, FLAG_SORT_BINNING, FLAG_SHARDED, FLAG_STAGED_SCAN, FLAG_COPY_READBACK = 1, 2, 4, 8, 16, 32, 64
+FLAG_QUERY_SPLIT = 128
 
 
 class RegistrationError(C.Structure):
@@ -86,7 +88,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
             "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram",
-            "so_icp_host_register", "so_icp_host_unregister"]
+            "so_icp_host_register", "so_icp_host_unregister", "so_icp_host_alloc", "so_icp_host_free", "so_icp_device_count"]
 
 _lib = None
 
@@ -150,6 +152,8 @@ def load():
     L.so_icp_stage_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
     L.so_icp_host_register.argtypes = [vp, vp, C.c_size_t]
     L.so_icp_host_unregister.argtypes = [vp, vp]
+    L.so_icp_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.so_icp_host_free.argtypes = [vp, vp]
     L.so_icp_debug_match_status.argtypes = [vp, u8p, C.c_size_t]
     L.so_icp_comm_init_inprocess.argtypes = [vp, C.c_uint64]
     L.so_icp_peer_export.argtypes = [vp, u8p]
@@ -284,6 +288,16 @@ class LidarSlamGpu:
         announced from inside it travel to HBM by DMA straight from the array."""
         assert isinstance(arr, np.ndarray) and arr.flags.c_contiguous
         self._check(self.L.so_icp_host_register(self.h, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def host_alloc_like(self, arr):
+        """A copy of `arr` in pinned host memory from so_icp_host_alloc (numpy view; valid until close())."""
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        self._check(self.L.so_icp_host_alloc(self.h, arr.nbytes, C.byref(p)))
+        buf = (C.c_char * arr.nbytes).from_address(p.value)
+        out = np.frombuffer(buf, dtype=arr.dtype).reshape(arr.shape)
+        out[...] = arr
+        return out
 
     def host_unregister(self, arr):
         self._check(self.L.so_icp_host_unregister(self.h, arr.ctypes.data_as(C.c_void_p)))
@@ -467,6 +481,10 @@ def registration_error(stats):
     out = RegistrationError()
     rc = load().so_icp_registration_error(C.byref(stats), C.byref(out))
     return out if rc == 0 else None
+
+
+def device_count():
+    return int(load().so_icp_device_count())
 
 
 def comm_unique_id():

@@ -11,11 +11,14 @@
 
 namespace soicp {
 
+// (member functions only.  An error exit may come between a round's counting kernel and the kernel that zeroes the counters
+//  again, or behind a clear that was only enqueued: the "already clean" marks are withdrawn, the next round fills everything)
 #define DM_TRY(expr)                                                      \
   do {                                                                    \
     hipError_t e__ = (expr);                                              \
     if (e__ != hipSuccess) {                                              \
       err = std::string(#expr) + ": " + hipGetErrorString(e__);           \
+      grid_zero_upto_ = 0; block_clean_ = false;                          \
       return -2;                                                          \
     }                                                                     \
   } while (0)
@@ -207,7 +210,12 @@ int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err)
     if (d_cell_start_) (void)hipFree(d_cell_start_);
     d_cell_start_ = nullptr;
     ncell1_ = new_ncell1;
-    if (slots_alloc_) DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cell_start_), (size_t)slots_alloc_ * ncell1_ * sizeof(uint32_t)));
+    if (slots_alloc_) {
+      DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cell_start_), (size_t)slots_alloc_ * ncell1_ * sizeof(uint32_t)));
+      // (a slot that is allocated but holds no point of this rank -- an empty shard after a re-cut -- must read "no points",
+      //  not whatever the allocation held)
+      DM_TRY(hipMemsetAsync(d_cell_start_, 0, (size_t)slots_alloc_ * ncell1_ * sizeof(uint32_t), stream_));
+    }
   }
   if (!had) return 0;
   std::vector<int> occupied;
@@ -366,7 +374,9 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
       const uint32_t sl = tt.slot[t];
       one_point_per_leaf = one_point_per_leaf && (slot_count_[sl] == 0 || slot_res_[sl] == plane_res_);
       // a cube last filtered on another grid (or marked by the drift watch: negative) goes in in the order of THAT grid's leaves
-      a.old_inv_leaf[t] = (slot_count_[sl] > 0 && slot_res_[sl] != 0.f && slot_res_[sl] != plane_res_) ? 1.0f / std::fabs(slot_res_[sl]) : 0.f;
+      // (a cube the drift watch marked at the CURRENT planeRes keeps pool order: its (cell, leaf) order is the output order of its
+      //  last VoxelGrid on this very grid, whereas re-keying the drifted centroid would file it under the neighbouring leaf)
+      a.old_inv_leaf[t] = (slot_count_[sl] > 0 && slot_res_[sl] != 0.f && std::fabs(slot_res_[sl]) != plane_res_) ? 1.0f / std::fabs(slot_res_[sl]) : 0.f;
       a.reorder_old = a.reorder_old || a.old_inv_leaf[t] > 0.f;
     }
     if (hash_grouping_ && one_point_per_leaf) {

@@ -97,13 +97,13 @@ struct InprocGroup {
   int world = 0, arrived = 0, members = 0; unsigned long long generation = 0;
   // A round is identified by (kind, size): members that disagree about what is being summed -- one in the LmSums reduce, another
   // in the per-cube counts after a failed insert -- must not be paired silently; a member that returns early (a failed HIP call
-  // before the exchange) or never arrives makes the round fail on every member instead of blocking the others for ever.
+  // before the exchange) or never arrives (wait_seconds) makes the round fail on every member instead of blocking the others for ever.
   int round_kind = -1; size_t round_size = 0; bool aborted = false;
-  static constexpr int kWaitSeconds = 60;
+  int wait_seconds = 60;  // patience with a member that has not arrived (first-call code-object load, a debugger): SOICP_GROUP_TIMEOUT_S
   std::vector<LmSums> slot; LmSums total{};
   std::vector<std::vector<int32_t>> islot; std::vector<int32_t> itotal;
   void abort_all() { std::lock_guard<std::mutex> lk(mu); aborted = true; cv.notify_all(); }
-  // returns false when the round failed (mismatch, abort, or a member missing for kWaitSeconds): the group is unusable afterwards
+  // returns false when the round failed (mismatch, abort, or a member missing for wait_seconds): the group is unusable afterwards
   template <class Publish, class Combine>
   bool round(int kind, size_t size, Publish&& publish, Combine&& combine) {
     std::unique_lock<std::mutex> lk(mu);
@@ -118,7 +118,7 @@ struct InprocGroup {
       return true;
     }
     const unsigned long long g = generation;
-    const bool done = cv.wait_for(lk, std::chrono::seconds(kWaitSeconds), [&] { return generation != g || aborted; });
+    const bool done = cv.wait_for(lk, std::chrono::seconds(wait_seconds), [&] { return generation != g || aborted; });
     if (!done || aborted) { aborted = true; cv.notify_all(); return false; }
     return true;
   }
@@ -264,12 +264,15 @@ struct so_icp_ctx {
   std::atomic<int> stage_pending{0};      // queued slots the copy thread has not picked up yet
   std::atomic<bool> stage_parked{false};  // the copy thread sleeps on stage_cv (it spins for a while after every job first)
   std::thread stage_thread; std::mutex stage_mu; std::condition_variable stage_cv;
-  struct HostRange { const char* p; size_t bytes; };
-  std::vector<HostRange> host_ranges;     // so_icp_host_register (under stage_mu)
+  struct HostRange { const char* p; size_t bytes; bool owned; };
+  std::vector<HostRange> host_ranges;     // so_icp_host_register / so_icp_host_alloc (under stage_mu)
+  bool stage_wait_on_host = false;        // SOICP_STAGE_WAIT=host: the registration thread waits for a DMA-staged copy itself (measurement aid)
   hipStream_t copy_stream = nullptr;
   bool retried = false;       // the current registration is the repeat of an abandoned one
   unsigned long long peer_timeout_ticks = 100000000ull;  // 1 s at 100 MHz: patience of a solve launch with the peer exchange (SOICP_PEER_TIMEOUT_MS)
   bool scan_staged = false;   // the scan of the current registration came from a stage slot
+  bool query_split = false;   // world_size > 1, SO_ICP_SHARD_QUERIES: map replicated, the scan's 64-point segments dealt to the ranks
+  DevBuf d_sub;               //   this rank's share of the current scan, gathered
 
   ~so_icp_ctx();
 };
@@ -404,7 +407,7 @@ const int* map_origin(const so_icp_ctx* c) { return c->dmap ? c->dmap->origin() 
 int upload_map(so_icp_ctx* c) {
   if (c->dmap) return c->dmap->view(c->view, c->err) ? SO_ICP_OK : SO_ICP_E_HIP;
   if (c->uploaded_version == c->map.version()) return SO_ICP_OK;
-  c->map.build_canonical(c->cfg.rank, c->cfg.world_size, c->cm);
+  c->map.build_canonical(c->query_split ? 0 : c->cfg.rank, c->query_split ? 1 : c->cfg.world_size, c->cm);
   const CanonicalMap& m = c->cm;
   const size_t n = m.n_points();
   HIP_TRY(c, c->d_mpts.reserve((n + 16) * 16));
@@ -547,7 +550,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // (kernels.hip: bin_offsets_kernel / knn_plane_kernel)
   if (n >= ((size_t)1 << 21)) return fail(c, SO_ICP_E_UNSUPPORTED, "scan of 2^21 points or more: the work-list counters hold 21 bits each (chunk descriptors 26)");
   st->flags = (c->retried ? SO_ICP_FLAG_RETRIED : 0u) | (!c->dmap && !c->borrow.on ? SO_ICP_FLAG_HOST_MAP : 0u) |
-              (c->cfg.world_size > 1 ? SO_ICP_FLAG_SHARDED : 0u) |
+              (c->cfg.world_size > 1 ? SO_ICP_FLAG_SHARDED : 0u) | (c->query_split ? SO_ICP_FLAG_QUERY_SPLIT : 0u) |
               (c->scan_staged ? SO_ICP_FLAG_STAGED_SCAN : 0u) | (c->direct_readback ? 0u : SO_ICP_FLAG_COPY_READBACK);
   double T[7];
   std::memcpy(T, pose_in, sizeof(T));  // LidarSlam.cpp:53-57 (T_w_initial_guess = last_T_w_lidar = T_w_lidar = the guess)
@@ -566,6 +569,23 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   int rc = SO_ICP_OK;
   if (c->borrow.on) c->view = c->borrow.view; else rc = upload_map(c);
   if (rc) return rc;
+  // SO_ICP_SHARD_QUERIES: this rank registers ITS share of the scan -- the 64-point segments rank, rank + world, ... (a 128-ring
+  // sweep in ring-major order gives every rank two 22.5-degree sectors of every ring: spatially compact, so its k-NN chunks are
+  // as full as the whole scan's) -- gathered into one array by a strided device copy; from here on the registration is a
+  // single-device one over n_own points, except that the sums of every evaluation are exchanged with the other ranks.
+  const bool qsplit = c->query_split && !c->batch_mode && !c->borrow.on;
+  const size_t n_total = n;
+  if (qsplit) {
+    const size_t W = (size_t)c->cfg.world_size, r = (size_t)c->cfg.rank, s_full = n / 64, tail = n % 64;
+    const size_t own_full = s_full > r ? (s_full - r + W - 1) / W : 0;
+    const bool own_tail = tail != 0 && (s_full % W) == r;  // (the partial last segment is segment number s_full)
+    const size_t n_own = own_full * 64 + (own_tail ? tail : 0);
+    HIP_TRY(c, c->d_sub.reserve((n_own + 64) * 12));
+    if (own_full) HIP_TRY(c, hipMemcpy2DAsync(c->d_sub.p, 768, d_scan + r * 192, W * 768, 768, own_full, hipMemcpyDeviceToDevice, c->stream));
+    if (own_tail) HIP_TRY(c, hipMemcpyAsync(c->d_sub.as<float>() + own_full * 192, d_scan + s_full * 192, tail * 12, hipMemcpyDeviceToDevice, c->stream));
+    d_scan = c->d_sub.as<float>();
+    n = n_own;
+  }
   rc = reserve_scan_buffers(c, n);
   if (rc) return rc;
   const auto t_icp = std::chrono::steady_clock::now();  // TicToc t_opt, LidarSlam.cpp:118
@@ -593,7 +613,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     bt = BinTable{c->d_bin_key.as<uint32_t>(), c->d_bin_cnt.as<uint32_t>(), c->d_bin_off.as<uint32_t>(), lg};
     c->bin_dirty = true;  // until bin_offsets has been enqueued behind scan_keys
     launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
-                     c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), bt, s);
+                     c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), bt, s, false, nullptr, 0,
+                     qsplit, (uint32_t)n_total);
     launch_bin_offsets(bt, c->d_chunks.as<uint32_t>(), (uint32_t)(c->d_chunks.cap / 4), ds, s);
     c->bin_dirty = false;
     launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(),
@@ -664,7 +685,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     return SO_ICP_OK;
   };
   auto enqueue_outer_a = [&](int it) -> int {
-    if (it > 0 && c->cfg.world_size > 1 && n) {
+    if (it > 0 && c->cfg.world_size > 1 && n && !qsplit) {
       // sharded map: ownership follows the query's cell under the CURRENT pose, so the scan is re-binned at the start of
       // every outer iteration (a 1 degree correction at 50 m moves a point by more than the one-cell halo of a shard)
       launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
@@ -808,7 +829,10 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
     c->retried = false;
     if (rc == kRetryWithoutPersistentSolve) rc = fail(c, SO_ICP_E_HIP, "registration state was not published by the device");
   }
-  if (rc < 0 && c->group) c->group->abort_all();  // the other members of an in-process group must not wait for this one's next exchange
+  // The other members of an in-process group must not wait for this one's next exchange -- when this one FAILED MID-SEQUENCE (a
+  // device or exchange error).  A call refused on its arguments (scan too large, bad stride: checked before anything is
+  // enqueued or exchanged, and refused alike on every member, which all pass the same scan) leaves the group usable.
+  if ((rc == SO_ICP_E_HIP || rc == SO_ICP_E_RCCL) && c->group) c->group->abort_all();
   return rc;
 }
 
@@ -897,12 +921,17 @@ void stage_worker(so_icp_ctx* c) {
         e = hipHostMalloc(reinterpret_cast<void**>(&sl.pinned), n * 12 + 4096);
         if (e == hipSuccess) sl.pinned_cap = n * 12 + 4096;
       }
-      if (e == hipSuccess) {
-        const size_t sf = stride / 4;
-        if (sf == 3) std::memcpy(sl.pinned, src, n * 12);
-        else for (size_t i = 0; i < n; ++i) { sl.pinned[3 * i] = src[i * sf]; sl.pinned[3 * i + 1] = src[i * sf + 1]; sl.pinned[3 * i + 2] = src[i * sf + 2]; }
+      // pack and copy in pieces of 16 384 points (192 KB): the DMA of a piece runs while the next one is being packed, so a
+      // scan is in HBM after max(pack, DMA) + one piece instead of pack + DMA (it matters for the one copy nothing hides:
+      // the first of a run)
+      const size_t sf = stride / 4, piece = 16384;
+      for (size_t i0 = 0; i0 < n && e == hipSuccess; i0 += piece) {
+        const size_t m = std::min(piece, n - i0);
+        float* dst = sl.pinned + 3 * i0;
+        if (sf == 3) std::memcpy(dst, src + 3 * i0, m * 12);
+        else for (size_t i = 0; i < m; ++i) { const float* p = src + (i0 + i) * sf; dst[3 * i] = p[0]; dst[3 * i + 1] = p[1]; dst[3 * i + 2] = p[2]; }
+        e = hipMemcpyAsync(sl.dev.as<float>() + 3 * i0, dst, m * 12, hipMemcpyHostToDevice, c->copy_stream);
       }
-      if (e == hipSuccess) e = hipMemcpyAsync(sl.dev.p, sl.pinned, n * 12, hipMemcpyHostToDevice, c->copy_stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
     }
     if (e != hipSuccess) err = std::string("so_icp_stage_scan: ") + hipGetErrorString(e);
@@ -950,6 +979,7 @@ const float* take_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t strid
   const int state = sl.state;
   sl.src = nullptr;
   if (state == 2) {
+    if (sl.ev_pending && c->stage_wait_on_host) stage_finish_direct(sl);
     if (sl.ev_pending && hipStreamWaitEvent(c->stream, sl.ev, 0) != hipSuccess) {
       (void)hipGetLastError();
       stage_finish_direct(sl);  // (cannot order the streams on the device: wait here)
@@ -1075,7 +1105,10 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
   ep.timeout_ticks = 20000000ull;  // 200 ms: a pass of one hypothesis on a few workgroups lasts up to a millisecond
   const uint32_t v_grid = solve_grid((uint32_t)n, (uint32_t)c->n_cus);
   const uint32_t resident = solve_batch_resident_blocks((uint32_t)c->n_cus, c->batch_degrade >= 1 ? 1 : 0);
-  if (resident < (uint32_t)B) return fail(c, SO_ICP_E_HIP, "so_icp_register_batch: fewer resident solve workgroups than hypotheses");
+  if (resident < (uint32_t)B) {  // (the driver below sizes its groups by the resident workgroups; this is the second line of defence)
+    c->err = "so_icp_register_batch: fewer resident solve workgroups (" + std::to_string(resident) + ") than hypotheses in the group (" + std::to_string(B) + ")";
+    return kRetryWithoutPersistentSolve;  // degrade (fewer workgroups per hypothesis is not possible: one each) -> concurrent sequential registrations
+  }
   BatchView bv{b.active.as<uint32_t>(), b.begin.as<RegBeginArgs>(), b.bs, (uint32_t)((size_t)1 << lg),
                (uint32_t)((size_t)kFitBlocksMax * kRecordChunksMax * 2), (uint32_t)(kSyncBytes / 4), 1u, v_grid};
   const BinTable bt{b.bin_key.as<uint32_t>(), b.bin_cnt.as<uint32_t>(), b.bin_off.as<uint32_t>(), lg};
@@ -1149,7 +1182,7 @@ so_icp_ctx::~so_icp_ctx() {
   }
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   for (StageSlot& sl : stage) { sl.dev.release(); if (sl.pinned) (void)hipHostFree(sl.pinned); if (sl.ev) (void)hipEventDestroy(sl.ev); }
-  for (const HostRange& r : host_ranges) (void)hipHostUnregister(const_cast<char*>(r.p));
+  for (const HostRange& r : host_ranges) { if (r.owned) (void)hipHostFree(const_cast<char*>(r.p)); else (void)hipHostUnregister(const_cast<char*>(r.p)); }
   for (int r = 0; r < 8; ++r) if (peer_opened[r] && peer_inbox[r]) (void)hipIpcCloseMemHandle(peer_inbox[r]);
   if (peer_own) (void)hipFree(peer_own);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -1159,7 +1192,7 @@ so_icp_ctx::~so_icp_ctx() {
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_vals0, &d_vals1, &d_chunks,
                     &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist, &d_kdbg, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
-                    &pf_heads, &pf_temp, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_counts})
+                    &pf_heads, &pf_temp, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_counts, &d_sub})
     b->release();
   for (DevBuf& b : resident_scans) b.release();
   d_state_buf.release();
@@ -1198,6 +1231,12 @@ void so_icp_default_config(so_icp_config* cfg) {
 int so_icp_device_available(void) {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+int so_icp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
 }
 
 const char* so_icp_last_error(const so_icp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -1265,11 +1304,14 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_ABLATE")) c->ablate = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_STAGE_WAIT")) c->stage_wait_on_host = std::string(ev) == "host";
   if (const char* ev = std::getenv("SOICP_BATCH_WG_PER_CU")) { if (std::atoi(ev) == 1) c->batch_degrade = 1; }  // (several processes on one device)
   if (const char* ev = std::getenv("SOICP_BATCH_MODE")) { if (std::string(ev) == "lanes") c->batch_degrade = 2; }
   const bool want_dmap = !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
   if (want_dmap) {  // world_size > 1: this rank's shard of the map, resident and updated on the device like the whole map is
-    c->dmap = std::make_unique<DeviceMap>(c->stream, cfg->rank, cfg->world_size);
+    c->query_split = cfg->world_size > 1 && cfg->shard_mode == SO_ICP_SHARD_QUERIES;
+    if (c->query_split) c->dmap = std::make_unique<DeviceMap>(c->stream, 0, 1);  // the whole map on every rank
+    else c->dmap = std::make_unique<DeviceMap>(c->stream, cfg->rank, cfg->world_size);
     if (!c->dmap->supported_resolution(cfg->plane_res)) c->dmap.reset();  // leaf keys hold 9 bits per axis
     else { std::string e2; c->dmap->set_resolution(cfg->line_res, cfg->plane_res, e2); }
   }
@@ -1289,7 +1331,7 @@ int so_icp_set_resolution(so_icp_ctx* c, float line_res, float plane_res) {
   if (c->dmap && !c->dmap->supported_resolution(plane_res)) return fail(c, SO_ICP_E_UNSUPPORTED, "device map needs plane_res >= 0.05 (leaf coordinates of the grouping keys hold 10 bits)");
   // ("non-empty" must be the same decision on every rank: the FULL map's count, which the ranks share after any insert under the
   //  communicator -- a rank whose own shard happens to be empty still takes part in the exchange)
-  if (c->dmap && c->cfg.world_size > 1 && plane_res != map_plane_res(c) &&
+  if (c->dmap && c->dmap->sharded() && c->cfg.world_size > 1 && plane_res != map_plane_res(c) &&
       ((c->group || c->comm) ? c->dmap->size() : c->dmap->size_local()) > 0) {
     // A shard holds the leaves within one CELL of the bricks it owns, and cell size and bricks follow planeRes: after a
     // change the resident subset would no longer cover the gate balls of the rank's queries (wrong neighbours, silently).
@@ -1515,9 +1557,22 @@ int so_icp_host_register(so_icp_ctx* c, const void* ptr, size_t bytes) {
   std::lock_guard<std::mutex> lk(c->stage_mu);
   if (host_range_registered(c, ptr, bytes)) return SO_ICP_OK;
   HIP_TRY(c, hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterDefault));
-  c->host_ranges.push_back(so_icp_ctx::HostRange{static_cast<const char*>(ptr), bytes});
+  c->host_ranges.push_back(so_icp_ctx::HostRange{static_cast<const char*>(ptr), bytes, false});
   return SO_ICP_OK;
 }
+// Pinned host memory from the runtime's own allocator (hipHostMalloc) for the caller's clouds: the fastest DMA source.
+int so_icp_host_alloc(so_icp_ctx* c, size_t bytes, void** out) {
+  if (!c || !out || !bytes) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  void* p = nullptr;
+  HIP_TRY(c, hipHostMalloc(&p, bytes));
+  std::lock_guard<std::mutex> lk(c->stage_mu);
+  c->host_ranges.push_back(so_icp_ctx::HostRange{static_cast<const char*>(p), bytes, true});
+  *out = p;
+  return SO_ICP_OK;
+}
+int so_icp_host_free(so_icp_ctx* c, void* ptr) { return so_icp_host_unregister(c, ptr); }
 int so_icp_host_unregister(so_icp_ctx* c, const void* ptr) {
   if (!c || !ptr) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);
@@ -1527,11 +1582,11 @@ int so_icp_host_unregister(so_icp_ctx* c, const void* ptr) {
     if (c->host_ranges[i].p != static_cast<const char*>(ptr)) continue;
     for (so_icp_ctx::StageSlot& sl : c->stage) stage_finish_direct(sl);  // no copy may still be reading the buffer
     if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-    HIP_TRY(c, hipHostUnregister(const_cast<void*>(ptr)));
+    if (c->host_ranges[i].owned) HIP_TRY(c, hipHostFree(const_cast<void*>(ptr))); else HIP_TRY(c, hipHostUnregister(const_cast<void*>(ptr)));
     c->host_ranges.erase(c->host_ranges.begin() + (long)i);
     return SO_ICP_OK;
   }
-  return fail(c, SO_ICP_E_INVALID, "so_icp_host_unregister: this pointer was not registered with so_icp_host_register");
+  return fail(c, SO_ICP_E_INVALID, "so_icp_host_unregister / so_icp_host_free: this pointer did not come from so_icp_host_register / so_icp_host_alloc");
 }
 
 int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, size_t n, size_t stride_bytes, const double* poses_in,
@@ -1558,8 +1613,13 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
     // batched kernels: groups of up to kBatchMaxConcurrent hypotheses advance together (kernels.hip, BatchView)
     const int count = map_count_5x5(c, pos);
     std::vector<int32_t> hrc((size_t)n_hyp, 0);
-    for (int base = 0; base < n_hyp; base += kBatchMaxConcurrent) {
-      const int B = std::min(kBatchMaxConcurrent, n_hyp - base);
+    for (int base = 0; base < n_hyp;) {
+      // a group never holds more hypotheses than solve workgroups can be resident together (one workgroup per hypothesis at
+      // least): on a device with few compute units -- SOICP_SOLVE_WORKGROUPS, a partitioned device, one workgroup per unit after
+      // a failed co-residency wait -- the batch goes through in smaller groups instead of failing
+      const int cap = (int)std::min<uint32_t>((uint32_t)kBatchMaxConcurrent, solve_batch_resident_blocks((uint32_t)c->n_cus, c->batch_degrade >= 1 ? 1 : 0));
+      if (cap < 1) { c->batch_degrade = 2; break; }
+      const int B = std::min(cap, n_hyp - base);
       rc = register_batch_group(c, scan, n, poses_in + 7 * (size_t)base, B, poses_out + 7 * (size_t)base, stats ? stats + base : nullptr,
                                 hrc.data() + base, pos, count);
       // A batched solve launch needs its workgroups resident together.  If the device could not provide that (shared with another
@@ -1568,10 +1628,11 @@ int so_icp_register_batch(so_icp_ctx* c, const float* xyz, const void* d_scan, s
       if (rc == kRetryWithoutPersistentSolve) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->batch.tables_clean = false;
-        if (++c->batch_degrade <= 1) { base -= kBatchMaxConcurrent; continue; }
+        if (++c->batch_degrade <= 1) continue;  // (the same group again)
         break;
       }
       if (rc < 0) return rc;
+      base += B;
     }
     if (c->batch_degrade < 2) {
       int ok = 0;
@@ -2023,6 +2084,7 @@ int so_icp_comm_init_inprocess(so_icp_ctx* c, uint64_t group_key) {
   for (auto& kv : g_groups) if (kv.first == group_key) g = kv.second;
   if (!g) {
     g = std::make_shared<InprocGroup>();
+    if (const char* ev = std::getenv("SOICP_GROUP_TIMEOUT_S")) { const int t = std::atoi(ev); if (t >= 1) g->wait_seconds = t; }
     g->world = c->cfg.world_size; g->slot.resize((size_t)g->world);
     g_groups.emplace_back(group_key, g);
   }

@@ -166,7 +166,10 @@ void launch_scan_keys(const float* d_scan_xyz, uint32_t n, DevState* st, const d
                       uint32_t* d_vals, uint8_t* d_status /* SO_MATCH_DROPPED for queries that are not processed */,
                       const BinTable& bin /* d_keys / d_vals receive the query's table slot / rank inside its bucket */, hipStream_t s,
                       bool rebin = false /* sharded map, outer iteration >= 1: keys under the CURRENT device-resident pose, no prologue */,
-                      const BatchView* bv = nullptr, uint32_t n_hyp = 0);
+                      const BatchView* bv = nullptr, uint32_t n_hyp = 0,
+                      bool qsplit = false /* N > 1 with the QUERIES split: d_scan is this rank's share (64-point segments rank, rank + world,
+                                             ... of a scan of n_total points); every query is owned, the sampling rule uses the global index */,
+                      uint32_t n_total = 0);
 void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* d_perm,
                       const uint32_t* d_chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
                       CorrBuffers corr, uint32_t* d_nbr5 /*5 canonical indices per query*/,

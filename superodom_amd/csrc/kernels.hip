@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
                                                         DevMapView map,
                                                         int max_surface_features, int rank, int world,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint8_t* __restrict__ status, BinTable bt, int rebin, BatchView bv) {
+                                                        uint8_t* __restrict__ status, BinTable bt, int rebin, BatchView bv,
+                                                        int qsplit, uint32_t n_total) {
   if (BATCH) {
     const uint32_t h = bv.active[blockIdx.y];
     st += h; hist += (size_t)h * (kHistReplicas * kHistStride);
@@ -146,9 +147,15 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   const uint32_t kDropped = (map.n_slots + 1u) << cell_bits, kNoCube = map.n_slots << cell_bits;
   uint32_t key = kDropped;
   bool process = true;
-  if (max_surface_features >= 0 && n > (uint32_t)max_surface_features) {  // calculateSamplingRate / shouldProcessPoint (0: rate 0, every point dropped)
-    const double rate = 1.0 * max_surface_features / n;
-    const double rem = fmod((double)i * rate, 1.0);
+  // qsplit (N > 1, map replicated, QUERIES split): `scan` is this rank's share of the scan -- its 64-point segments rank, rank +
+  // world, ... gathered into one array (icp_context.cpp) --, every query of it is this rank's, and the sampling rule runs on the
+  // point's index in the WHOLE scan of n_total points
+  const uint32_t gi = qsplit ? ((((i >> 6) * (uint32_t)world + (uint32_t)rank) << 6) + (i & 63u)) : i;
+  const uint32_t ntot = qsplit ? n_total : n;
+  const bool own_all = qsplit || world <= 1;
+  if (max_surface_features >= 0 && ntot > (uint32_t)max_surface_features) {  // calculateSamplingRate / shouldProcessPoint (0: rate 0, every point dropped)
+    const double rate = 1.0 * max_surface_features / ntot;
+    const double rem = fmod((double)gi * rate, 1.0);
     if (rem + 0.001 > rate) process = false;
   }
   if (process) {
@@ -159,10 +166,10 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
     int w[3];
     const CellRef c = locate(map, qx, qy, qz, w);
     if (c.slot < 0) {
-      key = (rank == 0) ? kNoCube : kDropped;  // counted once (NOT_ENOUGH_NEIGHBORS) by rank 0
+      key = (own_all || rank == 0) ? kNoCube : kDropped;  // counted once (NOT_ENOUGH_NEIGHBORS): by rank 0 when the MAP is sharded
     } else {
-      int owner = 0;
-      if (world > 1) owner = (int)(brick_hash(w[0], w[1], w[2], c.cx / kBrickCells, c.cy / kBrickCells, c.cz / kBrickCells) % (uint32_t)world);
+      int owner = rank;
+      if (!own_all) owner = (int)(brick_hash(w[0], w[1], w[2], c.cx / kBrickCells, c.cy / kBrickCells, c.cz / kBrickCells) % (uint32_t)world);
       if (owner == rank && cell_bits == 18) key = ((uint32_t)c.slot << 18) | morton3((uint32_t)c.cx, (uint32_t)c.cy, (uint32_t)c.cz);
       else if (owner == rank) {
         // Morton code of the HALF-cell: its three low bits are the octant of the cell the query sits in, so that a
@@ -1211,22 +1218,14 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
 constexpr int kNAcc = 29;  // cost, count, Jtr[6], JtJ[21]
 
 // Which queries a workgroup of the evaluation / solve launches walks: thread `tid` of (virtual) workgroup vb, trip q, grid of V
-// workgroups.  Round 3 gave a workgroup 256 CONSECUTIVE scan points per trip; a sweep's rejected points come in long runs
-// (whole ring segments that see nothing within the gate), so some workgroups fitted 512 planes and others almost none, and
-// the fit pass waited 3.7 us for the slowest (in-kernel stamps).  Now the scan is dealt in SEGMENTS of 64 points (one
-// wavefront's coalesced load): segment (4 q + wave) V + vb -- every workgroup samples the whole sweep evenly.  Every schedule
-// (persistent / per-evaluation launches, batched hypotheses standing in for virtual workgroups) goes through this one
-// function, so their sums stay bit-identical to each other.
-#ifndef SO_QUERY_INTERLEAVE
-#define SO_QUERY_INTERLEAVE 1
-#endif
-__device__ __forceinline__ uint32_t query_of(uint32_t vb, uint32_t V, int tid, uint32_t q) {
-#if SO_QUERY_INTERLEAVE
-  return (((q * 4u + (uint32_t)(tid >> 6)) * V + vb) << 6) + (uint32_t)(tid & 63);
-#else
-  return vb * 256u + (uint32_t)tid + q * V * 256u;
-#endif
-}
+// workgroups -- 256 consecutive scan points per workgroup and trip.  With V >= n / 256 every workgroup makes one trip over
+// the same 256 points whatever V is, so launches with different grids (the per-evaluation launches use 256 workgroups for
+// slots >= 1, the persistent and batched solves the grid of slot 0) add up the same records: bit-identical sums.
+// (Round 4 measured the alternative -- the scan dealt in 64-point segments, segment (4 q + wave) V + vb, so that every
+//  workgroup samples the whole sweep: the fit pass's wait for its slowest workgroup did not shrink (3.3 -> 4.5 us in the
+//  in-kernel stamps: it is the start skew of the 256 workgroups, not rejected ring segments -- 94 % of this scene's points
+//  are accepted), and the sums became grid-dependent.  Not kept.)
+__device__ __forceinline__ uint32_t query_of(uint32_t vb, uint32_t V, int tid, uint32_t q) { return vb * 256u + (uint32_t)tid + q * V * 256u; }
 
 // slot 0 evaluates at the outer pose T (lm_begin); slots >= 1 evaluate the candidate requested by the LM
 // controller and are no-ops once the controller has finished (or the registration has converged).
@@ -2162,19 +2161,19 @@ void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_
 static const BatchView kNoBatch{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
 void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist,
                       const DevMapView& map, int max_sf, int rank, int world, uint32_t* keys, uint32_t* vals, uint8_t* status,
-                      const BinTable& bin, hipStream_t s, bool rebin, const BatchView* bv, uint32_t n_hyp) {
+                      const BinTable& bin, hipStream_t s, bool rebin, const BatchView* bv, uint32_t n_hyp, bool qsplit, uint32_t n_total) {
   RegBeginArgs a{};
   if (bv) {  // (the hypotheses' prologue arguments are in bv->begin)
     if (!n || !n_hyp) return;
     hipLaunchKernelGGL(scan_keys_kernel<true>, dim3((n + 255u) / 256u, n_hyp), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world,
-                       keys, vals, status, bin, 0, *bv);
+                       keys, vals, status, bin, 0, *bv, 0, n);
     return;
   }
   if (!n) { if (!rebin) launch_reg_begin(st, pose, max_outer, lm_max, hist, s); return; }
   for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
   a.max_outer = max_outer; a.lm_max = lm_max;
   hipLaunchKernelGGL(scan_keys_kernel<false>, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals, status,
-                     bin, rebin ? 1 : 0, kNoBatch);
+                     bin, rebin ? 1 : 0, kNoBatch, qsplit ? 1 : 0, qsplit ? n_total : n);
 }
 void launch_bin_offsets(const BinTable& bt, uint32_t* chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s, const BatchView* bv,
                         uint32_t n_hyp) {
