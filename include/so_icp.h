@@ -214,14 +214,18 @@ int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t str
  * it on the device.  Anything else (pageable memory, strided pcl::PointXYZI records) is packed into a pinned buffer by the
  * context's copy thread first.  A following so_icp_register / so_icp_localization with the SAME (scan_xyz, n, stride_bytes)
  * consumes the staged copy instead of uploading again (so_icp_stats::flags carries SO_ICP_FLAG_STAGED_SCAN); any other call
- * simply ignores it.  The caller's buffer must stay valid and unchanged until that call (or the next so_icp_stage_scan)
- * returns.  Three slots: two scans may be announced ahead of the one being registered; a further announcement returns
+ * simply ignores it.  The caller's buffer must stay valid and unchanged until that call returns (a DMA copy reads it when the
+ * registration in flight has its launches in the queue, or 300 us after the announcement, whichever comes first); to take a
+ * staged buffer back without registering it, announce it again (the older copy is superseded) or call so_icp_stage_cancel.
+ * Three slots: two scans may be announced ahead of the one being registered; a further announcement returns
  * SO_ICP_STAGE_DECLINED (soft: that scan is uploaded by its own registration call).  Announcing a buffer again supersedes
  * its earlier copy; a copy announced BEFORE a scan that has been consumed since (a skipped frame) is never served and gives
  * its slot to the next announcement.  A staged copy is also dropped by a map-seeding so_icp_localization(initialization = 0)
  * on the same buffer.  Unlike the other entry points this one may be called from ANOTHER thread than the registration calls
  * (the node's feature callback, lmap.cpp:21-25). */
 int so_icp_stage_scan(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes);
+/* withdraw every staged copy of this host buffer (returns when nothing reads the buffer any more) */
+int so_icp_stage_cancel(so_icp_ctx *ctx, const float *scan_xyz);
 /* Pin a host buffer the caller keeps its clouds in (hipHostRegister; the node's copy of the message payload into its feature
  * cloud, pcl::fromROSMsg at lmap.cpp:250-263, then lands in pinned memory): so_icp_stage_scan and so_icp_register copy
  * packed scans that lie inside it by DMA without an intermediate copy.  Unregister before freeing the buffer. */

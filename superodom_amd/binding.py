@@ -88,7 +88,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
             "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram",
-            "so_icp_host_register", "so_icp_host_unregister", "so_icp_host_alloc", "so_icp_host_free", "so_icp_device_count"]
+            "so_icp_host_register", "so_icp_host_unregister", "so_icp_host_alloc", "so_icp_host_free", "so_icp_device_count", "so_icp_stage_cancel"]
 
 _lib = None
 
@@ -151,6 +151,7 @@ def load():
     L.so_icp_set_time_kernels.argtypes = [vp, C.c_int]
     L.so_icp_stage_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
     L.so_icp_host_register.argtypes = [vp, vp, C.c_size_t]
+    L.so_icp_stage_cancel.argtypes = [vp, f32p]
     L.so_icp_host_unregister.argtypes = [vp, vp]
     L.so_icp_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.so_icp_host_free.argtypes = [vp, vp]
@@ -282,6 +283,9 @@ class LidarSlamGpu:
         the register call that consumes it)."""
         assert isinstance(scan, np.ndarray) and scan.dtype == np.float32 and scan.flags.c_contiguous
         self._check(self.L.so_icp_stage_scan(self.h, _p(scan, C.c_float), len(scan), 12))
+
+    def stage_cancel(self, scan):
+        self._check(self.L.so_icp_stage_cancel(self.h, _p(scan, C.c_float)))
 
     def host_register(self, arr):
         """so_icp_host_register: pin the numpy array's memory (it must stay alive until host_unregister / close); packed scans

@@ -256,6 +256,8 @@ struct so_icp_ctx {
     unsigned long long seq = 0;          // announcement number (newer scans have larger ones)
     hipEvent_t ev = nullptr;             // direct path: end of the H2D copy on the copy stream
     bool ev_pending = false;             //   ... which may still be reading the caller's buffer
+    bool deferred = false;               // direct path: announced, the copy is not enqueued yet (see stage_issue_deferred)
+    std::chrono::steady_clock::time_point t_announced;
     std::string err;
   } stage[kStageSlots];
   StageSlot* stage_in_use = nullptr;  // the slot the current registration reads (released when the call returns)
@@ -267,6 +269,8 @@ struct so_icp_ctx {
   struct HostRange { const char* p; size_t bytes; bool owned; };
   std::vector<HostRange> host_ranges;     // so_icp_host_register / so_icp_host_alloc (under stage_mu)
   bool stage_wait_on_host = false;        // SOICP_STAGE_WAIT=host: the registration thread waits for a DMA-staged copy itself (measurement aid)
+  int stage_issue_at = 1;                 // SOICP_STAGE_AT: 0 = a DMA copy is enqueued by the announcement itself; 1 = by the registration in
+                                          // flight once its launches are in the queue (default); 2 = after its second solve launch
   hipStream_t copy_stream = nullptr;
   bool retried = false;       // the current registration is the repeat of an abandoned one
   unsigned long long peer_timeout_ticks = 100000000ull;  // 1 s at 100 MHz: patience of a solve launch with the peer exchange (SOICP_PEER_TIMEOUT_MS)
@@ -541,6 +545,7 @@ void fill_result(so_icp_ctx* c, const DevState& H, const double pose_in[7], so_i
 // and every kernel consults DevState (reg_done / lm_more) to turn itself into a no-op once the controller has
 // finished -- no host round trip per evaluation.  One small read-back per outer iteration tells the host when to stop
 // enqueuing.
+void stage_issue_deferred(so_icp_ctx* c);  // (so_icp_stage_scan machinery, below)
 constexpr int kRetryWithoutPersistentSolve = -1000;  // internal: never leaves register_core
 int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const double pose_in[7], double pose_out[7], so_icp_stats* st) {
   const auto t_begin = std::chrono::steady_clock::now();
@@ -779,6 +784,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   for (int it = 0;; ++it) {
     if (c->speculate && it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
     if (defer_reports && it + 1 < max_outer) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));  // behind the launch that reports it
+    // this registration's launches are in the queue and the host is about to idle: the moment for the NEXT scan's DMA
+    if (!c->batch_mode && ((it == 0 && c->stage_issue_at == 1) || (it == 1 && c->stage_issue_at == 2))) stage_issue_deferred(c);
     if ((rc = await_outer(it))) return rc;
     last = it;
     if (c->h_ring[it & 1]->reg_done || it + 1 >= max_outer) break;
@@ -866,7 +873,28 @@ bool stage_any_queued(const so_icp_ctx* c) {
 // the copy of a direct slot has left the caller's buffer (host-side wait; a no-op in steady state: the copy was enqueued
 // a registration ago)
 void stage_finish_direct(so_icp_ctx::StageSlot& sl) {
+  sl.deferred = false;  // (a copy that was never enqueued reads nothing)
   if (sl.ev_pending) { (void)hipEventSynchronize(sl.ev); sl.ev_pending = false; }
+}
+// enqueue the DMA of a direct slot on the copy stream (under stage_mu)
+hipError_t stage_issue(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
+  sl.deferred = false;
+  hipError_t e = hipMemcpyAsync(sl.dev.p, sl.src, sl.n * 12, hipMemcpyHostToDevice, c->copy_stream);
+  if (e == hipSuccess) e = hipEventRecord(sl.ev, c->copy_stream);
+  if (e == hipSuccess) { sl.ev_pending = true; return e; }
+  sl.state = -1; sl.err = std::string("so_icp_stage_scan: ") + hipGetErrorString(e);
+  return e;
+}
+// WHEN a DMA-staged scan travels.  A copy that is enqueued while the registration thread is enqueuing its launches slows
+// them down: the command processor fetches every dispatch packet and its arguments from host memory over the same PCIe link
+// the copy saturates with reads (measured, MI355X: registration core +10..15 us with the copy started by the announcement
+// right in front of the registration call, +0 with it started here).  So an announced copy waits for the registration in
+// flight to have its launches in the queue -- the host then idles for tens of microseconds, waiting for the first solve's
+// report -- and is enqueued from there.  Without a registration to piggy-back on, the copy thread enqueues it after 300 us.
+void stage_issue_deferred(so_icp_ctx* c) {
+  if (!c->stage_started) return;
+  std::lock_guard<std::mutex> lk(c->stage_mu);
+  for (so_icp_ctx::StageSlot& sl : c->stage) if (sl.state == 2 && sl.deferred) (void)stage_issue(c, sl);
 }
 bool host_range_registered(const so_icp_ctx* c, const void* p, size_t bytes) {
   const char* q = static_cast<const char*>(p);
@@ -883,9 +911,28 @@ void stage_worker(so_icp_ctx* c) {
   std::unique_lock<std::mutex> lk(c->stage_mu);
   for (;;) {
     if (!(c->stage_quit || stage_any_queued(c))) {
+      // DMA-staged scans waiting for a registration to enqueue them (stage_issue_deferred): after 300 us this thread does it
+      {
+        const auto now = std::chrono::steady_clock::now();
+        bool waiting = false;
+        auto deadline = now + std::chrono::hours(1);
+        for (so_icp_ctx::StageSlot& q : c->stage) {
+          if (!(q.state == 2 && q.deferred)) continue;
+          const auto due = q.t_announced + std::chrono::microseconds(300);
+          if (due <= now) (void)stage_issue(c, q); else { waiting = true; deadline = std::min(deadline, due); }
+        }
+        if (waiting) {
+          c->stage_pending.store(0, std::memory_order_relaxed);
+          c->stage_parked.store(true);
+          c->stage_cv.wait_until(lk, deadline, [&] { return c->stage_quit || stage_any_queued(c); });
+          c->stage_parked.store(false);
+          continue;
+        }
+      }
       // Nothing queued.  A registration stream announces the next scan within a few hundred microseconds: spin that long
       // on the pending counter (no futex wake-up on the announcing thread's path), then park on the condition variable
       // (a 10 Hz node finds the thread parked and pays one notify per frame).
+      c->stage_pending.store(0, std::memory_order_relaxed);
       lk.unlock();
       const auto t0 = std::chrono::steady_clock::now();
       bool got = false;
@@ -899,14 +946,14 @@ void stage_worker(so_icp_ctx* c) {
       }
       lk.lock();
       if (!got) {
+        auto any_deferred = [&] { for (const so_icp_ctx::StageSlot& q : c->stage) if (q.state == 2 && q.deferred) return true; return false; };
         c->stage_parked.store(true);
-        c->stage_cv.wait(lk, [&] { return c->stage_quit || stage_any_queued(c); });
+        c->stage_cv.wait(lk, [&] { return c->stage_quit || stage_any_queued(c) || any_deferred(); });
         c->stage_parked.store(false);
       }
       continue;
     }
     if (c->stage_quit) return;
-    c->stage_pending.fetch_sub(1, std::memory_order_acq_rel);
     so_icp_ctx::StageSlot* pick = nullptr;  // oldest queued announcement first
     for (so_icp_ctx::StageSlot& q : c->stage) if (q.state == 1 && (!pick || q.seq < pick->seq)) pick = &q;
     so_icp_ctx::StageSlot& sl = *pick;
@@ -979,7 +1026,16 @@ const float* take_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t strid
   const int state = sl.state;
   sl.src = nullptr;
   if (state == 2) {
+    if (sl.deferred) {  // (no registration came by to enqueue it: the first scan of a run)
+      sl.src = xyz;
+      if (stage_issue(c, sl) != hipSuccess) { c->err = sl.err; *rc = SO_ICP_E_HIP; sl.src = nullptr; sl.state = 0; return nullptr; }
+      sl.src = nullptr;
+    }
     if (sl.ev_pending && c->stage_wait_on_host) stage_finish_direct(sl);
+    // (in a stream of registrations the copy ended long ago -- it was enqueued a registration earlier: then no barrier packet
+    //  in front of this registration's first kernel either)
+    if (sl.ev_pending && hipEventQuery(sl.ev) == hipSuccess) sl.ev_pending = false;
+    else (void)hipGetLastError();
     if (sl.ev_pending && hipStreamWaitEvent(c->stream, sl.ev, 0) != hipSuccess) {
       (void)hipGetLastError();
       stage_finish_direct(sl);  // (cannot order the streams on the device: wait here)
@@ -1305,6 +1361,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_STAGE_WAIT")) c->stage_wait_on_host = std::string(ev) == "host";
+  if (const char* ev = std::getenv("SOICP_STAGE_AT")) { const int v = std::atoi(ev); if (v >= 0 && v <= 2) c->stage_issue_at = v; }
   if (const char* ev = std::getenv("SOICP_BATCH_WG_PER_CU")) { if (std::atoi(ev) == 1) c->batch_degrade = 1; }  // (several processes on one device)
   if (const char* ev = std::getenv("SOICP_BATCH_MODE")) { if (std::string(ev) == "lanes") c->batch_degrade = 2; }
   const bool want_dmap = !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
@@ -1491,7 +1548,7 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
   if (!c || (!xyz && n)) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);
   if (stride_bytes == 0) stride_bytes = 12;
-  if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
+  if (stride_bytes % 4 && stride_bytes != SIZE_MAX) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
   bool queued = false;
   {
     // (this entry point may be called from ANOTHER thread than the registration calls -- the node's feature callback --,
@@ -1503,16 +1560,13 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
       c->stage_thread = std::thread(stage_worker, c);
       c->stage_started = true;
     }
-    // Every earlier announcement has left ITS host buffer when this call returns (the contract of so_icp.h: a staged buffer
-    // stays unchanged until the call that consumes it, or the next so_icp_stage_scan, returns).  In steady state those copies
-    // ended a registration ago and nothing waits here.  The same buffer announced again supersedes its older copy.
+    // The same buffer announced again supersedes its older copy (so_icp.h: this is also how a caller takes a staged buffer
+    // back -- so_icp_stage_cancel); failed slots are recycled.
     for (so_icp_ctx::StageSlot& sl : c->stage) {
-      if (sl.state == 1) c->stage_cv.wait(lk, [&] { return sl.state != 1; });
-      if (sl.state == 2 || sl.state == -1) {
-        stage_finish_direct(sl);
-        if (sl.src == xyz || sl.state == -1) { sl.src = nullptr; sl.state = 0; }
-      }
+      if (sl.state == 1 && sl.src == xyz) c->stage_cv.wait(lk, [&] { return sl.state != 1; });
+      if ((sl.state == 2 && sl.src == xyz) || sl.state == -1) { stage_finish_direct(sl); sl.src = nullptr; sl.state = 0; }
     }
+    if (n == 0 && stride_bytes == SIZE_MAX) return SO_ICP_OK;  // (so_icp_stage_cancel: withdraw only)
     // Slot: an empty one; else a ready copy that was announced BEFORE the scan consumed last (its frame was skipped: it would
     // never be asked for again), oldest first; else, with no registration in flight, the oldest ready copy gives way (a caller
     // that announces scans it never registers cannot block the slots).  Otherwise every slot holds a scan that is still
@@ -1526,15 +1580,16 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
         if (sl.state == 2 && (sl.seq < c->stage_consumed_seq || !in_flight) && (!pick || sl.seq < pick->seq)) pick = &sl;
     if (!pick) { c->timing.stage_declined++; return SO_ICP_STAGE_DECLINED; }
     so_icp_ctx::StageSlot& sl = *pick;
+    stage_finish_direct(sl);  // (an evicted copy must have left its caller's buffer)
     sl.src = xyz; sl.n = n; sl.stride = stride_bytes; sl.err.clear(); sl.seq = ++c->stage_seq; sl.ev_pending = false;
     if (stride_bytes == 12 && n && host_range_registered(c, xyz, n * 12)) {
       // registered (pinned) host memory, packed xyz: no pack, no copy thread -- the DMA reads the caller's buffer itself
       sl.state = 0;  // (until the copy is enqueued: an error below leaves the slot empty)
       HIP_TRY(c, sl.dev.reserve((n + 64) * 12));
       if (!sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-      HIP_TRY(c, hipMemcpyAsync(sl.dev.p, xyz, n * 12, hipMemcpyHostToDevice, c->copy_stream));
-      HIP_TRY(c, hipEventRecord(sl.ev, c->copy_stream));
-      sl.ev_pending = true; sl.state = 2;
+      sl.state = 2;
+      if (c->stage_issue_at == 0) { if (stage_issue(c, sl) != hipSuccess) { c->err = sl.err; sl.state = 0; return SO_ICP_E_HIP; } }
+      else { sl.deferred = true; sl.t_announced = std::chrono::steady_clock::now(); queued = true; }  // (the copy thread is the time-out)
       c->timing.staged_direct++;
     } else {
       sl.state = 1; queued = true;
@@ -1550,6 +1605,12 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
 
 // Pin a host buffer of the caller (hipHostRegister): scans announced from inside it with stride 12 go to HBM by DMA straight
 // from the buffer.  The node side keeps its feature clouds in a few such buffers.
+int so_icp_stage_cancel(so_icp_ctx* c, const float* xyz) {
+  if (!c || !xyz) return SO_ICP_E_INVALID;
+  if (c->host_only || !c->stage_started) return SO_ICP_OK;
+  return so_icp_stage_scan(c, xyz, 0, SIZE_MAX);
+}
+
 int so_icp_host_register(so_icp_ctx* c, const void* ptr, size_t bytes) {
   if (!c || !ptr || !bytes) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);

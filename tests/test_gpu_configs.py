@@ -213,11 +213,19 @@ def test_batch_fallback_paths_give_the_same_bits(oracle, gpu_slam_factory, monke
         _assert_same_bits(sts[h], sts2[h], (env, h))
 
 
-def test_staged_scan_is_the_same_registration(oracle, gpu_slam_factory, soicp):
-    """so_icp_stage_scan + so_icp_register: the copy thread's upload feeds the same kernels -- bit-identical results, the
-    stats say which path ran; a staged scan that is never consumed, a re-staged one and strided input are handled."""
+@pytest.mark.parametrize("buffers", ["pageable", "registered", "pinned"])
+def test_staged_scan_is_the_same_registration(oracle, gpu_slam_factory, soicp, buffers):
+    """so_icp_stage_scan + so_icp_register: the staged upload -- through the copy thread (pageable host memory), or by DMA straight
+    from the caller's buffer (so_icp_host_register / so_icp_host_alloc), enqueued by the registration in flight -- feeds the same
+    kernels: bit-identical results, the stats say which path ran; a staged scan that is never consumed and a re-staged one are
+    handled; so_icp_stage_cancel withdraws a copy."""
     sc, slam, om = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
     scans = [np.ascontiguousarray(sc.scan(i), dtype=np.float32) for i in range(4)]
+    if buffers == "registered":
+        for s_ in scans:
+            slam.host_register(s_)
+    elif buffers == "pinned":
+        scans = [slam.host_alloc_like(s_) for s_ in scans]
     ref = [slam.register(scans[i], sc.guess(i)) for i in range(4)]
     assert all(not (r[2].flags & soicp.FLAG_STAGED_SCAN) for r in ref)
     slam.stage_scan(scans[0])
@@ -232,6 +240,21 @@ def test_staged_scan_is_the_same_registration(oracle, gpu_slam_factory, soicp):
     assert rc == 0 and not (st.flags & soicp.FLAG_STAGED_SCAN) and np.array_equal(pose, ref[3][1])
     rc, pose, st = slam.register(scans[2], sc.guess(2))  # still there
     assert rc == 0 and (st.flags & soicp.FLAG_STAGED_SCAN) and np.array_equal(pose, ref[2][1])
+    tm = slam.timing()
+    assert (tm.staged_direct > 0) == (buffers != "pageable") and (tm.staged_copied > 0) == (buffers == "pageable"), (tm.staged_direct, tm.staged_copied)
+    slam.stage_scan(scans[1])            # announced, then withdrawn: the buffer is the caller's again, a later register uploads it
+    slam.stage_cancel(scans[1])
+    keep = scans[1].copy()
+    scans[1][:] = scans[0]
+    rc, pose, st = slam.register(scans[1], sc.guess(0))
+    assert rc == 0 and not (st.flags & soicp.FLAG_STAGED_SCAN) and np.array_equal(pose, ref[0][1])
+    scans[1][:] = keep
+    # a skipped frame: 1 is announced, then 2 is announced and registered; a later register(1) is not served the old copy
+    slam.stage_scan(scans[1]); slam.stage_scan(scans[2])
+    rc, pose, st = slam.register(scans[2], sc.guess(2))
+    assert rc == 0 and (st.flags & soicp.FLAG_STAGED_SCAN) and np.array_equal(pose, ref[2][1])
+    rc, pose, st = slam.register(scans[1], sc.guess(1))  # (its copy was announced before a scan consumed since: dropped, uploaded afresh)
+    assert rc == 0 and not (st.flags & soicp.FLAG_STAGED_SCAN) and np.array_equal(pose, ref[1][1])
     # a feeder THREAD (the node's feature callback) announces scans while this thread registers: it may run ahead by more than
     # one scan (older announcements are dropped, the registration uploads those itself) but never touches the slot in use
     import threading

@@ -51,12 +51,12 @@ if [[ $ST == *a* ]]; then
 fi
 if [[ $ST == *g* ]]; then
   # staging matrix: where the host scan buffers live x who waits for a DMA-staged copy, under the driver's protocol and a long run
-  for m in pinned registered pageable; do
-    for w in device host; do
+  for m in pinned; do
+    for at in 0 1 2; do w=device
       [ $m = pageable ] && [ $w = host ] && continue
-      echo "== staging: scan buffers $m, wait on $w"
+      echo "== staging: scan buffers $m, copy enqueued at $at"
       for k in 20 240; do
-        SOICP_STAGE_WAIT=$w timeout 300 python bench.py --steps $k --warmup 5 --no-cpu-baseline --no-profile-pass --scan-buffers $m 2>>$O/stage.err | tail -1 > $O/stage_${m}_${w}_$k.json; line $O/stage_${m}_${w}_$k.json
+        SOICP_STAGE_AT=$at SOICP_STAGE_WAIT=$w timeout 300 python bench.py --steps $k --warmup 5 --no-cpu-baseline --no-profile-pass --scan-buffers $m 2>>$O/stage.err | tail -1 > $O/stage_${m}_at${at}_$k.json; line $O/stage_${m}_at${at}_$k.json
       done
     done
   done
