@@ -29,3 +29,69 @@ def noisy_planes_cloud(n, rng, offset=(0.0, 0.0, 0.0), sigma=0.01):
     yz = np.c_[rng.random(n - 3 * k) * 40 - 20, rng.random(n - 3 * k) * 7.5 - 1.5]
     parts.append(np.c_[-12.0 + sigma * rng.standard_normal(n - 3 * k), yz[:, 0], yz[:, 1]])
     return (np.concatenate(parts) + np.asarray(offset)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# A scene on which the reference's OWN k-NN engine (flann/octree.h, compiled into oracle/_ref) is exact, so that a whole
+# registration can be run with it in the loop and compared with the exact-search oracle and the product.
+#
+# The stock octree has two defects: initialize() derives the y / z bounds of the root cube from comparisons
+# against x (oct.h:384-385), and inside() tests the query's X coordinate against all three octant centres (oct.h:988-990).
+# Both are inert when, in every 50 m block, (a) the points' x range is at least as large as their y and z ranges -- the root
+# cube, sized by the x range, then contains every point wherever the broken y / z centres land -- and (b) x is far from every
+# y and z coordinate of the block -- inside() then never answers "yes" early and the search degenerates to an exhaustive,
+# correctly pruned one.  A corridor along x at x ~ 1 100 m (y within +-6.5 m, z within -1.5 .. 4.1 m) has both properties.
+# ------------------------------------------------------------------------------------------------------------------------
+class CorridorScene:
+    X0, LEN = 1003.7, 170.0
+
+    def __init__(self, plane_res=0.2, rings=32, azimuth=512, fov_deg=22.5, seed=21):
+        rng = np.random.default_rng(seed)
+        R = []
+
+        def add(o, u, v):
+            R.append((np.array(o, float), np.array(u, float), np.array(v, float)))
+        x0, L, z0, z1, ya, yb = self.X0, self.LEN, -1.5, 4.1, -6.3, 5.9
+        H = z1 - z0
+        add([x0, ya, z0], [L, 0, 0], [0, yb - ya, 0])          # floor
+        add([x0, ya, z1], [L, 0, 0], [0, yb - ya, 0])          # ceiling
+        add([x0, ya, z0], [L, 0, 0], [0, 0, H])                # side walls
+        add([x0, yb, z0], [L, 0, 0], [0, 0, H])
+        add([x0, ya, z0], [0, yb - ya, 0], [0, 0, H])          # end walls
+        add([x0 + L, ya, z0], [0, yb - ya, 0], [0, 0, H])
+        k = 0
+        for xc in np.arange(x0 + 11.6, x0 + L - 5.0, 12.3):    # partial cross walls, alternating sides: they fix the pose along x
+            if k % 2 == 0:
+                add([xc, ya, z0], [0, 4.6 + rng.random(), 0], [0, 0, H])
+            else:
+                add([xc, yb, z0], [0, -(4.3 + rng.random()), 0], [0, 0, H])
+            k += 1
+        for _ in range(14):                                     # leaning panels: roll / pitch observability
+            cx = x0 + 4.0 + rng.random() * (L - 12.0); cy = ya + 0.8 + rng.random() * (yb - ya - 4.5)
+            Lp, Wp = 1.5 + 1.5 * rng.random(), 1.5 + 1.5 * rng.random()
+            if rng.random() < 0.5:
+                add([cx, cy, z0], [Lp, 0, Lp], [0, Wp, 0])
+            else:
+                add([cx, cy, z0], [0, Lp, Lp], [Wp, 0, 0])
+        w = synth.World.__new__(synth.World)
+        w.o = np.stack([r[0] for r in R]); w.u = np.stack([r[1] for r in R]); w.v = np.stack([r[2] for r in R])
+        n = np.cross(w.u, w.v)
+        w.n = n / np.linalg.norm(n, axis=1, keepdims=True)
+        w.extent = L
+        w._groups = None
+        self.world = w
+        self.plane_res = plane_res
+        self.map_points = synth.sample_map(w, plane_res, None, seed=seed + 1)
+        self.dirs = synth.lidar_dirs(rings, azimuth, fov_deg)
+
+    def gt_pose(self, i):
+        s = i / 7.0
+        t = np.array([self.X0 + 62.0 + 9.0 * s, -0.9 + 1.1 * np.sin(2.0 * s), 0.15 * np.cos(3.0 * s)])
+        q = synth.quat_from_rotvec(np.array([0.02 * np.sin(5 * s), 0.03 * np.cos(3 * s), 0.2 + 0.7 * s]))
+        return np.concatenate([t, q])
+
+    def scan(self, i):
+        return synth.raycast(self.world, self.gt_pose(i), self.dirs, seed=40 + i)
+
+    def guess(self, i, dt=0.10, dth_deg=1.0):
+        return synth.perturb_pose(self.gt_pose(i), 2000 + i, dt, dth_deg)
