@@ -289,6 +289,9 @@ int so_icp_download_scan(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n, floa
 /* -------- the step before Seam A: laserMapping::adjustVoxelSize (lmap.cpp:598-651) on the device ----------------
  * auto_voxel_size != 0: average_distance = mean|x| * mean|y| * mean|z| of the surf cloud chooses the resolutions
  * (< 25: 0.1 / 0.2, > 65: 0.4 / 0.8, else unchanged), count_far_points (> 3 m) > 3000 raises increase_blind_radius.
+ * The choice is ALWAYS the reference's: it accumulates the three sums in float in input order (lmap.cpp:604-611), the device
+ * in an fp64 tree; when the statistic is within the reach of those roundings of a threshold, the reference's accumulation
+ * itself is run (so_icp_prefilter_info::statistic_in_input_order).
  * Then pcl::VoxelGrid (leaf = planeRes: float leaf coordinates, centroids accumulated in float in input order, output in
  * ascending leaf index; "leaf size too small" passes the cloud through) and localMap.lineRes_/planeRes_ = the result
  * (lmap.cpp:648-649).  *d_filtered_out (packed float xyz, owned by the context, valid until the next call) feeds
@@ -297,6 +300,10 @@ typedef struct {
   double average_distance;
   int32_t count_far_points, increase_blind_radius;
   float line_res, plane_res;  /* resolutions in effect after the call */
+  int32_t statistic_in_input_order; /* 1: average_distance is the reference's own float accumulation in input order, bit for bit
+                                       (taken whenever the value is close enough to 25 / 65 for its roundings to decide);
+                                       0: mean|x| mean|y| mean|z| from exact sums -- within 3 n 2^-24 of it, same decision */
+  int32_t reserved;
 } so_icp_prefilter_info;
 int so_icp_prefilter_scan(so_icp_ctx *ctx, const float *surf_xyz, size_t n, size_t stride_bytes, int auto_voxel_size,
                           float line_res, float plane_res, void **d_filtered_out, size_t *n_out, so_icp_prefilter_info *info);

@@ -55,7 +55,7 @@ class RegistrationError(C.Structure):
 
 class PrefilterInfo(C.Structure):
     _fields_ = [("average_distance", C.c_double), ("count_far_points", C.c_int32), ("increase_blind_radius", C.c_int32),
-                ("line_res", C.c_float), ("plane_res", C.c_float)]
+                ("line_res", C.c_float), ("plane_res", C.c_float), ("statistic_in_input_order", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DeskewInfo(C.Structure):

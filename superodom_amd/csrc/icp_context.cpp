@@ -2051,7 +2051,7 @@ int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stri
   // statistics + bounding box (fp64 tree sums; the reference accumulates |x|,|y|,|z| in float in input order --
   // the statistic only feeds the 25 / 65 thresholds and the 3000-far-points flag)
   constexpr int kStatBlocks = 256;
-  HIP_TRY(c, c->pf_small.reserve(kStatBlocks * 10 * sizeof(double) + 64));
+  HIP_TRY(c, c->pf_small.reserve(kStatBlocks * 10 * sizeof(double) + 128));
   launch_vg_stats(c->pf_in.as<float>(), (uint32_t)n, sf, c->pf_small.as<double>(), kStatBlocks, s);
   std::vector<double> part((size_t)kStatBlocks * 10);
   HIP_TRY(c, hipMemcpyAsync(part.data(), c->pf_small.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -2063,7 +2063,25 @@ int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stri
       acc[k] = k < 4 ? acc[k] + v : (k < 7 ? std::min(acc[k], v) : std::max(acc[k], v));
     }
   if (auto_voxel_size) {
-    const float ax = (float)(acc[0] / (double)n), ay = (float)(acc[1] / (double)n), az = (float)(acc[2] / (double)n);
+    float ax = (float)(acc[0] / (double)n), ay = (float)(acc[1] / (double)n), az = (float)(acc[2] / (double)n);
+    // The reference sums |x|, |y|, |z| in FLOAT in input order (laserMapping.cpp:604-611); the tree sums above are the exact sums
+    // to ~1e-16.  A sequential float sum of n non-negative terms is within n 2^-24 of the exact one (relative), so the
+    // reference's statistic lies within 3 n 2^-24 (+ the roundings of the divisions and the product) of this one: unless the
+    // value is that close to a threshold, the resolution it chooses is decided.  Inside the band the reference's own
+    // accumulation is run (one wavefront, ~3 ns per point) and ITS value decides -- and is reported.
+    const double stat64 = (acc[0] / (double)n) * (acc[1] / (double)n) * (acc[2] / (double)n);
+    const double band = 3.1 * (double)n * 5.9604644775390625e-8 + 1e-6;
+    li.statistic_in_input_order = 0;
+    if (std::fabs(stat64 - 25.0) <= 25.0 * band || std::fabs(stat64 - 65.0) <= 65.0 * band) {
+      float* d3 = reinterpret_cast<float*>(c->pf_small.as<double>() + (size_t)kStatBlocks * 10);
+      launch_vg_stats_inorder(c->pf_in.as<float>(), (uint32_t)n, sf, d3, s);
+      float h3[3] = {0, 0, 0};
+      HIP_TRY(c, hipMemcpyAsync(h3, d3, sizeof(h3), hipMemcpyDeviceToHost, s));
+      HIP_TRY(c, hipStreamSynchronize(s));
+      const float fn = (float)n;  // average /= laserCloudSurfLast->points.size()  (Eigen: the scalar becomes a float, one division per axis)
+      ax = h3[0] / fn; ay = h3[1] / fn; az = h3[2] / fn;
+      li.statistic_in_input_order = 1;
+    }
     li.average_distance = (double)(ax * ay * az);       // laserMapping.cpp:620-621 (float product)
     li.count_far_points = (int32_t)acc[3];
     li.increase_blind_radius = li.count_far_points > 3000;

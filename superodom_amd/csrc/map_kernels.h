@@ -70,6 +70,8 @@ struct VoxelFilterArgs {
   void* temp; size_t temp_bytes;
 };
 void launch_vg_stats(const float* d_xyz, uint32_t n, uint32_t stride_floats, double* d_part /* blocks x 10 */, int blocks, hipStream_t s);
+// sum |x|, sum |y|, sum |z| as the reference accumulates them: float, input order (one wavefront; see the kernel)
+void launch_vg_stats_inorder(const float* d_xyz, uint32_t n, uint32_t stride_floats, float* d_out3, hipStream_t s);
 void launch_voxel_filter(const VoxelFilterArgs& a, hipStream_t s);
 
 size_t map_sort_temp_bytes(size_t n);

@@ -1106,6 +1106,33 @@ void launch_map_retable(const MapInsertArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid_scan, a.cent, a.spts, a.flags, a.tt,
                      a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1, a.d_n_cent + 5);
 }
+// The reference's own accumulation of the auto-voxel statistic (laserMapping.cpp:604-611): Eigen::Vector3f average, one float
+// addition per point and axis IN INPUT ORDER.  A sequential float sum cannot be re-associated without changing its roundings,
+// so this is one wavefront whose lanes 0..2 carry the three running sums while all 64 lanes fetch the next 64 points into LDS
+// (~3 ns per point: 0.4 ms for a 131 072-point sweep).  Launched only when the fp64 tree statistic lies so close to a
+// threshold (25 / 65) that the rounding of the float sums could decide (icp_context.cpp: so_icp_prefilter_scan).
+__global__ __launch_bounds__(64) void vg_stats_inorder_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats,
+                                                              float* __restrict__ out3) {
+  __shared__ float buf[3][64];
+  const int lane = threadIdx.x;
+  float sum = 0.f;
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t i = base + (uint32_t)lane;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (i < n) { const float* p = xyz + (size_t)i * stride_floats; x = p[0]; y = p[1]; z = p[2]; }
+    __builtin_amdgcn_wave_barrier();
+    buf[0][lane] = fabsf(x); buf[1][lane] = fabsf(y); buf[2][lane] = fabsf(z);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t m = n - base < 64u ? n - base : 64u;
+    if (lane < 3)
+      for (uint32_t k = 0; k < m; ++k) sum += buf[lane][k];  // (-ffp-contract=off: a plain float addition, like the reference's)
+  }
+  if (lane < 3) out3[lane] = sum;
+}
+void launch_vg_stats_inorder(const float* d_xyz, uint32_t n, uint32_t stride_floats, float* d_out3, hipStream_t s) {
+  hipLaunchKernelGGL(vg_stats_inorder_kernel, dim3(1), dim3(64), 0, s, d_xyz, n, stride_floats, d_out3);
+}
 void launch_vg_stats(const float* d_xyz, uint32_t n, uint32_t stride_floats, double* d_part, int blocks, hipStream_t s) {
   hipLaunchKernelGGL(vg_stats_kernel, dim3(blocks), dim3(256), 0, s, d_xyz, n, stride_floats, d_part);
 }

@@ -138,6 +138,57 @@ def test_full_size_localization_rate(gpu_slam_factory):
     print("localization wall times (s):", [round(t, 5) for t in times])
 
 
+def _reference_statistic(cloud):
+    """average(0) * average(1) * average(2) as laserMapping::adjustVoxelSize forms it (lmap.cpp:604-621): Eigen::Vector3f sums of
+    |x|, |y|, |z| in input order, divided by the point count in float, float product."""
+    a = np.abs(cloud).astype(np.float32)
+    avg = [np.float32(np.add.accumulate(a[:, k], dtype=np.float32)[-1]) / np.float32(len(cloud)) for k in range(3)]
+    return float(np.float32(np.float32(avg[0] * avg[1]) * avg[2]))
+
+
+@pytest.mark.parametrize("threshold", [25.0, 65.0])
+def test_auto_voxel_size_decision_on_the_thresholds(gpu_slam_factory, threshold):
+    """Clouds whose statistic sits on a threshold of adjustVoxelSize (lmap.cpp:622-631): a raw sweep scaled so that the
+    REFERENCE's float, input-order value lands within a few 1e-6 of 25 / 65, on either side, in several input orders (the
+    float sums depend on the order, the exact sums do not).  The device's fp64 tree statistic differs from the reference's by up
+    to ~1e-3 there; the chosen resolution must be the reference's every time, and the reported value its value bit for bit."""
+    sc = synth.Scene("small")
+    base = sc.scan(2).astype(np.float32)
+    slam = gpu_slam_factory(plane_res=0.4, line_res=0.2, max_surface_features=-1, max_iterations=5)
+    rng = np.random.default_rng(5)
+    below = above = exact_differs = 0
+    for trial in range(12):
+        cloud0 = base[rng.permutation(len(base))] if trial else base
+        lo, hi = 0.2, 8.0  # bisect the scale on the reference's statistic (monotone up to rounding)
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            if _reference_statistic((cloud0 * np.float32(mid)).astype(np.float32)) < threshold:
+                lo = mid
+            else:
+                hi = mid
+        for scale in (lo, hi, lo * (1 - 3e-7), hi * (1 + 3e-7)):
+            cloud = np.ascontiguousarray((cloud0 * np.float32(scale)).astype(np.float32))
+            ref = _reference_statistic(cloud)
+            assert abs(ref - threshold) < 2e-4 * threshold
+            exact = float(np.prod(np.abs(cloud).astype(np.float64).mean(0)))
+            exact_differs += int((exact < threshold) != (ref < threshold) or (exact > threshold) != (ref > threshold))
+            d, n, info = slam.prefilter_scan(cloud, True, 0.2, 0.4)
+            assert info.statistic_in_input_order == 1
+            assert info.average_distance == ref, (trial, scale, info.average_distance, ref)
+            if threshold == 25.0:
+                want = 0.2 if ref < 25 else 0.4
+            else:
+                want = 0.8 if ref > 65 else 0.4
+            assert abs(info.plane_res - want) < 1e-7, (trial, scale, ref, info.plane_res)
+            below += int(ref < threshold); above += int(ref > threshold)
+            slam.set_resolution(0.2, 0.4)  # (auto_voxel_size is sticky upstream; the test starts every cloud from the middle setting)
+    assert below >= 8 and above >= 8
+    assert exact_differs >= 1, "the fixture should contain clouds on which exact sums and the reference's float sums decide differently"
+    # far from the thresholds the tree statistic decides (same decision by construction) and says so
+    d, n, info = slam.prefilter_scan(base, True, 0.2, 0.4)
+    assert info.statistic_in_input_order == 0 and abs(info.average_distance - _reference_statistic(base)) <= 1e-3 * info.average_distance
+
+
 def test_scan_prefilter_matches_pcl_voxelgrid_restatement(oracle, gpu_slam_factory):
     """so_icp_prefilter_scan = laserMapping::adjustVoxelSize (lmap.cpp:598-651): statistics, resolution choice and the
     VoxelGrid of the raw surf cloud, point for point against the oracle's pcl::VoxelGrid restatement; the filtered cloud
