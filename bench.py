@@ -81,6 +81,12 @@ def main():
     ap.add_argument("--shuffle-scan", action="store_true", help="experiment: random point order inside every scan (worst case for the binning atomics)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no HIP events around the k-NN launches (no roofline)")
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the kernel-split pass after the timed region (runs under rocprofv3 use it: one registration = one set of launches)")
+    ap.add_argument("--shard-mode", default="map", choices=["map", "queries"],
+                    help="N > 1: how `value` splits the registration over the ranks -- map = brick-hash shards of the voxel map, queries follow "
+                         "their cell's owner (BASELINE configs[3], north_star); queries = map replicated, the scan's 64-point segments dealt "
+                         "round-robin (equal shares, no halo, no re-binning).  The other mode is measured too and reported under `other_shard_mode`")
+    ap.add_argument("--xgmi-exchange-us", type=float, default=3.0, help="assumed cost of one 45-double exchange between the ranks' solve launches "
+                                                                        "over xGMI, for `predicted_scaling` (unmeasured on a one-GPU box)")
     ap.add_argument("--scan-buffers", default="pinned", choices=["pinned", "registered", "pageable"],
                     help="where the HOST scan buffers of the timed loop live: pinned = so_icp_host_alloc (a node that keeps its feature clouds in a pinned "
                          "pool: DMA straight from them), registered = numpy memory pinned with so_icp_host_register, pageable = plain numpy memory (the "
@@ -112,29 +118,33 @@ def main():
     device = int(os.environ.get("SOICP_BENCH_DEVICE", local_rank))
     mk = dict(device_id=device, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_iterations=max_outer, lm_max_iterations=lm_iters,
               max_surface_features=-1)
-    slam = binding.LidarSlamGpu(rank=rank, world_size=world, time_kernels=2 if args.time_all_kernels else (0 if args.no_kernel_events else 1), **mk)
-    if world > 1 and not os.environ.get("SOICP_BENCH_NO_RCCL"):  # (NO_RCCL: development on a one-GPU box, where RCCL refuses two ranks per device)
-        uid = [binding.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        slam.comm_init(uid[0])
-    peer = False
-    if world > 1 and not os.environ.get("SOICP_BENCH_NO_PEER"):
-        # peer exchange: the ranks' persistent solve launches trade their records through hipIpc-mapped inboxes instead of an
-        # RCCL all-reduce per evaluation.  gloo carries the handles and the agreement on the self-test (include/so_icp.h).
-        import torch
-        try:
-            handles = [None] * world
-            dist.all_gather_object(handles, slam.peer_export())
-            dist.barrier()
-            ok = slam.peer_connect(handles)
-        except Exception as e:  # noqa: BLE001 -- any failure means "use the collective path"
-            print(f"rank {rank}: peer exchange unavailable: {e}", file=sys.stderr)
-            ok = False
-        t = torch.tensor([1 if ok else 0])
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        peer = bool(t.item())
-        slam.peer_enable(peer)
-    n_map = slam.add_surf_point_cloud(sc.map_points)
+    def make_rank_context(shard_mode, time_kernels):
+        """This rank's context for one N > 1 mode: communicator, peer handshake (collective over gloo), map."""
+        ctx = binding.LidarSlamGpu(rank=rank, world_size=world, time_kernels=time_kernels,
+                                   shard_mode=binding.SHARD_QUERIES if shard_mode == "queries" else binding.SHARD_MAP, **mk)
+        if world > 1 and not os.environ.get("SOICP_BENCH_NO_RCCL"):  # (NO_RCCL: development on a one-GPU box, where RCCL refuses two ranks per device)
+            uid = [binding.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(uid[0])
+        on_peer = False
+        if world > 1 and not os.environ.get("SOICP_BENCH_NO_PEER"):
+            # peer exchange: the ranks' persistent solve launches trade their records through hipIpc-mapped inboxes instead of an
+            # RCCL all-reduce per evaluation.  gloo carries the handles and the agreement on the self-test (include/so_icp.h).
+            import torch
+            try:
+                handles = [None] * world
+                dist.all_gather_object(handles, ctx.peer_export())
+                dist.barrier()
+                ok = ctx.peer_connect(handles)
+            except Exception as e:  # noqa: BLE001 -- any failure means "use the collective path"
+                print(f"rank {rank}: peer exchange unavailable: {e}", file=sys.stderr)
+                ok = False
+            t = torch.tensor([1 if ok else 0])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            on_peer = bool(t.item())
+            ctx.peer_enable(on_peer)
+        return ctx, on_peer, ctx.add_surf_point_cloud(sc.map_points)
+    slam, peer, n_map = make_rank_context(args.shard_mode, 2 if args.time_all_kernels else (0 if args.no_kernel_events else 1))
     scans = [np.ascontiguousarray(sc.scan(i), dtype=np.float32) for i in range(args.scans)]
     if args.shuffle_scan:
         scans = [np.ascontiguousarray(s_[np.random.default_rng(77 + i).permutation(len(s_))]) for i, s_ in enumerate(scans)]
@@ -163,7 +173,7 @@ def main():
 
     g64 = [np.ascontiguousarray(g, dtype=np.float64) for g in guesses]
 
-    def timed_loop(entry, steps, rewarm=0):
+    def timed_loop(entry, steps, rewarm=0, slam=slam):
         """`steps` registrations through one entry point, only C calls between the two clock reads (arguments pre-built).
         rewarm: untimed registrations run right before the clock starts, after the argument lists are built -- the W warm-up
         steps of the contract leave the device idle for the milliseconds Python needs to build them, and the first
@@ -258,6 +268,32 @@ def main():
                 continue
             t_e, _, _ = timed_loop(entry, args.steps, rewarm=args.warmup)
             secondary[entry] = args.steps / t_e
+    other_mode = None
+    if world > 1 and not args.no_secondary:
+        # the other way of splitting one registration over the ranks, same scans, same protocol (collective: every rank runs it)
+        om_name = "queries" if args.shard_mode == "map" else "map"
+        try:
+            slam.peer_enable(False)
+            ctx2, peer2, _ = make_rank_context(om_name, 0)
+            scans2 = scans
+            if args.scan_buffers == "pinned":
+                scans2 = [ctx2.host_alloc_like(s_) for s_ in scans]
+            elif args.scan_buffers == "registered":
+                for s_ in scans:
+                    ctx2.host_register(s_)
+            keep = scans
+            scans = scans2  # (timed_loop reads the list by name)
+            try:
+                t2, st2, _ = timed_loop("staged", args.steps, rewarm=args.warmup, slam=ctx2)
+            finally:
+                scans = keep
+            other_mode = {"shard_mode": om_name, "value": args.steps / t2, "unit": "registrations/s", "ms_per_step": 1e3 * t2 / args.steps,
+                          "peer_exchange": bool(peer2), "map_points_this_rank": int(ctx2.map_size(this_rank=True)[1]),
+                          "outer_iterations_per_step": sum(s_.n_iterations for s_ in st2) / args.steps}
+            ctx2.close()
+            slam.peer_enable(peer)
+        except Exception as e:  # noqa: BLE001
+            other_mode = {"shard_mode": om_name, "error": str(e)}
     prof = None
     if not args.no_kernel_events and not args.no_profile_pass:
         # kernel split of a registration: every launch bracketed by events (would cost ~25 us per registration inside the
@@ -353,13 +389,50 @@ def main():
                 "kernels_hip_sha256": ctr.get("kernels_hip_sha256"), "source": ctr.get("source"), "solve_kernel": ctr.get("solve_kernel")}
     ms_per_step = 1e3 * t_max / args.steps
     shard_info = None
-    if world > 1:  # how the queries of the bench scans fall to the ranks under their initial poses (ownership rule of the sharded map)
+    if world > 1 and args.shard_mode == "queries":
+        shard_info = {"queries_owned_per_rank_mean": [Q / world] * world, "imbalance_max_over_mean_per_scan": [1.0] * args.scans,
+                      "note": "64-point segments of the scan dealt round-robin: equal shares by construction (+-64 points)"}
+    elif world > 1:  # how the queries of the bench scans fall to the ranks under their initial poses (ownership rule of the sharded map)
         hists = np.stack([binding.shard_histogram(scans[i], guesses[i], slam.origin(), sc.plane_res, world) for i in range(args.scans)])
         mean_owned = hists.mean(axis=0)
         shard_info = {"queries_owned_per_rank_mean": [float(v) for v in mean_owned],
                       "imbalance_max_over_mean_per_scan": [float(h.max() / h.mean()) for h in hists],
                       "note": "brick-hash ownership (4 x 4 x 4 cells): the dense near-field floor under the sensor is one or two bricks, so the "
                               "busiest rank sets the sweep and fit times; what sharding can gain is bounded by the step's serial chains (DESIGN section 5)"}
+
+    # ---- predicted_scaling: what splitting ONE registration over N ranks can deliver, from this run's own kernel split -- a claim
+    #      the first multi-GPU run tests.  Only the k-NN sweeps and the fit loops shrink with N (by the busiest rank's share of
+    #      the queries); binning, the pass chains of the solve and the launches do not, and every pass gains one exchange.
+    predicted = None
+    if prof:
+        o_per = iters_outer / args.steps
+        passes = iters_lm / args.steps + o_per
+        fit_loop_ms, knn_floor_ms = 0.0091, 0.005  # fit loop of a fit pass (in-kernel stamps, profiles/r04); a sweep never beats its launch + slowest chunk
+        rest_ms = max(ms_per_step - prof["knn_ms"] - prof["solve_ms"] - prof["binning_ms"], 0.0)
+
+        def step_ms(n, mode):
+            if n == 1:
+                return ms_per_step
+            if mode == "map":
+                h = np.stack([binding.shard_histogram(scans[i], guesses[i], slam.origin(), sc.plane_res, n) for i in range(args.scans)]) if world == 1 \
+                    else None
+                share = float(np.mean(h.max(axis=1) / h.sum(axis=1))) if h is not None else 1.0 / n
+                binning = prof["binning_ms"] * o_per          # re-binned under the current pose every outer iteration
+            else:
+                share = 1.0 / n
+                binning = max(prof["binning_ms"] * share, 0.012)  # three launches
+            knn = max(prof["knn_ms"] / max(prof["knn_launches"], 1) * share, knn_floor_ms) * o_per
+            solve = prof["solve_ms"] - o_per * fit_loop_ms * (1.0 - share) + passes * args.xgmi_exchange_us * 1e-3
+            return binning + knn + solve + rest_ms
+        predicted = {"unit": "registrations/s", "model": "step(N) = binning + outer x max(knn x share, 5 us) + [solve - outer x fit_loop x (1 - share) + passes x exchange] + rest; "
+                                                         "share = the busiest rank's part of the queries (brick-hash histogram of the bench scans / 1/N)",
+                     "assumptions": {"xgmi_exchange_us_per_pass": args.xgmi_exchange_us, "fit_loop_us": 1e3 * fit_loop_ms, "passes_per_step": passes,
+                                     "measured_on": "this run's profiling pass (N = %d)" % world},
+                     "map_shards": {str(n): 1.0 / step_ms(n, "map") * 1e3 for n in (1, 2, 4, 8)} if world == 1 else None,
+                     "query_split": {str(n): 1.0 / step_ms(n, "queries") * 1e3 for n in (1, 2, 4, 8)},
+                     "batch64_replicated_map": ({str(n): batch["value"] * n for n in (1, 2, 4, 8)} if (batch and world == 1) else None),
+                     "note": "one registration is a latency chain of ~7 passes: sharding it cannot scale; throughput over independent registrations "
+                             "(batch64: hypotheses split over the ranks, no collective) is what scales with N"}
 
     errs = [synth.pose_error(poses[i], sc.gt_pose(i)) for i in range(len(poses))]
     entry_text = {"staged": "so_icp_register on HOST scan buffers, the next scan announced with so_icp_stage_scan (copy thread + copy stream): "
@@ -375,9 +448,13 @@ def main():
                    "entry": args.entry, "queries": Q, "map_points": int(map_total), "map_points_this_rank": int(map_rank),
                    "max_iterations": max_outer, "lm_iterations": lm_iters, "plane_res": sc.plane_res, "k": 5,
                    "parallelism": ("single GPU" if world == 1 else
+                                   (f"map replicated on {world} ranks, the scan's 64-point segments dealt round-robin, " +
+                                    ("persistent solve launches trading their 45-double records through hipIpc-mapped inboxes over xGMI (peer exchange)" if peer
+                                     else "45-fp64 RCCL all-reduce per evaluation")) if args.shard_mode == "queries" else
                                    (f"map sharded by brick-hash x{world}, ownership re-derived every outer iteration, persistent solve launches trading their "
                                     f"45-double records through hipIpc-mapped inboxes over xGMI (peer exchange)" if peer else
                                     f"map sharded by brick-hash x{world}, ownership re-derived every outer iteration, 45-fp64 RCCL all-reduce per evaluation")),
+                   "shard_mode": (None if world == 1 else args.shard_mode),
                    "peer_exchange": bool(peer),
                    "transport": (None if world == 1 else ("peer exchange: tagged 16-byte chunks pushed into hipIpc-mapped inboxes by the persistent solve launches"
                                                           if peer else "RCCL all-reduce of 45 fp64 per evaluation + controller launch")),
@@ -423,6 +500,8 @@ def main():
                      "rest_ms_per_registration": max(ms_per_step - prof["knn_ms"] - prof["solve_ms"] - prof["binning_ms"], 0.0)}
                     if prof else None),
         "batch64": batch,
+        "other_shard_mode": other_mode,
+        "predicted_scaling": predicted,
     }
 
     # ---- CPU baselines: the oracle (restatement of the reference CPU path), same scans, bounded sample, N = 1 only
