@@ -269,6 +269,8 @@ struct so_icp_ctx {
   struct HostRange { const char* p; size_t bytes; bool owned; };
   std::vector<HostRange> host_ranges;     // so_icp_host_register / so_icp_host_alloc (under stage_mu)
   bool stage_wait_on_host = false;        // SOICP_STAGE_WAIT=host: the registration thread waits for a DMA-staged copy itself (measurement aid)
+  bool batch_small_report = true;         // (SOICP_BATCH_REPORT=full: the whole state blocks after every round, as in round 3)
+  bool batch_round0_full = true;          // so_icp_register_batch: round 0 starts with the full k-NN pass (SOICP_BATCH_ROUND0=near: the usual two passes)
   int stage_issue_at = 1;                 // SOICP_STAGE_AT: 0 = a DMA copy is enqueued by the announcement itself; 1 = by the registration in
                                           // flight once its launches are in the queue (default); 2 = after its second solve launch
   hipStream_t copy_stream = nullptr;
@@ -452,6 +454,7 @@ MatchParams match_params(float plane_res, int ablate) {
   mp.max_point_dist = (double)plane_res / 2.0; // LidarSlam.cpp:820
   mp.ablate = ablate;  // SOICP_ABLATE, read when the context is created (a getenv per registration is a walk over environ)
   mp.kdbg = nullptr;
+  mp.skip_near_pass = 0;
   return mp;
 }
 EvalParams eval_params(float plane_res, int variant, int ablate) {
@@ -1192,14 +1195,24 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
     uint32_t G = 1;
     while (2u * G * n_act <= resident && 2u * G <= v_grid) G *= 2u;
     bv.wg_per_hyp = G;
-    launch_knn_plane(b.spx.as<float>(), b.spy.as<float>(), b.spz.as<float>(), b.perm.as<uint32_t>(), b.chunks.as<uint32_t>(), ds, c->view, mp, corr,
+    MatchParams mp_it = mp;
+    mp_it.skip_near_pass = (it == 0 && c->batch_round0_full) ? 1 : 0;
+    launch_knn_plane(b.spx.as<float>(), b.spy.as<float>(), b.spz.as<float>(), b.perm.as<uint32_t>(), b.chunks.as<uint32_t>(), ds, c->view, mp_it, corr,
                      b.nbr5.as<uint32_t>(), b.hist.as<int32_t>(), s, nullptr, nullptr, &bv, n_act);
     EvalParams ep_it = ep;
     ep_it.epoch_base = (++c->solve_launches) << 5;
     launch_solve_batch(lm_max, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep_it, b.partials.as<double>(), b.sync.as<uint32_t>(), b.hist.as<int32_t>(),
                        c->view, b.nbr5.as<uint32_t>(), mp, bv, n_act, s);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(b.h_states, ds, (size_t)B * sizeof(DevState), hipMemcpyDeviceToHost, s));
+    // between rounds the host needs two words per hypothesis (outer_iter, reg_done); the whole state blocks (280 KB for 64
+    // hypotheses) are read once, after the last round
+    static_assert(offsetof(DevState, reg_done) == offsetof(DevState, outer_iter) + 4, "the round report reads outer_iter and reg_done together");
+    if (c->batch_small_report)
+      HIP_TRY(c, hipMemcpy2DAsync(reinterpret_cast<char*>(b.h_states) + offsetof(DevState, outer_iter), sizeof(DevState),
+                                  reinterpret_cast<const char*>(ds) + offsetof(DevState, outer_iter), sizeof(DevState), 8, (size_t)B,
+                                  hipMemcpyDeviceToHost, s));
+    else
+      HIP_TRY(c, hipMemcpyAsync(b.h_states, ds, (size_t)B * sizeof(DevState), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     std::vector<uint32_t> next;
     for (uint32_t h : act) {
@@ -1213,6 +1226,8 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
     }
     act.swap(next);
   }
+  HIP_TRY(c, hipMemcpyAsync(b.h_states, ds, (size_t)B * sizeof(DevState), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   for (int h = 0; h < B; ++h) {
     fill_result(c, b.h_states[h], poses_in + 7 * (size_t)h, stats + h, poses_out + 7 * (size_t)h, false);
@@ -1361,6 +1376,8 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_STAGE_WAIT")) c->stage_wait_on_host = std::string(ev) == "host";
+  if (const char* ev = std::getenv("SOICP_BATCH_REPORT")) c->batch_small_report = std::string(ev) != "full";
+  if (const char* ev = std::getenv("SOICP_BATCH_ROUND0")) c->batch_round0_full = std::string(ev) != "near";
   if (const char* ev = std::getenv("SOICP_STAGE_AT")) { const int v = std::atoi(ev); if (v >= 0 && v <= 2) c->stage_issue_at = v; }
   if (const char* ev = std::getenv("SOICP_BATCH_WG_PER_CU")) { if (std::atoi(ev) == 1) c->batch_degrade = 1; }  // (several processes on one device)
   if (const char* ev = std::getenv("SOICP_BATCH_MODE")) { if (std::string(ev) == "lanes") c->batch_degrade = 2; }

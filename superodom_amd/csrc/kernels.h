@@ -30,6 +30,8 @@ struct MatchParams {
   int32_t ablate;         // profiling / test switches (env SOICP_ABLATE), read only by the PROF instantiations of the kernels,
                           // which are launched when it is non-zero: bit0 skip plane fit, bit1 skip scan, bit2 skip re-rank, ...
   unsigned long long* kdbg;  // profiling only (SOICP_ABLATE bit 7): 2 sweeps x 4*kKnnBlocks wavefront records of 16 stamps, else nullptr
+  int32_t skip_near_pass; // 1: the sweep starts with the FULL pass (gate radius).  Round 0 of a batch of hypotheses +-0.5 m / +-5 degrees
+                          // off: the near pass (half a cell) certifies almost nothing there and its scan is wasted (exact either way)
   uint32_t chunk_cap;     // entries of the chunk list buffer: LIGHT chunks (<= 16 queries) are listed from its top downwards
   // deferred report: when the solve of outer iteration i-1 left the publication of its state block to the k-NN launch of
   // iteration i (EvalParams::defer_publish), that launch's first workgroup writes it to hring[(i-1) & 1] (see EvalParams)

@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   // sqrt(3*planeRes) (LidarSlam.cpp:526,741), where "not found inside the gate ball" is a certain TOO_FAR.
   const float r_gate = sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f;
   const float r_near = 0.5f * cell;
-  const int first_pass = (r_near < 0.8f * r_gate && !(abl & 256)) ? 0 : 1;
+  const int first_pass = (r_near < 0.8f * r_gate && !(abl & 256) && !mp.skip_near_pass) ? 0 : 1;
   // one wavefront per chunk of the work list (a second / further chunk when the list is longer than the grid)
   for (uint32_t chunk = blockIdx.x * 4 + wv; chunk < n_chunks; chunk += gridDim.x * 4) {
   if (stamp) ts[0] = wall_clock64();
