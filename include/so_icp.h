@@ -154,6 +154,9 @@ typedef struct {
   /* so_icp_stage_scan: host time registrations spent waiting for a staged scan that was still on its way through the copy
    * thread; announcements copied by DMA straight from registered host memory / through the copy thread / declined */
   double stage_wait_ms_total;  int64_t staged_direct, staged_copied, stage_declined;
+  /* packed light chunks of the k-NN sweep (time_kernels 2 + SOICP_ABLATE only): rows of 16 lanes with work, rows left to the
+   * group passes because their block has more than 16 x-runs / keeps more than its quarter of the tile, candidates kept */
+  int64_t knn_packed_rows, knn_packed_rows_too_many_runs, knn_packed_rows_tile_full, knn_packed_kept;
 } so_icp_timing;
 
 /* -------- lifecycle ------------------------------------------------------------------------ */

@@ -68,7 +68,9 @@ class Timing(C.Structure):
                 ("prep_ms_total", C.c_double), ("prep_launches", C.c_int64),
                 ("host_ms_total", C.c_double), ("registrations", C.c_int64),
                 ("knn_group_passes", C.c_int64), ("knn_fallback_lanes", C.c_int64), ("knn_candidates_scanned", C.c_int64),
-                ("stage_wait_ms_total", C.c_double), ("staged_direct", C.c_int64), ("staged_copied", C.c_int64), ("stage_declined", C.c_int64)]
+                ("stage_wait_ms_total", C.c_double), ("staged_direct", C.c_int64), ("staged_copied", C.c_int64), ("stage_declined", C.c_int64),
+                ("knn_packed_rows", C.c_int64), ("knn_packed_rows_too_many_runs", C.c_int64), ("knn_packed_rows_tile_full", C.c_int64),
+                ("knn_packed_kept", C.c_int64)]
 
 
 class Sums(C.Structure):

@@ -269,6 +269,9 @@ struct so_icp_ctx {
   struct HostRange { const char* p; size_t bytes; bool owned; };
   std::vector<HostRange> host_ranges;     // so_icp_host_register / so_icp_host_alloc (under stage_mu)
   bool stage_wait_on_host = false;        // SOICP_STAGE_WAIT=host: the registration thread waits for a DMA-staged copy itself (measurement aid)
+  bool knn_pack = true;                   // SOICP_KNN_PACK=0: one chunk per wavefront throughout (round-3 work list)
+  int knn_pack_hold = 0;                  // registrations left without packing after one in which the packed near pass left > 3 % of
+                                          // the queries to the exact per-lane scan (sparse map, far-off guess): then it is not a saving
   bool batch_small_report = true;         // (SOICP_BATCH_REPORT=full: the whole state blocks after every round, as in round 3)
   bool batch_round0_full = true;          // so_icp_register_batch: round 0 starts with the full k-NN pass (SOICP_BATCH_ROUND0=near: the usual two passes)
   int stage_issue_at = 1;                 // SOICP_STAGE_AT: 0 = a DMA copy is enqueued by the announcement itself; 1 = by the registration in
@@ -455,6 +458,8 @@ MatchParams match_params(float plane_res, int ablate) {
   mp.ablate = ablate;  // SOICP_ABLATE, read when the context is created (a getenv per registration is a walk over environ)
   mp.kdbg = nullptr;
   mp.skip_near_pass = 0;
+  mp.pack_light = 1;
+  mp.packed_leftover = nullptr;
   return mp;
 }
 EvalParams eval_params(float plane_res, int variant, int ablate) {
@@ -636,6 +641,9 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
   MatchParams mp = match_params(plane_res_now, c->ablate);
   mp.chunk_cap = (uint32_t)(c->d_chunks.cap / 4);
+  mp.pack_light = (c->knn_pack && c->knn_pack_hold == 0) ? 1 : 0;
+  mp.packed_leftover = &c->d_state->packed_leftover;
+  if (c->knn_pack_hold > 0) --c->knn_pack_hold;
   if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
     HIP_TRY(c, c->d_kdbg.reserve((size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemsetAsync(c->d_kdbg.p, 0, (size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long), s));
@@ -797,6 +805,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   }
   c->h_state = c->h_ring[last & 1];
   const DevState& H = *c->h_state;
+  if (mp.pack_light && (double)H.packed_leftover > 0.03 * (double)n * (double)std::max(H.n_iterations, 1)) c->knn_pack_hold = 32;
   fill_result(c, H, pose_in, st, pose_out, !c->batch_mode);
   st->time_elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_icp).count();  // :199-200
   if (timed) {  // keep only the launches that did real work (no-op launches after convergence are excluded)
@@ -822,6 +831,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
       for (int r = 0; r < kHistReplicas; ++r) {
         const int32_t* hh = c->h_hist + ((size_t)it * kHistReplicas + r) * kHistStride;
         c->timing.knn_group_passes += hh[16]; c->timing.knn_fallback_lanes += hh[17];
+        c->timing.knn_packed_rows += hh[20]; c->timing.knn_packed_rows_too_many_runs += hh[21]; c->timing.knn_packed_rows_tile_full += hh[22];
+        c->timing.knn_packed_kept += hh[23];
         c->timing.knn_candidates_scanned += (int64_t)hh[18] * 16;
       }
   }
@@ -1159,6 +1170,7 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
   MatchParams mp = match_params(plane_res_now, c->ablate);
   mp.chunk_cap = b.bs;
   mp.hring[0] = mp.hring[1] = nullptr; mp.seq_base = 0; mp.publish_prev = 0;
+  mp.packed_leftover = &b.states.as<DevState>()->packed_leftover;
   EvalParams ep = eval_params(plane_res_now, c->cfg.tukey_variant, c->ablate);
   ep.n_queries = (uint32_t)n; ep.q_stride = 3;
   ep.timeout_ticks = 20000000ull;  // 200 ms: a pass of one hypothesis on a few workgroups lasts up to a millisecond
@@ -1197,6 +1209,7 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
     bv.wg_per_hyp = G;
     MatchParams mp_it = mp;
     mp_it.skip_near_pass = (it == 0 && c->batch_round0_full) ? 1 : 0;
+    mp_it.pack_light = (c->knn_pack && !mp_it.skip_near_pass) ? 1 : 0;
     launch_knn_plane(b.spx.as<float>(), b.spy.as<float>(), b.spz.as<float>(), b.perm.as<uint32_t>(), b.chunks.as<uint32_t>(), ds, c->view, mp_it, corr,
                      b.nbr5.as<uint32_t>(), b.hist.as<int32_t>(), s, nullptr, nullptr, &bv, n_act);
     EvalParams ep_it = ep;
@@ -1376,6 +1389,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_STAGE_WAIT")) c->stage_wait_on_host = std::string(ev) == "host";
+  if (const char* ev = std::getenv("SOICP_KNN_PACK")) c->knn_pack = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BATCH_REPORT")) c->batch_small_report = std::string(ev) != "full";
   if (const char* ev = std::getenv("SOICP_BATCH_ROUND0")) c->batch_round0_full = std::string(ev) != "near";
   if (const char* ev = std::getenv("SOICP_STAGE_AT")) { const int v = std::atoi(ev); if (v >= 0 && v <= 2) c->stage_issue_at = v; }

@@ -30,6 +30,9 @@ struct MatchParams {
   int32_t ablate;         // profiling / test switches (env SOICP_ABLATE), read only by the PROF instantiations of the kernels,
                           // which are launched when it is non-zero: bit0 skip plane fit, bit1 skip scan, bit2 skip re-rank, ...
   unsigned long long* kdbg;  // profiling only (SOICP_ABLATE bit 7): 2 sweeps x 4*kKnnBlocks wavefront records of 16 stamps, else nullptr
+  uint32_t* packed_leftover;  // &DevState::packed_leftover of the registration (hypothesis 0 of a batch), passed beside `st` so that the
+                              // kernel's loads through its read-only, restrict-qualified `st` stay scalar loads
+  int32_t pack_light;     // 1: four light chunks per wavefront (knn_plane_kernel, SO_KNN_PACK); 0: one chunk per wavefront throughout
   int32_t skip_near_pass; // 1: the sweep starts with the FULL pass (gate radius).  Round 0 of a batch of hypotheses +-0.5 m / +-5 degrees
                           // off: the near pass (half a cell) certifies almost nothing there and its scan is wasted (exact either way)
   uint32_t chunk_cap;     // entries of the chunk list buffer: LIGHT chunks (<= 16 queries) are listed from its top downwards
@@ -95,7 +98,8 @@ struct DevState {
   int32_t max_outer, lm_max, pad0, pad1;
   // device-side control
   int32_t outer_iter, reg_done, lm_more, n_iterations;
-  uint32_t pad2[4];
+  uint32_t packed_leftover;  // k-NN sweeps of this registration: queries of packed light chunks that the packed near pass could not finish (exact per-lane scan)
+  uint32_t pad2[3];
   // work-list counters of the hash binning in ONE word (kept queries | normal chunks << 21 | light chunks (<= 16 queries,
   // listed separately) << 42), so that a workgroup of bin_offsets_kernel reserves its three ranges with one atomic round trip
   unsigned long long bin_packed;

@@ -25,6 +25,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #ifdef SO_LM_STAMPS  // profiling build: device clock at the phases of the LM controller (tools/eval_stamps.py prints them)
 #define SO_LM_STAMP(dbg, i) do { if (dbg) (dbg)[i] = wall_clock64(); } while (0)
@@ -101,6 +102,7 @@ __device__ __forceinline__ void reg_begin_state(DevState* st, const RegBeginArgs
     st->max_outer = a.max_outer; st->lm_max = a.lm_max;
     st->outer_iter = 0; st->reg_done = 0; st->lm_more = 0; st->n_iterations = 0;
     st->bin_packed = 0ull;
+    st->packed_leftover = 0u;
   }
 }
 // stand-alone prologue (empty scan: scan_keys_kernel, which normally carries it, is not launched)
@@ -648,7 +650,7 @@ __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const d
 constexpr int kKeyIdxBits = 11;                                  // a key addresses up to 2048 candidates of one group
 constexpr uint32_t kKeyIdxMask = (1u << kKeyIdxBits) - 1u;
 constexpr uint32_t kGroupMaxCand = 1u << kKeyIdxBits;
-constexpr uint32_t kTileCand = 256;                               // candidates staged in LDS at a time (5 KB per wavefront)
+constexpr uint32_t kTileCand = 384;                               // candidates staged in LDS at a time (7.8 KB per wavefront: 4 workgroups per CU = 132 KB)
 
 // v_med3_i32 has no clang builtin; it is a pure VALU op (no memory, no wait states needed).
 __device__ __forceinline__ int32_t imed3(int32_t a, int32_t b, int32_t c) {
@@ -730,6 +732,37 @@ __device__ __forceinline__ float wave_min_f32(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// All-reduce over a ROW of 16 lanes (DPP row_ror:1,2,4,8 -- rotations inside the row, no LDS): every lane of the row gets
+// the row's result.  The packed light chunks of knn_plane_kernel live one per row.
+__device__ __forceinline__ int row_min_i32(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xF, 0xF, false)); v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false)); v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));
+  return v;
+}
+__device__ __forceinline__ int row_max_i32(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xF, 0xF, false)); v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false)); v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));
+  return v;
+}
+__device__ __forceinline__ float row_min_f32(float v) {
+#define SO_ROR_F(ctrl) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xF, 0xF, false))
+  v = fminf(v, SO_ROR_F(0x121)); v = fminf(v, SO_ROR_F(0x122)); v = fminf(v, SO_ROR_F(0x124)); v = fminf(v, SO_ROR_F(0x128));
+#undef SO_ROR_F
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+#ifndef SO_KNN_PACK
+#define SO_KNN_PACK 1  // four light chunks (<= 16 queries each) per wavefront, one per row of 16 lanes (see knn_plane_kernel)
+#endif
+constexpr uint32_t kPartTile = kTileCand / 4;  // candidates a packed chunk may keep in its quarter of the wavefront's tile
+
 // PROF : the profiling / test-hook instantiation (per-wavefront stamps, SOICP_ABLATE switches, kernel statistics); the
 //        production instantiation carries none of it (the sweep is instruction-issue bound).
 // BATCH: so_icp_register_batch -- blockIdx.y picks the hypothesis, see BatchView.
@@ -743,15 +776,18 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
                                                         const uint32_t* __restrict__ mcell_start, DevMapView map,
                                                         MatchParams mp, CorrBuffers corr, uint32_t* __restrict__ nbr5,
                                                         int32_t* __restrict__ hist, BatchView bv) {
-  __shared__ int32_t lh[20];
+  __shared__ int32_t lh[24];
   __shared__ __attribute__((aligned(16))) float tiles[4][4][kTileCand + 16];  // per wavefront: x[], y[], z[], |c|^2 (block-local)
   __shared__ uint32_t tcanon[4][kTileCand + 16];  // per wavefront: canonical map index of the staged candidate
-  __shared__ uint32_t rowtab[4][2][36];  // per wavefront: exclusive candidate offsets [33] and first canonical index [32] of the block's x-runs
+  __shared__ uint32_t rowtab[4][2][72];  // per wavefront: exclusive candidate offsets [33] and first canonical index [32] of the block's x-runs
+                                         // (packed light chunks: four tables of 17 + 16 entries, one per row of 16 lanes)
   if (BATCH) {
     const size_t h = bv.active[blockIdx.y];
     st += h; spx += h * bv.bs; spy += h * bv.bs; spz += h * bv.bs; perm += h * bv.bs; chunk_start += h * bv.bs;
     corr.status += h * bv.bs; nbr5 += h * 5 * bv.bs; hist += h * (kHistReplicas * kHistStride);
   }
+  uint32_t* const leftover_ctr = (BATCH && mp.packed_leftover)
+      ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(mp.packed_leftover) + (size_t)bv.active[blockIdx.y] * sizeof(DevState)) : mp.packed_leftover;
   if (st->reg_done) return;  // the registration already converged: this launch is a no-op
   // the report of the previous outer iteration, left to this launch by its solve (MatchParams::publish_prev)
   if (!BATCH && mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
@@ -763,14 +799,24 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   // Wavefront w takes positions w, w + 4096, ...: with up to 8 192 chunks the wavefronts that get a second chunk are the
   // ones whose first chunk is light, and their second chunk is light too -- two light chunks cost about as much as one
   // full chunk, so the whole sweep runs in ONE round of resident wavefronts (a second round ran on a mostly empty chip).
-  const uint32_t n_chunks = n_normal + n_light, n_light1 = (n_light + 1u) >> 1;
+  // SO_KNN_PACK (round 4): a light chunk leaves three quarters of a wavefront idle and pays a whole wavefront's prologue, group
+  // set-up and epilogue (44 % of the chunks, 40 % of the sweep's instructions for 12 % of its queries).  Four of them now share
+  // one wavefront, one per ROW of 16 lanes, each with its own block, row table and quarter of the LDS tile: work list =
+  // [packed items: light chunks 4 m .. 4 m + 3][normal chunks].
+  // (MatchParams::pack_light = 0 -- the host's choice for a sweep that starts with the full pass, or after sweeps in which the packed
+  //  near pass left too many queries to the exact scan -- gives the round-3 list: [half of the light chunks][normal][other half])
+  const float cell_w = (float)(1.0 / map.inv_cell);
+  const bool first_pass_is_near = 0.5f * cell_w < 0.8f * (sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f) && !mp.skip_near_pass && !(PROF && (mp.ablate & 256));
+  const bool pack = SO_KNN_PACK && mp.pack_light && first_pass_is_near;
+  const uint32_t n_packed = pack ? (n_light + 3u) >> 2 : 0u;
+  const uint32_t n_chunks = n_normal + (pack ? n_packed : n_light), n_light1 = pack ? 0u : (n_light + 1u) >> 1;
   const Pose pose = pose_from_array(st->T);
   if (PROF) {  // kernel statistics (group passes, fallback lanes, candidates scanned): profiling instantiation only
-    if (threadIdx.x < 20) lh[threadIdx.x] = 0;
+    if (threadIdx.x < 24) lh[threadIdx.x] = 0;
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform, and the compiler is told so: the LDS bases below live in SGPRs)
   float* tx = tiles[wv][0];
   float* ty = tiles[wv][1];
   float* tz = tiles[wv][2];
@@ -796,16 +842,27 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   const float r_near = 0.5f * cell;
   const int first_pass = (r_near < 0.8f * r_gate && !(abl & 256) && !mp.skip_near_pass) ? 0 : 1;
   // one wavefront per chunk of the work list (a second / further chunk when the list is longer than the grid)
-  for (uint32_t chunk = blockIdx.x * 4 + wv; chunk < n_chunks; chunk += gridDim.x * 4) {
+  // (the body is instantiated twice -- packed light chunks / one chunk per wavefront -- so that neither path carries the other's
+  //  live values: the kernel sits at its 128-register budget)
+  auto do_item = [&](auto packed_tag, const uint32_t chunk) {
+  constexpr bool packed = decltype(packed_tag)::value;
   if (stamp) ts[0] = wall_clock64();
   uint32_t j = 0;
   bool valid_q = false;
   // A chunk of at most 32 queries is served by BOTH halves of the wavefront: lanes l and l + 32 hold the same query and
   // scan alternate candidate quads, then exchange their eight survivors (the average chunk has 27 queries).
   bool split = false, split4 = false;  // <= 16 queries: four parts of 16 lanes
-  {
-    const uint32_t entry = chunk < n_light1 ? mp.chunk_cap - 1u - chunk
-                         : (chunk < n_light1 + n_normal ? chunk - n_light1 : mp.chunk_cap - 1u - (chunk - n_normal));
+  const uint32_t part = (uint32_t)lane >> 4, lane16 = (uint32_t)lane & 15u;
+  if constexpr (packed) {  // four light chunks, one per row of 16 lanes
+    const uint32_t li = chunk * 4u + part;
+    const uint32_t desc = li < n_light ? chunk_start[mp.chunk_cap - 1u - li] : 0u;
+    const uint32_t start = desc & 0x03FFFFFFu, count = li < n_light ? (desc >> 26) + 1u : 0u;
+    j = start + lane16;
+    valid_q = (lane16 < count) && (j < n_kept);
+  } else {
+    const uint32_t entry = pack ? chunk - n_packed
+                         : (chunk < n_light1 ? mp.chunk_cap - 1u - chunk
+                            : (chunk < n_light1 + n_normal ? chunk - n_light1 : mp.chunk_cap - 1u - (chunk - n_normal)));
     const uint32_t desc = __builtin_amdgcn_readfirstlane(chunk_start[entry]);
     const uint32_t start = desc & 0x03FFFFFFu, count = (desc >> 26) + 1u;
     split = count <= 32u && !(abl & 1024);
@@ -843,13 +900,321 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   bool resolved = (ckey == 0xFFFFFFFFu);  // no cube: nothing to search
   bool too_far_certain = false, need_exact = false;
   int n_groups = 0;
-  uint32_t n_scanned = 0;
+  uint32_t n_scanned = 0, n_left_stat = 0;
   if (stamp) { ts[1] = wall_clock64(); acc[0] += ts[1] - ts[0]; }
+  // exact re-rank of a lane's survivors + certification (used by the packed near pass and by the group passes)
+  // returns 0: not certified (the lane stays pending), 1: exact 5-NN in `top`, 2: certainly beyond the gate, 3: needs the exact
+  // per-lane scan.  (Values in and out, no reference captures of the lane's flags: those must stay in registers.)
+  auto certify = [qx, qy, qz, mpts, &mp](int pass, const uint32_t (&gs)[8], int32_t k6, int32_t k8, float cov2, Top5& top) -> int {
+    // First the five best approximate keys only.  Every candidate that is NOT re-ranked has exact d2 >= R2:
+    //   in-block outsiders: approximate d2 >= L (the first key left out, index bits cleared), exact >= L - kApproxAbsErr;
+    //   points of the cube outside the block: farther than the block boundary (cov2).
+    unsigned long long e[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      e[t] = ~0ull;
+      if (gs[t] != 0xFFFFFFFFu) {
+        const float4 p = mpts[gs[t]];
+        e[t] = ((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, p.x, p.y, p.z)) << 32) | gs[t];
+      }
+    }
+    top.set5(e[0], e[1], e[2], e[3], e[4]);
+    const double cov = (double)cov2 * (1.0 - 1e-6);
+    double R2 = cov;
+    if (k6 != kKeyEmpty) R2 = fmin(R2, (double)__uint_as_float((uint32_t)k6 & ~kKeyIdxMask) * (1.0 - 1e-6) - (double)kApproxAbsErr);
+    bool have5 = top.b4 != ~0ull;
+    double d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
+    bool exact = have5 && d5 < R2;
+    bool far = !exact && R2 > (double)mp.sq_max_dist_f;
+    // a 5th and a 6th candidate too close to call on approximate keys (a few lanes in a thousand): re-rank all eight
+    if (__ballot(!exact && !far && gs[5] != 0xFFFFFFFFu)) {
+      if (!exact && !far) {
+#pragma unroll
+        for (int t = 5; t < 8; ++t) {
+          if (gs[t] != 0xFFFFFFFFu) {
+            const float4 p = mpts[gs[t]];
+            top.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, p.x, p.y, p.z)) << 32) | gs[t]);
+          }
+        }
+        R2 = cov;
+        if (k8 != kKeyEmpty) R2 = fmin(R2, (double)__uint_as_float((uint32_t)k8 & ~kKeyIdxMask) * (1.0 - 1e-6) - (double)kApproxAbsErr);
+        have5 = top.b4 != ~0ull;
+        d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
+        exact = have5 && d5 < R2;
+        far = !exact && R2 > (double)mp.sq_max_dist_f;
+      }
+    }
+    return exact ? 1 : (far ? 2 : (pass == 1 ? 3 : 0));  // (far: the true 5th neighbour is >= R2 > gate, LidarSlam.cpp:741)
+  };
+  // ---- packed light chunks: the NEAR pass of four chunks at once, one per row of 16 lanes.  What the wave-uniform scalars of
+  //      the group passes below are -- block bounds, row table, candidate count, tile -- lives in VGPRs here, uniform over a row
+  //      (DPP row all-reduces instead of ballots / readlanes), and every row streams its own quarter of the LDS tile (four LDS
+  //      addresses per read, like the split scan).  A row whose block has more than 16 x-runs or keeps more than 64 candidates,
+  //      and a lane in another cube than its row's first, is left to the group passes below; so is every lane the near pass
+  //      cannot certify (full pass) -- the results are the same exact lists either way.
+  constexpr bool near_done = false;  // (group passes only: every lane takes part in its near pass)
+  if constexpr (packed) if (first_pass == 0 && !(abl & 2))
+  for (int ppass = 0; ppass < 2; ++ppass) {  // near pass, then -- for the rows that still have uncertified lanes -- the full pass (gate radius)
+    const bool pend = !resolved && !need_exact;
+    if (ppass == 1 && __ballot(pend) == 0ull) break;
+    if (PROF) ++n_groups;
+    const int myslot = (int)(ckey >> 18);
+    const int gslot = row_min_i32(pend ? myslot : 0x7FFFFFFF);
+    const bool mine = pend && myslot == gslot;
+    const float r_cover = ppass == 0 ? r_near : r_gate;
+    const int lo_x = max(0, (int)floorf((ux - r_cover) * inv_cellf)), hi_x = min(nc - 1, (int)floorf((ux + r_cover) * inv_cellf));
+    const int lo_y = max(0, (int)floorf((uy - r_cover) * inv_cellf)), hi_y = min(nc - 1, (int)floorf((uy + r_cover) * inv_cellf));
+    const int lo_z = max(0, (int)floorf((uz - r_cover) * inv_cellf)), hi_z = min(nc - 1, (int)floorf((uz + r_cover) * inv_cellf));
+    const int bx0 = row_min_i32(mine ? lo_x : 0x7FFFFFFF), bx1 = row_max_i32(mine ? hi_x : -1);
+    const int by0 = row_min_i32(mine ? lo_y : 0x7FFFFFFF), by1 = row_max_i32(mine ? hi_y : -1);
+    const int bz0 = row_min_i32(mine ? lo_z : 0x7FFFFFFF), bz1 = row_max_i32(mine ? hi_z : -1);
+    const int nyr = by1 - by0 + 1, nrows = nyr * (bz1 - bz0 + 1);
+    bool part_ok = gslot != 0x7FFFFFFF && nrows >= 1 && nrows <= 16;  // (uniform over the row)
+    // squared distance from the query to the faces of the block (a face on the cube's boundary has nothing of the cube behind
+    // it), capped by the filter radius: formed here, while the bounds are at hand (six registers less across the scan)
+    float cov2p;
+    {
+      float cv = 1e15f;
+      if (bx0 > 0) cv = fminf(cv, ux - (float)bx0 * cell);
+      if (bx1 < nc - 1) cv = fminf(cv, (float)(bx1 + 1) * cell - ux);
+      if (by0 > 0) cv = fminf(cv, uy - (float)by0 * cell);
+      if (by1 < nc - 1) cv = fminf(cv, (float)(by1 + 1) * cell - uy);
+      if (bz0 > 0) cv = fminf(cv, uz - (float)bz0 * cell);
+      if (bz1 < nc - 1) cv = fminf(cv, (float)(bz1 + 1) * cell - uz);
+      cv = fmaxf(cv - 1e-4f, 0.f);  // cell membership of a map point is decided in fp64 on its own coordinates: keep a margin
+      if (ppass == 1) cv = 1e15f;   // (the full pass's block contains the lane's whole gate ball by construction)
+      cov2p = fminf(cv * cv, r_cover * r_cover);  // (candidates beyond r_cover of every lane of the group are not staged)
+    }
+    // row table of the part's block: lane r of the row fetches the bounds of x-run r, inclusive scan over the row
+    uint32_t vb = 0, vl = 0;
+    if (part_ok && (int)lane16 < nrows) {
+      const int zq = (int)(((float)lane16 + 0.5f) * __builtin_amdgcn_rcpf((float)nyr));  // lane16 / nyr (see the group passes)
+      const int z = bz0 + zq, y = by0 + ((int)lane16 - zq * nyr);
+      const uint32_t* row = mcell_start + (size_t)gslot * map.ncell1 + ((size_t)z * nc + y) * nc;
+      vb = row[bx0]; vl = row[bx1 + 1] - vb;
+    }
+    uint32_t inc = vl;
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);
+    const uint32_t total = (uint32_t)row_max_i32((int)inc);  // (the inclusive scan is monotone: its maximum is the row's total)
+    part_ok = part_ok && total <= 1024u;
+    uint32_t* prowoff = rowoff + part * 17u;   // [17] exclusive offsets (total from entry nrows on)
+    uint32_t* prowbeg = rowbeg + part * 16u;   // [16] first canonical index of the x-run
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    prowoff[lane16] = ((int)lane16 < nrows) ? inc - vl : total; prowbeg[lane16] = vb;
+    if (lane16 == 0) prowoff[16] = total;
+    // block-local frame of the part: origin at the centre of the block's middle cell, in the group's cube (the lanes of a group
+    // share the cube; the staging lanes below need the ROW's origin whatever their own query is, so it is reduced over the row)
+    const int gz = (bz0 + bz1) >> 1, gy = (by0 + by1) >> 1, gx = (bx0 + bx1) >> 1;
+    const int w0r = row_max_i32(mine ? wcube0 : -0x7FFFFFFF), w1r = row_max_i32(mine ? wcube1 : -0x7FFFFFFF), w2r = row_max_i32(mine ? wcube2 : -0x7FFFFFFF);
+    const double rox = (w0r * 50.0 - 25.0) + ((double)gx + 0.5) * (double)cell;
+    const double roy = (w1r * 50.0 - 25.0) + ((double)gy + 0.5) * (double)cell;
+    const double roz = (w2r * 50.0 - 25.0) + ((double)gz + 0.5) * (double)cell;
+    const float lqx = (float)((double)qx - rox), lqy = (float)((double)qy - roy), lqz = (float)((double)qz - roz);
+    const float m2qx = -2.f * lqx, m2qy = -2.f * lqy, m2qz = -2.f * lqz;
+    const float qq = __builtin_fmaf(lqz, lqz, __builtin_fmaf(lqy, lqy, lqx * lqx));
+    const float pinf = __int_as_float(0x7F800000);
+    const float bl0 = row_min_f32(mine ? lqx : pinf), bl1 = row_min_f32(mine ? lqy : pinf), bl2 = row_min_f32(mine ? lqz : pinf);
+    const float bh0 = -row_min_f32(mine ? -lqx : pinf), bh1 = -row_min_f32(mine ? -lqy : pinf), bh2 = -row_min_f32(mine ? -lqz : pinf);
+    const float dk = r_cover + 2e-4f, dk2 = dk * dk;
+    const uint32_t tbase = part * kPartTile;
+    const uint32_t tot_eff = part_ok ? total : 0u;
+    const uint32_t tmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)tot_eff, 0), (uint32_t)__builtin_amdgcn_readlane((int)tot_eff, 16)),
+                              max((uint32_t)__builtin_amdgcn_readlane((int)tot_eff, 32), (uint32_t)__builtin_amdgcn_readlane((int)tot_eff, 48)));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (PROF) n_scanned += tmax;
+    uint32_t w = 0;  // candidates the part has kept so far (uniform over the row)
+    // Staging.  A group of lanes -- width 16 = every row for itself (near pass: all four rows are busy), or width 64 = the
+    // whole wavefront for ONE row after the other (full pass: one or two rows still have lanes, their blocks hold hundreds of
+    // points) -- enumerates a row's block, `width` candidates per step.  Four steps' loads are issued together (four in flight
+    // per lane; a step per memory round trip made a 100-candidate block seven dependent round trips), the candidates are
+    // filtered against the row's box and compacted into the row's quarter of the tile in enumeration order.
+    auto stage = [&](const uint32_t tot, const uint32_t tend, const uint32_t gl /*lane in the group*/, const uint32_t width, const uint32_t shift,
+                     const uint32_t* poff, const uint32_t* pbeg, const uint32_t tb, const double sx, const double sy, const double sz,
+                     const float l0, const float l1, const float l2, const float h0, const float h1, const float h2) -> uint32_t {
+      uint32_t kept = 0;
+      const unsigned long long gmask = width == 64u ? ~0ull : 0xFFFFull;
+      for (uint32_t t0 = 0; t0 < tend; t0 += 4u * width) {
+        float px_[4], py_[4], pz_[4];
+        uint32_t cn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t t = t0 + width * (uint32_t)u + gl;
+          cn[u] = 0xFFFFFFFFu; px_[u] = 0.f; py_[u] = 0.f; pz_[u] = 0.f;
+          if (t < tot) {
+            int r = 0;
+#pragma unroll
+            for (int step = 8; step >= 1; step >>= 1) r = (r + step < 16 && poff[r + step] <= t) ? r + step : r;
+            cn[u] = pbeg[r] + (t - poff[r]);
+            const float4 p = mpts[cn[u]];
+            px_[u] = p.x; py_[u] = p.y; pz_[u] = p.z;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (t0 + width * (uint32_t)u >= tend) break;  // (uniform)
+          bool kp = false;
+          float lx = 0.f, ly = 0.f, lz = 0.f, lc = 0.f;
+          if (cn[u] != 0xFFFFFFFFu) {
+            lx = (float)((double)px_[u] - sx); ly = (float)((double)py_[u] - sy); lz = (float)((double)pz_[u] - sz);
+            lc = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+            const float ex = fmaxf(fmaxf(l0 - lx, lx - h0), 0.f), ey = fmaxf(fmaxf(l1 - ly, ly - h1), 0.f), ez = fmaxf(fmaxf(l2 - lz, lz - h2), 0.f);
+            kp = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) <= dk2;
+          }
+          const unsigned long long mg = (__ballot(kp) >> shift) & gmask;
+          const uint32_t pos = kept + (uint32_t)__popcll(mg & ((1ull << gl) - 1ull));
+          if (kp && pos < kPartTile) { tx[tb + pos] = lx; ty[tb + pos] = ly; tz[tb + pos] = lz; tc[tb + pos] = lc; ti[tb + pos] = cn[u]; }
+          kept += (uint32_t)__popcll(mg);
+        }
+      }
+      return kept;
+    };
+    if (ppass == 0) {
+      w = stage(tot_eff, tmax, lane16, 16u, part * 16u, prowoff, prowbeg, tbase, rox, roy, roz, bl0, bl1, bl2, bh0, bh1, bh2);
+    } else {
+      for (int rr = 0; rr < 4; ++rr) {  // one row after the other, all 64 lanes on it (row-uniform values from the row's first lane)
+        const int src = rr * 16;
+        const uint32_t tot_r = (uint32_t)__builtin_amdgcn_readlane((int)tot_eff, src);
+        if (!tot_r) continue;
+#define SO_RL_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src))
+#define SO_RL_D(v) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src))
+        const uint32_t wr = stage(tot_r, tot_r, (uint32_t)lane, 64u, 0u, rowoff + rr * 17, rowbeg + rr * 16, (uint32_t)rr * kPartTile,
+                                  SO_RL_D(rox), SO_RL_D(roy), SO_RL_D(roz), SO_RL_F(bl0), SO_RL_F(bl1), SO_RL_F(bl2), SO_RL_F(bh0), SO_RL_F(bh1), SO_RL_F(bh2));
+#undef SO_RL_F
+#undef SO_RL_D
+        if ((int)part == rr) w = wr;
+      }
+    }
+    if (PROF && lane16 == 0 && gslot != 0x7FFFFFFF) {  // statistics: rows with work / left to the group passes (x-runs, kept candidates) / kept candidates
+      atomicAdd(&lh[20], 1);
+      if (!(part_ok && w <= kPartTile)) atomicAdd(&lh[nrows > 16 || nrows < 1 ? 21 : 22], 1);
+      atomicAdd(&lh[23], (int)w);
+    }
+    part_ok = part_ok && w <= kPartTile;
+    const uint32_t wk = part_ok ? w : 0u;
+    for (uint32_t sl = wk + lane16; sl < kPartTile; sl += 16u) {  // the rest of the part's quarter: entries that lose against every real candidate
+      tx[tbase + sl] = 0.f; ty[tbase + sl] = 0.f; tz[tbase + sl] = 0.f; tc[tbase + sl] = 3.0e38f; ti[tbase + sl] = 0xFFFFFFFFu;
+    }
+    const uint32_t wmax = (max(max((uint32_t)__builtin_amdgcn_readlane((int)wk, 0), (uint32_t)__builtin_amdgcn_readlane((int)wk, 16)),
+                               max((uint32_t)__builtin_amdgcn_readlane((int)wk, 32), (uint32_t)__builtin_amdgcn_readlane((int)wk, 48))) + 3u) & ~3u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t keep = ~kKeyIdxMask;
+    const float2v pqx = {m2qx, m2qx}, pqy = {m2qy, m2qy}, pqz = {m2qz, m2qz}, pqq = {qq, qq};
+    Net8 net;
+    net.init();
+    if (!(abl & 8))
+    for (uint32_t jl = 0; jl < wmax; jl += 4u) {  // every row walks its own quarter of the tile: four LDS addresses per read
+      const uint32_t a = tbase + jl;
+      const float4 X = *reinterpret_cast<const float4*>(tx + a), Y = *reinterpret_cast<const float4*>(ty + a);
+      const float4 Z = *reinterpret_cast<const float4*>(tz + a), C = *reinterpret_cast<const float4*>(tc + a);
+      const float2v d01 = approx_d2_pair(pqx, pqy, pqz, pqq, float2v{X.x, X.y}, float2v{Y.x, Y.y}, float2v{Z.x, Z.y}, float2v{C.x, C.y});
+      const float2v d23 = approx_d2_pair(pqx, pqy, pqz, pqq, float2v{X.z, X.w}, float2v{Y.z, Y.w}, float2v{Z.z, Z.w}, float2v{C.z, C.w});
+      net.push(make_key(d01.x, jl, keep));
+      net.push(make_key(d01.y, jl + 1u, keep));
+      net.push(make_key(d23.x, jl + 2u, keep));
+      net.push(make_key(d23.y, jl + 3u, keep));
+    }
+    const int32_t ks[8] = {net.a0, net.a1, net.a2, net.a3, net.a4, net.a5, net.a6, net.a7};
+    uint32_t gs[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const uint32_t jl = (uint32_t)ks[t] & kKeyIdxMask;
+      gs[t] = (ks[t] == kKeyEmpty || jl >= wk) ? 0xFFFFFFFFu : ti[tbase + (jl < kPartTile ? jl : 0u)];
+    }
+    if (mine && part_ok) {
+      if (!(abl & 4)) {
+        const int v = certify(ppass, gs, net.a5, net.a7, cov2p, top);
+        resolved = v == 1 || v == 2; too_far_certain = v == 2; need_exact = v == 3;
+      } else resolved = true;
+    } else if (mine && ppass == 1) {
+      need_exact = true;  // (a row whose full-pass block has too many x-runs or keeps more than its quarter of the tile)
+    }
+  }
+  if constexpr (packed) {
+    // what the packed near pass could not finish -- a 5th neighbour beyond half a cell, a row with too many x-runs or kept
+    // candidates, a lane in another cube than its row -- goes to the exact per-lane scan of the 27 cells below (the group passes
+    // are not instantiated here: registers and code size).  The host watches the count and turns the packing off for sweeps
+    // where it is not rare.
+    unsigned long long left = __ballot(valid_q && c.slot >= 0 && !resolved);
+    if (left && lane == 0 && mp.packed_leftover) atomicAdd(leftover_ctr, (uint32_t)__popcll(left));
+    if (PROF) n_left_stat = (uint32_t)__popcll(left);
+    // One leftover query at a time, the WHOLE wavefront on it: the (clamped) 3 x 3 x 3 cells around the query -- every map point
+    // inside the gate ball lies there (one cell >= the gate radius) -- as <= 9 x-runs, their points dealt to the 64 lanes with
+    // the loads of a lane issued together, exact distances, lane-local top 5, five wavefront minima.  (The per-lane scan
+    // knn27() walks those ~300 points through dependent loads: 60 us for one lane, which ended the whole sweep.)
+    while (left) {
+      const int L = __ffsll((long long)left) - 1;
+      left &= left - 1ull;
+      const float sqx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), L)), sqy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), L));
+      const float sqz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), L));
+      const int sslot = __builtin_amdgcn_readlane(c.slot, L), scx = __builtin_amdgcn_readlane(c.cx, L);
+      const int scy = __builtin_amdgcn_readlane(c.cy, L), scz = __builtin_amdgcn_readlane(c.cz, L);
+      const int x0 = scx > 0 ? scx - 1 : 0, x1 = scx < nc - 1 ? scx + 1 : nc - 1;
+      uint32_t vb = 0, vl = 0;
+      if (lane < 9) {
+        const int y = scy + (lane % 3) - 1, z = scz + (lane / 3) - 1;
+        if (y >= 0 && y < nc && z >= 0 && z < nc) {
+          const uint32_t* row = mcell_start + (size_t)sslot * map.ncell1 + ((size_t)z * nc + y) * nc;
+          vb = row[x0]; vl = row[x1 + 1] - vb;
+        }
+      }
+      uint32_t inc = vl;  // inclusive scan over lanes 0..15 (the nine runs sit in the first row of 16 lanes)
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 15);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 16) { rowoff[lane] = lane < 9 ? inc - vl : total; rowbeg[lane] = vb; }
+      if (lane == 0) rowoff[16] = total;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      Top5 loc;
+      loc.init();
+      for (uint32_t t0 = 0; t0 < total; t0 += 256u) {
+        float ax_[4], ay_[4], az_[4];
+        uint32_t cn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
+          cn[u] = 0xFFFFFFFFu; ax_[u] = ay_[u] = az_[u] = 0.f;
+          if (t < total) {
+            int r = 0;
+#pragma unroll
+            for (int step = 8; step >= 1; step >>= 1) r = (r + step < 16 && rowoff[r + step] <= t) ? r + step : r;
+            cn[u] = rowbeg[r] + (t - rowoff[r]);
+            const float4 p = mpts[cn[u]];
+            ax_[u] = p.x; ay_[u] = p.y; az_[u] = p.z;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (cn[u] != 0xFFFFFFFFu) loc.insert(((unsigned long long)__float_as_uint(l2_d2(sqx, sqy, sqz, ax_[u], ay_[u], az_[u])) << 32) | cn[u]);
+      }
+      unsigned long long m5[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        m5[t] = wave_min_u64(loc.b0);
+        if (loc.b0 == m5[t] && m5[t] != ~0ull) { loc.b0 = loc.b1; loc.b1 = loc.b2; loc.b2 = loc.b3; loc.b3 = loc.b4; loc.b4 = ~0ull; }  // (keys are unique)
+      }
+      if (lane == L) {  // (fewer than five points in reach: b4 stays "none" and the gate below says TOO_FAR, like the per-lane scan)
+        top.b0 = m5[0]; top.b1 = m5[1]; top.b2 = m5[2]; top.b3 = m5[3]; top.b4 = m5[4];
+        too_far_certain = false; resolved = true;
+      }
+    }
+  }
+  if constexpr (!packed)
   for (int pass = first_pass; pass < 2; ++pass) {
-  bool pending = !resolved && !need_exact;
+  bool pending = !resolved && !need_exact && !(pass == 0 && near_done);
   unsigned long long todo = __ballot(pending);
   if (abl & 2) todo = 0;
-  if (!todo) break;
+  if (!todo) continue;  // (a packed wavefront may have nothing left for the near pass and still lanes for the full pass)
   if (stamp && pass == 1) ++n_pass2;
   const float r_cover = pass == 0 ? r_near : r_gate;
   // per-lane cell range that contains the lane's search ball (clamped to the cube: nothing of the cube lies beyond it)
@@ -1109,53 +1474,11 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   }
   // exact re-rank of the survivors + certification
   if (scanned && !need_exact && !(abl & 4)) {
-    // First the five best approximate keys only.  Every candidate that is NOT re-ranked has exact d2 >= R2:
-    //   in-block outsiders: approximate d2 >= L (the first key left out, index bits cleared), exact >= L - kApproxAbsErr;
-    //   points of the cube outside the block: farther than the block boundary (cov2).
     const uint32_t gs[8] = {g0, g1, g2, g3, g4, g5, g6, g7};
-    unsigned long long e[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      e[t] = ~0ull;
-      if (gs[t] != 0xFFFFFFFFu) {
-        const float4 p = mpts[gs[t]];
-        e[t] = ((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, p.x, p.y, p.z)) << 32) | gs[t];
-      }
-    }
-    top.set5(e[0], e[1], e[2], e[3], e[4]);
-    const double cov = (double)cov2 * (1.0 - 1e-6);
-    double R2 = cov;
-    if (k6 != kKeyEmpty) R2 = fmin(R2, (double)__uint_as_float((uint32_t)k6 & ~kKeyIdxMask) * (1.0 - 1e-6) - (double)kApproxAbsErr);
-    bool have5 = top.b4 != ~0ull;
-    double d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
-    bool exact = have5 && d5 < R2;
-    bool far = !exact && R2 > (double)mp.sq_max_dist_f;
-    // a 5th and a 6th candidate too close to call on approximate keys (a few lanes in a thousand): re-rank all eight
-    if (__ballot(!exact && !far && g5 != 0xFFFFFFFFu)) {
-      if (!exact && !far) {
-#pragma unroll
-        for (int t = 5; t < 8; ++t) {
-          if (gs[t] != 0xFFFFFFFFu) {
-            const float4 p = mpts[gs[t]];
-            top.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, p.x, p.y, p.z)) << 32) | gs[t]);
-          }
-        }
-        R2 = cov;
-        if (k8 != kKeyEmpty) R2 = fmin(R2, (double)__uint_as_float((uint32_t)k8 & ~kKeyIdxMask) * (1.0 - 1e-6) - (double)kApproxAbsErr);
-        have5 = top.b4 != ~0ull;
-        d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
-        exact = have5 && d5 < R2;
-        far = !exact && R2 > (double)mp.sq_max_dist_f;
-      }
-    }
-    if (exact) {
-      resolved = true;  // exact 5-NN
-    } else if (far) {
-      too_far_certain = true;  // the true 5th neighbour is >= R2 > gate (LidarSlam.cpp:741)
-      resolved = true;
-    } else if (pass == 1) {
-      need_exact = true;
-    }
+    const int v = certify(pass, gs, k6, k8, cov2, top);
+    if (v == 1 || v == 2) resolved = true;
+    if (v == 2) too_far_certain = true;
+    if (v == 3) need_exact = true;
   } else if (scanned && (abl & 4)) {
     resolved = true;
   }
@@ -1191,12 +1514,15 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   if (stamp) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ts[3] = wall_clock64(); acc[4] += ts[3] - ts[2]; ++n_mine;
-    const unsigned long long nfb = __popcll(__ballot(valid_q && c.slot >= 0 && (need_exact || !resolved)));
+    const unsigned long long nfb = packed ? n_left_stat : __popcll(__ballot(valid_q && c.slot >= 0 && (need_exact || !resolved)));
     if (ts[3] - ts[0] > t_maxchunk) { t_maxchunk = ts[3] - ts[0]; max_info = ((unsigned long long)n_scanned << 32) | (nfb << 16) | (unsigned long long)n_groups; }
     n_fb_total += nfb;
     n_cand_total += n_scanned; n_groups_total += n_groups; n_q_total += __popcll(__ballot(valid_q));
   }
-  }  // chunk loop
+  };  // do_item
+  for (uint32_t chunk = blockIdx.x * 4 + wv; chunk < n_chunks; chunk += gridDim.x * 4) {
+    if (SO_KNN_PACK && chunk < n_packed) do_item(std::true_type{}, chunk); else do_item(std::false_type{}, chunk);  // (n_packed = 0 unless `pack`)
+  }
   if (stamp && lane == 0) {  // one record per wavefront, no atomics (they would perturb the measurement)
     unsigned long long* d = mp.kdbg + ((size_t)(st->outer_iter & 1) * gridDim.x * 4 + blockIdx.x * 4 + wv) * 16;
     d[0] = t_first; d[1] = wall_clock64();
@@ -1207,7 +1533,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   }
   if (PROF) {
     __syncthreads();
-    if (threadIdx.x >= 16 && threadIdx.x < 20 && lh[threadIdx.x])  // kernel statistics only; the histograms are built by the fit pass
+    if (threadIdx.x >= 16 && threadIdx.x < 24 && lh[threadIdx.x])  // kernel statistics only; the histograms are built by the fit pass
       atomicAdd(&hist[(blockIdx.x % kHistReplicas) * kHistStride + threadIdx.x], lh[threadIdx.x]);
   }
 }
@@ -2098,15 +2424,6 @@ __global__ __launch_bounds__(256) void knn_only_kernel(const float* __restrict__
     if (idxo) idxo[(size_t)i * k + t] = (int32_t)id;
     { const float4 p = map.pts[id]; nbr[((size_t)i * k + t) * 3] = p.x; nbr[((size_t)i * k + t) * 3 + 1] = p.y; nbr[((size_t)i * k + t) * 3 + 2] = p.z; }
   }
-}
-
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o = __shfl_xor(v, off, 64);
-    v = o < v ? o : v;
-  }
-  return v;
 }
 
 // one WAVEFRONT per query: 64 lanes stride over every point of the query's cube, lane-local top-5,
