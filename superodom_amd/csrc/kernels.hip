@@ -3,8 +3,9 @@
 //   scan_keys_kernel    registration prologue, sampling rule, world transform, spatial key (cube | half-cell octant) and
 //                       the hash-binning count of every query                     (LidarSlam.cpp:346-359, 397-398)
 //   bin_offsets_kernel  bucket offsets + the k-NN work lists (normal / light chunks); bin_place_kernel: binned SoA scan
-//   knn_plane_kernel    one wavefront per chunk: cube-restricted exact 5-NN over the hashed-voxel cell grid (LDS-staged
-//                       candidate tiles, selection network, exact re-rank + certification), distance gate
+//   knn_plane_kernel    one wavefront per chunk (four light chunks per wavefront, one per row of 16 lanes): cube-restricted
+//                       exact 5-NN over the hashed-voxel cell grid (LDS-staged candidate tiles, selection network, exact
+//                       re-rank + certification), distance gate
 //                                                                                  (LocalMap.h:481-525, LidarSlam.cpp:720-747)
 //   solve_kernel        ONE persistent launch per outer iteration: plane fit (PCA gate, 5x3 LS plane, inlier gate,
 //                       coefficient, observability labels; LidarSlam.cpp:514-693) + every LM evaluation (residual,
@@ -646,6 +647,12 @@ __device__ __forceinline__ int plane_from_neighbours(const float nb[15], const d
 // lanes it could not certify, FULL (the reference's gate radius sqrt(3*planeRes), where "not inside the gate ball" is a
 // certain TOO_FAR).  What is still uncertified (8 near-equidistant candidates, or a block with more than 2048
 // candidates) falls back to the per-lane exact scan knn27().  Result: bit-identical neighbour lists to the oracle.
+// LIGHT chunks (<= 16 queries: 44 % of the chunks of a 128-beam sweep) are PACKED four to a wavefront, one per row of 16
+// lanes (round 4, SO_KNN_PACK / MatchParams::pack_light): the same two passes with the block bounds, the row table and the
+// candidate count of every row in VGPRs (DPP row all-reduces), a quarter of the tile per row, the full pass staged by all 64
+// lanes for one row after the other, and a wave-cooperative exact scan for what is left.  6.65 M -> 5.00 M VALU and 2.20 M ->
+// 1.57 M SALU wave-instructions per sweep (PMC), same lists bit for bit; the sweep's time did not follow (23 us: it is ended
+// by its heaviest single-chunk wavefronts), the batched sweeps' did (+2.4 % batch64).
 // ------------------------------------------------------------------------------------------------
 constexpr int kKeyIdxBits = 11;                                  // a key addresses up to 2048 candidates of one group
 constexpr uint32_t kKeyIdxMask = (1u << kKeyIdxBits) - 1u;
