@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
     if (threadIdx.x < 24) lh[threadIdx.x] = 0;
     __syncthreads();
   }
-  const int lane = threadIdx.x & 63;
+  const int lane_k = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform, and the compiler is told so: the LDS bases below live in SGPRs)
   float* tx = tiles[wv][0];
   float* ty = tiles[wv][1];
@@ -853,6 +853,12 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   //  live values: the kernel sits at its 128-register budget)
   auto do_item = [&](auto packed_tag, const uint32_t chunk) {
   constexpr bool packed = decltype(packed_tag)::value;
+  // The lane index of an item is opaque to the optimiser: whatever is derived from it (row, lane in the row, quad offsets, tile
+  // and row-table addresses) is formed per item.  Hoisted out of the item loop those values were SPILLED IN THE KERNEL'S PROLOGUE
+  // BY EVERY WAVEFRONT, working or idle -- 7 MB of scratch writes per sweep in the PMC traffic (16.8 MB against 9.8 MB
+  // algorithmic) for values a handful of integer operations rebuild.
+  int lane = lane_k;
+  asm volatile("" : "+v"(lane));
   if (stamp) ts[0] = wall_clock64();
   uint32_t j = 0;
   bool valid_q = false;
@@ -1530,7 +1536,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   for (uint32_t chunk = blockIdx.x * 4 + wv; chunk < n_chunks; chunk += gridDim.x * 4) {
     if (SO_KNN_PACK && chunk < n_packed) do_item(std::true_type{}, chunk); else do_item(std::false_type{}, chunk);  // (n_packed = 0 unless `pack`)
   }
-  if (stamp && lane == 0) {  // one record per wavefront, no atomics (they would perturb the measurement)
+  if (stamp && lane_k == 0) {  // one record per wavefront, no atomics (they would perturb the measurement)
     unsigned long long* d = mp.kdbg + ((size_t)(st->outer_iter & 1) * gridDim.x * 4 + blockIdx.x * 4 + wv) * 16;
     d[0] = t_first; d[1] = wall_clock64();
     for (int i = 0; i < 5; ++i) d[2 + i] = acc[i];
