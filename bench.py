@@ -404,7 +404,7 @@ def main():
     #      the first multi-GPU run tests.  Only the k-NN sweeps and the fit loops shrink with N (by the busiest rank's share of
     #      the queries); binning, the pass chains of the solve and the launches do not, and every pass gains one exchange.
     predicted = None
-    if prof:
+    if prof and world == 1:
         o_per = iters_outer / args.steps
         passes = iters_lm / args.steps + o_per
         fit_loop_ms, knn_floor_ms = 0.0091, 0.005  # fit loop of a fit pass (in-kernel stamps, profiles/r04); a sweep never beats its launch + slowest chunk
@@ -435,7 +435,8 @@ def main():
                              "(batch64: hypotheses split over the ranks, no collective) is what scales with N"}
 
     errs = [synth.pose_error(poses[i], sc.gt_pose(i)) for i in range(len(poses))]
-    entry_text = {"staged": "so_icp_register on HOST scan buffers, the next scan announced with so_icp_stage_scan (copy thread + copy stream): "
+    entry_text = {"staged": "so_icp_register on HOST scan buffers, the next scan announced with so_icp_stage_scan (DMA on the copy stream straight "
+                            "from pinned caller memory, enqueued by the registration in flight; copy thread for pageable buffers): "
                             "every scan's H2D copy is inside the timed region, overlapped with the previous registration",
                   "host": "so_icp_register on HOST scan buffers, copy then register (nothing overlapped)",
                   "resident": "so_icp_register_dev on scans uploaded BEFORE the timed region"}[args.entry]
