@@ -245,7 +245,31 @@ def main():
     else:
         warm()
     slam.reset_timing()
-    t_max, step_stats, step_pose = timed_loop(args.entry, args.steps, rewarm=args.warmup)  # (the W warm-up steps run again, back to back with the clock)
+    peer_lost = False
+    if peer:
+        # A rank that is descheduled for longer than SOICP_PEER_TIMEOUT_MS in the middle of the run makes its peers' solve launches
+        # give up: so_icp_register returns an error on EVERY rank (their states can no longer be assumed equal) and the peer path is
+        # off until a new handshake.  The decision to go on with the RCCL all-reduce per evaluation is collective: every rank reports
+        # whether its timed loop came through, and if one did not, all of them time the loop again on the fall-back transport.
+        import torch
+        try:
+            t_max, step_stats, step_pose = timed_loop(args.entry, args.steps, rewarm=args.warmup)
+            good = 1
+        except Exception as e:  # noqa: BLE001
+            print(f"rank {rank}: the peer exchange failed in the timed region ({e}); falling back to the RCCL all-reduce", file=sys.stderr)
+            good = 0
+        t = torch.tensor([good])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if not bool(t.item()):
+            peer = False; peer_lost = True
+            slam.peer_enable(False)
+            slam.synchronize()
+            dist.barrier()
+            warm()
+            slam.reset_timing()
+            t_max, step_stats, step_pose = timed_loop(args.entry, args.steps, rewarm=args.warmup)
+    else:
+        t_max, step_stats, step_pose = timed_loop(args.entry, args.steps, rewarm=args.warmup)  # (the W warm-up steps run again, back to back with the clock)
     tm = slam.timing()
     iters_outer = iters_lm = accepted = 0
     poses, flags = [], 0
@@ -456,7 +480,7 @@ def main():
                                     f"45-double records through hipIpc-mapped inboxes over xGMI (peer exchange)" if peer else
                                     f"map sharded by brick-hash x{world}, ownership re-derived every outer iteration, 45-fp64 RCCL all-reduce per evaluation")),
                    "shard_mode": (None if world == 1 else args.shard_mode),
-                   "peer_exchange": bool(peer),
+                   "peer_exchange": bool(peer), "peer_exchange_lost_mid_run": bool(peer_lost),
                    "transport": (None if world == 1 else ("peer exchange: tagged 16-byte chunks pushed into hipIpc-mapped inboxes by the persistent solve launches"
                                                           if peer else "RCCL all-reduce of 45 fp64 per evaluation + controller launch")),
                    "shards": shard_info,
