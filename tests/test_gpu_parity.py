@@ -153,10 +153,12 @@ def test_determinism_bitwise(gpu_slam_factory, oracle):
 
 
 @pytest.mark.parametrize("env", [{"SOICP_PERSISTENT": "0"}, {"SOICP_READBACK": "copy"}, {"SOICP_SPECULATE": "0"},
-                                 {"SOICP_SPECULATE": "0", "SOICP_PERSISTENT": "0"}, {"SOICP_PERSISTENT": "0", "SOICP_READBACK": "copy"}])
+                                 {"SOICP_SPECULATE": "0", "SOICP_PERSISTENT": "0"}, {"SOICP_PERSISTENT": "0", "SOICP_READBACK": "copy"},
+                                 {"SOICP_KNN_PACK": "0"}])
 def test_control_flow_variants_are_bit_identical(oracle, gpu_slam_factory, monkeypatch, env):
     """The same kernels under every host-side schedule: persistent solve launch vs one launch per evaluation, state
-    published by the device vs hipMemcpyAsync read-back, speculative per-iteration enqueue vs everything up front."""
+    published by the device vs hipMemcpyAsync read-back, speculative per-iteration enqueue vs everything up front; and the
+    k-NN sweep with four light chunks per wavefront (default) vs one chunk per wavefront throughout (exact lists either way)."""
     sc, ref, _ = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
     for k, v in env.items():
         monkeypatch.setenv(k, v)  # read by so_icp_create
@@ -434,3 +436,34 @@ def test_sharded_map_covers_every_query_exactly_once(oracle, gpu_slam_factory):
     assert np.array_equal(got_rej, want_rej) and np.array_equal(got_obs, want_obs)
     assert sum(owned) == len(sc.map_points), "every point is owned by exactly one rank"
     assert all(0 < m < len(sc.map_points) for m in sizes), "each rank holds a strict subset of the map (its bricks + a one-cell halo)"
+
+
+def test_packed_light_chunks_where_the_near_pass_fails(oracle, gpu_slam_factory, soicp, monkeypatch):
+    """The packed k-NN path off its happy path: a sparse map (planeRes 0.4: the 5th neighbour is often farther than half a cell) and
+    guesses 0.5 m / 4 degrees off make the near pass of many rows fail -- full pass per row, rows left to the wave-cooperative
+    exact scan -- and trip the host's switch that turns the packing off for the next registrations.  Every registration must
+    equal the oracle (iteration counts, codes, histograms, per-query MatchingResult) and the unpacked sweep bit for bit."""
+    sc = synth.Scene("small")
+    mk = dict(plane_res=0.4, line_res=0.2, max_surface_features=-1, max_iterations=3)
+    slam = gpu_slam_factory(**mk)
+    slam.add_surf_point_cloud(sc.map_points)
+    monkeypatch.setenv("SOICP_KNN_PACK", "0")
+    plain = gpu_slam_factory(**mk)
+    plain.add_surf_point_cloud(sc.map_points)
+    om = oracle.OracleMap(plane_res=0.4)
+    om.add_surf(slam.export_map(), raw=True)
+    for i in range(6):
+        scan, guess = sc.scan(i), sc.guess(i, dt=0.5, dth_deg=4.0)
+        rc, pose, st = slam.register(scan, guess)
+        rc2, pose2, st2 = plain.register(scan, guess)
+        orc, opose, ost, corrs = om.register(scan, guess, oracle.default_config(max_iterations=3), want_corrs=True)
+        assert rc == rc2 == orc == 0 and st.n_iterations == st2.n_iterations == ost.n_iterations
+        assert np.array_equal(pose, pose2), i
+        assert np.array_equal(slam.match_status(len(scan)), plain.match_status(len(scan)))
+        assert np.array_equal(slam.match_status(len(scan)), corrs["status"])
+        for it in range(st.n_iterations):
+            a, b = st.iterations[it], ost.iters[it]
+            assert (a.lm_iterations, a.num_successful_steps, a.termination, a.num_surf_from_scan) == (b.lm_iterations, b.num_successful_steps, b.termination, b.num_surf), (i, it)
+            assert list(a.reject_hist) == list(b.reject_hist) and list(a.obs_hist) == list(b.obs_hist), (i, it)
+        ok, dt, dr = pose_close(pose, opose, 1e-8, 1e-8)
+        assert ok, (i, dt, dr)
