@@ -1242,6 +1242,8 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
   HIP_TRY(c, hipMemcpyAsync(b.h_states, ds, (size_t)B * sizeof(DevState), hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if ((c->ablate & 128) && c->h_state)  // profiling: so_icp_debug_stamps shows the phase stamps of hypothesis 0's last solve
+    for (int i = 0; i < 16; ++i) c->h_state->dbg[i] = b.h_states[0].dbg[i];
   for (int h = 0; h < B; ++h) {
     fill_result(c, b.h_states[h], poses_in + 7 * (size_t)h, stats + h, poses_out + 7 * (size_t)h, false);
     stats[h].time_elapsed_ms = ms;  // (of the whole group: the hypotheses advance together)

@@ -1726,6 +1726,8 @@ constexpr int kRedStride = kNAcc + 2;  // 31 doubles per record in LDS: 62-dword
 
 // sum 256 records of kNAcc doubles held in red[256][kRedStride]: thread (a, c) adds rows 32c..32c+31 of value a in
 // order, then thread (a, 0) adds the 8 partial sums in order -- a fixed tree, identical on every launch.
+// Thread (a, c) belongs to wavefront c / 2 and so do the rows 32c..32c+31: when every thread has written ITS OWN row, a
+// wavefront reads only what it wrote itself -- the caller needs a wavefront-scope fence between the two, not a barrier.
 __device__ __forceinline__ double reduce_records(double (*red)[kRedStride], double (*part)[32], int tid) {
   const int a = tid & 31, cch = tid >> 5;
   if (a < kNAcc) {
@@ -1746,6 +1748,7 @@ __device__ __forceinline__ double reduce_records(double (*red)[kRedStride], doub
 struct EvalShared {
   double red[256][kRedStride];  // 60 KB: per-thread accumulators, later the workgroup records
   double part[8][32];
+  double part_odd[8][32];       // (BATCH: the odd virtual workgroups of a pass -- one barrier per virtual workgroup, see eval_pass)
   LmSums sums;
   LmState S;
   LmCtl ctl;
@@ -1906,6 +1909,23 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   double mine = 0;
   u4v* rec = reinterpret_cast<u4v*>(partials);        // PERSIST: the record table of the pushed workgroup records
   const unsigned int tag = (unsigned int)pass_tag;
+  // BATCH, plain evaluation: the two correspondence records a thread owns in a virtual workgroup are fetched one virtual
+  // workgroup AHEAD, status and record together (a rejected query's record is valid memory, just not used): the loads
+  // are in flight during the sums and the reduction of the workgroup before, where a pass used to sit through two
+  // dependent round trips per virtual workgroup with two wavefronts per SIMD to hide them (measured: 4 us each).
+  struct Fetched { int st; double4 nd; double c; float x, y, z; };
+  Fetched cur[2], nxt[2];
+  auto fetch2 = [&](uint32_t vb_, Fetched (&o)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t j = query_of(vb_, V, tid, (uint32_t)q);
+      const uint32_t js = j < n_kept ? j : 0u;
+      o[q].st = j < n_kept ? (int)corr.status[js] : (int)SO_MATCH_DROPPED;
+      o[q].nd = corr.nd[js]; o[q].c = corr.coeff[js];
+      o[q].x = spx[(size_t)js * qs]; o[q].y = spy[(size_t)js * qs]; o[q].z = spz[(size_t)js * qs];
+    }
+  };
+  if (BATCH && !FIT && vb_begin < vb_end) fetch2(vb_begin, cur);
   for (uint32_t vb = vb_begin, trip_ = 0; BATCH ? (vb < vb_end) : (trip_ < 1u); ++vb, ++trip_) {  // (exactly one trip unless BATCH)
 #pragma unroll
   for (int a = 0; a < kNAcc; ++a) acc[a] = 0;
@@ -1968,6 +1988,19 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       }
     }
     for (uint32_t q = 2, j; (j = query_of(vb, V, tid, q)) < n_kept; ++q) body(j, corr.status[j], nullptr, -1);
+  } else if (BATCH) {
+    if (vb + 1u < vb_end) fetch2(vb + 1u, nxt);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (cur[q].st == SO_MATCH_SUCCESS) {  // (the arithmetic of body(), on the record fetched ahead)
+        const double px = (double)cur[q].x, py = (double)cur[q].y, pz = (double)cur[q].z;
+        double wx, wy, wz;
+        quat_rotate<double>(pose.q, px, py, pz, wx, wy, wz);
+        wx += pose.t[0]; wy += pose.t[1]; wz += pose.t[2];
+        tail(px, py, pz, wx, wy, wz, cur[q].nd, cur[q].c);
+      }
+    for (uint32_t q = 2, j; (j = query_of(vb, V, tid, q)) < n_kept; ++q) body(j, corr.status[j], nullptr, -1);
+    cur[0] = nxt[0]; cur[1] = nxt[1];
   } else {
     for (uint32_t q = 0, j; (j = query_of(vb, V, tid, q)) < n_kept; ++q) body(j, corr.status[j], nullptr, -1);
   }
@@ -1975,8 +2008,12 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
   // workgroup reduction through LDS (transposed: no serial shuffle chains), fixed order
 #pragma unroll
   for (int a = 0; a < kNAcc; ++a) red[tid][a] = acc[a];
-  __syncthreads();
-  mine = reduce_records(red, part, tid);
+  // (LDS serves a wavefront's accesses in order: the rows this wavefront reads below are the ones it has just written)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // BATCH: the group partials alternate between two buffers, so that ONE barrier per virtual workgroup (the one inside
+  // reduce_records) orders everything: a wavefront that writes buffer b again has passed the barrier of the virtual
+  // workgroup in between, which the threads that read b reach only after their reads
+  mine = reduce_records(red, (BATCH && (trip_ & 1u)) ? sh.part_odd : part, tid);
   if (PERSIST) {
     // Push model: the record of this workgroup for this pass is kNAcc chunks of 16 bytes {value (8), pass tag (4), one
     // histogram counter of the fit pass (4)}, each written with ONE sc1 dwordx4 store -- fire and forget: no drain, no
