@@ -178,7 +178,7 @@ struct so_icp_ctx {
   DevBuf d_mpts, d_cell_start, d_cube_slot;
   DevMapView view{};
   // scan / correspondence buffers
-  DevBuf d_scan_own, d_keys0, d_vals0, d_vals1, d_chunks, d_spx, d_spy, d_spz, d_nd, d_coeff, d_status, d_nbr5;
+  DevBuf d_scan_own, d_keys0, d_vals0, d_chunks, d_binned, d_nd, d_coeff, d_status, d_nbr5;
   DevBuf d_kdbg;   // profiling only
   DevBuf d_counts; // sharded device map: per-cube counters on their way through the all-reduce
   DevBuf d_small;  // hist[16] int32 | ticket | n_kept | fb_count | LmSums | partials
@@ -208,10 +208,10 @@ struct so_icp_ctx {
   struct BatchBufs {
     uint32_t cap_hyp = 0, bs = 0, table_log2 = 0;
     bool tables_clean = false;
-    DevBuf states, begin, active, qslot, qrank, perm, spx, spy, spz, chunks, status, nbr5, nd, coeff, bin_key, bin_cnt, bin_off, partials, sync, hist;
+    DevBuf states, begin, active, qslot, qrank, binned, chunks, status, nbr5, nd, coeff, bin_key, bin_cnt, bin_off, partials, sync, hist;
     DevState* h_states = nullptr; RegBeginArgs* h_begin = nullptr; uint32_t* h_active = nullptr;  // pinned
     void release() {
-      for (DevBuf* b : {&states, &begin, &active, &qslot, &qrank, &perm, &spx, &spy, &spz, &chunks, &status, &nbr5, &nd, &coeff, &bin_key, &bin_cnt,
+      for (DevBuf* b : {&states, &begin, &active, &qslot, &qrank, &binned, &chunks, &status, &nbr5, &nd, &coeff, &bin_key, &bin_cnt,
                         &bin_off, &partials, &sync, &hist}) b->release();
       if (h_states) (void)hipHostFree(h_states);
       if (h_begin) (void)hipHostFree(h_begin);
@@ -272,6 +272,9 @@ struct so_icp_ctx {
   bool knn_pack = true;                   // SOICP_KNN_PACK=0: one chunk per wavefront throughout (round-3 work list)
   int knn_pack_hold = 0;                  // registrations left without packing after one in which the packed near pass left > 3 % of
                                           // the queries to the exact per-lane scan (sparse map, far-off guess): then it is not a saving
+  static constexpr int kBatchRoundsTracked = 16;
+  float batch_survivors[kBatchRoundsTracked] = {};  // so_icp_register_batch: share of round r's list still active after it, last batch (chaining of rounds)
+  bool batch_chain = true;                // (SOICP_BATCH_CHAIN=0: report + synchronisation after every round, as in round 3)
   bool batch_small_report = true;         // (SOICP_BATCH_REPORT=full: the whole state blocks after every round, as in round 3)
   bool batch_round0_full = true;          // so_icp_register_batch: round 0 starts with the full k-NN pass (SOICP_BATCH_ROUND0=near: the usual two passes)
   int stage_issue_at = 1;                 // SOICP_STAGE_AT: 0 = a DMA copy is enqueued by the announcement itself; 1 = by the registration in
@@ -443,8 +446,8 @@ int upload_map(so_icp_ctx* c) {
 int reserve_scan_buffers(so_icp_ctx* c, size_t n) {
   const size_t m = n + 256;
   HIP_TRY(c, c->d_keys0.reserve(m * 4));
-  HIP_TRY(c, c->d_vals0.reserve(m * 4)); HIP_TRY(c, c->d_vals1.reserve(m * 4)); HIP_TRY(c, c->d_chunks.reserve(m * 4));
-  HIP_TRY(c, c->d_spx.reserve(m * 4)); HIP_TRY(c, c->d_spy.reserve(m * 4)); HIP_TRY(c, c->d_spz.reserve(m * 4));
+  HIP_TRY(c, c->d_vals0.reserve(m * 4)); HIP_TRY(c, c->d_chunks.reserve(m * 4));
+  HIP_TRY(c, c->d_binned.reserve(m * 16));
   HIP_TRY(c, c->d_nd.reserve(m * 32)); HIP_TRY(c, c->d_coeff.reserve(m * 8)); HIP_TRY(c, c->d_status.reserve(m));
   HIP_TRY(c, c->d_nbr5.reserve(m * 20));
   return SO_ICP_OK;
@@ -630,8 +633,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
                      qsplit, (uint32_t)n_total);
     launch_bin_offsets(bt, c->d_chunks.as<uint32_t>(), (uint32_t)(c->d_chunks.cap / 4), ds, s);
     c->bin_dirty = false;
-    launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(),
-                     c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s);
+    launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_binned.as<float4>(), s);
   } else {
     launch_scan_keys(d_scan, 0, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
                      c->cfg.world_size, nullptr, nullptr, nullptr, bt, s);  // (empty scan: the prologue alone)
@@ -707,8 +709,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
       launch_scan_keys(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, c->d_hist, c->view, c->cfg.max_surface_features, c->cfg.rank,
                        c->cfg.world_size, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_status.as<uint8_t>(), bt, s, true);
       launch_bin_offsets(bt, c->d_chunks.as<uint32_t>(), (uint32_t)(c->d_chunks.cap / 4), ds, s);
-      launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_vals1.as<uint32_t>(),
-                       c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), s, ds);
+      launch_bin_place(bt, d_scan, (uint32_t)n, c->d_keys0.as<uint32_t>(), c->d_vals0.as<uint32_t>(), c->d_binned.as<float4>(), s, ds);
     }
     // processPlannerFeatures: every kept query in parallel (LidarSlam.cpp:323-344)
     knn_span_of_outer.push_back(c->spans.size());
@@ -717,7 +718,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
       ka = next_event(c); kb = next_event(c);
       if (ka && kb) c->spans.push_back(EventSpan{0, ka, kb, (uint32_t)n});
     }
-    launch_knn_plane(c->d_spx.as<float>(), c->d_spy.as<float>(), c->d_spz.as<float>(), c->d_vals1.as<uint32_t>(),
+    launch_knn_plane(c->d_binned.as<float4>(),
                      c->d_chunks.as<uint32_t>(), ds, c->view, mp, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s, ka, kb);
     if (c->cfg.time_kernels >= 2)  // kernel statistics of this sweep (profiling mode only)
       HIP_TRY(c, hipMemcpyAsync(c->h_hist + (size_t)it * kHistReplicas * kHistStride, c->d_hist,
@@ -1111,7 +1112,8 @@ int batch_reserve(so_icp_ctx* c, uint32_t B, size_t n, uint32_t lg) {
     b.release();
     HIP_TRY(c, b.states.reserve((size_t)cap * sizeof(DevState))); HIP_TRY(c, b.begin.reserve((size_t)cap * sizeof(RegBeginArgs)));
     HIP_TRY(c, b.active.reserve((size_t)cap * 4));
-    for (DevBuf* d : {&b.qslot, &b.qrank, &b.perm, &b.spx, &b.spy, &b.spz, &b.chunks}) HIP_TRY(c, d->reserve((size_t)cap * nbs * 4));
+    for (DevBuf* d : {&b.qslot, &b.qrank, &b.chunks}) HIP_TRY(c, d->reserve((size_t)cap * nbs * 4));
+    HIP_TRY(c, b.binned.reserve((size_t)cap * nbs * 16));
     HIP_TRY(c, b.status.reserve((size_t)cap * nbs)); HIP_TRY(c, b.nbr5.reserve((size_t)cap * nbs * 20));
     HIP_TRY(c, b.nd.reserve((size_t)cap * nbs * 32)); HIP_TRY(c, b.coeff.reserve((size_t)cap * nbs * 8));
     for (DevBuf* d : {&b.bin_key, &b.bin_cnt, &b.bin_off}) HIP_TRY(c, d->reserve((size_t)cap * T * 4));
@@ -1192,12 +1194,17 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
                    b.qslot.as<uint32_t>(), b.qrank.as<uint32_t>(), b.status.as<uint8_t>(), bt, s, false, &bv, (uint32_t)B);
   launch_bin_offsets(bt, b.chunks.as<uint32_t>(), b.bs, ds, s, &bv, (uint32_t)B);
   b.tables_clean = true;
-  launch_bin_place(bt, d_scan, (uint32_t)n, b.qslot.as<uint32_t>(), b.qrank.as<uint32_t>(), b.perm.as<uint32_t>(), b.spx.as<float>(),
-                   b.spy.as<float>(), b.spz.as<float>(), s, nullptr, &bv, (uint32_t)B);
+  launch_bin_place(bt, d_scan, (uint32_t)n, b.qslot.as<uint32_t>(), b.qrank.as<uint32_t>(), b.binned.as<float4>(), s, nullptr, &bv, (uint32_t)B);
   HIP_TRY(c, hipGetLastError());
   std::vector<uint32_t> act((size_t)B);
   for (int h = 0; h < B; ++h) act[(size_t)h] = (uint32_t)h;
-  for (int it = 0; it < max_outer && !act.empty(); ++it) {
+  // Rounds are CHAINED -- enqueued on the same list without the host looking at the report in between -- while most of the list is
+  // expected to go on: a hypothesis that has finished makes its workgroups of a later round return at once (reg_done), so a stale
+  // list costs launches, never results.  After round 0 always (one outer iteration cannot meet the convergence test of most
+  // guesses, and a list that shrinks by less than half keeps its workgroups per hypothesis anyway); after a later round when
+  // the previous batch of this context found three quarters of that round's list still active (batch_survivors).  Every
+  // report + synchronisation left out is 35 us in which the device sits idle (measured: 4 per batch of 5.7 ms).
+  for (int it = 0; it < max_outer && !act.empty();) {
     const uint32_t n_act = (uint32_t)act.size();
     if (it > 0) {  // (round 0 uses the identity list uploaded with the poses; the stream was synchronised by the last read-back)
       for (uint32_t k = 0; k < n_act; ++k) b.h_active[k] = act[k];
@@ -1207,18 +1214,24 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
     uint32_t G = 1;
     while (2u * G * n_act <= resident && 2u * G <= v_grid) G *= 2u;
     bv.wg_per_hyp = G;
-    MatchParams mp_it = mp;
-    mp_it.skip_near_pass = (it == 0 && c->batch_round0_full) ? 1 : 0;
-    mp_it.pack_light = (c->knn_pack && !mp_it.skip_near_pass) ? 1 : 0;
-    launch_knn_plane(b.spx.as<float>(), b.spy.as<float>(), b.spz.as<float>(), b.perm.as<uint32_t>(), b.chunks.as<uint32_t>(), ds, c->view, mp_it, corr,
-                     b.nbr5.as<uint32_t>(), b.hist.as<int32_t>(), s, nullptr, nullptr, &bv, n_act);
-    EvalParams ep_it = ep;
-    ep_it.epoch_base = (++c->solve_launches) << 5;
-    launch_solve_batch(lm_max, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep_it, b.partials.as<double>(), b.sync.as<uint32_t>(), b.hist.as<int32_t>(),
-                       c->view, b.nbr5.as<uint32_t>(), mp, bv, n_act, s);
-    HIP_TRY(c, hipGetLastError());
-    // between rounds the host needs two words per hypothesis (outer_iter, reg_done); the whole state blocks (280 KB for 64
-    // hypotheses) are read once, after the last round
+    const int first = it;
+    for (;;) {
+      MatchParams mp_it = mp;
+      mp_it.skip_near_pass = (it == 0 && c->batch_round0_full) ? 1 : 0;
+      mp_it.pack_light = (c->knn_pack && !mp_it.skip_near_pass) ? 1 : 0;
+      launch_knn_plane(b.binned.as<float4>(), b.chunks.as<uint32_t>(), ds, c->view, mp_it, corr,
+                       b.nbr5.as<uint32_t>(), b.hist.as<int32_t>(), s, nullptr, nullptr, &bv, n_act);
+      EvalParams ep_it = ep;
+      ep_it.epoch_base = (++c->solve_launches) << 5;
+      launch_solve_batch(lm_max, d_scan, d_scan + 1, d_scan + 2, corr, ds, ep_it, b.partials.as<double>(), b.sync.as<uint32_t>(), b.hist.as<int32_t>(),
+                         c->view, b.nbr5.as<uint32_t>(), mp, bv, n_act, s);
+      HIP_TRY(c, hipGetLastError());
+      ++it;
+      const bool chain = c->batch_chain && it < max_outer && it - 1 < so_icp_ctx::kBatchRoundsTracked && (it - 1 == 0 || c->batch_survivors[it - 1] >= 0.75f);
+      if (!chain) break;
+    }
+    // at a synchronisation point the host needs two words per hypothesis (outer_iter, reg_done); the whole state blocks (280 KB
+    // for 64 hypotheses) are read once, after the last round
     static_assert(offsetof(DevState, reg_done) == offsetof(DevState, outer_iter) + 4, "the round report reads outer_iter and reg_done together");
     if (c->batch_small_report)
       HIP_TRY(c, hipMemcpy2DAsync(reinterpret_cast<char*>(b.h_states) + offsetof(DevState, outer_iter), sizeof(DevState),
@@ -1228,15 +1241,21 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
       HIP_TRY(c, hipMemcpyAsync(b.h_states, ds, (size_t)B * sizeof(DevState), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     std::vector<uint32_t> next;
+    uint32_t alive_after[so_icp_ctx::kBatchRoundsTracked] = {};
     for (uint32_t h : act) {
       const DevState& H = b.h_states[h];
-      if (H.outer_iter != it + 1) {  // the hypothesis' solve did not finish (a wait inside the launch gave up)
-        c->err = "so_icp_register_batch: the solve of hypothesis " + std::to_string(h) + " did not complete in round " + std::to_string(it) +
+      // a hypothesis of the list ran the rounds first .. it-1 unless it finished on the way (then outer_iter says where)
+      const bool ran_all = H.outer_iter == it, finished_early = H.reg_done && H.outer_iter > first && H.outer_iter < it;
+      if (!ran_all && !finished_early) {  // the hypothesis' solve did not finish (a wait inside the launch gave up)
+        c->err = "so_icp_register_batch: the solve of hypothesis " + std::to_string(h) + " did not complete in round " + std::to_string(H.outer_iter) +
                  " (workgroups not co-resident: compute units held by another process?)";
         return kRetryWithoutPersistentSolve;
       }
-      if (!H.reg_done && it + 1 < max_outer) next.push_back(h);
+      for (int r = first; r < it && r < so_icp_ctx::kBatchRoundsTracked; ++r)
+        if (!(H.reg_done && H.outer_iter <= r + 1)) ++alive_after[r];
+      if (!H.reg_done && it < max_outer) next.push_back(h);
     }
+    for (int r = first; r < it && r < so_icp_ctx::kBatchRoundsTracked; ++r) c->batch_survivors[r] = (float)alive_after[r] / (float)n_act;
     act.swap(next);
   }
   HIP_TRY(c, hipMemcpyAsync(b.h_states, ds, (size_t)B * sizeof(DevState), hipMemcpyDeviceToHost, s));
@@ -1275,8 +1294,8 @@ so_icp_ctx::~so_icp_ctx() {
   for (so_icp_ctx* w : workers) delete w;
   batch.release();
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
-  for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_vals0, &d_vals1, &d_chunks,
-                    &d_spx, &d_spy, &d_spz, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
+  for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_vals0, &d_chunks,
+                    &d_binned, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist, &d_kdbg, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
                     &pf_heads, &pf_temp, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_counts, &d_sub})
     b->release();
@@ -1392,6 +1411,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_STAGE_WAIT")) c->stage_wait_on_host = std::string(ev) == "host";
   if (const char* ev = std::getenv("SOICP_KNN_PACK")) c->knn_pack = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_BATCH_CHAIN")) c->batch_chain = std::string(ev) != "0";
   if (const char* ev = std::getenv("SOICP_BATCH_REPORT")) c->batch_small_report = std::string(ev) != "full";
   if (const char* ev = std::getenv("SOICP_BATCH_ROUND0")) c->batch_round0_full = std::string(ev) != "near";
   if (const char* ev = std::getenv("SOICP_STAGE_AT")) { const int v = std::atoi(ev); if (v >= 0 && v <= 2) c->stage_issue_at = v; }

@@ -162,8 +162,9 @@ struct BinTable {
 // (bv / n_hyp: batched launch over the hypotheses bv->active[0 .. n_hyp), see BatchView; nullptr / 0 = one registration)
 void launch_bin_offsets(const BinTable& bt, uint32_t* d_chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s,
                         const BatchView* bv = nullptr, uint32_t n_hyp = 0);
+// binned[pos] = {x, y, z, query index (bits)} of the query filed at position pos of its bucket
 void launch_bin_place(const BinTable& bt, const float* d_scan_xyz, uint32_t n, const uint32_t* d_qslot, const uint32_t* d_qrank,
-                      uint32_t* d_perm, float* spx, float* spy, float* spz, hipStream_t s, const DevState* st_if_rebin = nullptr,
+                      float4* d_binned, hipStream_t s, const DevState* st_if_rebin = nullptr,
                       const BatchView* bv = nullptr, uint32_t n_hyp = 0);
 
 // scan_keys also runs the registration prologue (reg_begin) in its first workgroup; n == 0 launches the prologue alone
@@ -176,7 +177,7 @@ void launch_scan_keys(const float* d_scan_xyz, uint32_t n, DevState* st, const d
                       bool qsplit = false /* N > 1 with the QUERIES split: d_scan is this rank's share (64-point segments rank, rank + world,
                                              ... of a scan of n_total points); every query is owned, the sampling rule uses the global index */,
                       uint32_t n_total = 0);
-void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* d_perm,
+void launch_knn_plane(const float4* d_binned,
                       const uint32_t* d_chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
                       CorrBuffers corr, uint32_t* d_nbr5 /*5 canonical indices per query*/,
                       int32_t* d_hist /*kHistReplicas*kHistStride*/, hipStream_t s, hipEvent_t ev_start = nullptr,

@@ -289,16 +289,16 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t
   }
 }
 
-// queries into their binned positions (SoA) + the position -> query index map the k-NN kernel files its results with
+// queries into their binned positions: one 16-byte record {x, y, z, query index} per position -- one scattered store per query
+// where the round-3 layout (three coordinate arrays + the position -> query map) took four, and one load in the k-NN kernel
+typedef float f4v __attribute__((ext_vector_type(4)));
 template <bool BATCH>
 __global__ __launch_bounds__(256) void bin_place_kernel(BinTable bt, const float* __restrict__ scan, uint32_t n,
                                                         const uint32_t* __restrict__ qslot, const uint32_t* __restrict__ qrank,
-                                                        uint32_t* __restrict__ perm, float* __restrict__ spx, float* __restrict__ spy,
-                                                        float* __restrict__ spz, const DevState* __restrict__ st_if_rebin, BatchView bv) {
+                                                        float4* __restrict__ binned, const DevState* __restrict__ st_if_rebin, BatchView bv) {
   if (BATCH) {
     const size_t h = bv.active[blockIdx.y];
-    bt.off += h * bv.table_stride; qslot += h * bv.bs; qrank += h * bv.bs; perm += h * bv.bs;
-    spx += h * bv.bs; spy += h * bv.bs; spz += h * bv.bs;
+    bt.off += h * bv.table_stride; qslot += h * bv.bs; qrank += h * bv.bs; binned += h * bv.bs;
   }
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -306,9 +306,8 @@ __global__ __launch_bounds__(256) void bin_place_kernel(BinTable bt, const float
   const uint32_t sl = qslot[i];
   if (sl == 0xFFFFFFFFu) return;
   const uint32_t pos = bt.off[sl] + qrank[i];
-  __builtin_nontemporal_store(i, &perm[pos]);
-  __builtin_nontemporal_store(scan[3 * i], &spx[pos]); __builtin_nontemporal_store(scan[3 * i + 1], &spy[pos]);
-  __builtin_nontemporal_store(scan[3 * i + 2], &spz[pos]);
+  const f4v rec = {scan[3 * i], scan[3 * i + 1], scan[3 * i + 2], __uint_as_float(i)};
+  __builtin_nontemporal_store(rec, reinterpret_cast<f4v*>(binned) + pos);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -774,9 +773,7 @@ constexpr uint32_t kPartTile = kTileCand / 4;  // candidates a packed chunk may 
 //        production instantiation carries none of it (the sweep is instruction-issue bound).
 // BATCH: so_icp_register_batch -- blockIdx.y picks the hypothesis, see BatchView.
 template <bool PROF, bool BATCH>
-__global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restrict__ spx, const float* __restrict__ spy,
-                                                        const float* __restrict__ spz,
-                                                        const uint32_t* __restrict__ perm /* binned position -> query index */,
+__global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restrict__ binned /* {x, y, z, query index} per binned position */,
                                                         const uint32_t* __restrict__ chunk_start,
                                                         const DevState* __restrict__ st,
                                                         const float4* __restrict__ mpts,
@@ -790,7 +787,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
                                          // (packed light chunks: four tables of 17 + 16 entries, one per row of 16 lanes)
   if (BATCH) {
     const size_t h = bv.active[blockIdx.y];
-    st += h; spx += h * bv.bs; spy += h * bv.bs; spz += h * bv.bs; perm += h * bv.bs; chunk_start += h * bv.bs;
+    st += h; binned += h * bv.bs; chunk_start += h * bv.bs;
     corr.status += h * bv.bs; nbr5 += h * 5 * bv.bs; hist += h * (kHistReplicas * kHistStride);
   }
   uint32_t* const leftover_ctr = (BATCH && mp.packed_leftover)
@@ -895,8 +892,9 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float* __restri
   c.slot = -1; c.cx = c.cy = c.cz = 0;
   uint32_t oi = 0;  // the query's index in the scan (results are filed under it): fetched with the coordinates, used at the very end
   if (valid_q) {
-    oi = perm[j];
-    quat_rotate<double>(pose.q, (double)spx[j], (double)spy[j], (double)spz[j], pw[0], pw[1], pw[2]);  // LidarSlam.cpp:397-398
+    const float4 rec = binned[j];
+    oi = __float_as_uint(rec.w);
+    quat_rotate<double>(pose.q, (double)rec.x, (double)rec.y, (double)rec.z, pw[0], pw[1], pw[2]);  // LidarSlam.cpp:397-398
     pw[0] += pose.t[0]; pw[1] += pose.t[1]; pw[2] += pose.t[2];
     qx = (float)pw[0]; qy = (float)pw[1]; qz = (float)pw[2];                                            // LidarSlam.cpp:728-731
     int w[3] = {0, 0, 0};
@@ -2548,13 +2546,13 @@ void launch_bin_offsets(const BinTable& bt, uint32_t* chunk_start, uint32_t chun
   if (bv) { if (n_hyp) hipLaunchKernelGGL(bin_offsets_kernel<true>, dim3(gx, n_hyp), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st, *bv); }
   else hipLaunchKernelGGL(bin_offsets_kernel<false>, dim3(gx), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st, kNoBatch);
 }
-void launch_bin_place(const BinTable& bt, const float* d_scan, uint32_t n, const uint32_t* qslot, const uint32_t* qrank, uint32_t* perm,
-                      float* spx, float* spy, float* spz, hipStream_t s, const DevState* st_if_rebin, const BatchView* bv, uint32_t n_hyp) {
+void launch_bin_place(const BinTable& bt, const float* d_scan, uint32_t n, const uint32_t* qslot, const uint32_t* qrank, float4* binned,
+                      hipStream_t s, const DevState* st_if_rebin, const BatchView* bv, uint32_t n_hyp) {
   if (!n) return;
-  if (bv) { if (n_hyp) hipLaunchKernelGGL(bin_place_kernel<true>, dim3((n + 255u) / 256u, n_hyp), dim3(256), 0, s, bt, d_scan, n, qslot, qrank, perm, spx, spy, spz, nullptr, *bv); }
-  else hipLaunchKernelGGL(bin_place_kernel<false>, grid_for(n, 256), dim3(256), 0, s, bt, d_scan, n, qslot, qrank, perm, spx, spy, spz, st_if_rebin, kNoBatch);
+  if (bv) { if (n_hyp) hipLaunchKernelGGL(bin_place_kernel<true>, dim3((n + 255u) / 256u, n_hyp), dim3(256), 0, s, bt, d_scan, n, qslot, qrank, binned, nullptr, *bv); }
+  else hipLaunchKernelGGL(bin_place_kernel<false>, grid_for(n, 256), dim3(256), 0, s, bt, d_scan, n, qslot, qrank, binned, st_if_rebin, kNoBatch);
 }
-void launch_knn_plane(const float* spx, const float* spy, const float* spz, const uint32_t* perm,
+void launch_knn_plane(const float4* binned,
                       const uint32_t* chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
                       CorrBuffers corr, uint32_t* nbr5, int32_t* hist, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop,
                       const BatchView* bv, uint32_t n_hyp) {
@@ -2562,9 +2560,9 @@ void launch_knn_plane(const float* spx, const float* spy, const float* spz, cons
     // B x ~4 800 chunks: 256 workgroups per hypothesis, every wavefront walks ~5 chunks (no tail to hide with 64 hypotheses in
     // flight, and a quarter of the workgroup prologues of the one-round grid of the single registration)
     if (!n_hyp) return;
-    if (mp.ablate) hipLaunchKernelGGL((knn_plane_kernel<true, true>), dim3(kKnnBlocks / 4, n_hyp), dim3(256), 0, s, spx, spy, spz, perm, chunk_start, st,
+    if (mp.ablate) hipLaunchKernelGGL((knn_plane_kernel<true, true>), dim3(kKnnBlocks / 4, n_hyp), dim3(256), 0, s, binned, chunk_start, st,
                                       map.pts, map.cell_start, map, mp, corr, nbr5, hist, *bv);
-    else hipLaunchKernelGGL((knn_plane_kernel<false, true>), dim3(kKnnBlocks / 4, n_hyp), dim3(256), 0, s, spx, spy, spz, perm, chunk_start, st,
+    else hipLaunchKernelGGL((knn_plane_kernel<false, true>), dim3(kKnnBlocks / 4, n_hyp), dim3(256), 0, s, binned, chunk_start, st,
                             map.pts, map.cell_start, map, mp, corr, nbr5, hist, *bv);
     return;
   }
@@ -2573,10 +2571,10 @@ void launch_knn_plane(const float* spx, const float* spy, const float* spz, cons
   // ~3.7 us of stream time each, 8 % of a registration when every sweep is timed)
   auto* k = mp.ablate ? knn_plane_kernel<true, false> : knn_plane_kernel<false, false>;
   if (ev_start && ev_stop)
-    hipExtLaunchKernelGGL(k, dim3(kKnnBlocks), dim3(256), 0, s, ev_start, ev_stop, 0, spx, spy, spz, perm,
+    hipExtLaunchKernelGGL(k, dim3(kKnnBlocks), dim3(256), 0, s, ev_start, ev_stop, 0, binned,
                           chunk_start, st, map.pts, map.cell_start, map, mp, corr, nbr5, hist, kNoBatch);
   else
-    hipLaunchKernelGGL(k, dim3(kKnnBlocks), dim3(256), 0, s, spx, spy, spz, perm, chunk_start, st, map.pts,
+    hipLaunchKernelGGL(k, dim3(kKnnBlocks), dim3(256), 0, s, binned, chunk_start, st, map.pts,
                        map.cell_start, map, mp, corr, nbr5, hist, kNoBatch);
 }
 uint32_t solve_grid(uint32_t n_upper, uint32_t max_blocks) {

@@ -194,16 +194,22 @@ def test_batch_with_hypotheses_that_fail_and_degenerate_inputs(oracle, gpu_slam_
     assert [int(r) for r in rcs] == [slam.register(none, p)[0] for p in poses[:3]] and ok == int((rcs == 0).sum())
 
 
-@pytest.mark.parametrize("env", [{"SOICP_BATCH_MODE": "lanes"}, {"SOICP_BATCH_WG_PER_CU": "1"}])
+@pytest.mark.parametrize("env", [{"SOICP_BATCH_MODE": "lanes"}, {"SOICP_BATCH_WG_PER_CU": "1"}, {"SOICP_BATCH_CHAIN": "0"}])
 def test_batch_fallback_paths_give_the_same_bits(oracle, gpu_slam_factory, monkeypatch, env):
     """The degraded forms of so_icp_register_batch -- one solve workgroup per compute unit, and concurrent sequential
     registrations on worker contexts (what a device that cannot keep the batched solve resident falls back to) -- return the
-    poses of the batched kernels bit for bit."""
+    poses of the batched kernels bit for bit; so do the rounds with a report + synchronisation after every one of them
+    (SOICP_BATCH_CHAIN=0) against the chained rounds, whose lists go stale (second batch of a context: chained by the
+    survivor counts of the first)."""
     sc, slam, _ = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
     scan = sc.scan(6)
     poses = np.stack([synth.perturb_pose(sc.gt_pose(6), 9000 + h, 0.05 + 0.4 * (h % 5) / 4.0, 0.5 + 4.0 * (h % 3) / 2.0) for h in range(19)])
     ok, rcs, out, sts = slam.register_batch(scan, poses)
     assert ok == 19
+    ok1, _, out1, sts1 = slam.register_batch(scan, poses)  # (chained further, by what the first batch saw)
+    assert ok1 == 19 and np.array_equal(out1, out)
+    for h in range(19):
+        _assert_same_bits(sts[h], sts1[h], ("second batch", h))
     for k, v in env.items():
         monkeypatch.setenv(k, v)  # read by so_icp_create
     _, alt, _ = _setup("small", oracle, gpu_slam_factory, max_iterations=5)
