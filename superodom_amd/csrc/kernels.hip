@@ -968,6 +968,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   for (int ppass = 0; ppass < 2; ++ppass) {  // near pass, then -- for the rows that still have uncertified lanes -- the full pass (gate radius)
     const bool pend = !resolved && !need_exact;
     if (ppass == 1 && __ballot(pend) == 0ull) break;
+    if (ppass == 1) __builtin_amdgcn_s_setprio(3);  // (a wavefront with a second pass ahead is one of the sweep's stragglers: issue priority from here on)
     if (PROF) ++n_groups;
     const int myslot = (int)(ckey >> 18);
     const int gslot = row_min_i32(pend ? myslot : 0x7FFFFFFF);
@@ -1152,6 +1153,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
     // are not instantiated here: registers and code size).  The host watches the count and turns the packing off for sweeps
     // where it is not rare.
     unsigned long long left = __ballot(valid_q && c.slot >= 0 && !resolved);
+    if (left) __builtin_amdgcn_s_setprio(3);
     if (left && lane == 0 && mp.packed_leftover) atomicAdd(leftover_ctr, (uint32_t)__popcll(left));
     if (PROF) n_left_stat = (uint32_t)__popcll(left);
     // One leftover query at a time, the WHOLE wavefront on it: the (clamped) 3 x 3 x 3 cells around the query -- every map point
@@ -1226,6 +1228,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   unsigned long long todo = __ballot(pending);
   if (abl & 2) todo = 0;
   if (!todo) continue;  // (a packed wavefront may have nothing left for the near pass and still lanes for the full pass)
+  if (pass == 1 && first_pass == 0) __builtin_amdgcn_s_setprio(3);  // (a second pass: one of the sweep's stragglers -- issue priority from here on)
   if (stamp && pass == 1) ++n_pass2;
   const float r_cover = pass == 0 ? r_near : r_gate;
   // per-lane cell range that contains the lane's search ball (clamped to the cube: nothing of the cube lies beyond it)

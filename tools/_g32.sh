@@ -1,0 +1,31 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/g32; mkdir -p $O
+cd $R
+timeout 120 python - <<'PY'
+import sys, time, numpy as np
+sys.path.insert(0, '.')
+from superodom_amd import binding, synth
+sc = synth.Scene("os1_128_2m")
+slam = binding.LidarSlamGpu(device_id=0, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_iterations=5, lm_max_iterations=4, max_surface_features=-1)
+slam.add_surf_point_cloud(sc.map_points)
+for i in range(6):
+    d = slam.upload_scan(sc.scan(i % 4)); st = binding.Stats()
+    t0 = slam.timing().knn_deferred_queries
+    t = time.perf_counter()
+    try:
+        rc = slam.register_dev(d[0], d[1], sc.guess(i % 4), st)
+    except Exception as ex:
+        rc = repr(ex)
+    print("scan", i, "rc", rc if not isinstance(rc, tuple) else rc[0], "ms", round(1e3 * (time.perf_counter() - t), 3), "deferred", slam.timing().knn_deferred_queries - t0, "outer", st.n_iterations, flush=True)
+PY
+for e in 2 0 2 0; do
+SOICP_KNN_DEFER=$e timeout 300 python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > $O/bench_line.json
+python - $O/bench_line.json $e <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+print("defer", sys.argv[2], "value", round(d["value"], 1), "knn us", round(1e3 * d["roofline"]["avg_launch_ms"], 2), "kernels", {k: round(v, 4) for k, v in d["kernels"].items() if isinstance(v, float) and 'launches' not in k})
+PY
+done
+SOICP_ABLATE=128 timeout 120 python tools/eval_stamps.py 2>&1 | tail -28 > $O/stamps.txt
+grep -E "knn sweep|life us|slowest chunk|      [0-9]" $O/stamps.txt
