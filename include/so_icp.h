@@ -195,6 +195,11 @@ int so_icp_map_export(so_icp_ctx *ctx, float *xyz, size_t cap_points, size_t *n_
 int so_icp_map_size(so_icp_ctx *ctx, size_t *n_points, size_t *n_points_this_rank);
 int so_icp_map_clear(so_icp_ctx *ctx);
 int so_icp_map_get_origin(so_icp_ctx *ctx, int origin_out[3]);
+/* Diagnostics of the device-resident map's insert (LM.h:591-645 on the device): how many inserts the device laid out itself
+ * -- touched cubes, slots and counts worked out by the insert's first kernel, no read-back -- and how many of those it had
+ * to hand back to the host (a cube without a slot, more cubes than a round holds, a cube that needs the sort).  Both 0
+ * with the host-side map (world_size > 1) or SOICP_MAP_FAST=0. */
+int so_icp_map_insert_stats(so_icp_ctx *ctx, unsigned *device_built, unsigned *handed_back);
 
 /* -------- Seam B: LocalMap::nearestKSearchSurf (LM.h:481-525), batched ------------------------ */
 /* Host buffers. found[i]=0 reproduces the `return false` paths (cube outside the window, LM.h:499-502,

@@ -90,7 +90,8 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_get_timing", "so_icp_reset_timing", "so_icp_set_time_kernels", "so_icp_synchronize", "so_icp_debug_stamps", "so_icp_debug_knn_stamps", "so_icp_register_batch", "so_icp_registration_error",
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
             "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram",
-            "so_icp_host_register", "so_icp_host_unregister", "so_icp_host_alloc", "so_icp_host_free", "so_icp_device_count", "so_icp_stage_cancel"]
+            "so_icp_host_register", "so_icp_host_unregister", "so_icp_host_alloc", "so_icp_host_free", "so_icp_device_count", "so_icp_stage_cancel",
+            "so_icp_map_insert_stats"]
 
 _lib = None
 
@@ -120,6 +121,7 @@ def load():
     L.so_icp_map_export.argtypes = [vp, f32p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, i32p]
     L.so_icp_map_size.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.so_icp_map_clear.argtypes = [vp]
+    L.so_icp_map_insert_stats.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     L.so_icp_map_get_origin.argtypes = [vp, i32p]
     L.so_icp_knn_surf.argtypes = [vp, f32p, C.c_size_t, C.c_int, f32p, f32p, i32p, u8p]
     L.so_icp_register.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, f64p, C.POINTER(Stats)]
@@ -262,6 +264,12 @@ class LidarSlamGpu:
 
     def clear_map(self):
         self._check(self.L.so_icp_map_clear(self.h))
+
+    def map_insert_stats(self):
+        """(inserts laid out by the device, of those handed back to the host's round-by-round path)"""
+        a = C.c_uint(); b = C.c_uint()
+        self._check(self.L.so_icp_map_insert_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     # ---- Seam B ----
     def nearest_k_search_surf(self, q, k=5, want_index=True):

@@ -3,6 +3,7 @@
 #include "device_map.h"
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -19,6 +20,7 @@ namespace soicp {
     if (e__ != hipSuccess) {                                              \
       err = std::string(#expr) + ": " + hipGetErrorString(e__);           \
       grid_zero_upto_ = 0; block_clean_ = false;                          \
+      fast_clean_ = false; meta_dirty_ = true;                            \
       return -2;                                                          \
     }                                                                     \
   } while (0)
@@ -26,6 +28,11 @@ namespace soicp {
 static inline int cidx(int i, int j, int k) { return i + kMapW * j + kMapW * kMapH * k; }
 
 DeviceMap::~DeviceMap() {
+  (void)hipStreamSynchronize(stream_);  // (a deferred insert may still be writing its report)
+  for (void* p : {(void*)d_tt_, (void*)d_slot_count_, (void*)d_cube_cnt_, (void*)d_scan_state_})
+    if (p) (void)hipFree(p);
+  if (h_report_) (void)hipHostFree(h_report_);
+  if (ev_fast_) (void)hipEventDestroy(ev_fast_);
   for (void* p : {(void*)d_pool_, (void*)d_cell_start_, (void*)d_cube_slot_, (void*)d_wpts_, (void*)d_cent_, (void*)d_k0_, (void*)d_k1_,
                   (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, (void*)d_spts_, (void*)d_heads_, (void*)d_grid_, (void*)d_grid_scan_, d_temp_, (void*)d_cube_of_,
                   (void*)d_small_, (void*)d_stage_, (void*)d_ht_key_, (void*)d_ht_cnt_, (void*)d_ht_off_})
@@ -34,6 +41,8 @@ DeviceMap::~DeviceMap() {
 }
 
 void DeviceMap::clear() {
+  settle_quiet();
+  meta_dirty_ = true;
   std::fill(cube_slot_.begin(), cube_slot_.end(), -1);
   std::fill(slot_cube_.begin(), slot_cube_.end(), -1);
   std::fill(slot_count_.begin(), slot_count_.end(), 0u);
@@ -43,11 +52,13 @@ void DeviceMap::clear() {
 }
 
 void DeviceMap::set_origin(const double t[3]) {  // LocalMap.h:146-164
+  settle_quiet();
   for (int a = 0; a < 3; ++a) origin_[a] = -cube_coord(t[a], 0);
   slot_table_dirty_ = true;
 }
 
 int DeviceMap::alloc_slot(int cube) {
+  meta_dirty_ = true;
   for (size_t s = 0; s < slot_cube_.size(); ++s)
     if (slot_cube_[s] < 0) { slot_cube_[s] = cube; slot_count_[s] = 0; slot_owned_[s] = 0; slot_full_[s] = 0; slot_res_[s] = 0.f; cube_slot_[cube] = (int)s; slot_table_dirty_ = true; return (int)s; }
   slot_cube_.push_back(cube); slot_count_.push_back(0); slot_owned_.push_back(0); slot_full_.push_back(0); slot_res_.push_back(0.f);
@@ -59,10 +70,11 @@ int DeviceMap::alloc_slot(int cube) {
 // LocalMap::shiftMap, LocalMap.h:169-287: the block array rolls so that the sensor's block stays >= 3 blocks from the
 // border; blocks leaving the window are dropped.  Here a block is just its slot id -- no point data moves.
 void DeviceMap::shift(const double t[3], int pos[3]) {
+  settle_quiet();
   int c[3] = {cube_coord(t[0], origin_[0]), cube_coord(t[1], origin_[1]), cube_coord(t[2], origin_[2])};
   const int dim[3] = {kMapW, kMapH, kMapD};
   auto at = [&](int i, int j, int k) -> int32_t& { return cube_slot_[cidx(i, j, k)]; };
-  auto drop = [&](int32_t& s) { if (s >= 0) { slot_cube_[s] = -1; slot_count_[s] = 0; slot_owned_[s] = 0; slot_full_[s] = 0; slot_res_[s] = 0.f; } s = -1; };
+  auto drop = [&](int32_t& s) { if (s >= 0) { meta_dirty_ = true; slot_cube_[s] = -1; slot_count_[s] = 0; slot_owned_[s] = 0; slot_full_[s] = 0; slot_res_[s] = 0.f; } s = -1; };
   bool moved = false;
   for (int axis = 0; axis < 3; ++axis) {
     while (c[axis] < 3 || c[axis] >= dim[axis] - 3) {
@@ -86,6 +98,7 @@ void DeviceMap::shift(const double t[3], int pos[3]) {
 }
 
 int DeviceMap::count_5x5(const int pos[3]) const {  // LocalMap.h:292-318
+  settle_quiet();
   int n = 0;
   for (int i = pos[0] - 2; i <= pos[0] + 2; ++i) for (int j = pos[1] - 2; j <= pos[1] + 2; ++j) for (int k = pos[2] - 1; k <= pos[2] + 1; ++k)
     if (i >= 0 && i < kMapW && j >= 0 && j < kMapH && k >= 0 && k < kMapD && cube_slot_[cidx(i, j, k)] >= 0)
@@ -94,21 +107,25 @@ int DeviceMap::count_5x5(const int pos[3]) const {  // LocalMap.h:292-318
 }
 
 size_t DeviceMap::size_local() const {
+  settle_quiet();
   size_t n = 0;
   for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) n += slot_count_[s];
   return n;
 }
 size_t DeviceMap::size() const {
+  settle_quiet();
   if (world_ <= 1) return size_local();
   size_t n = 0;
   for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) n += slot_full_[s];
   return n;
 }
 void DeviceMap::owned_counts(std::vector<int32_t>& out) const {
+  settle_quiet();
   out.assign(kMapNum, 0);
   for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) out[(size_t)slot_cube_[s]] = (int32_t)slot_owned_[s];
 }
 void DeviceMap::set_full_counts(const std::vector<int32_t>& full) {
+  settle_quiet();
   for (size_t s = 0; s < slot_cube_.size(); ++s) if (slot_cube_[s] >= 0) slot_full_[s] = (uint32_t)std::max(0, full[(size_t)slot_cube_[s]]);
 }
 
@@ -161,6 +178,7 @@ int DeviceMap::ensure_work(size_t total, std::string& err) {
     DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_small_), kSmallWords * sizeof(uint32_t) + kMapNum));
     d_touched_ = reinterpret_cast<uint8_t*>(d_small_ + kSmallWords);
   }
+  if (!d_tt_) DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_tt_), sizeof(MapTouched)));
   if (total <= work_cap_) return 0;
   const size_t cap = total + total / 4 + 1024;
   for (void* p : {(void*)d_wpts_, (void*)d_cent_, (void*)d_spts_, (void*)d_heads_, (void*)d_k0_, (void*)d_k1_, (void*)d_v0_, (void*)d_v1_, (void*)d_flags_, (void*)d_pos_, d_temp_})
@@ -177,13 +195,18 @@ int DeviceMap::ensure_work(size_t total, std::string& err) {
   return 0;
 }
 
+int DeviceMap::upload_slot_table(std::string& err) {
+  if (!slot_table_dirty_) return 0;
+  if (hipMemcpyAsync(d_cube_slot_, cube_slot_.data(), kMapNum * sizeof(int32_t), hipMemcpyHostToDevice, stream_) != hipSuccess ||
+      hipStreamSynchronize(stream_) != hipSuccess) { err = "DeviceMap: cube_slot upload failed"; return -2; }
+  slot_table_dirty_ = false;
+  return 0;
+}
+
 bool DeviceMap::view(DevMapView& v, std::string& err) {
+  if (settle(err) < 0) return false;
   if (ensure_pool(std::max<int>(1, (int)slot_cube_.size()), err)) return false;
-  if (slot_table_dirty_) {
-    if (hipMemcpyAsync(d_cube_slot_, cube_slot_.data(), kMapNum * sizeof(int32_t), hipMemcpyHostToDevice, stream_) != hipSuccess ||
-        hipStreamSynchronize(stream_) != hipSuccess) { err = "DeviceMap: cube_slot upload failed"; return false; }
-    slot_table_dirty_ = false;
-  }
+  if (upload_slot_table(err)) return false;
   v.pts = d_pool_; v.cell_start = d_cell_start_; v.cube_slot = d_cube_slot_;
   v.nc = nc_; v.ncell1 = ncell1_; v.inv_cell = 1.0 / cell_;
   v.origin[0] = origin_[0]; v.origin[1] = origin_[1]; v.origin[2] = origin_[2];
@@ -196,8 +219,10 @@ bool DeviceMap::view(DevMapView& v, std::string& err) {
 // the reference re-filters a block only when the next insert touches it (LocalMap.h:617-641), untouched blocks keep
 // their points.  Only the cell tables are rebuilt for the new cell size (launch_map_retable), on the device.
 int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err) {
+  if (const int rs = settle(err); rs < 0) return rs;
   line_res_ = line_res;
   if (plane_res == plane_res_ && nc_ > 1) return 0;
+  meta_dirty_ = true;  // ("filtered on the current grid" changes its meaning with planeRes)
   const float old_res = plane_res_;
   const bool had = size_local() > 0 && nc_ > 1;
   plane_res_ = plane_res;
@@ -255,6 +280,7 @@ int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err)
     a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
     a.grid = d_grid_; a.grid_scan = d_grid_scan_;
     a.temp = d_temp_; a.temp_bytes = temp_bytes_;
+    a.d_tt = d_tt_;
     {
       const size_t need = (size_t)tt.n * ncell1_ + 1;
       a.grid_is_clean = need <= grid_zero_upto_;
@@ -286,6 +312,7 @@ int DeviceMap::ensure_grid(size_t gn, std::string& err) {
 }
 
 int DeviceMap::add_surf_host(const float* xyz, size_t n, size_t stride_floats, std::string& err) {
+  if (const int rs = settle(err); rs < 0) return rs;  // (a deferred insert may still read the staging buffer)
   if (!n) return 0;
   if (stride_floats == 0) stride_floats = 3;
   if (n * stride_floats > stage_cap_) {
@@ -299,8 +326,178 @@ int DeviceMap::add_surf_host(const float* xyz, size_t n, size_t stride_floats, s
 }
 
 int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, std::string& err) {
+  if (const int rs = settle(err); rs < 0) return rs;
   if (!n) return 0;
   if (stride_floats == 0) stride_floats = 3;
+  const int r = insert_fast(d_xyz, n, stride_floats, nullptr, nullptr, false, err);
+  return r != kNotFast ? r : add_surf_legacy(d_xyz, n, stride_floats, err);
+}
+
+int DeviceMap::add_scan_dev(const float* d_scan, size_t n, const double T[7], float* d_world, bool defer, std::string& err) {
+  if (const int rs = settle(err); rs < 0) return rs;
+  if (!n) return 0;
+  const int r = insert_fast(d_scan, n, 3, T, d_world, defer, err);
+  if (r != kNotFast) return r;
+  launch_transform_scan(d_scan, (uint32_t)n, pose_from_array(T), d_world, stream_);
+  return add_surf_legacy(d_world, n, 3, err);
+}
+
+// ---- the insert laid out by the device -----------------------------------------------------------------------------
+int DeviceMap::ensure_fast(std::string& err) {
+  if (d_slot_count_) return 0;
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_slot_count_), 2 * kMaxSlots * sizeof(uint32_t)));
+  d_slot_ok_ = d_slot_count_ + kMaxSlots;
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cube_cnt_), (kMapNum + kMaxTouched + 1) * sizeof(uint32_t)));
+  d_tickets_ = d_cube_cnt_ + kMapNum;
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_scan_state_), kScanStateWords * sizeof(unsigned long long)));
+  DM_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_report_), sizeof(MapFastReport)));
+  std::memset(h_report_, 0, sizeof(MapFastReport));
+  DM_TRY(hipEventCreateWithFlags(&ev_fast_, hipEventDisableTiming));
+  meta_dirty_ = true; fast_clean_ = false;
+  return 0;
+}
+
+// the device's copies of the per-slot bookkeeping, after the HOST changed it (a slot allocated or dropped, a round laid out
+// by the host, planeRes changed, the map cleared): rare, so the upload simply waits
+int DeviceMap::sync_meta(std::string& err) {
+  if (!meta_dirty_) return 0;
+  std::vector<uint32_t> m(2 * (size_t)kMaxSlots, 0u);
+  for (size_t s = 0; s < slot_cube_.size() && s < (size_t)kMaxSlots; ++s) {
+    m[s] = slot_cube_[s] >= 0 ? slot_count_[s] : 0u;
+    m[kMaxSlots + s] = (m[s] == 0u || slot_res_[s] == plane_res_) ? 1u : 0u;
+  }
+  DM_TRY(hipMemcpyAsync(d_slot_count_, m.data(), m.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream_));
+  DM_TRY(hipStreamSynchronize(stream_));
+  meta_dirty_ = false;
+  return 0;
+}
+
+int DeviceMap::insert_fast(const float* d_in, size_t n, size_t stride_floats, const double* T, float* d_world, bool defer, std::string& err) {
+  if (!fast_enabled_ || !hash_grouping_ || world_ > 1 || slot_cube_.empty() || n >= (1u << 30)) return kNotFast;
+  if (skip_fast_ > 0) { --skip_fast_; return kNotFast; }
+  if (nc_ <= 1 && ncell1_ <= 2) return kNotFast;  // (no resolution yet: the map is empty)
+  const uint32_t lbits = leaf_bits(plane_res_);
+  const size_t per_round = max_touched(lbits);
+  if (ensure_pool(std::max<int>(1, (int)slot_cube_.size()), err)) return -2;
+  if (upload_slot_table(err)) return -2;
+  const size_t n_old_ub = size_local();
+  if (n_old_ub + n >= (1u << 31)) return kNotFast;
+  if (ensure_work(n_old_ub + n, err)) return -2;
+  if (ensure_fast(err)) return -2;
+  if (sync_meta(err)) return -2;
+  if (n > new_cap_) {
+    if (d_cube_of_) (void)hipFree(d_cube_of_);
+    d_cube_of_ = nullptr; new_cap_ = 0;
+    DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cube_of_), (n + 1024) * sizeof(int32_t)));
+    new_cap_ = n + 1024;
+  }
+  if (ensure_grid(per_round * ncell1_ + 1024, err)) return -2;
+  if (ensure_leaf_table(n, err)) return -2;
+  if (!block_clean_) { DM_TRY(hipMemsetAsync(d_small_, 0, kSmallWords * sizeof(uint32_t) + kMapNum, stream_)); block_clean_ = true; }
+  if (!fast_clean_) {
+    DM_TRY(hipMemsetAsync(d_cube_cnt_, 0, (kMapNum + kMaxTouched + 1) * sizeof(uint32_t), stream_));
+    DM_TRY(hipMemsetAsync(d_scan_state_, 0, kScanStateWords * sizeof(unsigned long long), stream_));
+    fast_clean_ = true;
+  }
+  {
+    const size_t need = per_round * ncell1_ + 1;
+    if (need > grid_zero_upto_) { DM_TRY(hipMemsetAsync(d_grid_, 0, need * sizeof(uint32_t), stream_)); grid_zero_upto_ = need; }
+  }
+  MapInsertArgs a{};
+  a.tt.lbits = lbits; a.d_tt = d_tt_;
+  a.d_xyz = T ? d_world : d_in; a.n_new = (uint32_t)n; a.stride_floats = T ? 3u : (uint32_t)stride_floats; a.n_old = (uint32_t)n_old_ub;
+  // the launches are sized for what the last device-built round held (+ 25 %), not for the whole map: the kernels stride
+  a.n_old_grid = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_old_ub, est_old_ ? est_old_ + est_old_ / 4 + 16384 : n_old_ub));
+  a.d_cube_of = d_cube_of_; a.inv_leaf = 1.0f / plane_res_;
+  a.nc = nc_; a.ncell1 = ncell1_; a.inv_cell = 1.0 / cell_;
+  a.pool = d_pool_; a.cap = kCapPerSlot; a.cell_start = d_cell_start_;
+  a.wpts = d_wpts_; a.cent = d_cent_; a.spts = d_spts_; a.heads = d_heads_;
+  a.keys0 = d_k0_; a.keys1 = d_k1_; a.vals0 = d_v0_; a.vals1 = d_v1_; a.flags = d_flags_; a.pos = d_pos_;
+  a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
+  a.rank = 0; a.world = 1; a.d_owned = nullptr;
+  a.grid = d_grid_; a.grid_scan = d_grid_scan_; a.grid_is_clean = true;
+  a.temp = d_temp_; a.temp_bytes = temp_bytes_;
+  a.ht_key = d_ht_key_; a.ht_cnt = d_ht_cnt_; a.ht_off = d_ht_off_;
+  a.ht_log2 = 12;
+  while (((size_t)1 << a.ht_log2) < 2 * (n + 1)) ++a.ht_log2;
+  MapFastArgs f{};
+  f.d_in = d_in; f.n = (uint32_t)n; f.stride_floats = (uint32_t)stride_floats;
+  f.transform = T != nullptr; if (T) f.pose = pose_from_array(T);
+  f.d_world = d_world;
+  f.origin[0] = origin_[0]; f.origin[1] = origin_[1]; f.origin[2] = origin_[2];
+  f.d_cube_slot = d_cube_slot_; f.d_slot_count = d_slot_count_; f.d_slot_ok = d_slot_ok_;
+  f.d_cube_cnt = d_cube_cnt_; f.d_scan_state = d_scan_state_; f.d_tickets = d_tickets_;
+  f.d_small = d_small_; f.small_words = (uint32_t)kSmallWords;
+  f.h_report = h_report_; f.seq = ++fast_seq_;
+  f.per_round = (int32_t)per_round;
+  launch_map_insert_fast(a, f, stream_);
+  DM_TRY(hipGetLastError());
+  DM_TRY(hipEventRecord(ev_fast_, stream_));
+  pending_.on = true; pending_.d_xyz = a.d_xyz; pending_.n = n; pending_.stride = a.stride_floats; pending_.seq = f.seq;
+  if (!defer) return settle(err);
+  // the caller may recycle the buffer of the input points as soon as this returns: wait until the front kernel (the only one
+  // that reads them; long done by the time a dozen launches have been enqueued) says so
+  volatile unsigned long long* fs = &h_report_->front_seq;
+  for (unsigned spin = 1; *fs != f.seq; ++spin)
+    if ((spin & 0x3FFu) == 0 && hipEventQuery(ev_fast_) != hipErrorNotReady) break;  // (everything completed or failed: settle() sorts it out)
+  (void)hipGetLastError();
+  return 0;
+}
+
+void DeviceMap::settle_quiet() const {
+  if (!pending_.on) return;
+  DeviceMap* self = const_cast<DeviceMap*>(this);
+  std::string e;
+  if (self->settle(e) < 0) self->deferred_err_ = e;
+}
+
+int DeviceMap::settle(std::string& err) {
+  if (!pending_.on) {
+    if (!deferred_err_.empty()) { err = deferred_err_; deferred_err_.clear(); return -2; }
+    return 0;
+  }
+  volatile unsigned long long* seq = &h_report_->seq;
+  for (unsigned spin = 1;; ++spin) {
+    if (*seq == pending_.seq) break;
+    if ((spin & 0x3FFu) == 0 && hipEventQuery(ev_fast_) != hipErrorNotReady) {
+      (void)hipGetLastError();
+      if (*seq == pending_.seq) break;
+      // the launches are over and the report is not there: a kernel failed.  Nothing of the bookkeeping can be trusted to
+      // match the device any more than after any other failed insert.
+      pending_.on = false;
+      grid_zero_upto_ = 0; block_clean_ = false; fast_clean_ = false; meta_dirty_ = true;
+      err = "DeviceMap: the device-built insert did not report";
+      return -2;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  pending_.on = false;
+  MapFastReport R;
+  std::memcpy(&R, h_report_, sizeof(R));
+  if (R.halt == kFastHaltNone) {
+    ++fast_inserts_;
+    for (uint32_t t = 0; t < R.n && t < (uint32_t)kMaxTouched; ++t) {
+      const int cube = R.cube[t];
+      const int s = (cube >= 0 && cube < kMapNum) ? cube_slot_[cube] : -1;
+      if (s < 0) { meta_dirty_ = true; err = "DeviceMap: the device reported a cube without a slot"; return -2; }
+      if (R.count[t] > kCapPerSlot) { meta_dirty_ = true; err = "DeviceMap: a 50 m cube exceeds the per-cube capacity of 1M points"; return -1; }
+      slot_count_[s] = R.count[t];
+      slot_res_[s] = ((R.dirty >> t) & 1u) ? -plane_res_ : plane_res_;  // (see add_surf_legacy)
+    }
+    est_old_ = R.n_old;
+    return (int)R.n_inside;
+  }
+  // the device could not lay the round out (or met a leaf the grouping kernels cannot sort): the map is unchanged, every
+  // counter is back at zero -- the insert is repeated round by round
+  ++fast_fallbacks_;
+  if (R.halt == kFastHaltMultiRound) skip_fast_ = 16;
+  return add_surf_legacy(pending_.d_xyz, pending_.n, pending_.stride, err);
+}
+
+int DeviceMap::add_surf_legacy(const float* d_xyz, size_t n, size_t stride_floats, std::string& err) {
+  if (!n) return 0;
+  if (stride_floats == 0) stride_floats = 3;
+  meta_dirty_ = true;  // (the host lays the rounds out and changes counts / slots: the device's copies follow before its next round)
   if (nc_ <= 1 && ncell1_ <= 2) { double cell; nc_ = cells_per_cube(plane_res_, &cell); cell_ = cell; ncell1_ = (uint32_t)((size_t)nc_ * nc_ * nc_ + 1); }
   if (ensure_work(n, err)) return -2;
   if (n > new_cap_) {
@@ -357,6 +554,7 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
     a.wpts = d_wpts_; a.cent = d_cent_; a.spts = d_spts_; a.heads = d_heads_;
     a.keys0 = d_k0_; a.keys1 = d_k1_; a.vals0 = d_v0_; a.vals1 = d_v1_; a.flags = d_flags_; a.pos = d_pos_;
     a.d_n_cent = d_small_; a.d_counts = d_small_ + 8;
+    a.d_tt = d_tt_;
     if (ensure_grid((size_t)tt.n * ncell1_ + 1024, err)) return -2;
     a.grid = d_grid_; a.grid_scan = d_grid_scan_;
     {  // the round leaves the counters it used at zero again (cell_table_kernel): fill only what no round has cleared yet
@@ -437,6 +635,7 @@ int DeviceMap::add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, 
 // reshard() then keeps, of all points, those whose leaf on the NEW grid this rank would keep at an insert, and rebuilds
 // the index.  Record: int32 cube, float res (negative: the drift watch had marked the cube), uint32 n, n x 3 floats.
 int DeviceMap::export_owned(std::vector<uint8_t>& blob, std::string& err) {
+  if (const int rs = settle(err); rs < 0) return rs;
   blob.clear();
   std::vector<float> tmp;
   const double inv_cell = 1.0 / cell_;
@@ -477,6 +676,8 @@ int DeviceMap::export_owned(std::vector<uint8_t>& blob, std::string& err) {
 }
 
 int DeviceMap::reshard(const std::vector<std::vector<uint8_t>>& blobs, float line_res, float plane_res, std::string& err) {
+  if (const int rs = settle(err); rs < 0) return rs;
+  meta_dirty_ = true;
   struct CubeSet { float res = 0.f; std::vector<float> xyz; };
   std::map<int, CubeSet> cubes;  // ascending block index
   for (const std::vector<uint8_t>& b : blobs) {
@@ -536,6 +737,7 @@ int DeviceMap::reshard(const std::vector<std::vector<uint8_t>>& blobs, float lin
 }
 
 size_t DeviceMap::export_points(float* xyz, size_t cap, bool only_5x5, const int pos[3], std::string& err) {
+  if (settle(err) < 0) return 0;
   size_t n = 0;
   for (int cube = 0; cube < kMapNum; ++cube) {  // ascending cube index, canonical order inside the cube
     const int s = cube_slot_[cube];

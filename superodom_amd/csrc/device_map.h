@@ -28,6 +28,10 @@ class DeviceMap {
     origin_[0] = 10; origin_[1] = 10; origin_[2] = 5; cube_slot_.assign(kMapNum, -1);
     const char* ev = std::getenv("SOICP_MAP_GROUPING");  // "sort": first stage of an insert by the stable radix sort (read per context)
     hash_grouping_ = !(ev && std::string(ev) == "sort");
+    ev = std::getenv("SOICP_MAP_FAST");   // "0": every insert round by round, laid out by the host (two read-backs per insert)
+    fast_enabled_ = !(ev && std::string(ev) == "0");
+    ev = std::getenv("SOICP_MAP_DEFER");  // "0": Localization() waits for the insert's report before it returns
+    defer_enabled_ = !(ev && std::string(ev) == "0");
   }
   ~DeviceMap();
   // changing planeRes rebuilds the cell tables over the resident points (they are re-filtered when an insert next touches
@@ -51,6 +55,17 @@ class DeviceMap {
   // LocalMap::addSurfPointCloud on the device.  d_xyz: device pointer, stride in floats.  Returns #points inside the window or <0.
   int add_surf_dev(const float* d_xyz, size_t n, size_t stride_floats, std::string& err);
   int add_surf_host(const float* xyz, size_t n, size_t stride_floats, std::string& err);
+  // transformAndAddToMap (LidarSlam.cpp:60-80) on the device: world = T * scan (packed xyz, sensor frame) is written to d_world
+  // and inserted.  defer: return as soon as the launches are in the queue and nothing reads d_scan any more; the map's
+  // bookkeeping is brought up to date by the next call of any member (settle).  Returns the number of points inside the
+  // window (0 when deferred) or < 0.
+  int add_scan_dev(const float* d_scan, size_t n, const double T[7], float* d_world, bool defer, std::string& err);
+  bool defer_enabled() const { return defer_enabled_; }
+  // completes a deferred insert: bookkeeping from the device's report, or -- when the device could not lay the round out --
+  // the insert round by round.  Every member that reads or changes the bookkeeping calls it first.
+  int settle(std::string& err);
+  // (inserts laid out by the device / of those, the ones the host had to repeat round by round)
+  void fast_stats(unsigned& inserts, unsigned& fallbacks) const { inserts = fast_inserts_; fallbacks = fast_fallbacks_; }
   size_t export_points(float* xyz, size_t cap, bool only_5x5, const int pos[3], std::string& err);
   bool view(DevMapView& v, std::string& err);  // refreshes the device cube_slot table when the bookkeeping changed
   // leaf keys hold 9 or 10 bits per axis (50 / planeRes + 4 leaves per cube axis must fit): planeRes >= 0.05
@@ -59,6 +74,13 @@ class DeviceMap {
   static size_t max_touched(uint32_t lbits) { return lbits == 9u ? (size_t)kMaxTouched : (size_t)4; }
 
  private:
+  int add_surf_legacy(const float* d_xyz, size_t n, size_t stride_floats, std::string& err);  // host-built rounds
+  static constexpr int kNotFast = -100;
+  int insert_fast(const float* d_in, size_t n, size_t stride_floats, const double* T, float* d_world, bool defer, std::string& err);
+  int ensure_fast(std::string& err);
+  int sync_meta(std::string& err);
+  int upload_slot_table(std::string& err);
+  void settle_quiet() const;
   int ensure_pool(int slots_needed, std::string& err);
   int ensure_work(size_t total, std::string& err);
   int ensure_grid(size_t gn, std::string& err);
@@ -92,6 +114,22 @@ class DeviceMap {
   static constexpr size_t kSmallWords = 128;
   size_t grid_zero_upto_ = 0;          // d_grid_[0 .. this) is all zero between inserts (a round cleans up after itself)
   bool block_clean_ = false;           // d_small_ / d_touched_ were cleared behind the previous insert
+  // device-built inserts (insert_fast; map_kernels.hip: insert_front_kernel)
+  static constexpr int kMaxSlots = 4096;
+  bool fast_enabled_ = true, defer_enabled_ = true;
+  MapTouched* d_tt_ = nullptr;                                   // the round as the kernels read it (host- or device-built)
+  uint32_t *d_slot_count_ = nullptr, *d_slot_ok_ = nullptr;      // [kMaxSlots] each: the device's copy of slot_count_ / "slot_res_ == plane_res_"
+  uint32_t* d_cube_cnt_ = nullptr; unsigned long long* d_scan_state_ = nullptr; uint32_t* d_tickets_ = nullptr;
+  MapFastReport* h_report_ = nullptr;                            // pinned
+  hipEvent_t ev_fast_ = nullptr;
+  bool meta_dirty_ = true;    // the host changed slot counts / resolutions / slots behind the device's back: upload before the next device-built round
+  bool fast_clean_ = false;   // d_cube_cnt_ / d_scan_state_ / d_tickets_ are all zero (the report kernel leaves them so)
+  unsigned long long fast_seq_ = 0;
+  struct Pending { bool on = false; const float* d_xyz = nullptr; size_t n = 0, stride = 0; unsigned long long seq = 0; } pending_;
+  size_t est_old_ = 0;        // old points of the last device-built round (sizes the next one's launches)
+  int skip_fast_ = 0;         // inserts to go round by round after the device met a scan that needs several rounds
+  unsigned fast_inserts_ = 0, fast_fallbacks_ = 0;
+  std::string deferred_err_;  // error of a settle() inside a const member: reported by the next call that can
 };
 
 }  // namespace soicp

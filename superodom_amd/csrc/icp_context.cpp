@@ -1307,6 +1307,7 @@ so_icp_ctx::~so_icp_ctx() {
   if (h_sums) (void)hipHostFree(h_sums);
   if (h_u32) (void)hipHostFree(h_u32);
   for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+  dmap.reset();  // (waits for a deferred insert on `stream`)
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -1518,6 +1519,14 @@ int so_icp_map_size(so_icp_ctx* c, size_t* n, size_t* n_rank) {
   if (!c) return SO_ICP_E_INVALID;
   if (n) *n = c->dmap ? c->dmap->size() : c->map.size();
   if (n_rank) { NEED_DEVICE(c); const int rc = upload_map(c); if (rc) return rc; *n_rank = c->view.n_points; }
+  return SO_ICP_OK;
+}
+int so_icp_map_insert_stats(so_icp_ctx* c, unsigned* device_built, unsigned* handed_back) {
+  if (!c) return SO_ICP_E_INVALID;
+  unsigned a = 0, b = 0;
+  if (c->dmap) { std::string e; (void)c->dmap->settle(e); c->dmap->fast_stats(a, b); }
+  if (device_built) *device_built = a;
+  if (handed_back) *handed_back = b;
   return SO_ICP_OK;
 }
 int so_icp_map_clear(so_icp_ctx* c) { if (!c) return SO_ICP_E_INVALID; if (c->dmap) c->dmap->clear(); else c->map.clear(); return SO_ICP_OK; }
@@ -1897,9 +1906,11 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
     return c->map.add_surf(w.data(), n, 3) < 0 ? fail(c, SO_ICP_E_INVALID, "LocalMap insert failed") : SO_ICP_OK;
   };
   auto transform_and_add_dev = [&](const float* d_scan, const double T[7]) -> int {  // same, entirely on the device
+    // (one launch transforms the scan, finds every point's cube and lays the insert round out on the device; the insert is
+    //  enqueued without a read-back and -- unless SOICP_MAP_DEFER=0 -- completes behind this call: device_map.h, settle)
+    if (const int rs = c->dmap->settle(c->err); rs < 0) return rs == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP;  // (before d_world may be re-allocated)
     HIP_TRY(c, c->d_world.reserve((n + 64) * 12));
-    launch_transform_scan(d_scan, (uint32_t)n, pose_from_array(T), c->d_world.as<float>(), c->stream);
-    const int r = c->dmap->add_surf_dev(c->d_world.as<float>(), n, 3, c->err);
+    const int r = c->dmap->add_scan_dev(d_scan, n, T, c->d_world.as<float>(), c->dmap->defer_enabled() && !c->dmap->sharded(), c->err);
     return r < 0 ? (r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP) : exchange_map_counts(c);
   };
   if (!initialization) {  // initializeMapping, LidarSlam.cpp:83-94
@@ -2055,9 +2066,9 @@ int so_icp_localization_dev(so_icp_ctx* c, int initialization, const double T_in
     return so_icp_localization(c, initialization, T_in, h.data(), n, 12, time_laser_odometry, pose_out, st);
   }
   auto transform_and_add_dev = [&](const double T[7]) -> int {  // transformAndAddToMap (LidarSlam.cpp:60-80) on the device
+    if (const int rs = c->dmap->settle(c->err); rs < 0) return rs == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP;
     HIP_TRY(c, c->d_world.reserve((n + 64) * 12));
-    launch_transform_scan(static_cast<const float*>(d_scan), (uint32_t)n, pose_from_array(T), c->d_world.as<float>(), c->stream);
-    const int r = c->dmap->add_surf_dev(c->d_world.as<float>(), n, 3, c->err);
+    const int r = c->dmap->add_scan_dev(static_cast<const float*>(d_scan), n, T, c->d_world.as<float>(), c->dmap->defer_enabled() && !c->dmap->sharded(), c->err);
     return r < 0 ? (r == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP) : exchange_map_counts(c);
   };
   if (!initialization) {  // initializeMapping, LidarSlam.cpp:83-94

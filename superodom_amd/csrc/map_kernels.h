@@ -28,12 +28,53 @@ struct MapTouched {
   float inv_leaf_watch;
   uint32_t* dirty;
   uint32_t lbits;  // bits per leaf coordinate in the keys (9: up to kMaxTouched cubes per round, 10: up to 4; map_kernels.hip leaf_key)
+  // device-built rounds (insert_front_kernel): first position of cube t's range in the second stage's scratch arrays -- the
+  // cubes' cell grids are scanned one by one there, each from this base (exclusive prefix of old + new points per cube)
+  uint32_t region_base[kMaxTouched];
+};
+// (the kernels read the struct from device memory: the host-built one is stored there by a one-wavefront launch, the
+//  device-built one never visits the host; old_prefix[kMaxTouched] = number of old points of the round)
+
+// Device-built insert round (DeviceMap::insert_fast): the touched cubes, their slots and point counts are worked out on
+// the device from tables it keeps itself, so the host enqueues the whole insert without a read-back; what it has to know
+// afterwards arrives in pinned memory.
+enum : uint32_t { kFastHaltNone = 0, kFastHaltOverflow = 1 /* a leaf too large for the grouping kernels */, kFastHaltMultiRound = 2 /* more cubes than a round holds */,
+                  kFastHaltUnallocated = 3 /* a cube without a slot */, kFastHaltNeedsSort = 4 /* a cube last filtered on another grid / marked by the drift watch */ };
+struct MapFastReport {
+  uint32_t halt;      // kFastHalt*: != 0 -> the map is unchanged, the host repeats the insert round by round
+  uint32_t n;         // touched cubes
+  uint32_t n_inside;  // new points inside the 21x21x11 window
+  uint32_t dirty;     // MapTouched::dirty bits
+  int32_t cube[kMaxTouched];
+  uint32_t count[kMaxTouched];  // the cubes' new point counts
+  uint32_t n_old, pad;
+  unsigned long long front_seq;  // written by the front kernel's last workgroup: nobody reads the input points any more
+  unsigned long long seq;        // written last (system scope): the insert is complete
+};
+constexpr uint32_t kScanItems = 2048;                     // cell counters per workgroup of cell_scan_table_kernel
+constexpr uint32_t kScanBlocksMax = (64u * 64u * 64u + 1u + kScanItems - 1u) / kScanItems;  // 129
+constexpr size_t kScanStateWords = (size_t)kMaxTouched * kScanBlocksMax;  // 64-bit look-back records
+struct MapFastArgs {
+  const float* d_in; uint32_t n, stride_floats;  // the new points: world frame, or (transform) the scan in the sensor frame
+  bool transform; Pose pose; float* d_world;     // transform: world = pose * in, packed xyz, written to d_world (and inserted)
+  int32_t origin[3];
+  const int32_t* d_cube_slot;                    // [kMapNum], the table the k-NN uses
+  uint32_t* d_slot_count; uint32_t* d_slot_ok;   // per slot: resident points / "one point per leaf of the current grid"
+  uint32_t* d_cube_cnt;                          // [kMapNum] new points per cube (zero between inserts)
+  unsigned long long* d_scan_state;              // [kScanStateWords] (zero between inserts)
+  uint32_t* d_tickets;                           // [kMaxTouched + 1] (zero between inserts): [kMaxTouched] = the front kernel's
+  uint32_t* d_small;                             // DeviceMap's counter block (zero between inserts)
+  MapFastReport* h_report; unsigned long long seq;
+  int32_t per_round;
+  uint32_t small_words;
 };
 
 struct MapInsertArgs {
-  MapTouched tt;
+  MapTouched tt;             // host-built round (stored to d_tt by the launch) -- unused when the device builds the round
+  MapTouched* d_tt;          // the round as the kernels read it
   const float* d_xyz;        // new world-frame points (device)
-  uint32_t n_new, stride_floats, n_old;
+  uint32_t n_new, stride_floats, n_old;  // n_old: the round's old points (device-built round: an upper bound -- the kernels take the number from d_tt)
+  uint32_t n_old_grid;       // device-built round: the number of old points the launches are sized for (an estimate; the kernels stride); 0 = n_old
   const int32_t* d_cube_of;  // per new point: cube index or -1
   float inv_leaf;
   int32_t nc; uint32_t ncell1; double inv_cell;
@@ -79,6 +120,9 @@ void launch_world_cube(const float* d_xyz, uint32_t n, uint32_t stride_floats, c
                        uint8_t* d_touched, uint32_t* d_n_inside, hipStream_t s);
 void launch_transform_scan(const float* d_scan, uint32_t n, const Pose& pose, float* d_out, hipStream_t s);
 void launch_map_insert(const MapInsertArgs& a, hipStream_t s);
+// the whole insert without a host round trip: front kernel (world transform, cube of every point, the round built on the
+// device), the hashed first stage, the second stage with its own scan, the report into pinned memory
+void launch_map_insert_fast(const MapInsertArgs& a, const MapFastArgs& f, hipStream_t s);
 void launch_map_retable(const MapInsertArgs& a, hipStream_t s);  // resolution change: new cell tables over the resident points
 // re-cut of a shard: keep the candidates whose new-grid leaf this rank keeps; counters[0] = kept, [1] = of all candidates, those whose own cell it owns
 void launch_shard_select(const float* d_xyz, uint32_t n, const MapTouched& tt, float inv_leaf, int nc, double inv_cell, int rank, int world,

@@ -24,6 +24,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "deskew_math.h"
+#include "local_map.h"
 #include "map_kernels.h"
 #include "so_math.h"
 
@@ -86,9 +87,10 @@ __device__ __forceinline__ uint32_t leaf_key(float x, float y, float z, float in
   return (tid << (3u * lbits)) | (((uint32_t)l2 & m) << (2u * lbits)) | (((uint32_t)l1 & m) << lbits) | ((uint32_t)l0 & m);
 }
 
-__global__ __launch_bounds__(256) void gather_old_kernel(MapTouched tt, const float4* __restrict__ pool, uint32_t cap, float inv_leaf,
+__global__ __launch_bounds__(256) void gather_old_kernel(const MapTouched* __restrict__ ttp, const float4* __restrict__ pool, uint32_t cap, float inv_leaf,
                                                          uint32_t n_old, float4* __restrict__ wpts, uint32_t* __restrict__ keys,
                                                          uint32_t* __restrict__ vals) {
+  const MapTouched& tt = *ttp;
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_old) return;
   int t = 0;
@@ -107,8 +109,9 @@ __global__ __launch_bounds__(256) void gather_old_kernel(MapTouched tt, const fl
 // key every old point by its leaf on the OLD grid of its cube (10 bits per axis, no cube id: the main sort groups by cube
 // and is stable), sort, and gather the working set's head in that order.
 struct OldGrids { float inv_leaf[kMaxTouched]; };
-__global__ __launch_bounds__(256) void old_order_key_kernel(MapTouched tt, OldGrids og, const float4* __restrict__ pool, uint32_t cap, uint32_t n_old,
+__global__ __launch_bounds__(256) void old_order_key_kernel(const MapTouched* __restrict__ ttp, OldGrids og, const float4* __restrict__ pool, uint32_t cap, uint32_t n_old,
                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const MapTouched& tt = *ttp;
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_old) return;
   int t = 0;
@@ -125,9 +128,10 @@ __global__ __launch_bounds__(256) void old_order_key_kernel(MapTouched tt, OldGr
   keys[e] = k;
   vals[e] = e;
 }
-__global__ __launch_bounds__(256) void gather_old_ordered_kernel(MapTouched tt, const float4* __restrict__ pool, uint32_t cap, float inv_leaf,
+__global__ __launch_bounds__(256) void gather_old_ordered_kernel(const MapTouched* __restrict__ ttp, const float4* __restrict__ pool, uint32_t cap, float inv_leaf,
                                                                  uint32_t n_old, const uint32_t* __restrict__ order, float4* __restrict__ wpts,
                                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const MapTouched& tt = *ttp;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_old) return;
   const uint32_t e = order[i];
@@ -177,9 +181,10 @@ __device__ __forceinline__ int touched_index(const MapTouched& tt, int cube) {
 
 __global__ __launch_bounds__(256) void append_new_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats,
                                                          const int32_t* __restrict__ cube_of,
-                                                         MapTouched tt, float inv_leaf, uint32_t n_old, float4* __restrict__ wpts,
+                                                         const MapTouched* __restrict__ ttp, float inv_leaf, uint32_t n_old, float4* __restrict__ wpts,
                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int nc, double inv_cell,
                                                          int rank, int world) {
+  const MapTouched& tt = *ttp;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float* p = xyz + (size_t)i * stride_floats;
@@ -196,9 +201,10 @@ __global__ __launch_bounds__(256) void append_new_kernel(const float* __restrict
 
 // sharded map: number of the cube's points whose OWN cell lies in a brick of this rank (every point of the full map is
 // counted by exactly one rank: the sum over the ranks is the block's cloud size the reference reports, LocalMap.h:292-318)
-__global__ __launch_bounds__(256) void count_owned_kernel(const float4* __restrict__ pool, uint32_t cap, MapTouched tt,
+__global__ __launch_bounds__(256) void count_owned_kernel(const float4* __restrict__ pool, uint32_t cap, const MapTouched* __restrict__ ttp,
                                                           const uint32_t* __restrict__ counts, int nc, double inv_cell, int rank, int world,
                                                           uint32_t* __restrict__ owned) {
+  const MapTouched& tt = *ttp;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   bool mine = false;
@@ -312,9 +318,10 @@ __global__ __launch_bounds__(256) void leaf_heads_kernel(const uint32_t* __restr
 // The points are contiguous now; sixteen are fetched per round trip, the next sixteen while these are added.
 __global__ __launch_bounds__(256) void leaf_centroid_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ heads,
                                                             const uint32_t* __restrict__ n_cent, const float4* __restrict__ spts,
-                                                            MapTouched tt, int nc, double inv_cell, float4* __restrict__ cent,
+                                                            const MapTouched* __restrict__ ttp, int nc, double inv_cell, float4* __restrict__ cent,
                                                             uint32_t* __restrict__ keys2, uint32_t* __restrict__ vals2,
                                                             uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count) {
+  const MapTouched& tt = *ttp;
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= *n_cent) return;
   const uint32_t beg = heads[o], end = heads[o + 1];
@@ -346,10 +353,11 @@ __global__ __launch_bounds__(256) void leaf_centroid_kernel(const uint32_t* __re
 // leaves with more than kLongLeaf points (the ground right under the sensor: ~1000 scan points in one 0.2 m leaf): one
 // WAVEFRONT per leaf loads 64 points per instruction (next 64 in flight) and adds them in order out of its lanes
 __global__ __launch_bounds__(256) void leaf_centroid_long_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ heads,
-                                                                 const float4* __restrict__ spts, MapTouched tt, int nc, double inv_cell,
+                                                                 const float4* __restrict__ spts, const MapTouched* __restrict__ ttp, int nc, double inv_cell,
                                                                  float4* __restrict__ cent, uint32_t* __restrict__ keys2,
                                                                  uint32_t* __restrict__ vals2, const uint32_t* __restrict__ long_list,
                                                                  const uint32_t* __restrict__ long_count) {
+  const MapTouched& tt = *ttp;
   const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const uint32_t n_long = *long_count < kMaxLongLeaves ? *long_count : kMaxLongLeaves;
@@ -398,9 +406,11 @@ __device__ __forceinline__ uint32_t leaf_hash(uint32_t key, uint32_t log2_size) 
 // (the new points' part of the working set -- append_new_kernel's job on the sort path -- is produced here as well: one launch less)
 __global__ __launch_bounds__(256) void leafhash_insert_new_kernel(const float* __restrict__ xyz, uint32_t n_new, uint32_t stride_floats,
                                                                   const int32_t* __restrict__ cube_of,
-                                                                  MapTouched tt, float inv_leaf, int nc, double inv_cell, int rank, int world,
-                                                                  float4* __restrict__ wpts, uint32_t* __restrict__ keys, uint32_t n_old, LeafTable ht,
+                                                                  const MapTouched* __restrict__ ttp, float inv_leaf, int nc, double inv_cell, int rank, int world,
+                                                                  float4* __restrict__ wpts, uint32_t* __restrict__ keys, LeafTable ht,
                                                                   uint32_t* __restrict__ mslot, uint32_t* __restrict__ mrank) {
+  const MapTouched& tt = *ttp;
+  const uint32_t n_old = tt.old_prefix[kMaxTouched];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t e = n_old + i, total = n_old + n_new;
   uint32_t key = kLeafEmpty;
@@ -448,74 +458,90 @@ __global__ __launch_bounds__(256) void leafhash_insert_new_kernel(const float* _
 // (launched after leafhash_insert_new_kernel has completed: the table's keys are final, only the counts still move)
 // (the old points' part of the working set -- gather_old_kernel's job on the sort path -- is produced here as well)
 __global__ __launch_bounds__(256) void leafhash_match_old_kernel(const float4* __restrict__ pool, uint32_t cap, float inv_leaf, uint32_t* __restrict__ keys,
-                                                                 uint32_t n_old, float4* __restrict__ wpts,
+                                                                 float4* __restrict__ wpts,
                                                                  LeafTable ht, uint32_t* __restrict__ mslot, uint32_t* __restrict__ mrank,
-                                                                 MapTouched tt, int nc, double inv_cell, float4* __restrict__ cent,
+                                                                 const MapTouched* __restrict__ ttp, int nc, double inv_cell, float4* __restrict__ cent,
                                                                  uint32_t* __restrict__ keys2) {
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_old) return;
-  int t = 0;
+  const MapTouched& tt = *ttp;
+  // (grid-stride: a device-built round knows the number of old points, the host that sized the launch only an estimate)
+  const uint32_t n_old = tt.old_prefix[kMaxTouched];
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_old; e += gridDim.x * blockDim.x) {
+    int t = 0;
 #pragma unroll
-  for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
-  const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
-  const uint32_t key = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
-  wpts[e] = p; keys[e] = key;
-  const uint32_t mask = (1u << ht.log2_size) - 1u;
-  uint32_t h = leaf_hash(key, ht.log2_size), slot = kLeafEmpty;
-  for (;;) {
-    const uint32_t k = ht.key[h];
-    if (k == key) { slot = h; break; }
-    if (k == kLeafEmpty) break;
-    h = (h + 1) & mask;
+    for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
+    const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
+    const uint32_t key = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
+    wpts[e] = p; keys[e] = key;
+    const uint32_t mask = (1u << ht.log2_size) - 1u;
+    uint32_t h = leaf_hash(key, ht.log2_size), slot = kLeafEmpty;
+    for (;;) {
+      const uint32_t k = ht.key[h];
+      if (k == key) { slot = h; break; }
+      if (k == kLeafEmpty) break;
+      h = (h + 1) & mask;
+    }
+    mslot[e] = slot;
+    if (slot != kLeafEmpty) {
+      mrank[e] = atomicAdd(&ht.cnt[slot], 1u);
+      keys2[e] = kLeafEmpty;  // a hole of the centroid index space: the point lives on in its group
+      continue;
+    }
+    // the only point of its leaf: sum = 0 + p, count = 1
+    emit_centroid(e, key, 0.f + p.x, 0.f + p.y, 0.f + p.z, 1u, tt, nc, inv_cell, cent, keys2, nullptr);
   }
-  mslot[e] = slot;
-  if (slot != kLeafEmpty) {
-    mrank[e] = atomicAdd(&ht.cnt[slot], 1u);
-    keys2[e] = kLeafEmpty;  // a hole of the centroid index space: the point lives on in its group
-    return;
-  }
-  // the only point of its leaf: sum = 0 + p, count = 1
-  emit_centroid(e, key, 0.f + p.x, 0.f + p.y, 0.f + p.z, 1u, tt, nc, inv_cell, cent, keys2, nullptr);
 }
 
 // member-list ranges + group ordinals from the table counts (four slots per thread, 1024 threads per workgroup: workgroup
 // scan, ONE packed atomic per workgroup: members in the low word, groups in the high word -- the ranges only have to be
-// disjoint, not ordered); leaves the table empty for the next insert
+// disjoint, not ordered); leaves the table empty for the next insert.  The groups of more than 16 / more than kGiantLeaf
+// members are listed here (their sizes are known): the kernels that sum them need not wait for the one that sums the rest.
 __global__ __launch_bounds__(1024) void leafhash_offsets_kernel(LeafTable ht, uint32_t* __restrict__ gstart, uint32_t* __restrict__ gcount,
-                                                                unsigned long long* __restrict__ cursor) {
-  __shared__ uint32_t wm[16], wg[16], base_m, base_g;
+                                                                unsigned long long* __restrict__ cursor,
+                                                                uint32_t* __restrict__ medium_list, uint32_t* __restrict__ medium_count,
+                                                                uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count) {
+  __shared__ uint32_t wm[16], wg[16], wl[16], base_m, base_g, base_med, base_gia;
   const uint32_t t4 = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint4 c4 = reinterpret_cast<const uint4*>(ht.cnt)[t4];
   const uint32_t cnt[4] = {c4.x, c4.y, c4.z, c4.w};
-  uint32_t tm = 0, tg = 0;
+  uint32_t tm = 0, tg = 0, tl = 0;  // members, groups, listed groups (medium in the low half, giant in the high half)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { tm += cnt[k]; tg += cnt[k] ? 1u : 0u; }
-  uint32_t im = tm, ig = tg;
+  for (int k = 0; k < 4; ++k) {
+    tm += cnt[k]; tg += cnt[k] ? 1u : 0u;
+    tl += cnt[k] > kGiantLeaf ? 0x10000u : (cnt[k] > 16u ? 1u : 0u);
+  }
+  uint32_t im = tm, ig = tg, il = tl;
   if (__ballot(tm != 0)) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t a = (uint32_t)__shfl_up((int)im, d, 64), b = (uint32_t)__shfl_up((int)ig, d, 64);
-      if (lane >= d) { im += a; ig += b; }
+      const uint32_t a = (uint32_t)__shfl_up((int)im, d, 64), b = (uint32_t)__shfl_up((int)ig, d, 64), c = (uint32_t)__shfl_up((int)il, d, 64);
+      if (lane >= d) { im += a; ig += b; il += c; }
     }
   }
-  if (lane == 63) { wm[wave] = im; wg[wave] = ig; }
+  if (lane == 63) { wm[wave] = im; wg[wave] = ig; wl[wave] = il; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t sm = 0, sg = 0;
-    for (int w = 0; w < 16; ++w) { const uint32_t a = wm[w], b = wg[w]; wm[w] = sm; wg[w] = sg; sm += a; sg += b; }
+    uint32_t sm = 0, sg = 0, sl = 0;
+    for (int w = 0; w < 16; ++w) { const uint32_t a = wm[w], b = wg[w], c = wl[w]; wm[w] = sm; wg[w] = sg; wl[w] = sl; sm += a; sg += b; sl += c; }
     unsigned long long old = 0ull;
     if (sm) old = atomicAdd(cursor, (unsigned long long)sm | ((unsigned long long)sg << 32));
     base_m = (uint32_t)old; base_g = (uint32_t)(old >> 32);
+    // (one atomic per workgroup and list: every group appending for itself took 11 us on the two counters)
+    base_med = (sl & 0xFFFFu) ? atomicAdd(medium_count, sl & 0xFFFFu) : 0u;
+    base_gia = (sl >> 16) ? atomicAdd(giant_count, sl >> 16) : 0u;
   }
   __syncthreads();
   if (tm) {
     uint32_t off = base_m + wm[wave] + (im - tm), g = base_g + wg[wave] + (ig - tg);
+    const uint32_t lb = wl[wave] + (il - tl);
+    uint32_t pm = base_med + (lb & 0xFFFFu), pg = base_gia + (lb >> 16);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (!cnt[k]) continue;
       ht.off[4 * t4 + k] = off;
       gstart[g] = off; gcount[g] = cnt[k];
+      if (cnt[k] > kGiantLeaf) giant_list[pg++] = g;
+      else if (cnt[k] > 16u) medium_list[pm++] = g;
       off += cnt[k]; ++g;
       ht.key[4 * t4 + k] = kLeafEmpty;
     }
@@ -523,40 +549,27 @@ __global__ __launch_bounds__(1024) void leafhash_offsets_kernel(LeafTable ht, ui
   }
 }
 
-__global__ __launch_bounds__(256) void leafhash_place_kernel(const uint32_t* __restrict__ mslot, const uint32_t* __restrict__ mrank, uint32_t total,
-                                                             const uint32_t* __restrict__ off, uint32_t* __restrict__ members) {
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const uint32_t sl = mslot[e];
-  if (sl != kLeafEmpty) members[off[sl] + mrank[e]] = e;
+__global__ __launch_bounds__(256) void leafhash_place_kernel(const uint32_t* __restrict__ mslot, const uint32_t* __restrict__ mrank, uint32_t n_new,
+                                                             const MapTouched* __restrict__ ttp, const uint32_t* __restrict__ off, uint32_t* __restrict__ members) {
+  const uint32_t total = ttp->old_prefix[kMaxTouched] + n_new;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const uint32_t sl = mslot[e];
+    if (sl != kLeafEmpty) members[off[sl] + mrank[e]] = e;
+  }
 }
 
-// one thread per group for up to 16 members (sorting network in registers): 95 % of the groups of a raw 128-beam sweep.
-// Groups of 17..64 go to leafhash_medium_kernel's list (one wavefront each), larger ones to leafhash_giant_kernel's.
-__global__ __launch_bounds__(256) void leafhash_centroid_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
-                                                                const unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ members,
-                                                                const float4* __restrict__ wpts, const uint32_t* __restrict__ leaf_keys,
-                                                                uint32_t n_old, MapTouched tt, int nc, double inv_cell, float4* __restrict__ cent,
-                                                                uint32_t* __restrict__ keys2, uint32_t* __restrict__ n_cent,
-                                                                uint32_t* __restrict__ medium_list, uint32_t* __restrict__ medium_count,
-                                                                uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+// Groups of up to 16 members: one thread per group (sorting network in registers): 95 % of the groups of a raw 128-beam
+// sweep.  Groups of 17..64 (leafhash_offsets_kernel's medium list): one wavefront each (bitonic network over the lanes,
+// then the sum in lane order).  ONE launch: workgroups [0, small_blocks) take the first kind, the others the second.
+__device__ __forceinline__ void leafhash_small_groups(uint32_t g, const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
+                                                      const unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ members,
+                                                      const float4* __restrict__ wpts, const uint32_t* __restrict__ leaf_keys,
+                                                      uint32_t n_old, const MapTouched& tt, int nc, double inv_cell, float4* __restrict__ cent,
+                                                      uint32_t* __restrict__ keys2, uint32_t* __restrict__ n_cent) {
   const uint32_t n_groups = (uint32_t)(*cursor >> 32);
   if (g == 0) *n_cent = n_old + n_groups;
-  const int lane = threadIdx.x & 63;
   const bool have = g < n_groups;
   const uint32_t cnt = have ? gcount[g] : 0u, beg = have ? gstart[g] : 0u;
-  // the larger groups: one list append per wavefront and list
-  {
-    const bool med = cnt > 16u && cnt <= kGiantLeaf, big = cnt > kGiantLeaf;
-    const unsigned long long mm = __ballot(med), mb = __ballot(big);
-    uint32_t bm = 0, bb = 0;
-    if (lane == 0 && mm) bm = atomicAdd(medium_count, (uint32_t)__popcll(mm));
-    if (lane == 0 && mb) bb = atomicAdd(giant_count, (uint32_t)__popcll(mb));
-    bm = (uint32_t)__shfl((int)bm, 0, 64); bb = (uint32_t)__shfl((int)bb, 0, 64);
-    if (med) medium_list[bm + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = g;
-    if (big) giant_list[bb + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull))] = g;
-  }
   if (!have || cnt > 16u) return;
   uint32_t e[16];
   if (cnt <= 4u) {
@@ -604,41 +617,56 @@ __global__ __launch_bounds__(256) void leafhash_centroid_kernel(const uint32_t* 
   emit_centroid(n_old + g, leaf_keys[e[0]], s0, s1, s2, cnt, tt, nc, inv_cell, cent, keys2, nullptr);
 }
 
-// groups of 17..64 members: one wavefront each (bitonic network over the lanes, then the sum in lane order)
-__global__ __launch_bounds__(256) void leafhash_medium_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
-                                                              const uint32_t* __restrict__ members, const float4* __restrict__ wpts,
-                                                              const uint32_t* __restrict__ leaf_keys, uint32_t n_old, MapTouched tt, int nc,
-                                                              double inv_cell, float4* __restrict__ cent, uint32_t* __restrict__ keys2,
-                                                              const uint32_t* __restrict__ medium_list, const uint32_t* __restrict__ medium_count) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t n_medium = *medium_count, n_waves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_medium; w += n_waves) {
-  const uint32_t g = medium_list[w];
-  const uint32_t c = gcount[g], b = gstart[g];
-  uint32_t v = (uint32_t)lane < c ? members[b + lane] : kLeafEmpty;
+__device__ __forceinline__ void leafhash_medium_groups(uint32_t first_wave, uint32_t n_waves, int lane, const uint32_t* __restrict__ gstart,
+                                                       const uint32_t* __restrict__ gcount, const uint32_t* __restrict__ members,
+                                                       const float4* __restrict__ wpts, const uint32_t* __restrict__ leaf_keys, uint32_t n_old,
+                                                       const MapTouched& tt, int nc, double inv_cell, float4* __restrict__ cent,
+                                                       uint32_t* __restrict__ keys2, const uint32_t* __restrict__ medium_list,
+                                                       const uint32_t* __restrict__ medium_count) {
+  const uint32_t n_medium = *medium_count;
+  for (uint32_t w = first_wave; w < n_medium; w += n_waves) {
+    const uint32_t g = medium_list[w];
+    const uint32_t c = gcount[g], b = gstart[g];
+    uint32_t v = (uint32_t)lane < c ? members[b + lane] : kLeafEmpty;
 #pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
+    for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const uint32_t o = (uint32_t)__shfl_xor((int)v, j, 64);
-      const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-      v = keep_min ? min(v, o) : max(v, o);
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, j, 64);
+        const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+        v = keep_min ? min(v, o) : max(v, o);
+      }
     }
-  }
-  // lane i now holds the group's i-th member in working-set order; lanes behind the end contribute +0.0f (s + 0.0f == s)
-  const float4 p = wpts[(uint32_t)lane < c ? v : 0u];
-  const bool live = (uint32_t)lane < c;
-  const float x = live ? p.x : 0.f, y = live ? p.y : 0.f, z = live ? p.z : 0.f;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    // lane i now holds the group's i-th member in working-set order; lanes behind the end contribute +0.0f (s + 0.0f == s)
+    const float4 p = wpts[(uint32_t)lane < c ? v : 0u];
+    const bool live = (uint32_t)lane < c;
+    const float x = live ? p.x : 0.f, y = live ? p.y : 0.f, z = live ? p.z : 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < 64; ++k) {
-    s0 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), k));
-    s1 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), k));
-    s2 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), k));
+    for (int k = 0; k < 64; ++k) {
+      s0 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), k));
+      s1 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), k));
+      s2 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), k));
+    }
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+    if (lane == 0) emit_centroid(n_old + g, leaf_keys[first], s0, s1, s2, c, tt, nc, inv_cell, cent, keys2, nullptr);
   }
-  const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
-  if (lane == 0) emit_centroid(n_old + g, leaf_keys[first], s0, s1, s2, c, tt, nc, inv_cell, cent, keys2, nullptr);
-  }
+}
+
+__global__ __launch_bounds__(256) void leafhash_centroid_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
+                                                                const unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ members,
+                                                                const float4* __restrict__ wpts, const uint32_t* __restrict__ leaf_keys,
+                                                                const MapTouched* __restrict__ ttp, int nc, double inv_cell, float4* __restrict__ cent,
+                                                                uint32_t* __restrict__ keys2, uint32_t* __restrict__ n_cent,
+                                                                const uint32_t* __restrict__ medium_list, const uint32_t* __restrict__ medium_count,
+                                                                uint32_t small_blocks) {
+  const MapTouched& tt = *ttp;
+  const uint32_t n_old = tt.old_prefix[kMaxTouched];
+  if (blockIdx.x < small_blocks)
+    leafhash_small_groups(blockIdx.x * blockDim.x + threadIdx.x, gstart, gcount, cursor, members, wpts, leaf_keys, n_old, tt, nc, inv_cell, cent, keys2, n_cent);
+  else
+    leafhash_medium_groups(((blockIdx.x - small_blocks) * blockDim.x + threadIdx.x) >> 6, ((gridDim.x - small_blocks) * blockDim.x) >> 6, threadIdx.x & 63,
+                           gstart, gcount, members, wpts, leaf_keys, n_old, tt, nc, inv_cell, cent, keys2, medium_list, medium_count);
 }
 
 // leaves with more than 64 points (the ground under the sensor: up to ~1 600 points of a raw 128-beam sweep in one 0.2 m
@@ -655,10 +683,12 @@ constexpr size_t kGiantLds = (size_t)kGiantCap * 5 * 4;  // x, y, z, per-wavefro
 constexpr int kGiantThreads = 1024;                       // four members per thread at most: one round trip per phase
 __global__ __launch_bounds__(kGiantThreads) void leafhash_giant_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
                                                              const uint32_t* __restrict__ members, const float4* __restrict__ wpts,
-                                                             const uint32_t* __restrict__ leaf_keys, uint32_t n_old, uint32_t n_new,
-                                                             MapTouched tt, int nc, double inv_cell, float4* __restrict__ cent,
+                                                             const uint32_t* __restrict__ leaf_keys, uint32_t n_new,
+                                                             const MapTouched* __restrict__ ttp, int nc, double inv_cell, float4* __restrict__ cent,
                                                              uint32_t* __restrict__ keys2, const uint32_t* __restrict__ giant_list,
                                                              const uint32_t* __restrict__ giant_count, uint32_t* __restrict__ overflow) {
+  const MapTouched& tt = *ttp;
+  const uint32_t n_old = tt.old_prefix[kMaxTouched];
   extern __shared__ uint32_t lds[];
   float* sx = reinterpret_cast<float*>(lds);
   float* sy = reinterpret_cast<float*>(lds + kGiantCap);
@@ -771,36 +801,41 @@ static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1)
 __global__ __launch_bounds__(256) void cell_count_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ n_cent,
                                                          uint32_t ncell1, uint32_t* __restrict__ grid, uint32_t* __restrict__ rank,
                                                          const uint32_t* __restrict__ halt) {
-  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
   if (*halt) return;
-  // hole of the centroid index space (hash grouping: an old point that joined a group): key 0xFFFFFFFF
-  const uint32_t k = o < *n_cent ? keys2[o] : 0xFFFFFFFFu;
-  const bool kept = k != 0xFFFFFFFFu;
-  // one atomic per DISTINCT cell of the wavefront: with the old points in pool order (cell after cell) the lanes of a
-  // wavefront hit two or three counters, and 64 atomics on one word serialise
+  const uint32_t n_c = *n_cent;
   const int lane = threadIdx.x & 63;
-  uint32_t my_idx = 0, my_cnt = 0;
-  int lead = lane;
-  unsigned long long todo = __ballot(kept);
-  while (todo) {
-    const int L = __ffsll((long long)todo) - 1;
-    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)k, L);
-    const unsigned long long m = __ballot(kept && k == kk);
-    if (kept && k == kk) { my_idx = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); my_cnt = (uint32_t)__popcll(m); lead = L; }
-    todo &= ~m;
+  // (grid-stride, the trip count the same for every lane of a workgroup: the ballots below need whole wavefronts)
+  for (uint32_t first = blockIdx.x * blockDim.x; first < n_c; first += gridDim.x * blockDim.x) {
+    const uint32_t o = first + threadIdx.x;
+    // hole of the centroid index space (hash grouping: an old point that joined a group): key 0xFFFFFFFF
+    const uint32_t k = o < n_c ? keys2[o] : 0xFFFFFFFFu;
+    const bool kept = k != 0xFFFFFFFFu;
+    // one atomic per DISTINCT cell of the wavefront: with the old points in pool order (cell after cell) the lanes of a
+    // wavefront hit two or three counters, and 64 atomics on one word serialise
+    uint32_t my_idx = 0, my_cnt = 0;
+    int lead = lane;
+    unsigned long long todo = __ballot(kept);
+    while (todo) {
+      const int L = __ffsll((long long)todo) - 1;
+      const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)k, L);
+      const unsigned long long m = __ballot(kept && k == kk);
+      if (kept && k == kk) { my_idx = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); my_cnt = (uint32_t)__popcll(m); lead = L; }
+      todo &= ~m;
+    }
+    uint32_t base = 0;
+    if (kept && lead == lane) base = atomicAdd(&grid[(size_t)(k >> 18) * ncell1 + (k & 0x3FFFFu)], my_cnt);
+    base = (uint32_t)__shfl((int)base, lead, 64);
+    if (kept) rank[o] = base + my_idx;
   }
-  uint32_t base = 0;
-  if (kept && lead == lane) base = atomicAdd(&grid[(size_t)(k >> 18) * ncell1 + (k & 0x3FFFFu)], my_cnt);
-  base = (uint32_t)__shfl((int)base, lead, 64);
-  if (kept) rank[o] = base + my_idx;
 }
 // grid_scan = exclusive scan of grid over all touched cubes (one entry more than cells: the total); per cube: table entry =
 // slot*cap + (scan - scan at the cube's first cell); the entry behind the last cell = the cube's new point count.
 // The counters have done their work once they are scanned: this launch, one thread per cell, puts them back to zero, so
 // that the next insert finds the grids clean (a 12 MB fill per insert otherwise).
-__global__ __launch_bounds__(256) void cell_table_kernel(const uint32_t* __restrict__ grid_scan, MapTouched tt, uint32_t cap, uint32_t ncell1,
+__global__ __launch_bounds__(256) void cell_table_kernel(const uint32_t* __restrict__ grid_scan, const MapTouched* __restrict__ ttp, uint32_t cap, uint32_t ncell1,
                                                          uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts,
                                                          const uint32_t* __restrict__ halt, uint32_t* __restrict__ grid) {
+  const MapTouched& tt = *ttp;
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t t = blockIdx.y;
   if (c >= ncell1 || *halt) return;  // (halted before the counting: the grids are still clean)
@@ -812,17 +847,20 @@ __global__ __launch_bounds__(256) void cell_table_kernel(const uint32_t* __restr
 // pass 1: every centroid into its cell's range of a scratch array, at the atomic rank, leaf key in .w
 __global__ __launch_bounds__(256) void cell_place_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ rank,
                                                          const uint32_t* __restrict__ n_cent, const uint32_t* __restrict__ grid_scan,
-                                                         const float4* __restrict__ cent, MapTouched tt, uint32_t ncell1, float inv_leaf,
+                                                         const float4* __restrict__ cent, const MapTouched* __restrict__ ttp, uint32_t ncell1, float inv_leaf,
                                                          float4* __restrict__ tmp, uint32_t* __restrict__ tmpk,
                                                          const uint32_t* __restrict__ halt) {
-  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= *n_cent || *halt) return;
-  const uint32_t k = keys2[o], t = k >> 18;
-  if (k == 0xFFFFFFFFu) return;
-  const float4 v = cent[o];
-  const uint32_t at = grid_scan[(size_t)t * ncell1 + (k & 0x3FFFFu)] + rank[o];  // global position over all touched cubes
-  tmp[at] = v;
-  tmpk[at] = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t, tt.lbits);  // (the ranking pass reads 4 bytes per comparison)
+  const MapTouched& tt = *ttp;
+  if (*halt) return;
+  const uint32_t n_c = *n_cent;
+  for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n_c; o += gridDim.x * blockDim.x) {
+    const uint32_t k = keys2[o], t = k >> 18;
+    if (k == 0xFFFFFFFFu) continue;
+    const float4 v = cent[o];
+    const uint32_t at = grid_scan[(size_t)t * ncell1 + (k & 0x3FFFFu)] + rank[o];  // position over all touched cubes
+    tmp[at] = v;
+    tmpk[at] = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t, tt.lbits);  // (the ranking pass reads 4 bytes per comparison)
+  }
 }
 // pass 2: final position inside the cell = number of the cell's centroids with a smaller leaf key (one centroid per leaf:
 // the keys are distinct), i.e. ascending leaf order -- what the stable sort by (cell, leaf) produced
@@ -832,32 +870,307 @@ __global__ __launch_bounds__(256) void cell_place_kernel(const uint32_t* __restr
 __global__ __launch_bounds__(256) void cell_rank_kernel(const uint32_t* __restrict__ keys2, const uint32_t* __restrict__ n_cent,
                                                         const uint32_t* __restrict__ grid_scan,
                                                         const float4* __restrict__ cent, const float4* __restrict__ tmp,
-                                                        const uint32_t* __restrict__ tmpk, MapTouched tt,
+                                                        const uint32_t* __restrict__ tmpk, const MapTouched* __restrict__ ttp,
                                                         uint32_t cap, uint32_t ncell1, float inv_leaf, float4* __restrict__ pool,
                                                         const uint32_t* __restrict__ rank, const uint32_t* __restrict__ halt) {
-  const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= *n_cent || *halt) return;
-  const uint32_t k = keys2[o], t = k >> 18;
-  if (k == 0xFFFFFFFFu) return;
-  const size_t gi = (size_t)t * ncell1 + (k & 0x3FFFFu);
-  const uint32_t beg = grid_scan[gi], cnt = grid_scan[gi + 1] - beg;  // (the scan has one entry behind the last cell)
-  const float4 v = cent[o];
-  const uint32_t kv = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t, tt.lbits);
-  const uint32_t mine = rank[o];
-  uint32_t r = 0;
-  for (uint32_t j = 0; j < cnt; ++j) {
-    const uint32_t ku = tmpk[beg + j];
-    bool less = ku < kv;
-    if (ku == kv && j != mine) {
-      const float4 u = tmp[beg + j];
-      const uint32_t ux = __float_as_uint(u.x), uy = __float_as_uint(u.y), uz = __float_as_uint(u.z);
-      const uint32_t vx = __float_as_uint(v.x), vy = __float_as_uint(v.y), vz = __float_as_uint(v.z);
-      less = uz != vz ? uz < vz : (uy != vy ? uy < vy : (ux != vx ? ux < vx : j < mine));
+  const MapTouched& tt = *ttp;
+  if (*halt) return;
+  const uint32_t n_c = *n_cent;
+  for (uint32_t o = blockIdx.x * blockDim.x + threadIdx.x; o < n_c; o += gridDim.x * blockDim.x) {
+    const uint32_t k = keys2[o], t = k >> 18;
+    if (k == 0xFFFFFFFFu) continue;
+    const size_t gi = (size_t)t * ncell1 + (k & 0x3FFFFu);
+    const uint32_t beg = grid_scan[gi], cnt = grid_scan[gi + 1] - beg;  // (the scan has one entry behind the last cell)
+    const float4 v = cent[o];
+    const uint32_t kv = leaf_key(v.x, v.y, v.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], t, tt.lbits);
+    const uint32_t mine = rank[o];
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const uint32_t ku = tmpk[beg + j];
+      bool less = ku < kv;
+      if (ku == kv && j != mine) {
+        const float4 u = tmp[beg + j];
+        const uint32_t ux = __float_as_uint(u.x), uy = __float_as_uint(u.y), uz = __float_as_uint(u.z);
+        const uint32_t vx = __float_as_uint(v.x), vy = __float_as_uint(v.y), vz = __float_as_uint(v.z);
+        less = uz != vz ? uz < vz : (uy != vy ? uy < vy : (ux != vx ? ux < vx : j < mine));
+      }
+      r += less ? 1u : 0u;
     }
-    r += less ? 1u : 0u;
+    const uint32_t local = beg - grid_scan[(size_t)t * ncell1] + r;
+    if (local < cap) pool[(size_t)tt.slot[t] * cap + local] = v;
   }
-  const uint32_t local = beg - grid_scan[(size_t)t * ncell1] + r;
-  if (local < cap) pool[(size_t)tt.slot[t] * cap + local] = v;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The insert without a host round trip (DeviceMap::insert_fast).  What the host used to do between world_cube_kernel and
+// the first stage -- read the touched flags back, list the touched cubes, look up their slots and point counts, lay out
+// the round (MapTouched) -- is done by the LAST workgroup of the front kernel from tables the device keeps itself
+// (cube -> slot: the k-NN's table; points per slot: written by the scan of every round; "one point per leaf of the current
+// grid" per slot: written by the report of every round).  A round the device cannot lay out (a cube without a slot, more
+// cubes than a round holds, a cube that must go through the sort) raises *halt with an EMPTY round: every later kernel
+// of the insert is then a no-op, the map is unchanged, and the host -- told by the report -- repeats the insert round by round.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tt_store_kernel(MapTouched tt, MapTouched* __restrict__ out) {
+  if (threadIdx.x == 0) *out = tt;
+}
+
+struct FrontBuild {
+  const int32_t* cube_slot; const uint32_t* slot_count; const uint32_t* slot_ok;
+  uint32_t* cube_cnt; uint32_t* n_inside; uint32_t* ticket; uint32_t* halt; uint32_t* dirty; MapTouched* tt;
+  float inv_leaf; uint32_t lbits; int32_t per_round;
+  MapFastReport* rep; unsigned long long seq;
+};
+static_assert(kMapW == 21 && kMapH == 21 && kMapD == 11, "cube index arithmetic below");
+
+// transformAndAddToMap's transform (LidarSlam.cpp:60-80; TransformPoint, superodom_utils.h:119-123) + LocalMap.h:596-610 in
+// one pass over the scan: world point (TRANSFORM), cube of every point, new points per cube; then the round (see above)
+template <bool TRANSFORM>
+__global__ __launch_bounds__(1024) void insert_front_kernel(const float* __restrict__ in, uint32_t n, uint32_t stride_floats, Pose pose,
+                                                            float* __restrict__ world, int o0, int o1, int o2, int32_t* __restrict__ cube_of,
+                                                            FrontBuild b) {
+  constexpr int kCntPad = (kMapNum + 63) / 64 * 64;
+  __shared__ uint32_t cnt, s_n;
+  __shared__ bool last;
+  __shared__ int32_t s_cube[kMaxTouched];
+  __shared__ uint32_t s_new[kMaxTouched];
+  __shared__ uint32_t s_cnt[kCntPad];
+  // the workgroup's own tally of (cube, new points) first -- a sweep touches a handful of cubes, and 2 048 wavefronts adding
+  // to the same few words of memory took 60 us --, then one atomic per distinct cube and workgroup
+  constexpr int kTally = 8;
+  __shared__ int32_t s_tkey[kTally];
+  __shared__ uint32_t s_tval[kTally];
+  if (threadIdx.x == 0) cnt = 0;
+  if (threadIdx.x < kTally) { s_tkey[threadIdx.x] = -1; s_tval[threadIdx.x] = 0u; }
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int cube = -1;
+  if (i < n) {
+    float x, y, z;
+    if (TRANSFORM) {
+      double wx, wy, wz;
+      quat_rotate<double>(pose.q, (double)in[3 * (size_t)i], (double)in[3 * (size_t)i + 1], (double)in[3 * (size_t)i + 2], wx, wy, wz);
+      x = (float)(wx + pose.t[0]); y = (float)(wy + pose.t[1]); z = (float)(wz + pose.t[2]);
+      world[3 * (size_t)i] = x; world[3 * (size_t)i + 1] = y; world[3 * (size_t)i + 2] = z;
+    } else {
+      const float* p = in + (size_t)i * stride_floats;
+      x = p[0]; y = p[1]; z = p[2];
+    }
+    const int ci = cube_coord_f(x, o0), cj = cube_coord_f(y, o1), ck = cube_coord_f(z, o2);
+    if (ci >= 0 && ci < kMapW && cj >= 0 && cj < kMapH && ck >= 0 && ck < kMapD) cube = ci + kMapW * cj + kMapW * kMapH * ck;
+    cube_of[i] = cube;
+  }
+  // one counter atomic per DISTINCT cube of the wavefront (a sweep touches a handful of cubes)
+  unsigned long long todo = __ballot(cube >= 0);
+  const unsigned long long inside = todo;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int c = __builtin_amdgcn_readlane(cube, leader);
+    const unsigned long long m = __ballot(cube == c);
+    if (lane == leader) {
+      const uint32_t add = (uint32_t)__popcll(m);
+      bool done = false;
+      for (int k = 0; k < kTally && !done; ++k) {
+        const int32_t prev = atomicCAS(&s_tkey[k], -1, c);
+        if (prev == -1 || prev == c) { atomicAdd(&s_tval[k], add); done = true; }
+      }
+      if (!done) {  // (more than kTally cubes in one workgroup's 1 024 points)
+        const uint32_t before = __hip_atomic_fetch_add(&b.cube_cnt[c], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(before));
+      }
+    }
+    todo &= ~m;
+  }
+  if (lane == 0 && inside) atomicAdd(&cnt, (uint32_t)__popcll(inside));
+  __syncthreads();
+  if (threadIdx.x == 0 && cnt) atomicAdd(b.n_inside, cnt);
+  // The last workgroup to get here lays out the round.  All it takes from the others are the per-cube counters, which are
+  // only ever touched by device-scope atomics (read-modify-write here, atomic loads below): the adds return their old value,
+  // so they have been performed when their thread reaches the barrier, and the ticket is taken behind the barrier.  No
+  // fence: a release fence in every wavefront writes the L2 back 2 048 times (measured: 40 us); cube_of and the world points
+  // are read by later launches only.
+  if (threadIdx.x < kTally && s_tkey[threadIdx.x] >= 0) {
+    const uint32_t before = __hip_atomic_fetch_add(&b.cube_cnt[s_tkey[threadIdx.x]], s_tval[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(before));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(b.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+  __syncthreads();
+  if (!last) return;
+  // the touched cubes in ascending order: the counters into LDS by the whole workgroup, then one wavefront walks them
+  // (cube = 64 k + lane: ascending in (k, lane))
+  for (int c = (int)threadIdx.x; c < kCntPad; c += (int)blockDim.x)
+    s_cnt[c] = c < kMapNum ? __hip_atomic_load(&b.cube_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    uint32_t total = 0;
+    for (int k = 0; k < kCntPad / 64; ++k) {
+      const uint32_t v = s_cnt[k * 64 + lane];
+      const bool has = v != 0u;
+      const unsigned long long m = __ballot(has);
+      if (has) {
+        const uint32_t pos = total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < (uint32_t)kMaxTouched) { s_cube[pos] = k * 64 + lane; s_new[pos] = v; }
+      }
+      total += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) s_n = total;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint32_t n_t = s_n;
+    uint32_t h = n_t > (uint32_t)b.per_round ? (uint32_t)kFastHaltMultiRound : 0u;
+    const int t = lane;
+    const bool cand = h == 0u && (uint32_t)t < n_t;  // (n_t <= per_round <= kMaxTouched here)
+    const int cb = cand ? s_cube[t] : INT32_MAX;
+    uint32_t newc = cand ? s_new[t] : 0u, oldc = 0u, bad = 0u;
+    int slot = 0;
+    if (cand) {
+      slot = b.cube_slot[cb];
+      if (slot < 0) bad = kFastHaltUnallocated;
+      else {
+        oldc = b.slot_count[slot];
+        if (oldc != 0u && b.slot_ok[slot] == 0u) bad = kFastHaltNeedsSort;
+      }
+    }
+    const unsigned long long mu = __ballot(bad == (uint32_t)kFastHaltUnallocated), ms = __ballot(bad == (uint32_t)kFastHaltNeedsSort);
+    if (h == 0u) h = mu ? (uint32_t)kFastHaltUnallocated : (ms ? (uint32_t)kFastHaltNeedsSort : 0u);
+    const bool live = cand && h == 0u;
+    if (!live) { oldc = 0u; newc = 0u; slot = 0; }
+    uint32_t io = oldc, ir = oldc + newc;  // inclusive scans over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t a0 = (uint32_t)__shfl_up((int)io, d, 64), a1 = (uint32_t)__shfl_up((int)ir, d, 64);
+      if (lane >= d) { io += a0; ir += a1; }
+    }
+    const uint32_t n_old = (uint32_t)__shfl((int)io, 63, 64);
+    MapTouched& T = *b.tt;
+    if (t < kMaxTouched) {
+      T.cube[t] = live ? cb : INT32_MAX;
+      T.slot[t] = (uint32_t)slot;
+      T.old_prefix[t] = live ? io - oldc : n_old;
+      T.region_base[t] = live ? ir - (oldc + newc) : 0u;
+      int w[3] = {0, 0, 0};
+      if (live) { w[0] = cb % kMapW - o0; w[1] = (cb / kMapW) % kMapH - o1; w[2] = cb / (kMapW * kMapH) - o2; }
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {  // DeviceMap::add_surf_dev's arithmetic
+        const double cm = w[ax] * kCube - kHalfCube;
+        T.cube_min[t][ax] = live ? cm : 0.0;
+        T.leaf_lo[t][ax] = live ? (int)floorf((float)cm * b.inv_leaf) - 2 : 0;
+        T.wcube[t][ax] = w[ax];
+      }
+    }
+    if (t == kMaxTouched) T.old_prefix[kMaxTouched] = n_old;
+    if (t == 0) {
+      T.n = h ? 0 : (int32_t)n_t;
+      T.inv_leaf_watch = b.inv_leaf; T.dirty = b.dirty; T.lbits = b.lbits;
+      if (h) *b.halt = h;
+      // every workgroup has passed the ticket: the input points have been read (the caller may hand their buffer on)
+      __hip_atomic_store(&b.rep->front_seq, b.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// Second stage of a device-built round: exclusive scan of the touched cubes' cell grids, cube by cube (blockIdx.y), each
+// from its own base (MapTouched::region_base) -- so the cube's new cell_start table, its point count and the positions of
+// the scratch arrays all come out of the SAME launch (the host-built round needs a device-wide scan whose length the host
+// knows, and cell_table_kernel behind it).  Single pass with decoupled look-back: a workgroup takes a ticket (so that its
+// predecessors are running), publishes its aggregate, and one wavefront sums the 64 records before it at a time until it
+// meets an inclusive one.  Records: flag (1 = aggregate, 2 = inclusive) << 62 | value; all zero between inserts.
+__global__ __launch_bounds__(256) void cell_scan_table_kernel(uint32_t* __restrict__ grid, uint32_t* __restrict__ grid_scan,
+                                                              const MapTouched* __restrict__ ttp, uint32_t cap, uint32_t ncell1,
+                                                              uint32_t* __restrict__ cell_start, uint32_t* __restrict__ counts,
+                                                              uint32_t* __restrict__ slot_count, const uint32_t* __restrict__ halt,
+                                                              unsigned long long* __restrict__ state, uint32_t* __restrict__ tickets, uint32_t nblk) {
+  const uint32_t t = blockIdx.y;
+  if ((int)t >= ttp->n || *halt) return;
+  __shared__ uint32_t s_bid, s_wsum[4], s_excl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_bid = atomicAdd(&tickets[t], 1u);
+  __syncthreads();
+  const uint32_t bid = s_bid;
+  constexpr int kPer = (int)(kScanItems / 256u);
+  const uint32_t c0 = bid * kScanItems + (uint32_t)tid * kPer;
+  uint32_t* g = grid + (size_t)t * ncell1;
+  uint32_t v[kPer], tsum = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) { v[k] = c0 + k < ncell1 ? g[c0 + k] : 0u; tsum += v[k]; }
+  uint32_t inc = tsum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t a0 = (uint32_t)__shfl_up((int)inc, d, 64);
+    if (lane >= d) inc += a0;
+  }
+  if (lane == 63) s_wsum[wave] = inc;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
+  const uint32_t agg = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+  const uint32_t texcl = wbase + inc - tsum;
+  if (wave == 0) {
+    unsigned long long* st = state + (size_t)t * nblk;
+    if (lane == 0) __hip_atomic_store(&st[bid], ((bid == 0u ? 2ull : 1ull) << 62) | (unsigned long long)agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    int base = (int)bid - 1;
+    while (base >= 0) {
+      const int j = base - lane;
+      unsigned long long rec = 2ull << 62;  // before the first workgroup: "inclusive prefix 0"
+      if (j >= 0) {
+        do { rec = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((rec >> 62) == 0ull);
+      }
+      const unsigned long long mi = __ballot((rec >> 62) == 2ull);
+      const int first = mi ? __ffsll((long long)mi) - 1 : 64;  // the nearest predecessor with an inclusive prefix
+      uint32_t contrib = lane <= first ? (uint32_t)(rec & 0xFFFFFFFFull) : 0u;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) contrib += (uint32_t)__shfl_xor((int)contrib, d, 64);
+      excl += contrib;
+      if (mi) break;
+      base -= 64;
+    }
+    if (lane == 0) {
+      if (bid != 0u) __hip_atomic_store(&st[bid], (2ull << 62) | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_excl = excl;
+    }
+  }
+  __syncthreads();
+  const uint32_t slot = ttp->slot[t], rb = ttp->region_base[t];
+  uint32_t run = s_excl + texcl;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const uint32_t c = c0 + k;
+    if (c < ncell1) {
+      grid_scan[(size_t)t * ncell1 + c] = rb + run;
+      cell_start[(size_t)slot * ncell1 + c] = slot * cap + run;
+      g[c] = 0u;  // (the counters have done their work: the next insert finds the grids clean)
+      if (c == ncell1 - 1u) { counts[t] = run; slot_count[slot] = run; }
+      run += v[k];
+    }
+  }
+}
+
+// End of a device-built insert: what the host has to know goes to pinned memory, the per-slot "one point per leaf" marks
+// follow the drift watch, and every counter of the insert is put back to zero (no fill before the next one).
+__global__ __launch_bounds__(256) void insert_report_kernel(const MapTouched* __restrict__ ttp, uint32_t* __restrict__ small, uint32_t small_words,
+                                                            uint32_t* __restrict__ cube_cnt, unsigned long long* __restrict__ scan_state,
+                                                            uint32_t* __restrict__ tickets, uint32_t* __restrict__ slot_ok,
+                                                            MapFastReport* __restrict__ rep, unsigned long long seq) {
+  const int tid = threadIdx.x;
+  const uint32_t halt = small[5], n = (uint32_t)ttp->n, dirty = small[7];
+  if (tid < kMaxTouched) {
+    rep->cube[tid] = ttp->cube[tid];
+    rep->count[tid] = small[8 + tid];
+    if (!halt && (uint32_t)tid < n) slot_ok[ttp->slot[tid]] = ((dirty >> tid) & 1u) ? 0u : 1u;
+  }
+  if (tid == 0) { rep->halt = halt; rep->n = n; rep->n_inside = small[48]; rep->dirty = dirty; rep->n_old = ttp->old_prefix[kMaxTouched]; rep->pad = 0u; }
+  __syncthreads();  // (every thread has read the counters)
+  for (uint32_t i = (uint32_t)tid; i < small_words; i += 256u) small[i] = 0u;
+  for (uint32_t i = (uint32_t)tid; i < (uint32_t)kMapNum; i += 256u) cube_cnt[i] = 0u;
+  for (uint32_t i = (uint32_t)tid; i < (uint32_t)kScanStateWords; i += 256u) scan_state[i] = 0ull;
+  if (tid <= kMaxTouched) tickets[tid] = 0u;
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&rep->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -985,53 +1298,61 @@ void launch_transform_scan(const float* d_scan, uint32_t n, const Pose& pose, fl
   if (!n) return;
   hipLaunchKernelGGL(transform_scan_kernel, grid_for(n, 256), dim3(256), 0, s, d_scan, n, pose, d_out);
 }
+// first stage by hash grouping: mslot = keys1, mrank = vals1, member list = pos, group ranges = heads / flags, cell keys =
+// vals0; lists of the larger groups in spts (first-stage scratch of the sort path, the second stage's scratch later): at
+// most n_new / 16 groups of more than 16 members, n_new / 64 of more than 64; counters in d_n_cent[2..6]
+// (a.n_old: the number of old points, or -- device-built round -- a bound on it: the kernels take the number from d_tt)
+static uint32_t* launch_first_stage_hashed(const MapInsertArgs& a, hipStream_t s) {
+  const LeafTable ht{a.ht_key, a.ht_cnt, a.ht_off, a.ht_log2};
+  unsigned long long* cursor = reinterpret_cast<unsigned long long*>(a.d_n_cent + 2);
+  uint32_t* keys2 = a.vals0;
+  uint32_t* medium_list = reinterpret_cast<uint32_t*>(a.spts);
+  uint32_t* giant_list = medium_list + a.n_new / 16u + 2u;
+  const uint32_t n_old_grid = a.n_old_grid ? a.n_old_grid : a.n_old, total = n_old_grid + a.n_new;  // (launch sizes)
+  if (a.n_new)
+    hipLaunchKernelGGL(leafhash_insert_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of,
+                       a.d_tt, a.inv_leaf, a.nc, a.inv_cell, a.rank, a.world, a.wpts, a.keys0, ht, a.keys1, a.vals1);
+  if (a.n_old)
+    hipLaunchKernelGGL(leafhash_match_old_kernel, grid_for(n_old_grid, 256), dim3(256), 0, s, a.pool, a.cap, a.inv_leaf, a.keys0, a.wpts, ht,
+                       a.keys1, a.vals1, a.d_tt, a.nc, a.inv_cell, a.cent, keys2);
+  hipLaunchKernelGGL(leafhash_offsets_kernel, dim3((1u << a.ht_log2) / 4096u), dim3(1024), 0, s, ht, a.heads, a.flags, cursor, medium_list, a.d_n_cent + 6,
+                     giant_list, a.d_n_cent + 4);
+  hipLaunchKernelGGL(leafhash_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.n_new, a.d_tt, a.ht_off, a.pos);
+  const uint32_t max_medium = a.n_new / 16u + 1u, max_giant = a.n_new / 64u + 1u;
+  const uint32_t small_blocks = (a.n_new ? a.n_new + 255u : 256u) / 256u, medium_blocks = max_medium < 2048u ? (max_medium + 3u) / 4u : 512u;
+  hipLaunchKernelGGL(leafhash_centroid_kernel, dim3(small_blocks + medium_blocks), dim3(256), 0, s, a.heads, a.flags, cursor, a.pos, a.wpts, a.keys0,
+                     a.d_tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, small_blocks);
+  // (per launch, not once per process: the attribute belongs to the current device, and one process may drive several)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leafhash_giant_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGiantLds);
+  hipLaunchKernelGGL(leafhash_giant_kernel, dim3(max_giant < 1024u ? max_giant : 1024u), dim3(kGiantThreads), kGiantLds, s, a.heads, a.flags, a.pos, a.wpts, a.keys0,
+                     a.n_new, a.d_tt, a.nc, a.inv_cell, a.cent, keys2, giant_list, a.d_n_cent + 4, a.d_n_cent + 5);
+  return keys2;
+}
+
 void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
   const uint32_t total = a.n_old + a.n_new;
   if (!total) return;
+  hipLaunchKernelGGL(tt_store_kernel, dim3(1), dim3(64), 0, s, a.tt, a.d_tt);
   size_t tb = a.temp_bytes;
   const bool hashed = a.ht_key != nullptr && a.grid != nullptr;
   if (!hashed) {  // (the hash grouping's first two kernels build the working set themselves)
     if (a.n_old && a.reorder_old) {
       OldGrids og;
       for (int t = 0; t < kMaxTouched; ++t) og.inv_leaf[t] = a.old_inv_leaf[t];
-      hipLaunchKernelGGL(old_order_key_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.tt, og, a.pool, a.cap, a.n_old, a.keys0, a.vals0);
+      hipLaunchKernelGGL(old_order_key_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.d_tt, og, a.pool, a.cap, a.n_old, a.keys0, a.vals0);
       (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)a.n_old, 30, s);  // stable
       tb = a.temp_bytes;
-      hipLaunchKernelGGL(gather_old_ordered_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, a.inv_leaf, a.n_old, a.vals1, a.wpts,
+      hipLaunchKernelGGL(gather_old_ordered_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.d_tt, a.pool, a.cap, a.inv_leaf, a.n_old, a.vals1, a.wpts,
                          a.keys0, a.vals0);
     } else if (a.n_old)
-      hipLaunchKernelGGL(gather_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0);
+      hipLaunchKernelGGL(gather_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.d_tt, a.pool, a.cap, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0);
     if (a.n_new)
       hipLaunchKernelGGL(append_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of,
-                         a.tt, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0, a.nc, a.inv_cell, a.rank, a.world);
+                         a.d_tt, a.inv_leaf, a.n_old, a.wpts, a.keys0, a.vals0, a.nc, a.inv_cell, a.rank, a.world);
   }
   uint32_t* keys2 = a.keys0;  // cell key per centroid, input of the second stage
   if (hashed) {
-    // first stage without a sort (see leafhash_insert_new_kernel): mslot = keys1, mrank = vals1, member list = pos, group ranges =
-    // heads / flags, giant list = keys1 again (free once the members are placed), cell keys = vals0; counters in d_n_cent[2..5]
-    const LeafTable ht{a.ht_key, a.ht_cnt, a.ht_off, a.ht_log2};
-    unsigned long long* cursor = reinterpret_cast<unsigned long long*>(a.d_n_cent + 2);
-    keys2 = a.vals0;
-    if (a.n_new)
-      hipLaunchKernelGGL(leafhash_insert_new_kernel, grid_for(a.n_new, 256), dim3(256), 0, s, a.d_xyz, a.n_new, a.stride_floats, a.d_cube_of,
-                         a.tt, a.inv_leaf, a.nc, a.inv_cell, a.rank, a.world, a.wpts, a.keys0, a.n_old, ht, a.keys1, a.vals1);
-    if (a.n_old)
-      hipLaunchKernelGGL(leafhash_match_old_kernel, grid_for(a.n_old, 256), dim3(256), 0, s, a.pool, a.cap, a.inv_leaf, a.keys0, a.n_old, a.wpts, ht,
-                         a.keys1, a.vals1, a.tt, a.nc, a.inv_cell, a.cent, keys2);
-    hipLaunchKernelGGL(leafhash_offsets_kernel, dim3((1u << a.ht_log2) / 4096u), dim3(1024), 0, s, ht, a.heads, a.flags, cursor);
-    hipLaunchKernelGGL(leafhash_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, total, a.ht_off, a.pos);
-    // lists of the larger groups in keys1 (free once the members are placed): at most n_new / 17 medium, n_new / 65 giant ones
-    uint32_t* medium_list = a.keys1;
-    uint32_t* giant_list = a.keys1 + a.n_new / 2 + 1;
-    const uint32_t max_medium = a.n_new / 17u + 1u, max_giant = a.n_new / 65u + 1u;
-    hipLaunchKernelGGL(leafhash_centroid_kernel, grid_for(a.n_new ? a.n_new : 1u, 256), dim3(256), 0, s, a.heads, a.flags, cursor, a.pos, a.wpts, a.keys0,
-                       a.n_old, a.tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, giant_list, a.d_n_cent + 4);
-    hipLaunchKernelGGL(leafhash_medium_kernel, dim3(max_medium < 2048u ? (max_medium + 3u) / 4u : 512u), dim3(256), 0, s, a.heads, a.flags, a.pos, a.wpts, a.keys0, a.n_old, a.tt,
-                       a.nc, a.inv_cell, a.cent, keys2, medium_list, a.d_n_cent + 6);
-    // (per launch, not once per process: the attribute belongs to the current device, and one process may drive several)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leafhash_giant_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGiantLds);
-    hipLaunchKernelGGL(leafhash_giant_kernel, dim3(max_giant < 1024u ? max_giant : 1024u), dim3(kGiantThreads), kGiantLds, s, a.heads, a.flags, a.pos, a.wpts, a.keys0,
-                       a.n_old, a.n_new, a.tt, a.nc, a.inv_cell, a.cent, keys2, giant_list, a.d_n_cent + 4, a.d_n_cent + 5);
+    keys2 = launch_first_stage_hashed(a, s);  // first stage without a sort (see leafhash_insert_new_kernel)
   } else {
     (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable
     hipLaunchKernelGGL(leaf_flags_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, total, a.flags);
@@ -1040,9 +1361,9 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(leaf_heads_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.flags, a.pos, total, a.wpts, a.spts, a.heads,
                        a.d_n_cent);
     // d_n_cent + 1 = number of long leaves (cleared with d_small_), list = the flags array (free after the scan)
-    hipLaunchKernelGGL(leaf_centroid_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.heads, a.d_n_cent, a.spts, a.tt, a.nc, a.inv_cell,
+    hipLaunchKernelGGL(leaf_centroid_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.heads, a.d_n_cent, a.spts, a.d_tt, a.nc, a.inv_cell,
                        a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
-    hipLaunchKernelGGL(leaf_centroid_long_kernel, dim3(kMaxLongLeaves / 4), dim3(256), 0, s, a.keys1, a.heads, a.spts, a.tt, a.nc, a.inv_cell,
+    hipLaunchKernelGGL(leaf_centroid_long_kernel, dim3(kMaxLongLeaves / 4), dim3(256), 0, s, a.keys1, a.heads, a.spts, a.d_tt, a.nc, a.inv_cell,
                        a.cent, a.keys0, a.vals0, a.flags, a.d_n_cent + 1);
   }
   {  // second stage by counting into the cell grids (no sort)
@@ -1052,25 +1373,53 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.ncell1, a.grid, a.vals1, halt);
     tb = a.temp_bytes;
     (void)rocprim::exclusive_scan(a.temp, tb, a.grid, a.grid_scan, 0u, gn + 1, rocprim::plus<uint32_t>(), s);
-    hipLaunchKernelGGL(cell_table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.grid_scan, a.tt, a.cap, a.ncell1, a.cell_start,
+    hipLaunchKernelGGL(cell_table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.grid_scan, a.d_tt, a.cap, a.ncell1, a.cell_start,
                        a.d_counts, halt, a.grid);
-    hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.tt, a.ncell1,
+    hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.d_tt, a.ncell1,
                        a.inv_leaf, a.spts, a.flags, halt);  // spts / flags (first-stage scratch) are free after the centroids
-    hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.grid_scan, a.cent, a.spts, a.flags, a.tt,
+    hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.grid_scan, a.cent, a.spts, a.flags, a.d_tt,
                        a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1, halt);
     if (a.world > 1 && a.d_owned)
-      hipLaunchKernelGGL(count_owned_kernel, dim3((total + 255) / 256, a.tt.n), dim3(256), 0, s, a.pool, a.cap, a.tt, a.d_counts, a.nc, a.inv_cell,
+      hipLaunchKernelGGL(count_owned_kernel, dim3((total + 255) / 256, a.tt.n), dim3(256), 0, s, a.pool, a.cap, a.d_tt, a.d_counts, a.nc, a.inv_cell,
                          a.rank, a.world, a.d_owned);
     return;
   }
+}
+
+// The insert as one uninterrupted sequence of launches (DeviceMap::insert_fast): a.n_old is a BOUND on the round's old points
+// (the launches are sized by it), a.tt only carries lbits; everything else of the round is laid out by the front kernel.
+void launch_map_insert_fast(const MapInsertArgs& a, const MapFastArgs& f, hipStream_t s) {
+  if (!f.n) return;
+  const FrontBuild b{f.d_cube_slot, f.d_slot_count, f.d_slot_ok, f.d_cube_cnt, f.d_small + 48, f.d_tickets + kMaxTouched, f.d_small + 5, f.d_small + 7,
+                     a.d_tt, a.inv_leaf, a.tt.lbits, f.per_round, f.h_report, f.seq};
+  if (f.transform)
+    hipLaunchKernelGGL(insert_front_kernel<true>, grid_for(f.n, 1024), dim3(1024), 0, s, f.d_in, f.n, 3u, f.pose, f.d_world, f.origin[0], f.origin[1],
+                       f.origin[2], const_cast<int32_t*>(a.d_cube_of), b);
+  else
+    hipLaunchKernelGGL(insert_front_kernel<false>, grid_for(f.n, 1024), dim3(1024), 0, s, f.d_in, f.n, f.stride_floats, f.pose, (float*)nullptr, f.origin[0],
+                       f.origin[1], f.origin[2], const_cast<int32_t*>(a.d_cube_of), b);
+  uint32_t* keys2 = launch_first_stage_hashed(a, s);
+  const uint32_t total = (a.n_old_grid ? a.n_old_grid : a.n_old) + a.n_new;
+  const uint32_t* halt = a.d_n_cent + 5;
+  const uint32_t nblk = (a.ncell1 + kScanItems - 1u) / kScanItems;
+  hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.ncell1, a.grid, a.vals1, halt);
+  hipLaunchKernelGGL(cell_scan_table_kernel, dim3(nblk, (uint32_t)f.per_round), dim3(256), 0, s, a.grid, a.grid_scan, a.d_tt, a.cap, a.ncell1, a.cell_start,
+                     a.d_counts, f.d_slot_count, halt, f.d_scan_state, f.d_tickets, nblk);
+  hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.d_tt, a.ncell1,
+                     a.inv_leaf, a.spts, a.flags, halt);
+  hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.grid_scan, a.cent, a.spts, a.flags, a.d_tt,
+                     a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1, halt);
+  hipLaunchKernelGGL(insert_report_kernel, dim3(1), dim3(256), 0, s, a.d_tt, f.d_small, f.small_words, f.d_cube_cnt, f.d_scan_state, f.d_tickets, f.d_slot_ok,
+                     f.h_report, f.seq);
 }
 // Resolution change (localMap.planeRes_ is pushed every frame, laserMapping.cpp:648-649): the points of a cube stay as they
 // are -- the reference re-filters a block only when the next insert touches it (LocalMap.h:617-641) -- only the cell
 // grid of the index follows the new planeRes.  The resident points take the place of the "centroids" of an insert's
 // second stage: counted into the new cell grids, scanned into the new tables, placed in ascending (old) leaf order.
-__global__ __launch_bounds__(256) void retable_gather_kernel(MapTouched tt, const float4* __restrict__ pool, uint32_t cap, uint32_t n_old, int nc,
+__global__ __launch_bounds__(256) void retable_gather_kernel(const MapTouched* __restrict__ ttp, const float4* __restrict__ pool, uint32_t cap, uint32_t n_old, int nc,
                                                              double inv_cell, float4* __restrict__ cent, uint32_t* __restrict__ keys2,
                                                              uint32_t* __restrict__ n_cent) {
+  const MapTouched& tt = *ttp;
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e == 0) *n_cent = n_old;
   if (e >= n_old) return;
@@ -1092,18 +1441,19 @@ __global__ __launch_bounds__(256) void retable_gather_kernel(MapTouched tt, cons
 void launch_map_retable(const MapInsertArgs& a, hipStream_t s) {
   const uint32_t total = a.n_old;
   if (!total) return;
-  hipLaunchKernelGGL(retable_gather_kernel, grid_for(total, 256), dim3(256), 0, s, a.tt, a.pool, a.cap, total, a.nc, a.inv_cell, a.cent, a.keys0,
+  hipLaunchKernelGGL(tt_store_kernel, dim3(1), dim3(64), 0, s, a.tt, a.d_tt);
+  hipLaunchKernelGGL(retable_gather_kernel, grid_for(total, 256), dim3(256), 0, s, a.d_tt, a.pool, a.cap, total, a.nc, a.inv_cell, a.cent, a.keys0,
                      a.d_n_cent);
   const size_t gn = (size_t)a.tt.n * a.ncell1;
   if (!a.grid_is_clean) (void)hipMemsetAsync(a.grid, 0, (gn + 1) * sizeof(uint32_t), s);
   hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.ncell1, a.grid, a.vals1, a.d_n_cent + 5);
   size_t tb = a.temp_bytes;
   (void)rocprim::exclusive_scan(a.temp, tb, a.grid, a.grid_scan, 0u, gn + 1, rocprim::plus<uint32_t>(), s);
-  hipLaunchKernelGGL(cell_table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.grid_scan, a.tt, a.cap, a.ncell1, a.cell_start,
+  hipLaunchKernelGGL(cell_table_kernel, dim3((a.ncell1 + 255) / 256, a.tt.n), dim3(256), 0, s, a.grid_scan, a.d_tt, a.cap, a.ncell1, a.cell_start,
                      a.d_counts, a.d_n_cent + 5, a.grid);
-  hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.tt, a.ncell1,
+  hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.d_tt, a.ncell1,
                      a.inv_leaf, a.spts, a.flags, a.d_n_cent + 5);
-  hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid_scan, a.cent, a.spts, a.flags, a.tt,
+  hipLaunchKernelGGL(cell_rank_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys0, a.d_n_cent, a.grid_scan, a.cent, a.spts, a.flags, a.d_tt,
                      a.cap, a.ncell1, a.inv_leaf, a.pool, a.vals1, a.d_n_cent + 5);
 }
 // The reference's own accumulation of the auto-voxel statistic (laserMapping.cpp:604-611): Eigen::Vector3f average, one float

@@ -312,3 +312,72 @@ def test_trajectory_that_gains_and_loses_cubes_matches_the_oracle(oracle, gpu_sl
         slam.close()
     for step, (a, b) in enumerate(zip(*exports)):
         assert np.array_equal(a, b), f"insert {step}: the two first stages left different maps (or orders)"
+
+
+def test_device_built_inserts_equal_host_built_ones(oracle, gpu_slam_factory, monkeypatch):
+    """An insert is laid out by its first kernel on the device (touched cubes, slots, counts from tables the device keeps;
+    no read-back: map_kernels.hip insert_front_kernel) whenever it can be -- and handed back to the host's round-by-round
+    path when it cannot: a cube without a slot (the trajectory gains cubes), a cube last filtered on another grid (the
+    resolution change), a leaf too large for the grouping kernels (the 9 000-point leaf), a window roll in between.  Same
+    trajectory with SOICP_MAP_FAST=0 (every round laid out by the host): after every insert the same points in the same
+    canonical order, bit for bit; and both equal the oracle's LocalMap."""
+    rng = np.random.default_rng(33)
+    centres = [(0, 0), (3, 2), (20, 5), (22, 4), (48, 10), (52, 10), (52, 11), (80, 30), (80, 30), (20, 5), (300, -200), (300, -190), (301, -191), (0, 0), (1, 1)]
+    clouds = [np.concatenate([noisy_planes_cloud(9000, rng, offset=(cx + dx, cy + dy, 0)) for dx, dy in ((-12, -12), (14, 9))]) for cx, cy in centres]
+    big = (np.array([2.05, 1.05, 0.45]) + rng.uniform(-0.04, 0.04, (9000, 3))).astype(np.float32)     # one leaf, beyond the workgroup kernel
+    mid = (np.array([4.05, -3.05, 0.45]) + rng.uniform(-0.04, 0.04, (700, 3))).astype(np.float32)      # one leaf for the workgroup kernel
+    clouds[1] = np.concatenate([clouds[1], mid])[rng.permutation(len(clouds[1]) + len(mid))]
+    clouds[14] = np.concatenate([clouds[14], big])[rng.permutation(len(clouds[14]) + len(big))]
+    exports, stats = [], []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("SOICP_MAP_FAST", fast)
+        slam = gpu_slam_factory(plane_res=0.2)
+        om = oracle.OracleMap(plane_res=0.2)
+        out = []
+        for step, pts in enumerate(clouds):
+            if step == 10:
+                t = np.array([300.0, -200.0, 0.0])
+                assert list(slam.shift_map(t)) == list(om.shift(t))
+            if step == 8:
+                slam.set_resolution(0.15, 0.3); om.set_resolution(0.15, 0.3)
+            assert slam.add_surf_point_cloud(pts) == om.add_surf(pts), (fast, step)
+            e = slam.export_map()
+            assert slam.map_size() == om.size() == len(e), (fast, step)
+            assert _same_points(e, om.export()), (fast, step)
+            out.append(e)
+        exports.append(out)
+        stats.append(slam.map_insert_stats())
+        slam.close()
+    for step, (a, b) in enumerate(zip(*exports)):
+        assert np.array_equal(a, b), f"insert {step}: device-built and host-built rounds left different maps (or orders)"
+    assert stats[1] == (0, 0)
+    built, handed_back = stats[0]
+    assert built >= 3, stats        # the repeated centres: every cube has its slot, one grid, no giant leaf
+    assert handed_back >= 3, stats  # new cubes, the resolution change, the giant leaf
+    print("device-built inserts / handed back:", stats[0])
+
+
+def test_localization_with_deferred_insert_equals_the_synchronous_one(gpu_slam_factory, monkeypatch):
+    """Localization() returns once the insert's launches are enqueued (the bookkeeping is settled by whatever touches the
+    map next); SOICP_MAP_DEFER=0 waits for the insert's report, SOICP_MAP_FAST=0 lays every round out on the host.  The
+    three give the same poses, the same map sizes after every frame and the same final map, bit for bit."""
+    sc = synth.Scene("tiny")
+    runs = []
+    for fast, defer in (("1", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("SOICP_MAP_FAST", fast)
+        monkeypatch.setenv("SOICP_MAP_DEFER", defer)
+        slam = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=3)
+        slam.add_surf_point_cloud(sc.map_points)
+        slam.shift_map(sc.gt_pose(0)[:3])
+        poses, sizes = [], []
+        for i in range(1, 9):
+            rc, pose, st = slam.localization(True, sc.guess(i), sc.scan(i), 0.1 * i)
+            assert rc == 0
+            poses.append(np.array(pose))
+            if i % 3 == 0:
+                sizes.append(slam.map_size())  # (settles the deferred insert; the other frames leave it to the next call)
+        runs.append((np.array(poses), sizes, slam.export_map(), slam.map_insert_stats()))
+        slam.close()
+    for r in runs[1:]:
+        assert np.array_equal(runs[0][0], r[0]) and runs[0][1] == r[1] and np.array_equal(runs[0][2], r[2])
+    assert runs[0][3][0] >= 3 and runs[0][3] == runs[1][3] and runs[2][3] == (0, 0), [r[3] for r in runs]
