@@ -347,7 +347,7 @@ int DeviceMap::ensure_fast(std::string& err) {
   if (d_slot_count_) return 0;
   DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_slot_count_), 2 * kMaxSlots * sizeof(uint32_t)));
   d_slot_ok_ = d_slot_count_ + kMaxSlots;
-  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cube_cnt_), (kMapNum + kMaxTouched + 1) * sizeof(uint32_t)));
+  DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cube_cnt_), (kMapNum + kFastTicketWords) * sizeof(uint32_t)));
   d_tickets_ = d_cube_cnt_ + kMapNum;
   DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_scan_state_), kScanStateWords * sizeof(unsigned long long)));
   DM_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_report_), sizeof(MapFastReport)));
@@ -395,7 +395,7 @@ int DeviceMap::insert_fast(const float* d_in, size_t n, size_t stride_floats, co
   if (ensure_leaf_table(n, err)) return -2;
   if (!block_clean_) { DM_TRY(hipMemsetAsync(d_small_, 0, kSmallWords * sizeof(uint32_t) + kMapNum, stream_)); block_clean_ = true; }
   if (!fast_clean_) {
-    DM_TRY(hipMemsetAsync(d_cube_cnt_, 0, (kMapNum + kMaxTouched + 1) * sizeof(uint32_t), stream_));
+    DM_TRY(hipMemsetAsync(d_cube_cnt_, 0, (kMapNum + kFastTicketWords) * sizeof(uint32_t), stream_));
     DM_TRY(hipMemsetAsync(d_scan_state_, 0, kScanStateWords * sizeof(unsigned long long), stream_));
     fast_clean_ = true;
   }
@@ -491,6 +491,7 @@ int DeviceMap::settle(std::string& err) {
   // counter is back at zero -- the insert is repeated round by round
   ++fast_fallbacks_;
   if (R.halt == kFastHaltMultiRound) skip_fast_ = 16;
+  if (R.halt == kFastHaltOverflow) grid_zero_upto_ = 0;  // (the centroids of the round were counted into the grids as they were produced)
   return add_surf_legacy(pending_.d_xyz, pending_.n, pending_.stride, err);
 }
 

@@ -225,6 +225,9 @@ struct so_icp_ctx {
   int n_cus = 256;            // compute units of the device: upper bound of the persistent solve launch's workgroups
   int ablate = 0;             // SOICP_ABLATE (profiling / test switches), read at creation
   bool speculate = true;      // enqueue outer iteration i+1 before the report of i is in (SOICP_SPECULATE=0: wait first)
+  bool outer_events = true;   // an event behind the launch that reports an outer iteration is the watchdog of the host's wait for that report.
+                              // SOICP_OUTER_EVENTS=0: hipStreamQuery instead, no marker packet between the speculated k-NN sweep and the solve
+                              // behind it (round 4, A/B on one box: 5 811 / 5 784 with the events, 5 866 / 5 793 without -- noise; kept as it was)
   bool batch_mode = false;    // no kernel timing, tracker state read-only
   bool batch_single = false;  // batch on ONE lane: nothing runs next to it, the persistent solve launch is safe
   bool no_map_shift = false;  // so_icp_register_batch: hypotheses after the first keep the window of the first
@@ -745,7 +748,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     // the whole state block (pose, per-iteration statistics, final normal equations) into this iteration's pinned mirror
     if (!direct_rb) HIP_TRY(c, hipMemcpyAsync(c->h_ring[it & 1], ds, sizeof(DevState), hipMemcpyDeviceToHost, s));
     // (a deferred report is complete only after the NEXT k-NN launch: the event is recorded behind that one, see the loop)
-    if (!deferred) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));
+    // (the pinned mirrors are polled; the event is the watchdog of that wait only where the stream itself cannot serve as one)
+    if (!deferred && (!direct_rb || c->outer_events)) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));
     HIP_TRY(c, hipGetLastError());
     return SO_ICP_OK;
   };
@@ -756,7 +760,10 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     const unsigned long long want = seq_base | (unsigned long long)(it + 1);
     for (unsigned spin = 1;; ++spin) {
       if (*seq == want) break;
-      if ((spin & 0x3FFu) == 0 && hipEventQuery(c->ev_outer[it & 1]) == hipSuccess) {
+      // watchdog: everything enqueued so far -- the launch that reports this iteration included -- has completed
+      // (hipStreamQuery: no marker packet in the queue; SOICP_OUTER_EVENTS=1: the event recorded behind that launch)
+      if ((spin & 0x3FFu) == 0 && (c->outer_events ? hipEventQuery(c->ev_outer[it & 1]) : hipStreamQuery(s)) != hipErrorNotReady) {
+        (void)hipGetLastError();  // (hipErrorNotReady of the earlier polls, or the error the synchronize below reports)
         // the iteration's launches have all completed: either it was a no-op (converged earlier: cannot happen for the
         // iteration the host waits on) or a kernel failed -- report instead of spinning forever
         if (*seq == want) break;
@@ -795,7 +802,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   if ((rc = enqueue_outer_a(0)) || (rc = enqueue_outer_b(0))) return rc;
   for (int it = 0;; ++it) {
     if (c->speculate && it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
-    if (defer_reports && it + 1 < max_outer) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));  // behind the launch that reports it
+    if (defer_reports && it + 1 < max_outer && c->outer_events) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));  // behind the launch that reports it
     // this registration's launches are in the queue and the host is about to idle: the moment for the NEXT scan's DMA
     if (!c->batch_mode && ((it == 0 && c->stage_issue_at == 1) || (it == 1 && c->stage_issue_at == 2))) stage_issue_deferred(c);
     if ((rc = await_outer(it))) return rc;
@@ -1407,6 +1414,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
     return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if (const char* ev = std::getenv("SOICP_READBACK")) c->direct_readback = std::string(ev) != "copy";
   if (const char* ev = std::getenv("SOICP_SPECULATE")) c->speculate = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_OUTER_EVENTS")) c->outer_events = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_ABLATE")) c->ablate = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;

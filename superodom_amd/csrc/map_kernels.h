@@ -51,6 +51,7 @@ struct MapFastReport {
   unsigned long long front_seq;  // written by the front kernel's last workgroup: nobody reads the input points any more
   unsigned long long seq;        // written last (system scope): the insert is complete
 };
+constexpr uint32_t kFastTicketWords = kMaxTouched + 2 + 64;
 constexpr uint32_t kScanItems = 2048;                     // cell counters per workgroup of cell_scan_table_kernel
 constexpr uint32_t kScanBlocksMax = (64u * 64u * 64u + 1u + kScanItems - 1u) / kScanItems;  // 129
 constexpr size_t kScanStateWords = (size_t)kMaxTouched * kScanBlocksMax;  // 64-bit look-back records
@@ -62,7 +63,8 @@ struct MapFastArgs {
   uint32_t* d_slot_count; uint32_t* d_slot_ok;   // per slot: resident points / "one point per leaf of the current grid"
   uint32_t* d_cube_cnt;                          // [kMapNum] new points per cube (zero between inserts)
   unsigned long long* d_scan_state;              // [kScanStateWords] (zero between inserts)
-  uint32_t* d_tickets;                           // [kMaxTouched + 1] (zero between inserts): [kMaxTouched] = the front kernel's
+  uint32_t* d_tickets;                           // [kFastTicketWords]: [0, kMaxTouched) the scan's, [kMaxTouched] the front kernel's, [kMaxTouched + 1] its
+                                                 // count of touched cubes (all zero between inserts), then its list of them (64 entries)
   uint32_t* d_small;                             // DeviceMap's counter block (zero between inserts)
   MapFastReport* h_report; unsigned long long seq;
   int32_t per_round;

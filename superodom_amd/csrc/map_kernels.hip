@@ -274,9 +274,12 @@ __global__ __launch_bounds__(256) void leaf_flags_kernel(const uint32_t* __restr
 constexpr uint32_t kLongLeaf = 64, kMaxLongLeaves = 4096;
 
 // centroid = float sum / float count, then its cell key for the second sort
-__device__ __forceinline__ void emit_centroid(uint32_t o, uint32_t key, float s0, float s1, float s2, uint32_t count, const MapTouched& tt,
-                                              int nc, double inv_cell, float4* __restrict__ cent, uint32_t* __restrict__ keys2,
-                                              uint32_t* __restrict__ vals2) {
+// (cc.grid != nullptr: the centroid is also counted into its cell of the dense grids right away -- the second stage's
+//  cell_count_kernel folded into the kernels that produce the centroids; its rank inside the cell goes to cc.rank[o])
+struct CellCount { uint32_t* grid; uint32_t* rank; uint32_t ncell1; };
+__device__ __forceinline__ uint32_t emit_centroid(uint32_t o, uint32_t key, float s0, float s1, float s2, uint32_t count, const MapTouched& tt,
+                                                  int nc, double inv_cell, float4* __restrict__ cent, uint32_t* __restrict__ keys2,
+                                                  uint32_t* __restrict__ vals2, const CellCount cc = CellCount{nullptr, nullptr, 0u}) {
   const float cnt = (float)count;
   const float cx = s0 / cnt, cy = s1 / cnt, cz = s2 / cnt;
   cent[o] = make_float4(cx, cy, cz, 0.f);
@@ -288,11 +291,15 @@ __device__ __forceinline__ void emit_centroid(uint32_t o, uint32_t key, float s0
     const int v = (int)floor(((double)c3[a] - tt.cube_min[t][a]) * inv_cell);
     g[a] = v < 0 ? 0 : (v >= nc ? nc - 1 : v);
   }
-  keys2[o] = ((uint32_t)t << 18) | (uint32_t)((g[2] * nc + g[1]) * nc + g[0]);  // linear cell index, as in the cube's table
+  const uint32_t cell = (uint32_t)((g[2] * nc + g[1]) * nc + g[0]);
+  const uint32_t k2 = ((uint32_t)t << 18) | cell;  // linear cell index, as in the cube's table
+  keys2[o] = k2;
   if (vals2) vals2[o] = o;  // (only the sort-based second stage reads it)
+  if (cc.grid) cc.rank[o] = atomicAdd(&cc.grid[(size_t)t * cc.ncell1 + cell], 1u);
   // (a lone point is its own centroid and lies in its leaf by construction; see MapTouched::dirty)
   if (count > 1u && tt.dirty && leaf_key(cx, cy, cz, tt.inv_leaf_watch, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits) != key)
     atomicOr(tt.dirty, 1u << t);
+  return k2;
 }
 
 // leaf-sorted working set made contiguous (spts[i] = wpts[vals[i]]) + first index of every leaf (heads[ordinal]; the
@@ -461,33 +468,59 @@ __global__ __launch_bounds__(256) void leafhash_match_old_kernel(const float4* _
                                                                  float4* __restrict__ wpts,
                                                                  LeafTable ht, uint32_t* __restrict__ mslot, uint32_t* __restrict__ mrank,
                                                                  const MapTouched* __restrict__ ttp, int nc, double inv_cell, float4* __restrict__ cent,
-                                                                 uint32_t* __restrict__ keys2) {
+                                                                 uint32_t* __restrict__ keys2, const CellCount cc) {
   const MapTouched& tt = *ttp;
-  // (grid-stride: a device-built round knows the number of old points, the host that sized the launch only an estimate)
+  // (grid-stride: a device-built round knows the number of old points, the host that sized the launch only an estimate; the
+  //  trip count is the same for every lane of a workgroup: the ballots of the counting below need whole wavefronts)
   const uint32_t n_old = tt.old_prefix[kMaxTouched];
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n_old; e += gridDim.x * blockDim.x) {
-    int t = 0;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t first = blockIdx.x * blockDim.x; first < n_old; first += gridDim.x * blockDim.x) {
+    const uint32_t e = first + threadIdx.x;
+    uint32_t k2 = kLeafEmpty;  // cell key of a point that passes through (stays empty for a point that joins a group)
+    if (e < n_old) {
+      int t = 0;
 #pragma unroll
-    for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
-    const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
-    const uint32_t key = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
-    wpts[e] = p; keys[e] = key;
-    const uint32_t mask = (1u << ht.log2_size) - 1u;
-    uint32_t h = leaf_hash(key, ht.log2_size), slot = kLeafEmpty;
-    for (;;) {
-      const uint32_t k = ht.key[h];
-      if (k == key) { slot = h; break; }
-      if (k == kLeafEmpty) break;
-      h = (h + 1) & mask;
+      for (int step = 16; step >= 1; step >>= 1) t = (t + step < tt.n && tt.old_prefix[t + step] <= e) ? t + step : t;
+      const float4 p = pool[(size_t)tt.slot[t] * cap + (e - tt.old_prefix[t])];
+      const uint32_t key = leaf_key(p.x, p.y, p.z, inv_leaf, tt.leaf_lo[t][0], tt.leaf_lo[t][1], tt.leaf_lo[t][2], (uint32_t)t, tt.lbits);
+      wpts[e] = p; keys[e] = key;
+      const uint32_t mask = (1u << ht.log2_size) - 1u;
+      uint32_t h = leaf_hash(key, ht.log2_size), slot = kLeafEmpty;
+      for (;;) {
+        const uint32_t k = ht.key[h];
+        if (k == key) { slot = h; break; }
+        if (k == kLeafEmpty) break;
+        h = (h + 1) & mask;
+      }
+      mslot[e] = slot;
+      if (slot != kLeafEmpty) {
+        mrank[e] = atomicAdd(&ht.cnt[slot], 1u);
+        keys2[e] = kLeafEmpty;  // a hole of the centroid index space: the point lives on in its group
+      } else {
+        // the only point of its leaf: sum = 0 + p, count = 1
+        k2 = emit_centroid(e, key, 0.f + p.x, 0.f + p.y, 0.f + p.z, 1u, tt, nc, inv_cell, cent, keys2, nullptr);
+      }
     }
-    mslot[e] = slot;
-    if (slot != kLeafEmpty) {
-      mrank[e] = atomicAdd(&ht.cnt[slot], 1u);
-      keys2[e] = kLeafEmpty;  // a hole of the centroid index space: the point lives on in its group
-      continue;
+    if (cc.grid) {
+      // cell_count_kernel's counting, here: one atomic per DISTINCT cell of the wavefront (the old points come in pool
+      // order, cell after cell: the lanes hit two or three counters, and 64 atomics on one word serialise).  The rank goes
+      // where a matched point keeps its member rank (mrank == cc.rank: a point is one or the other)
+      const bool kept = k2 != kLeafEmpty;
+      uint32_t my_idx = 0, my_cnt = 0;
+      int lead = lane;
+      unsigned long long todo = __ballot(kept);
+      while (todo) {
+        const int L = __ffsll((long long)todo) - 1;
+        const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)k2, L);
+        const unsigned long long m = __ballot(kept && k2 == kk);
+        if (kept && k2 == kk) { my_idx = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); my_cnt = (uint32_t)__popcll(m); lead = L; }
+        todo &= ~m;
+      }
+      uint32_t base = 0;
+      if (kept && lead == lane) base = atomicAdd(&cc.grid[(size_t)(k2 >> 18) * cc.ncell1 + (k2 & 0x3FFFFu)], my_cnt);
+      base = (uint32_t)__shfl((int)base, lead, 64);
+      if (kept) cc.rank[e] = base + my_idx;
     }
-    // the only point of its leaf: sum = 0 + p, count = 1
-    emit_centroid(e, key, 0.f + p.x, 0.f + p.y, 0.f + p.z, 1u, tt, nc, inv_cell, cent, keys2, nullptr);
   }
 }
 
@@ -565,7 +598,7 @@ __device__ __forceinline__ void leafhash_small_groups(uint32_t g, const uint32_t
                                                       const unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ members,
                                                       const float4* __restrict__ wpts, const uint32_t* __restrict__ leaf_keys,
                                                       uint32_t n_old, const MapTouched& tt, int nc, double inv_cell, float4* __restrict__ cent,
-                                                      uint32_t* __restrict__ keys2, uint32_t* __restrict__ n_cent) {
+                                                      uint32_t* __restrict__ keys2, uint32_t* __restrict__ n_cent, const CellCount cc) {
   const uint32_t n_groups = (uint32_t)(*cursor >> 32);
   if (g == 0) *n_cent = n_old + n_groups;
   const bool have = g < n_groups;
@@ -586,7 +619,7 @@ __device__ __forceinline__ void leafhash_small_groups(uint32_t g, const uint32_t
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if ((uint32_t)k < cnt) { s0 += p[k].x; s1 += p[k].y; s2 += p[k].z; }
-    emit_centroid(n_old + g, leaf_keys[e[0]], s0, s1, s2, cnt, tt, nc, inv_cell, cent, keys2, nullptr);
+    emit_centroid(n_old + g, leaf_keys[e[0]], s0, s1, s2, cnt, tt, nc, inv_cell, cent, keys2, nullptr, cc);
     return;
   }
 #pragma unroll
@@ -614,7 +647,7 @@ __device__ __forceinline__ void leafhash_small_groups(uint32_t g, const uint32_t
 #pragma unroll
   for (int k = 0; k < 16; ++k)
     if ((uint32_t)k < cnt) { s0 += p[k].x; s1 += p[k].y; s2 += p[k].z; }
-  emit_centroid(n_old + g, leaf_keys[e[0]], s0, s1, s2, cnt, tt, nc, inv_cell, cent, keys2, nullptr);
+  emit_centroid(n_old + g, leaf_keys[e[0]], s0, s1, s2, cnt, tt, nc, inv_cell, cent, keys2, nullptr, cc);
 }
 
 __device__ __forceinline__ void leafhash_medium_groups(uint32_t first_wave, uint32_t n_waves, int lane, const uint32_t* __restrict__ gstart,
@@ -622,7 +655,7 @@ __device__ __forceinline__ void leafhash_medium_groups(uint32_t first_wave, uint
                                                        const float4* __restrict__ wpts, const uint32_t* __restrict__ leaf_keys, uint32_t n_old,
                                                        const MapTouched& tt, int nc, double inv_cell, float4* __restrict__ cent,
                                                        uint32_t* __restrict__ keys2, const uint32_t* __restrict__ medium_list,
-                                                       const uint32_t* __restrict__ medium_count) {
+                                                       const uint32_t* __restrict__ medium_count, const CellCount cc) {
   const uint32_t n_medium = *medium_count;
   for (uint32_t w = first_wave; w < n_medium; w += n_waves) {
     const uint32_t g = medium_list[w];
@@ -649,24 +682,8 @@ __device__ __forceinline__ void leafhash_medium_groups(uint32_t first_wave, uint
       s2 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), k));
     }
     const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
-    if (lane == 0) emit_centroid(n_old + g, leaf_keys[first], s0, s1, s2, c, tt, nc, inv_cell, cent, keys2, nullptr);
+    if (lane == 0) emit_centroid(n_old + g, leaf_keys[first], s0, s1, s2, c, tt, nc, inv_cell, cent, keys2, nullptr, cc);
   }
-}
-
-__global__ __launch_bounds__(256) void leafhash_centroid_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
-                                                                const unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ members,
-                                                                const float4* __restrict__ wpts, const uint32_t* __restrict__ leaf_keys,
-                                                                const MapTouched* __restrict__ ttp, int nc, double inv_cell, float4* __restrict__ cent,
-                                                                uint32_t* __restrict__ keys2, uint32_t* __restrict__ n_cent,
-                                                                const uint32_t* __restrict__ medium_list, const uint32_t* __restrict__ medium_count,
-                                                                uint32_t small_blocks) {
-  const MapTouched& tt = *ttp;
-  const uint32_t n_old = tt.old_prefix[kMaxTouched];
-  if (blockIdx.x < small_blocks)
-    leafhash_small_groups(blockIdx.x * blockDim.x + threadIdx.x, gstart, gcount, cursor, members, wpts, leaf_keys, n_old, tt, nc, inv_cell, cent, keys2, n_cent);
-  else
-    leafhash_medium_groups(((blockIdx.x - small_blocks) * blockDim.x + threadIdx.x) >> 6, ((gridDim.x - small_blocks) * blockDim.x) >> 6, threadIdx.x & 63,
-                           gstart, gcount, members, wpts, leaf_keys, n_old, tt, nc, inv_cell, cent, keys2, medium_list, medium_count);
 }
 
 // leaves with more than 64 points (the ground under the sensor: up to ~1 600 points of a raw 128-beam sweep in one 0.2 m
@@ -679,31 +696,37 @@ __global__ __launch_bounds__(256) void leafhash_centroid_kernel(const uint32_t* 
 // round out of their lanes.  More members than kGiantCap, more than 64 x kGiantCap new points in the round, or more than
 // 64 old points in one leaf: *overflow is raised, the second stage stands still and the host repeats the round with the
 // sort-based first stage.
-constexpr size_t kGiantLds = (size_t)kGiantCap * 5 * 4;  // x, y, z, per-wavefront counts, per-wavefront first list position
 constexpr int kGiantThreads = 1024;                       // four members per thread at most: one round trip per phase
-__global__ __launch_bounds__(kGiantThreads) void leafhash_giant_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
-                                                             const uint32_t* __restrict__ members, const float4* __restrict__ wpts,
-                                                             const uint32_t* __restrict__ leaf_keys, uint32_t n_new,
-                                                             const MapTouched* __restrict__ ttp, int nc, double inv_cell, float4* __restrict__ cent,
-                                                             uint32_t* __restrict__ keys2, const uint32_t* __restrict__ giant_list,
-                                                             const uint32_t* __restrict__ giant_count, uint32_t* __restrict__ overflow) {
-  const MapTouched& tt = *ttp;
-  const uint32_t n_old = tt.old_prefix[kMaxTouched];
-  extern __shared__ uint32_t lds[];
+// dynamic LDS: x, y, z of up to kGiantCap members + per-wavefront counts and first list positions, one entry per wavefront of
+// leafhash_insert_new_kernel rounded up to the workgroup size (64 KB for a 131 072-point sweep: two workgroups per CU)
+static inline uint32_t giant_hist_entries(uint32_t n_new) {
+  const uint32_t nb = (n_new + 63u) >> 6;
+  const uint32_t r = (nb + kGiantThreads - 1u) / kGiantThreads * kGiantThreads;
+  return r < (uint32_t)kGiantThreads ? (uint32_t)kGiantThreads : (r > kGiantCap ? kGiantCap : r);
+}
+static inline size_t giant_lds_bytes(uint32_t n_new) { return ((size_t)kGiantCap * 3 + (size_t)giant_hist_entries(n_new) * 2) * 4; }
+__device__ __forceinline__ void leafhash_giant_groups(uint32_t first_leaf, uint32_t leaf_stride, const uint32_t* __restrict__ gstart,
+                                                      const uint32_t* __restrict__ gcount, const uint32_t* __restrict__ members,
+                                                      const float4* __restrict__ wpts, const uint32_t* __restrict__ leaf_keys, uint32_t n_old,
+                                                      uint32_t n_new, uint32_t nhist, const MapTouched& tt, int nc, double inv_cell,
+                                                      float4* __restrict__ cent, uint32_t* __restrict__ keys2, const uint32_t* __restrict__ giant_list,
+                                                      const uint32_t* __restrict__ giant_count, uint32_t* __restrict__ overflow, const CellCount cc) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   float* sx = reinterpret_cast<float*>(lds);
   float* sy = reinterpret_cast<float*>(lds + kGiantCap);
   float* sz = reinterpret_cast<float*>(lds + 2 * kGiantCap);
-  uint32_t* hist = lds + 3 * kGiantCap;
-  uint32_t* fpos = lds + 4 * kGiantCap;
-  __shared__ uint32_t wsum[kGiantThreads], olds[64], n_olds, first_e;
-  const int tid = threadIdx.x, lane = threadIdx.x & 63;
+  uint32_t* hist = lds + 3 * kGiantCap;   // [nhist]: nhist = giant_hist_entries(n_new), a multiple of the workgroup size
+  uint32_t* fpos = hist + nhist;
+  __shared__ uint32_t wtot[kGiantThreads / 64], sums[3], olds[64], n_olds, first_e;
+  const int tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int kPer = kGiantCap / kGiantThreads;  // 4
+  const uint32_t hper = nhist / (uint32_t)kGiantThreads;  // 1..4 table entries per thread
   const uint32_t n_giant = *giant_count;
   const uint32_t nb = (n_new + 63u) >> 6;  // wavefronts of leafhash_insert_new_kernel
-  for (uint32_t w = blockIdx.x; w < n_giant; w += gridDim.x) {
+  for (uint32_t w = first_leaf; w < n_giant; w += leaf_stride) {
     const uint32_t g = giant_list[w];
     const uint32_t cnt = gcount[g], beg = gstart[g];
-    if (cnt > kGiantCap || nb > kGiantCap) { if (tid == 0) *overflow = 1u; continue; }
+    if (cnt > kGiantCap || nb > nhist) { if (tid == 0) *overflow = 1u; continue; }
     __syncthreads();  // (the previous leaf of this workgroup is done with the arrays)
     uint32_t e[kPer];
     float4 p[kPer];
@@ -711,8 +734,8 @@ __global__ __launch_bounds__(kGiantThreads) void leafhash_giant_kernel(const uin
     for (int k = 0; k < kPer; ++k) {
       const uint32_t i = (uint32_t)tid + (uint32_t)k * kGiantThreads;
       e[k] = i < cnt ? members[beg + i] : kLeafEmpty;
-      hist[i] = 0u; fpos[i] = 0xFFFFFFFFu;
     }
+    for (uint32_t k = 0; k < hper; ++k) { hist[(uint32_t)tid + k * kGiantThreads] = 0u; fpos[(uint32_t)tid + k * kGiantThreads] = 0xFFFFFFFFu; }
     if (tid == 0) n_olds = 0u;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) p[k] = wpts[e[k] != kLeafEmpty ? e[k] : 0u];  // (on their way while the places are worked out)
@@ -727,21 +750,24 @@ __global__ __launch_bounds__(kGiantThreads) void leafhash_giant_kernel(const uin
     __syncthreads();
     const uint32_t n_o = n_olds;
     if (n_o > 64u) { if (tid == 0) *overflow = 1u; continue; }  // (uniform: every thread read the same n_olds)
-    // exclusive scan of the per-wavefront counts: four entries per thread, then the 1 024 partial sums
+    // exclusive scan of the per-wavefront counts: hper consecutive entries per thread, a shuffle scan over the wavefront's
+    // threads, the sixteen wavefront totals through LDS (two barriers; twenty with a workgroup-wide Hillis-Steele)
     uint32_t local[kPer], sum = 0;
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) { local[k] = sum; sum += hist[kPer * tid + k]; }
-    wsum[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < kGiantThreads; d <<= 1) {
-      const uint32_t v = tid >= d ? wsum[tid - d] : 0u;
-      __syncthreads();
-      wsum[tid] += v;
-      __syncthreads();
-    }
-    const uint32_t before = wsum[tid] - sum;
+    for (int k = 0; k < kPer; ++k) { local[k] = sum; sum += (uint32_t)k < hper ? hist[hper * (uint32_t)tid + k] : 0u; }
+    uint32_t inc = sum;
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) hist[kPer * tid + k] = before + local[k];
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t a0 = (uint32_t)__shfl_up((int)inc, d, 64);
+      if (lane >= d) inc += a0;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t before = inc - sum;
+    for (int q = 0; q < wave; ++q) before += wtot[q];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if ((uint32_t)k < hper) hist[hper * (uint32_t)tid + k] = before + local[k];
     __syncthreads();
     // points into their final places: the old points first (in index order), then wavefront after wavefront; inside its
     // wavefront's run a member keeps its distance from the run's first list position
@@ -761,24 +787,62 @@ __global__ __launch_bounds__(kGiantThreads) void leafhash_giant_kernel(const uin
       if (at == 0) first_e = e[k];  // the first member in working-set order (its leaf key goes with the centroid)
     }
     __syncthreads();
-    if (tid < 192) {  // wavefronts 0, 1, 2 add x, y, z: three independent chains of dependent additions
+    if (tid < 192) {
+      // wavefronts 0, 1, 2 add x, y, z: three independent chains of dependent additions, one addition per element.  Every
+      // lane reads the SAME sixteen values from LDS (a broadcast, no bank conflict) and adds them in order -- the operands
+      // arrive in the lane's own registers, the next sixteen are on their way meanwhile.  (Handing the elements of one
+      // register around with v_readlane cost readlane + wait state + add per element: 28 us for a leaf of 1 636 points.)
       const float* src = tid < 64 ? sx : (tid < 128 ? sy : sz);
       float acc = 0.f;
-      float cur = (uint32_t)lane < cnt ? src[lane] : 0.f;
-      for (uint32_t j = 0; j < cnt; j += 64) {
-        const uint32_t jn = j + 64u + (uint32_t)lane;
-        const float nxt = jn < cnt ? src[jn] : 0.f;  // (lanes behind the end contribute +0.0f: s + 0.0f == s)
+      const uint32_t n16 = cnt & ~15u;
+      float4 cur[4], nxt[4];
 #pragma unroll
-        for (int k = 0; k < 64; ++k) acc += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cur), k));
-        cur = nxt;
+      for (int q = 0; q < 4; ++q) cur[q] = n16 ? *reinterpret_cast<const float4*>(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (uint32_t j = 0; j < n16; j += 16) {
+        if (j + 16 < n16) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const float4*>(src + j + 16 + 4 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc += cur[q].x; acc += cur[q].y; acc += cur[q].z; acc += cur[q].w; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
       }
-      if (lane == 0) wsum[tid >> 6] = __float_as_uint(acc);
+      for (uint32_t j = n16; j < cnt; ++j) acc += src[j];
+      if (lane == 0) sums[tid >> 6] = __float_as_uint(acc);
     }
     __syncthreads();
     if (tid == 0)
-      emit_centroid(n_old + g, leaf_keys[first_e], __uint_as_float(wsum[0]), __uint_as_float(wsum[1]), __uint_as_float(wsum[2]), cnt, tt, nc, inv_cell,
-                    cent, keys2, nullptr);
+      emit_centroid(n_old + g, leaf_keys[first_e], __uint_as_float(sums[0]), __uint_as_float(sums[1]), __uint_as_float(sums[2]), cnt, tt, nc, inv_cell,
+                    cent, keys2, nullptr, cc);
   }
+}
+
+// The centroids of every group in ONE launch of 1 024-thread workgroups: workgroups [0, giant_blocks) walk the list of
+// leaves with more than 64 members (one leaf at a time each), the next small_blocks take one group of up to 16 members per
+// thread, the rest one group of 17..64 members per wavefront.  The few long leaves of a raw sweep (its slowest took 23 us)
+// run beside the ten thousand short ones instead of behind them; workgroups of the first kind without a leaf end at once.
+__global__ __launch_bounds__(kGiantThreads) void leafhash_centroids_kernel(const uint32_t* __restrict__ gstart, const uint32_t* __restrict__ gcount,
+                                                                 const unsigned long long* __restrict__ cursor, const uint32_t* __restrict__ members,
+                                                                 const float4* __restrict__ wpts, const uint32_t* __restrict__ leaf_keys,
+                                                                 uint32_t n_new, uint32_t nhist, const MapTouched* __restrict__ ttp, int nc,
+                                                                 double inv_cell, float4* __restrict__ cent, uint32_t* __restrict__ keys2,
+                                                                 uint32_t* __restrict__ n_cent, const uint32_t* __restrict__ medium_list,
+                                                                 const uint32_t* __restrict__ medium_count, const uint32_t* __restrict__ giant_list,
+                                                                 const uint32_t* __restrict__ giant_count, uint32_t* __restrict__ overflow,
+                                                                 uint32_t giant_blocks, uint32_t small_blocks, const CellCount cc) {
+  const MapTouched& tt = *ttp;
+  const uint32_t n_old = tt.old_prefix[kMaxTouched];
+  if (blockIdx.x < giant_blocks)
+    leafhash_giant_groups(blockIdx.x, giant_blocks, gstart, gcount, members, wpts, leaf_keys, n_old, n_new, nhist, tt, nc, inv_cell, cent, keys2, giant_list,
+                          giant_count, overflow, cc);
+  else if (blockIdx.x < giant_blocks + small_blocks)
+    leafhash_small_groups((blockIdx.x - giant_blocks) * blockDim.x + threadIdx.x, gstart, gcount, cursor, members, wpts, leaf_keys, n_old, tt, nc, inv_cell,
+                          cent, keys2, n_cent, cc);
+  else
+    leafhash_medium_groups(((blockIdx.x - giant_blocks - small_blocks) * blockDim.x + threadIdx.x) >> 6,
+                           ((gridDim.x - giant_blocks - small_blocks) * blockDim.x) >> 6, threadIdx.x & 63, gstart, gcount, members, wpts, leaf_keys, n_old, tt,
+                           nc, inv_cell, cent, keys2, medium_list, medium_count, cc);
 }
 
 __global__ __launch_bounds__(256) void gather_export_kernel(const float4* __restrict__ pool, uint32_t cap, uint32_t slot, uint32_t count,
@@ -920,7 +984,21 @@ struct FrontBuild {
   uint32_t* cube_cnt; uint32_t* n_inside; uint32_t* ticket; uint32_t* halt; uint32_t* dirty; MapTouched* tt;
   float inv_leaf; uint32_t lbits; int32_t per_round;
   MapFastReport* rep; unsigned long long seq;
+  uint32_t* touched_n; int32_t* touched_list;  // the cubes that received points, in the order their counters left zero (kTouchedCap entries)
 };
+constexpr uint32_t kTouchedCap = 64;
+// new points of a cube into its counter; whoever moves the counter off zero lists the cube.  Every access is a device-scope
+// read-modify-write whose result is consumed: performed before the thread goes on (see the ticket below)
+__device__ __forceinline__ void front_count(const FrontBuild& b, int c, uint32_t add) {
+  const uint32_t before = __hip_atomic_fetch_add(&b.cube_cnt[c], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (before == 0u) {
+    const uint32_t pos = __hip_atomic_fetch_add(b.touched_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pos < kTouchedCap) {
+      const int32_t was = __hip_atomic_exchange(&b.touched_list[pos], (int32_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(was));
+    }
+  }
+}
 static_assert(kMapW == 21 && kMapH == 21 && kMapD == 11, "cube index arithmetic below");
 
 // transformAndAddToMap's transform (LidarSlam.cpp:60-80; TransformPoint, superodom_utils.h:119-123) + LocalMap.h:596-610 in
@@ -929,12 +1007,8 @@ template <bool TRANSFORM>
 __global__ __launch_bounds__(1024) void insert_front_kernel(const float* __restrict__ in, uint32_t n, uint32_t stride_floats, Pose pose,
                                                             float* __restrict__ world, int o0, int o1, int o2, int32_t* __restrict__ cube_of,
                                                             FrontBuild b) {
-  constexpr int kCntPad = (kMapNum + 63) / 64 * 64;
-  __shared__ uint32_t cnt, s_n;
+  __shared__ uint32_t cnt;
   __shared__ bool last;
-  __shared__ int32_t s_cube[kMaxTouched];
-  __shared__ uint32_t s_new[kMaxTouched];
-  __shared__ uint32_t s_cnt[kCntPad];
   // the workgroup's own tally of (cube, new points) first -- a sweep touches a handful of cubes, and 2 048 wavefronts adding
   // to the same few words of memory took 60 us --, then one atomic per distinct cube and workgroup
   constexpr int kTally = 8;
@@ -975,56 +1049,40 @@ __global__ __launch_bounds__(1024) void insert_front_kernel(const float* __restr
         const int32_t prev = atomicCAS(&s_tkey[k], -1, c);
         if (prev == -1 || prev == c) { atomicAdd(&s_tval[k], add); done = true; }
       }
-      if (!done) {  // (more than kTally cubes in one workgroup's 1 024 points)
-        const uint32_t before = __hip_atomic_fetch_add(&b.cube_cnt[c], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(before));
-      }
+      if (!done) front_count(b, c, add);  // (more than kTally cubes in one workgroup's 1 024 points)
     }
     todo &= ~m;
   }
   if (lane == 0 && inside) atomicAdd(&cnt, (uint32_t)__popcll(inside));
   __syncthreads();
   if (threadIdx.x == 0 && cnt) atomicAdd(b.n_inside, cnt);
-  // The last workgroup to get here lays out the round.  All it takes from the others are the per-cube counters, which are
-  // only ever touched by device-scope atomics (read-modify-write here, atomic loads below): the adds return their old value,
-  // so they have been performed when their thread reaches the barrier, and the ticket is taken behind the barrier.  No
-  // fence: a release fence in every wavefront writes the L2 back 2 048 times (measured: 40 us); cube_of and the world points
-  // are read by later launches only.
-  if (threadIdx.x < kTally && s_tkey[threadIdx.x] >= 0) {
-    const uint32_t before = __hip_atomic_fetch_add(&b.cube_cnt[s_tkey[threadIdx.x]], s_tval[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("" ::"v"(before));
-  }
+  // The last workgroup to get here lays out the round.  All it takes from the others are the per-cube counters and the list
+  // of touched cubes, which are only ever touched by device-scope atomics (read-modify-write here, atomic loads below) whose
+  // results are consumed: they have been performed when their thread reaches the barrier, and the ticket is taken behind
+  // the barrier.  No fence: a release fence in every wavefront writes the L2 back 2 048 times (measured: 40 us); cube_of and
+  // the world points are read by later launches only.
+  if (threadIdx.x < kTally && s_tkey[threadIdx.x] >= 0) front_count(b, s_tkey[threadIdx.x], s_tval[threadIdx.x]);
   __syncthreads();
   if (threadIdx.x == 0) last = __hip_atomic_fetch_add(b.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
   __syncthreads();
   if (!last) return;
-  // the touched cubes in ascending order: the counters into LDS by the whole workgroup, then one wavefront walks them
-  // (cube = 64 k + lane: ascending in (k, lane))
-  for (int c = (int)threadIdx.x; c < kCntPad; c += (int)blockDim.x)
-    s_cnt[c] = c < kMapNum ? __hip_atomic_load(&b.cube_cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  __syncthreads();
   if (threadIdx.x < 64) {
-    uint32_t total = 0;
-    for (int k = 0; k < kCntPad / 64; ++k) {
-      const uint32_t v = s_cnt[k * 64 + lane];
-      const bool has = v != 0u;
-      const unsigned long long m = __ballot(has);
-      if (has) {
-        const uint32_t pos = total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (pos < (uint32_t)kMaxTouched) { s_cube[pos] = k * 64 + lane; s_new[pos] = v; }
-      }
-      total += (uint32_t)__popcll(m);
-    }
-    if (lane == 0) s_n = total;
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const uint32_t n_t = s_n;
-    uint32_t h = n_t > (uint32_t)b.per_round ? (uint32_t)kFastHaltMultiRound : 0u;
+    const uint32_t n_t = __hip_atomic_load(b.touched_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t h = n_t > (uint32_t)b.per_round ? (uint32_t)kFastHaltMultiRound : 0u;  // (per_round <= kMaxTouched < kTouchedCap)
     const int t = lane;
-    const bool cand = h == 0u && (uint32_t)t < n_t;  // (n_t <= per_round <= kMaxTouched here)
-    const int cb = cand ? s_cube[t] : INT32_MAX;
-    uint32_t newc = cand ? s_new[t] : 0u, oldc = 0u, bad = 0u;
+    // the touched cubes in ascending order: bitonic network over the lanes, absent entries (INT32_MAX) end up behind
+    int cb = (h == 0u && (uint32_t)t < n_t) ? __hip_atomic_load(&b.touched_list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MAX;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const int o = __shfl_xor(cb, j, 64);
+        const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+        cb = keep_min ? min(cb, o) : max(cb, o);
+      }
+    }
+    const bool cand = h == 0u && (uint32_t)t < n_t;
+    uint32_t newc = cand ? __hip_atomic_load(&b.cube_cnt[cb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u, oldc = 0u, bad = 0u;
     int slot = 0;
     if (cand) {
       slot = b.cube_slot[cb];
@@ -1167,7 +1225,7 @@ __global__ __launch_bounds__(256) void insert_report_kernel(const MapTouched* __
   for (uint32_t i = (uint32_t)tid; i < small_words; i += 256u) small[i] = 0u;
   for (uint32_t i = (uint32_t)tid; i < (uint32_t)kMapNum; i += 256u) cube_cnt[i] = 0u;
   for (uint32_t i = (uint32_t)tid; i < (uint32_t)kScanStateWords; i += 256u) scan_state[i] = 0ull;
-  if (tid <= kMaxTouched) tickets[tid] = 0u;
+  if (tid <= kMaxTouched + 1) tickets[tid] = 0u;  // (the scan's tickets, the front kernel's ticket, its count of touched cubes)
   __threadfence_system();
   __syncthreads();
   if (tid == 0) __hip_atomic_store(&rep->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1302,8 +1360,12 @@ void launch_transform_scan(const float* d_scan, uint32_t n, const Pose& pose, fl
 // vals0; lists of the larger groups in spts (first-stage scratch of the sort path, the second stage's scratch later): at
 // most n_new / 16 groups of more than 16 members, n_new / 64 of more than 64; counters in d_n_cent[2..6]
 // (a.n_old: the number of old points, or -- device-built round -- a bound on it: the kernels take the number from d_tt)
-static uint32_t* launch_first_stage_hashed(const MapInsertArgs& a, hipStream_t s) {
+// (count_cells: the centroids are counted into the cell grids as they are produced -- no cell_count_kernel behind this stage;
+//  the ranks go to vals1, where a matched old point and every new point keep their member ranks until the members are placed:
+//  an old point has one or the other, and the groups' ranks are written after the placement)
+static uint32_t* launch_first_stage_hashed(const MapInsertArgs& a, hipStream_t s, bool count_cells) {
   const LeafTable ht{a.ht_key, a.ht_cnt, a.ht_off, a.ht_log2};
+  const CellCount cc{count_cells ? a.grid : nullptr, a.vals1, a.ncell1};
   unsigned long long* cursor = reinterpret_cast<unsigned long long*>(a.d_n_cent + 2);
   uint32_t* keys2 = a.vals0;
   uint32_t* medium_list = reinterpret_cast<uint32_t*>(a.spts);
@@ -1314,18 +1376,31 @@ static uint32_t* launch_first_stage_hashed(const MapInsertArgs& a, hipStream_t s
                        a.d_tt, a.inv_leaf, a.nc, a.inv_cell, a.rank, a.world, a.wpts, a.keys0, ht, a.keys1, a.vals1);
   if (a.n_old)
     hipLaunchKernelGGL(leafhash_match_old_kernel, grid_for(n_old_grid, 256), dim3(256), 0, s, a.pool, a.cap, a.inv_leaf, a.keys0, a.wpts, ht,
-                       a.keys1, a.vals1, a.d_tt, a.nc, a.inv_cell, a.cent, keys2);
+                       a.keys1, a.vals1, a.d_tt, a.nc, a.inv_cell, a.cent, keys2, cc);
   hipLaunchKernelGGL(leafhash_offsets_kernel, dim3((1u << a.ht_log2) / 4096u), dim3(1024), 0, s, ht, a.heads, a.flags, cursor, medium_list, a.d_n_cent + 6,
                      giant_list, a.d_n_cent + 4);
   hipLaunchKernelGGL(leafhash_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.n_new, a.d_tt, a.ht_off, a.pos);
   const uint32_t max_medium = a.n_new / 16u + 1u, max_giant = a.n_new / 64u + 1u;
-  const uint32_t small_blocks = (a.n_new ? a.n_new + 255u : 256u) / 256u, medium_blocks = max_medium < 2048u ? (max_medium + 3u) / 4u : 512u;
-  hipLaunchKernelGGL(leafhash_centroid_kernel, dim3(small_blocks + medium_blocks), dim3(256), 0, s, a.heads, a.flags, cursor, a.pos, a.wpts, a.keys0,
-                     a.d_tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, small_blocks);
+  const uint32_t small_blocks = (a.n_new ? a.n_new + kGiantThreads - 1u : (uint32_t)kGiantThreads) / kGiantThreads;
+  const uint32_t medium_blocks = max_medium < 2048u ? (max_medium + 15u) / 16u : 128u, giant_blocks = max_giant < 512u ? max_giant : 512u;
+  const size_t giant_lds = giant_lds_bytes(a.n_new);
+  const uint32_t nhist = giant_hist_entries(a.n_new);
   // (per launch, not once per process: the attribute belongs to the current device, and one process may drive several)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leafhash_giant_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGiantLds);
-  hipLaunchKernelGGL(leafhash_giant_kernel, dim3(max_giant < 1024u ? max_giant : 1024u), dim3(kGiantThreads), kGiantLds, s, a.heads, a.flags, a.pos, a.wpts, a.keys0,
-                     a.n_new, a.d_tt, a.nc, a.inv_cell, a.cent, keys2, giant_list, a.d_n_cent + 4, a.d_n_cent + 5);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leafhash_centroids_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)giant_lds);
+  // (SOICP_MAP_SPLIT_CENTROIDS=1: the long leaves in a launch of their own behind the others, as rounds 2-3 had it)
+  static const bool split = [] { const char* e = std::getenv("SOICP_MAP_SPLIT_CENTROIDS"); return e && e[0] == '1'; }();
+  if (split) {
+    hipLaunchKernelGGL(leafhash_centroids_kernel, dim3(small_blocks + medium_blocks), dim3(kGiantThreads), giant_lds, s, a.heads, a.flags, cursor, a.pos, a.wpts,
+                       a.keys0, a.n_new, nhist, a.d_tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, giant_list, a.d_n_cent + 4,
+                       a.d_n_cent + 5, 0u, small_blocks, cc);
+    hipLaunchKernelGGL(leafhash_centroids_kernel, dim3(giant_blocks), dim3(kGiantThreads), giant_lds, s, a.heads, a.flags, cursor, a.pos, a.wpts,
+                       a.keys0, a.n_new, nhist, a.d_tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, giant_list, a.d_n_cent + 4,
+                       a.d_n_cent + 5, giant_blocks, 0u, cc);
+  } else {
+    hipLaunchKernelGGL(leafhash_centroids_kernel, dim3(giant_blocks + small_blocks + medium_blocks), dim3(kGiantThreads), giant_lds, s, a.heads, a.flags, cursor,
+                       a.pos, a.wpts, a.keys0, a.n_new, nhist, a.d_tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, giant_list,
+                       a.d_n_cent + 4, a.d_n_cent + 5, giant_blocks, small_blocks, cc);
+  }
   return keys2;
 }
 
@@ -1352,7 +1427,7 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
   }
   uint32_t* keys2 = a.keys0;  // cell key per centroid, input of the second stage
   if (hashed) {
-    keys2 = launch_first_stage_hashed(a, s);  // first stage without a sort (see leafhash_insert_new_kernel)
+    keys2 = launch_first_stage_hashed(a, s, false);  // first stage without a sort (see leafhash_insert_new_kernel)
   } else {
     (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)total, 32, s);  // stable
     hipLaunchKernelGGL(leaf_flags_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, total, a.flags);
@@ -1391,18 +1466,21 @@ void launch_map_insert(const MapInsertArgs& a, hipStream_t s) {
 void launch_map_insert_fast(const MapInsertArgs& a, const MapFastArgs& f, hipStream_t s) {
   if (!f.n) return;
   const FrontBuild b{f.d_cube_slot, f.d_slot_count, f.d_slot_ok, f.d_cube_cnt, f.d_small + 48, f.d_tickets + kMaxTouched, f.d_small + 5, f.d_small + 7,
-                     a.d_tt, a.inv_leaf, a.tt.lbits, f.per_round, f.h_report, f.seq};
+                     a.d_tt, a.inv_leaf, a.tt.lbits, f.per_round, f.h_report, f.seq,
+                     f.d_tickets + kMaxTouched + 1, reinterpret_cast<int32_t*>(f.d_tickets + kMaxTouched + 2)};
   if (f.transform)
     hipLaunchKernelGGL(insert_front_kernel<true>, grid_for(f.n, 1024), dim3(1024), 0, s, f.d_in, f.n, 3u, f.pose, f.d_world, f.origin[0], f.origin[1],
                        f.origin[2], const_cast<int32_t*>(a.d_cube_of), b);
   else
     hipLaunchKernelGGL(insert_front_kernel<false>, grid_for(f.n, 1024), dim3(1024), 0, s, f.d_in, f.n, f.stride_floats, f.pose, (float*)nullptr, f.origin[0],
                        f.origin[1], f.origin[2], const_cast<int32_t*>(a.d_cube_of), b);
-  uint32_t* keys2 = launch_first_stage_hashed(a, s);
+  // (SOICP_MAP_FUSE_COUNT=0: cell_count_kernel as its own launch, like the host-built rounds)
+  static const bool fuse_count = [] { const char* e = std::getenv("SOICP_MAP_FUSE_COUNT"); return !(e && e[0] == '0'); }();
+  uint32_t* keys2 = launch_first_stage_hashed(a, s, fuse_count);
   const uint32_t total = (a.n_old_grid ? a.n_old_grid : a.n_old) + a.n_new;
   const uint32_t* halt = a.d_n_cent + 5;
   const uint32_t nblk = (a.ncell1 + kScanItems - 1u) / kScanItems;
-  hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.ncell1, a.grid, a.vals1, halt);
+  if (!fuse_count) hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.ncell1, a.grid, a.vals1, halt);
   hipLaunchKernelGGL(cell_scan_table_kernel, dim3(nblk, (uint32_t)f.per_round), dim3(256), 0, s, a.grid, a.grid_scan, a.d_tt, a.cap, a.ncell1, a.cell_start,
                      a.d_counts, f.d_slot_count, halt, f.d_scan_state, f.d_tickets, nblk);
   hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.d_tt, a.ncell1,

@@ -2,9 +2,11 @@
 # timeline of ONE Localization() call (registration + map insert): kernels and copies with start offsets, durations, gaps
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
+# usage: bash tools/localization_timeline.sh <tag> [mode of tools/localization_rate.py, default "default"]
 OUT=$R/gpurun_out/${1:-loc_tl}; mkdir -p $OUT
-rm -rf /tmp/ltl && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/ltl -- python $R/tools/localization_rate.py > /tmp/ltl.log 2>&1
-python - <<'PY' | tee $OUT/localization_timeline.txt
+MODE=${2:-default}
+rm -rf /tmp/ltl && rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/ltl -- python $R/tools/localization_rate.py --modes $MODE > /tmp/ltl.log 2>&1
+python - <<'PY' | tee $OUT/localization_timeline_$MODE.txt
 import csv, glob
 rows = []
 for f in glob.glob("/tmp/ltl/**/*kernel_trace.csv", recursive=True):

@@ -29,9 +29,24 @@ if [[ $ST == *p* ]]; then
   timeout 400 bash tools/localization_timeline.sh $TAG 2>&1 | tail -60
   timeout 400 bash tools/prof_localization.sh $TAG 2>&1 | tail -45
 fi
+if [[ $ST == *n* ]]; then
+  timeout 400 bash tools/localization_timeline.sh $TAG node 2>&1 | tail -70
+fi
 if [[ $ST == *s* ]]; then
   timeout 500 python tools/soak_map_insert.py --oracle --seconds 40 2>&1 | tail -6 | tee $O/soak_map_insert.txt
   timeout 500 python tools/soak_localization.py --seconds 40 2>&1 | tail -6 | tee $O/soak_localization.txt
+fi
+if [[ $ST == *e* ]]; then
+  # A/B on one box: the watchdog event behind the reporting launch (1) against hipStreamQuery (0, default)
+  for rep in 1 2; do for ev in 1 0; do
+    SOICP_OUTER_EVENTS=$ev timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile-pass 2>>$O/ab_events.err | tail -1 > $O/ab_events_${ev}_$rep.json
+    python - $O/ab_events_${ev}_$rep.json $ev <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("outer_events=%s value %.1f ms/step %.4f | entry_points %s | batch64 %s | parity %s" % (sys.argv[2], d["value"], d["ms_per_step"],
+      {k: round(v, 1) for k, v in d["entry_points"].items() if k != "note"}, round((d.get("batch64") or {}).get("value", 0), 1), d.get("parity_vs_oracle_m_rad")))
+PY
+  done; done
 fi
 if [[ $ST == *b* ]]; then
   timeout 600 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1 > $O/bench_steps20.json
