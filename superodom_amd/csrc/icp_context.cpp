@@ -195,6 +195,10 @@ struct so_icp_ctx {
   int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
   std::vector<DevBuf> resident_scans;  // so_icp_upload_scan
   DevBuf pf_in, pf_out, pf_small, pf_w, pf_s, pf_k0, pf_k1, pf_v0, pf_v1, pf_flags, pf_pos, pf_heads, pf_temp;  // so_icp_prefilter_scan
+  DevBuf pf_dec;                      // {counters[16], VgDecision, partial statistics}: the pre-filter decided on the device
+  VgDecision* h_pf = nullptr;         // pinned read-back of the decision
+  size_t pf_temp_for = 0, pf_temp_need = 0;  // map_sort_temp_bytes(pf_temp_for) == pf_temp_need (the query costs two library calls)
+  bool pf_fast = true;                // SOICP_PREFILTER_FAST=0: statistics read back, decided on the host, then the filter (rounds 1-3)
   // Seam B scratch
   DevBuf d_q, d_nbr, d_d2, d_idx, d_found, d_fblist;
   // persistent LidarSLAM state
@@ -1304,7 +1308,7 @@ so_icp_ctx::~so_icp_ctx() {
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_vals0, &d_chunks,
                     &d_binned, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist, &d_kdbg, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
-                    &pf_heads, &pf_temp, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_counts, &d_sub})
+                    &pf_heads, &pf_temp, &pf_dec, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_counts, &d_sub})
     b->release();
   for (DevBuf& b : resident_scans) b.release();
   d_state_buf.release();
@@ -1313,6 +1317,7 @@ so_icp_ctx::~so_icp_ctx() {
   if (h_hist) (void)hipHostFree(h_hist);
   if (h_sums) (void)hipHostFree(h_sums);
   if (h_u32) (void)hipHostFree(h_u32);
+  if (h_pf) (void)hipHostFree(h_pf);
   for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
   dmap.reset();  // (waits for a deferred insert on `stream`)
   if (stream) (void)hipStreamDestroy(stream);
@@ -1415,6 +1420,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_READBACK")) c->direct_readback = std::string(ev) != "copy";
   if (const char* ev = std::getenv("SOICP_SPECULATE")) c->speculate = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_OUTER_EVENTS")) c->outer_events = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_PREFILTER_FAST")) c->pf_fast = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_ABLATE")) c->ablate = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
@@ -2103,6 +2109,69 @@ int so_icp_localization_dev(so_icp_ctx* c, int initialization, const double T_in
 
 // laserMapping::adjustVoxelSize (laserMapping.cpp:598-651) on the device: cloud statistics -> resolution choice ->
 // pcl::VoxelGrid of the surf cloud at planeRes; the resolutions are pushed into the context like the node does.
+// The pre-filter as ONE enqueue: statistics -> decision and leaf grid on the device (vg_decide_kernel) -> VoxelGrid -> one
+// read-back (decision + number of leaves).  kPrefilterHostPath: a case the device leaves to the host (the statistic within
+// the rounding band of a threshold, a leaf grid that overflows int32): the caller goes on with the host-decided sequence.
+constexpr int kPrefilterHostPath = 1000;
+static int prefilter_reserve_work(so_icp_ctx* c, size_t n) {
+  const size_t cap = n + 1024;
+  HIP_TRY(c, c->pf_w.reserve(cap * 16)); HIP_TRY(c, c->pf_s.reserve(cap * 16));
+  for (DevBuf* b : {&c->pf_k0, &c->pf_k1, &c->pf_v0, &c->pf_v1, &c->pf_flags, &c->pf_pos, &c->pf_heads}) HIP_TRY(c, b->reserve((cap + 1) * 4));
+  if (c->pf_temp_for != cap) { c->pf_temp_need = map_sort_temp_bytes(cap) + 256; c->pf_temp_for = cap; }
+  HIP_TRY(c, c->pf_temp.reserve(c->pf_temp_need));
+  HIP_TRY(c, c->pf_out.reserve((n + 64) * 12));
+  return SO_ICP_OK;
+}
+static int prefilter_fast(so_icp_ctx* c, size_t n, uint32_t sf, int auto_voxel_size, float line_res, float plane_res, so_icp_prefilter_info& li,
+                          void** d_out, size_t* n_out) {
+  hipStream_t s = c->stream;
+  constexpr int kStatBlocks = 256;
+  constexpr size_t kDecOff = 64, kPartOff = 512;
+  static_assert(kDecOff + sizeof(VgDecision) <= kPartOff, "layout of pf_dec");
+  constexpr uint32_t kScanRecords = 1024;  // look-back records of the filter's fused scan: 2 048 points each
+  constexpr size_t kStateOff = kPartOff + kStatBlocks * 10 * sizeof(double);
+  HIP_TRY(c, c->pf_dec.reserve(kStateOff + kScanRecords * sizeof(unsigned long long) + 64));
+  if (!c->h_pf) HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pf), sizeof(VgDecision)));
+  uint32_t* d_counters = c->pf_dec.as<uint32_t>();
+  VgDecision* d_dec = reinterpret_cast<VgDecision*>(c->pf_dec.as<uint8_t>() + kDecOff);
+  double* d_part = reinterpret_cast<double*>(c->pf_dec.as<uint8_t>() + kPartOff);
+  int rc = prefilter_reserve_work(c, n);
+  if (rc) return rc;
+  VgCandidates cand;
+  cand.line_res[0] = 0.1f; cand.plane_res[0] = 0.2f;            // laserMapping.cpp:622-626
+  cand.line_res[1] = line_res; cand.plane_res[1] = plane_res;
+  cand.line_res[2] = 0.4f; cand.plane_res[2] = 0.8f;            // :627-631
+  for (int k = 0; k < 3; ++k) cand.inv_leaf[k] = 1.0f / cand.plane_res[k];
+  launch_vg_stats(c->pf_in.as<float>(), (uint32_t)n, sf, d_part, kStatBlocks, s);
+  unsigned long long* d_state = reinterpret_cast<unsigned long long*>(c->pf_dec.as<uint8_t>() + kStateOff);
+  launch_vg_decide(d_part, kStatBlocks, (uint32_t)n, auto_voxel_size, cand, d_dec, d_counters, d_state, kScanRecords, s);
+  VoxelFilterArgs a{};
+  a.d_decision = d_dec; a.scan_state = d_state; a.n_scan_state = kScanRecords;
+  a.d_xyz = c->pf_in.as<float>(); a.n = (uint32_t)n; a.stride_floats = sf;
+  a.wpts = c->pf_w.as<float4>(); a.spts = c->pf_s.as<float4>();
+  a.keys0 = c->pf_k0.as<uint32_t>(); a.keys1 = c->pf_k1.as<uint32_t>(); a.vals0 = c->pf_v0.as<uint32_t>(); a.vals1 = c->pf_v1.as<uint32_t>();
+  a.flags = c->pf_flags.as<uint32_t>(); a.pos = c->pf_pos.as<uint32_t>(); a.heads = c->pf_heads.as<uint32_t>();
+  a.d_n_cent = d_counters; a.d_out = c->pf_out.as<float>();
+  a.temp = c->pf_temp.p; a.temp_bytes = c->pf_temp.cap;
+  launch_voxel_filter(a, s);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->h_pf, d_dec, sizeof(VgDecision), hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  const VgDecision& H = *c->h_pf;
+  if (H.flags) return kPrefilterHostPath;
+  if (auto_voxel_size) {
+    li.statistic_in_input_order = 0;
+    li.average_distance = (double)H.average_distance;
+    li.count_far_points = (int32_t)H.acc[3];
+    li.increase_blind_radius = li.count_far_points > 3000;
+  }
+  li.line_res = H.line_res; li.plane_res = H.plane_res;
+  rc = so_icp_set_resolution(c, li.line_res, li.plane_res);  // lmap.cpp:648-649
+  if (rc) return rc;
+  *d_out = c->pf_out.p; *n_out = H.n_leaves;
+  return SO_ICP_OK;
+}
+
 int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, int auto_voxel_size, float line_res,
                           float plane_res, void** d_out, size_t* n_out, so_icp_prefilter_info* info) {
   if (!c || (!xyz && n) || !d_out || !n_out) return SO_ICP_E_INVALID;
@@ -2120,6 +2189,11 @@ int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stri
   // raw cloud -> device (with its stride)
   HIP_TRY(c, c->pf_in.reserve(n * stride_bytes + 64));
   HIP_TRY(c, hipMemcpyAsync(c->pf_in.p, xyz, n * stride_bytes, hipMemcpyHostToDevice, s));
+  if (c->pf_fast) {
+    const int frc = prefilter_fast(c, n, sf, auto_voxel_size, line_res, plane_res, li, d_out, n_out);
+    if (frc != kPrefilterHostPath) { if (frc == SO_ICP_OK && info) *info = li; return frc; }
+    std::memset(&li, 0, sizeof(li)); li.line_res = line_res; li.plane_res = plane_res;
+  }
   // statistics + bounding box (fp64 tree sums; the reference accumulates |x|,|y|,|z| in float in input order --
   // the statistic only feeds the 25 / 65 thresholds and the 3000-far-points flag)
   constexpr int kStatBlocks = 256;

@@ -103,9 +103,29 @@ struct MapInsertArgs {
 };
 
 // scan pre-filter (adjustVoxelSize): statistics + VoxelGrid of one cloud
+// The decisions of adjustVoxelSize + pcl::VoxelGrid's grid set-up, taken on the device (vg_decide_kernel) so that the
+// whole pre-filter is ONE enqueue and one read-back: reduced statistics, the resolution the reference would choose
+// (laserMapping.cpp:604-636), min_b / div_b of the leaf grid (voxel_grid.hpp applyFilter).
+enum : uint32_t { kVgNeedInputOrder = 1u /* the statistic is within the rounding band of a threshold: the reference's own float
+                                            accumulation has to decide (host path) */,
+                  kVgLeafTooSmall = 2u /* dx dy dz overflows int32: PCL passes the cloud through (host path) */ };
+struct VgDecision {
+  double acc[10];  // sum |x|, |y|, |z|, points beyond 3 m, min x y z, max x y z
+  float average_distance, leaf, inv_leaf, line_res, plane_res;
+  int32_t choice;  // 0: statistic < 25 (0.1 / 0.2), 1: the caller's resolutions, 2: > 65 (0.4 / 0.8)
+  int32_t min_b[3], div_b[3];
+  uint32_t flags, n_leaves;
+};
+struct VgCandidates { float line_res[3], plane_res[3], inv_leaf[3]; };  // per choice; the reciprocals formed on the host
+// partial sums -> VgDecision; zeroes counters[0..16)
+// (also zeroes the look-back records of the filter's fused scan: d_scan_state[0..n_state))
+void launch_vg_decide(const double* d_part, int blocks, uint32_t n, int auto_voxel_size, const VgCandidates& cand, VgDecision* d_out,
+                      uint32_t* d_counters, unsigned long long* d_scan_state, uint32_t n_state, hipStream_t s);
 struct VoxelFilterArgs {
   const float* d_xyz; uint32_t n, stride_floats;
   float inv_leaf; int min_b[3], div_b[3];
+  const VgDecision* d_decision;  // non-null: inv_leaf / min_b / div_b are read from here on the device; d_n_cent[0] is copied to its n_leaves
+  unsigned long long* scan_state; uint32_t n_scan_state;  // non-null (all zero, d_n_cent[8] too): flags + scan + heads in one launch
   float4 *wpts, *spts;
   uint32_t *keys0, *keys1, *vals0, *vals1, *flags, *pos, *heads;
   uint32_t* d_n_cent;  // [0] number of leaves, [1] long-leaf counter (both zeroed by the caller)

@@ -318,6 +318,85 @@ __global__ __launch_bounds__(256) void leaf_heads_kernel(const uint32_t* __restr
   if (i == 0 && !valid) *n_cent = 0;
 }
 
+// leaf_flags_kernel + exclusive scan + leaf_heads_kernel in ONE launch (the scan pre-filter; four launches before): a
+// single-pass scan of the "first element of its leaf" flags with decoupled look-back (see cell_scan_table_kernel: ticket for
+// the workgroup order, records = flag << 62 | value, all zero before the launch), 2 048 elements per workgroup.
+constexpr uint32_t kHeadsItems = 2048;
+__global__ __launch_bounds__(256) void leaf_heads_scan_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n,
+                                                              const float4* __restrict__ wpts, float4* __restrict__ spts, uint32_t* __restrict__ heads,
+                                                              uint32_t* __restrict__ n_cent, unsigned long long* __restrict__ state,
+                                                              uint32_t* __restrict__ ticket) {
+  __shared__ uint32_t s_bid, s_wsum[4], s_excl;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_bid = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const uint32_t bid = s_bid;
+  constexpr int kPer = (int)(kHeadsItems / 256u);
+  const uint32_t i0 = bid * kHeadsItems + (uint32_t)tid * kPer;
+  uint32_t k[kPer + 2];  // the element before the thread's first, its kPer elements, the one behind
+#pragma unroll
+  for (int q = 0; q < kPer + 2; ++q) {
+    const uint32_t i = i0 + (uint32_t)q;  // (index of k[q] is i - 1)
+    k[q] = (i >= 1u && i - 1u < n) ? keys[i - 1u] : 0xFFFFFFFFu;
+  }
+  uint32_t f[kPer], tsum = 0;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const uint32_t i = i0 + (uint32_t)q;
+    f[q] = (i < n && k[q + 1] != 0xFFFFFFFFu && (i == 0u || k[q + 1] != k[q])) ? 1u : 0u;
+    tsum += f[q];
+  }
+  uint32_t inc = tsum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t a0 = (uint32_t)__shfl_up((int)inc, d, 64);
+    if (lane >= d) inc += a0;
+  }
+  if (lane == 63) s_wsum[wave] = inc;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
+  const uint32_t agg = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+  if (wave == 0) {
+    if (lane == 0) __hip_atomic_store(&state[bid], ((bid == 0u ? 2ull : 1ull) << 62) | (unsigned long long)agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t excl = 0;
+    int base = (int)bid - 1;
+    while (base >= 0) {
+      const int j = base - lane;
+      unsigned long long rec = 2ull << 62;
+      if (j >= 0) {
+        do { rec = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((rec >> 62) == 0ull);
+      }
+      const unsigned long long mi = __ballot((rec >> 62) == 2ull);
+      const int first = mi ? __ffsll((long long)mi) - 1 : 64;
+      uint32_t contrib = lane <= first ? (uint32_t)(rec & 0xFFFFFFFFull) : 0u;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) contrib += (uint32_t)__shfl_xor((int)contrib, d, 64);
+      excl += contrib;
+      if (mi) break;
+      base -= 64;
+    }
+    if (lane == 0) {
+      if (bid != 0u) __hip_atomic_store(&state[bid], (2ull << 62) | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_excl = excl;
+    }
+  }
+  __syncthreads();
+  uint32_t o = s_excl + wbase + inc - tsum;  // exclusive prefix of the flags in front of the thread's first element
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const uint32_t i = i0 + (uint32_t)q;
+    if (i < n) {
+      spts[i] = wpts[vals[i]];
+      if (f[q]) heads[o] = i;
+      const bool valid = k[q + 1] != 0xFFFFFFFFu;
+      if (valid && (i + 1u == n || k[q + 2] == 0xFFFFFFFFu)) { heads[o + f[q]] = i + 1u; *n_cent = o + f[q]; }  // last valid element
+      if (i == 0u && !valid) *n_cent = 0u;
+      o += f[q];
+    }
+  }
+}
+
 // one thread per leaf: accumulate the leaf's points in (stable-sorted) input order in float, divide by float(count)
 // (pcl::CentroidPoint / AccumulatorXYZ semantics); emits the cell key of the centroid for the second sort.
 // The sums must run in order (float addition, PCL accumulates in input order), the LOADS need not: a leaf under the
@@ -1265,9 +1344,14 @@ __global__ __launch_bounds__(256) void vg_stats_kernel(const float* __restrict__
 // pcl::VoxelGrid leaf index: ijk = floor(p * inv_leaf) - min_b in float arithmetic, idx = i0 + i1*d0 + i2*d0*d1
 __global__ __launch_bounds__(256) void vg_keys_kernel(const float* __restrict__ xyz, uint32_t n, uint32_t stride_floats, float inv_leaf,
                                                       int mb0, int mb1, int mb2, int d0, int d01, float4* __restrict__ wpts,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                      const VgDecision* __restrict__ dec) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (dec) {  // the grid was laid out on the device (vg_decide_kernel)
+    inv_leaf = dec->inv_leaf; mb0 = dec->min_b[0]; mb1 = dec->min_b[1]; mb2 = dec->min_b[2];
+    d0 = dec->div_b[0]; d01 = dec->div_b[0] * dec->div_b[1];
+  }
   const float* p = xyz + (size_t)i * stride_floats;
   const float x = p[0], y = p[1], z = p[2];
   wpts[i] = make_float4(x, y, z, 0.f);
@@ -1279,8 +1363,10 @@ __global__ __launch_bounds__(256) void vg_keys_kernel(const float* __restrict__ 
 // centroid of every leaf (float sums in the stable-sorted input order), packed xyz out; long leaves go to the wavefront kernel
 __global__ __launch_bounds__(256) void vg_centroid_kernel(const uint32_t* __restrict__ heads, const uint32_t* __restrict__ n_cent,
                                                           const float4* __restrict__ spts, float* __restrict__ out,
-                                                          uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count) {
+                                                          uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count,
+                                                          VgDecision* __restrict__ dec) {
   const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o == 0u && dec) dec->n_leaves = *n_cent;  // (read back with the decision)
   if (o >= *n_cent) return;
   const uint32_t beg = heads[o], end = heads[o + 1];
   if (end - beg > kLongLeaf) {
@@ -1300,37 +1386,120 @@ __global__ __launch_bounds__(256) void vg_centroid_kernel(const uint32_t* __rest
   const float cnt = (float)(end - beg);
   out[3 * (size_t)o] = s0 / cnt; out[3 * (size_t)o + 1] = s1 / cnt; out[3 * (size_t)o + 2] = s2 / cnt;
 }
+// long leaves (the ground under the sensor: up to ~1 600 points of a raw sweep in one leaf): one WAVEFRONT per leaf and
+// coordinate.  The wavefront fetches 256 points at a time (coalesced, the next 256 in flight), parks its coordinate in LDS,
+// and every lane adds the same values in order from its own registers: one dependent addition per element (handing the
+// elements around with v_readlane cost readlane + wait state + add per element and coordinate: 20 us for 1 636 points).
+// Values behind the end of the leaf are +0.0f (s + 0.0f == s).
 __global__ __launch_bounds__(256) void vg_centroid_long_kernel(const uint32_t* __restrict__ heads, const float4* __restrict__ spts,
                                                                float* __restrict__ out, const uint32_t* __restrict__ long_list,
                                                                const uint32_t* __restrict__ long_count) {
+  __shared__ __attribute__((aligned(16))) float buf[4][2][256];
   const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t n_long = *long_count < kMaxLongLeaves ? *long_count : kMaxLongLeaves;
-  if (w >= n_long) return;
-  const uint32_t o = long_list[w];
+  if (w >= 3u * n_long) return;
+  const uint32_t o = long_list[w / 3u];
+  const uint32_t axis = w % 3u;
   const uint32_t beg = heads[o], end = heads[o + 1];
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  float4 cur = spts[beg + lane < end ? beg + lane : end - 1];
-  for (uint32_t j = beg; j < end; j += 64) {
-    const uint32_t jn = j + 64;
-    float4 nxt = cur;
-    if (jn < end) nxt = spts[jn + lane < end ? jn + lane : end - 1];
-    const bool live = j + (uint32_t)lane < end;
-    const float x = live ? cur.x : 0.f, y = live ? cur.y : 0.f, z = live ? cur.z : 0.f;
+  const float* src = reinterpret_cast<const float*>(spts) + axis;
+  float s = 0.f;
+  float nxt[4];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) {
-      s0 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), k));
-      s1 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(y), k));
-      s2 += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(z), k));
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t idx = beg + (uint32_t)k * 64u + (uint32_t)lane;
+    nxt[k] = idx < end ? src[4 * (size_t)idx] : 0.f;
+  }
+  int ph = 0;
+  for (uint32_t base = beg; base < end; base += 256u, ph ^= 1) {
+    float* b = buf[wv][ph];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k * 64 + lane] = nxt[k];
+    if (base + 256u < end) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t idx = base + 256u + (uint32_t)k * 64u + (uint32_t)lane;
+        nxt[k] = idx < end ? src[4 * (size_t)idx] : 0.f;
+      }
     }
-    cur = nxt;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t m = end - base < 256u ? end - base : 256u, m4 = (m + 3u) & ~3u;
+    for (uint32_t q = 0; q < m4; q += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(b + q);
+      s += v.x; s += v.y; s += v.z; s += v.w;
+    }
   }
-  if (lane == 0) {
-    const float cnt = (float)(end - beg);
-    out[3 * (size_t)o] = s0 / cnt; out[3 * (size_t)o + 1] = s1 / cnt; out[3 * (size_t)o + 2] = s2 / cnt;
-  }
+  if (lane == 0) out[3 * (size_t)o + axis] = s / (float)(end - beg);
 }
 
+// adjustVoxelSize's decision and the leaf grid of pcl::VoxelGrid, on the device (VgDecision): what so_icp_prefilter_scan used to
+// work out on the host between two read-backs.  Threads 0..9 add the workgroups' partial statistics in workgroup order (the
+// order the host used), thread 0 decides with the host's arithmetic (laserMapping.cpp:604-636; voxel_grid.hpp applyFilter).
+constexpr int kVgStatBlocksMax = 256;
+__global__ __launch_bounds__(256) void vg_decide_kernel(const double* __restrict__ part, int blocks, uint32_t n, int auto_voxel_size, VgCandidates cand,
+                                                        VgDecision* __restrict__ out, uint32_t* __restrict__ counters,
+                                                        unsigned long long* __restrict__ scan_state, uint32_t n_state) {
+  __shared__ double acc[10];
+  __shared__ double sp[kVgStatBlocksMax * 10];  // (the partials through LDS: 256 dependent round trips to memory per thread took 54 us)
+  const int k = threadIdx.x;
+  if (k < 16) counters[k] = 0u;
+  for (uint32_t i = (uint32_t)k; i < n_state; i += blockDim.x) scan_state[i] = 0ull;
+  {  // (all of a thread's loads in flight together: a loop of unknown length made ten round trips of them)
+    constexpr int kLoads = kVgStatBlocksMax * 10 / 256;
+    double v[kLoads];
+#pragma unroll
+    for (int q = 0; q < kLoads; ++q) v[q] = k + q * 256 < blocks * 10 ? part[k + q * 256] : 0.0;
+#pragma unroll
+    for (int q = 0; q < kLoads; ++q) sp[k + q * 256] = v[q];
+  }
+  __syncthreads();
+  if (k < 10) {
+    double a = k < 4 ? 0.0 : (k < 7 ? 3.0e38 : -3.0e38);
+    for (int b0 = 0; b0 < blocks; b0 += 16) {  // sixteen values on their way at a time, folded in workgroup order
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = b0 + q < blocks ? sp[(b0 + q) * 10 + k] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (b0 + q < blocks) a = k < 4 ? a + v[q] : (k < 7 ? fmin(a, v[q]) : fmax(a, v[q]));
+    }
+    acc[k] = a;
+    out->acc[k] = a;
+  }
+  __syncthreads();
+  if (k != 0) return;
+  uint32_t flags = 0u;
+  int choice = 1;
+  float avg = 0.f;
+  if (auto_voxel_size) {
+    const double dn = (double)n;
+    const float ax = (float)(acc[0] / dn), ay = (float)(acc[1] / dn), az = (float)(acc[2] / dn);
+    const double stat64 = (acc[0] / dn) * (acc[1] / dn) * (acc[2] / dn);
+    const double band = 3.1 * dn * 5.9604644775390625e-8 + 1e-6;
+    if (fabs(stat64 - 25.0) <= 25.0 * band || fabs(stat64 - 65.0) <= 65.0 * band) flags |= kVgNeedInputOrder;
+    avg = ax * ay * az;  // laserMapping.cpp:620-621 (float product)
+    if ((double)avg < 25) choice = 0;
+    else if ((double)avg > 65) choice = 2;
+  }
+  const float inv = cand.inv_leaf[choice];
+  const float mn[3] = {(float)acc[4], (float)acc[5], (float)acc[6]}, mx[3] = {(float)acc[7], (float)acc[8], (float)acc[9]};
+  const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  if (dx * dy * dz > (long long)INT32_MAX) flags |= kVgLeafTooSmall;
+  for (int a = 0; a < 3; ++a) {
+    out->min_b[a] = (int)floorf(mn[a] * inv);
+    out->div_b[a] = (int)floorf(mx[a] * inv) - out->min_b[a] + 1;
+  }
+  out->average_distance = avg; out->leaf = cand.plane_res[choice]; out->inv_leaf = inv;
+  out->line_res = cand.line_res[choice]; out->plane_res = cand.plane_res[choice];
+  out->choice = choice; out->flags = flags; out->n_leaves = 0u;
+}
+void launch_vg_decide(const double* d_part, int blocks, uint32_t n, int auto_voxel_size, const VgCandidates& cand, VgDecision* d_out,
+                      uint32_t* d_counters, unsigned long long* d_scan_state, uint32_t n_state, hipStream_t s) {
+  hipLaunchKernelGGL(vg_decide_kernel, dim3(1), dim3(256), 0, s, d_part, blocks <= kVgStatBlocksMax ? blocks : kVgStatBlocksMax, n, auto_voxel_size, cand,
+                     d_out, d_counters, d_scan_state, n_state);
+}
 // Stable (key, index) sort of the working set: merge sort with 2048-item block sorts and odd-even merges (measured against
 // rocPRIM's own choice, its Onesweep radix sort and two other merge configurations in rounds 1-2: the fastest at these sizes).
 static hipError_t map_sort(void* tmp, size_t& bytes, const uint32_t* ki, uint32_t* ko, const uint32_t* vi, uint32_t* vo, size_t n,
@@ -1567,16 +1736,22 @@ void launch_vg_stats(const float* d_xyz, uint32_t n, uint32_t stride_floats, dou
 void launch_voxel_filter(const VoxelFilterArgs& a, hipStream_t s) {
   const uint32_t n = a.n;
   hipLaunchKernelGGL(vg_keys_kernel, grid_for(n, 256), dim3(256), 0, s, a.d_xyz, n, a.stride_floats, a.inv_leaf, a.min_b[0], a.min_b[1],
-                     a.min_b[2], a.div_b[0], a.div_b[0] * a.div_b[1], a.wpts, a.keys0, a.vals0);
+                     a.min_b[2], a.div_b[0], a.div_b[0] * a.div_b[1], a.wpts, a.keys0, a.vals0, a.d_decision);
   size_t tb = a.temp_bytes;
   (void)map_sort(a.temp, tb, a.keys0, a.keys1, a.vals0, a.vals1, (size_t)n, 32, s);  // stable: input order inside a leaf
-  hipLaunchKernelGGL(leaf_flags_kernel, grid_for(n, 256), dim3(256), 0, s, a.keys1, n, a.flags);
-  tb = a.temp_bytes;
-  (void)rocprim::exclusive_scan(a.temp, tb, a.flags, a.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), s);
-  hipLaunchKernelGGL(leaf_heads_kernel, grid_for(n, 256), dim3(256), 0, s, a.keys1, a.vals1, a.flags, a.pos, n, a.wpts, a.spts, a.heads,
-                     a.d_n_cent);
-  hipLaunchKernelGGL(vg_centroid_kernel, grid_for(n, 256), dim3(256), 0, s, a.heads, a.d_n_cent, a.spts, a.d_out, a.flags, a.d_n_cent + 1);
-  hipLaunchKernelGGL(vg_centroid_long_kernel, dim3(kMaxLongLeaves / 4), dim3(256), 0, s, a.heads, a.spts, a.d_out, a.flags, a.d_n_cent + 1);
+  if (a.scan_state && (n + kHeadsItems - 1u) / kHeadsItems <= a.n_scan_state) {
+    hipLaunchKernelGGL(leaf_heads_scan_kernel, dim3((n + kHeadsItems - 1u) / kHeadsItems), dim3(256), 0, s, a.keys1, a.vals1, n, a.wpts, a.spts, a.heads,
+                       a.d_n_cent, a.scan_state, a.d_n_cent + 8);
+  } else {
+    hipLaunchKernelGGL(leaf_flags_kernel, grid_for(n, 256), dim3(256), 0, s, a.keys1, n, a.flags);
+    tb = a.temp_bytes;
+    (void)rocprim::exclusive_scan(a.temp, tb, a.flags, a.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), s);
+    hipLaunchKernelGGL(leaf_heads_kernel, grid_for(n, 256), dim3(256), 0, s, a.keys1, a.vals1, a.flags, a.pos, n, a.wpts, a.spts, a.heads,
+                       a.d_n_cent);
+  }
+  hipLaunchKernelGGL(vg_centroid_kernel, grid_for(n, 256), dim3(256), 0, s, a.heads, a.d_n_cent, a.spts, a.d_out, a.flags, a.d_n_cent + 1,
+                     const_cast<VgDecision*>(a.d_decision));
+  hipLaunchKernelGGL(vg_centroid_long_kernel, dim3(3 * kMaxLongLeaves / 4), dim3(256), 0, s, a.heads, a.spts, a.d_out, a.flags, a.d_n_cent + 1);
 }
 // ---- featureExtraction::removePointDistortion (featureExtraction.cpp:223-314): SURVEY 8(f) row f4, the step that produces
 // the cloud the feature extraction (and through it this path) consumes.  One thread per point: pose of the stamped-pose

@@ -381,3 +381,32 @@ def test_localization_with_deferred_insert_equals_the_synchronous_one(gpu_slam_f
     for r in runs[1:]:
         assert np.array_equal(runs[0][0], r[0]) and runs[0][1] == r[1] and np.array_equal(runs[0][2], r[2])
     assert runs[0][3][0] >= 3 and runs[0][3] == runs[1][3] and runs[2][3] == (0, 0), [r[3] for r in runs]
+
+
+def test_prefilter_decided_on_the_device_equals_the_host_decided_one(oracle, gpu_slam_factory, monkeypatch):
+    """so_icp_prefilter_scan as one enqueue (statistics -> resolution choice and leaf grid on the device -> VoxelGrid -> one
+    read-back) against SOICP_PREFILTER_FAST=0 (statistics read back, decided on the host): the same info, the same filtered
+    cloud bit for bit, on clouds of three scales (the three resolution choices), with and without auto_voxel_size, and with the
+    long leaves of a raw sweep; one of them against the oracle's pcl::VoxelGrid restatement."""
+    sc = synth.Scene("small")
+    base = sc.scan(3).astype(np.float32)
+    rng = np.random.default_rng(17)
+    clouds = [base, (base * np.float32(0.35)).astype(np.float32), (base * np.float32(3.0)).astype(np.float32),
+              np.concatenate([base, (rng.normal(0, 0.03, (5000, 3)) + [1.0, 0.5, -1.0]).astype(np.float32)])[rng.permutation(len(base) + 5000)]]
+    outs = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("SOICP_PREFILTER_FAST", fast)
+        slam = gpu_slam_factory(plane_res=0.4, line_res=0.2, max_surface_features=-1, max_iterations=3)
+        res = []
+        for cl in clouds:
+            for auto in (True, False):
+                slam.set_resolution(0.2, 0.4)
+                d, n, info = slam.prefilter_scan(np.ascontiguousarray(cl), auto, 0.2, 0.4)
+                res.append((slam.download_scan(d, n), info.average_distance, info.count_far_points, info.increase_blind_radius, info.line_res,
+                            info.plane_res, info.statistic_in_input_order))
+        outs.append(res)
+        slam.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (a[1:], b[1:])
+    assert {round(r[5], 3) for r in outs[0]} == {0.2, 0.4, 0.8}, "the three clouds should exercise the three choices"
+    assert np.array_equal(outs[0][6][0], oracle.voxel_grid(clouds[3], outs[0][6][5]))

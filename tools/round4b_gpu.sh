@@ -32,6 +32,10 @@ fi
 if [[ $ST == *n* ]]; then
   timeout 400 bash tools/localization_timeline.sh $TAG node 2>&1 | tail -70
 fi
+if [[ $ST == *f* ]]; then
+  timeout 300 python tools/soak_prefilter.py --seconds 30 2>&1 | tail -4 | tee $O/soak_prefilter.txt
+  timeout 300 python -m pytest tests/test_gpu_node.py -x -q -m gpu 2>&1 | tail -4
+fi
 if [[ $ST == *s* ]]; then
   timeout 500 python tools/soak_map_insert.py --oracle --seconds 40 2>&1 | tail -6 | tee $O/soak_map_insert.txt
   timeout 500 python tools/soak_localization.py --seconds 40 2>&1 | tail -6 | tee $O/soak_localization.txt
