@@ -219,9 +219,9 @@ bool DeviceMap::view(DevMapView& v, std::string& err) {
 // the reference re-filters a block only when the next insert touches it (LocalMap.h:617-641), untouched blocks keep
 // their points.  Only the cell tables are rebuilt for the new cell size (launch_map_retable), on the device.
 int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err) {
-  if (const int rs = settle(err); rs < 0) return rs;
   line_res_ = line_res;
-  if (plane_res == plane_res_ && nc_ > 1) return 0;
+  if (plane_res == plane_res_ && nc_ > 1) return 0;  // (pushed every frame, lmap.cpp:648-649: nothing to wait for)
+  if (const int rs = settle(err); rs < 0) return rs;
   meta_dirty_ = true;  // ("filtered on the current grid" changes its meaning with planeRes)
   const float old_res = plane_res_;
   const bool had = size_local() > 0 && nc_ > 1;

@@ -199,6 +199,8 @@ struct so_icp_ctx {
   VgDecision* h_pf = nullptr;         // pinned read-back of the decision
   size_t pf_temp_for = 0, pf_temp_need = 0;  // map_sort_temp_bytes(pf_temp_for) == pf_temp_need (the query costs two library calls)
   bool pf_fast = true;                // SOICP_PREFILTER_FAST=0: statistics read back, decided on the host, then the filter (rounds 1-3)
+  hipStream_t pf_stream = nullptr;    // the pre-filter's own queue: the next frame's upload + VoxelGrid run BESIDE the map insert the previous
+  bool pf_own_stream = true;          // Localization() left in the context's queue (SOICP_PREFILTER_STREAM=0: behind it, in that queue)
   // Seam B scratch
   DevBuf d_q, d_nbr, d_d2, d_idx, d_found, d_fblist;
   // persistent LidarSLAM state
@@ -1320,6 +1322,7 @@ so_icp_ctx::~so_icp_ctx() {
   if (h_pf) (void)hipHostFree(h_pf);
   for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
   dmap.reset();  // (waits for a deferred insert on `stream`)
+  if (pf_stream) { (void)hipStreamSynchronize(pf_stream); (void)hipStreamDestroy(pf_stream); }
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -1421,6 +1424,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_SPECULATE")) c->speculate = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_OUTER_EVENTS")) c->outer_events = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PREFILTER_FAST")) c->pf_fast = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_PREFILTER_STREAM")) c->pf_own_stream = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_ABLATE")) c->ablate = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
@@ -2122,9 +2126,8 @@ static int prefilter_reserve_work(so_icp_ctx* c, size_t n) {
   HIP_TRY(c, c->pf_out.reserve((n + 64) * 12));
   return SO_ICP_OK;
 }
-static int prefilter_fast(so_icp_ctx* c, size_t n, uint32_t sf, int auto_voxel_size, float line_res, float plane_res, so_icp_prefilter_info& li,
-                          void** d_out, size_t* n_out) {
-  hipStream_t s = c->stream;
+static int prefilter_fast(so_icp_ctx* c, hipStream_t s, size_t n, uint32_t sf, int auto_voxel_size, float line_res, float plane_res,
+                          so_icp_prefilter_info& li, void** d_out, size_t* n_out) {
   constexpr int kStatBlocks = 256;
   constexpr size_t kDecOff = 64, kPartOff = 512;
   static_assert(kDecOff + sizeof(VgDecision) <= kPartOff, "layout of pf_dec");
@@ -2180,7 +2183,12 @@ int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stri
   if (stride_bytes == 0) stride_bytes = 12;
   if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
   const uint32_t sf = (uint32_t)(stride_bytes / 4);
-  hipStream_t s = c->stream;
+  // The pre-filter reads the caller's cloud and writes its own buffers: nothing the map insert of the previous frame (still in the
+  // context's queue when Localization() returned) touches -- that insert's first kernel, the only reader of the previous filtered
+  // cloud, had finished before Localization() returned.  On its own queue it runs beside the insert instead of behind it; the call
+  // returns after its own read-back, so the registration that follows finds the filtered cloud complete.
+  if (c->pf_own_stream && !c->pf_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking));
+  hipStream_t s = c->pf_own_stream ? c->pf_stream : c->stream;
   so_icp_prefilter_info li;
   std::memset(&li, 0, sizeof(li));
   li.line_res = line_res; li.plane_res = plane_res;
@@ -2190,7 +2198,7 @@ int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stri
   HIP_TRY(c, c->pf_in.reserve(n * stride_bytes + 64));
   HIP_TRY(c, hipMemcpyAsync(c->pf_in.p, xyz, n * stride_bytes, hipMemcpyHostToDevice, s));
   if (c->pf_fast) {
-    const int frc = prefilter_fast(c, n, sf, auto_voxel_size, line_res, plane_res, li, d_out, n_out);
+    const int frc = prefilter_fast(c, s, n, sf, auto_voxel_size, line_res, plane_res, li, d_out, n_out);
     if (frc != kPrefilterHostPath) { if (frc == SO_ICP_OK && info) *info = li; return frc; }
     std::memset(&li, 0, sizeof(li)); li.line_res = line_res; li.plane_res = plane_res;
   }

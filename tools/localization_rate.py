@@ -18,11 +18,13 @@ ap = argparse.ArgumentParser(); ap.add_argument("--calls", type=int, default=64)
 a = ap.parse_args()
 # node / node_hostbuilt: what laserMapping does per frame (lmap.cpp:600-651, then :250-263): the surf cloud is voxel-filtered at
 # planeRes on the device (so_icp_prefilter_scan) and Localization() runs on the filtered cloud, which is also what is inserted
-ENV = {"node": {}, "node_hostbuilt": {"SOICP_MAP_FAST": "0"}, "default": {}, "nodefer": {"SOICP_MAP_DEFER": "0"}, "hostbuilt": {"SOICP_MAP_FAST": "0"}, "staged": {}, "staged_hostbuilt": {"SOICP_MAP_FAST": "0"}}
+# node_r3: the node order with this session's switches off (host-built insert rounds, host-decided pre-filter in the context's queue)
+ENV = {"node": {}, "node_pageable": {}, "node_samequeue": {"SOICP_PREFILTER_STREAM": "0"}, "node_hostbuilt": {"SOICP_MAP_FAST": "0"},
+       "node_r3": {"SOICP_MAP_FAST": "0", "SOICP_PREFILTER_FAST": "0", "SOICP_PREFILTER_STREAM": "0"}, "default": {}, "nodefer": {"SOICP_MAP_DEFER": "0"}, "hostbuilt": {"SOICP_MAP_FAST": "0"}, "staged": {}, "staged_hostbuilt": {"SOICP_MAP_FAST": "0"}}
 sc = synth.Scene("os1_128_2m")
 scans = [sc.scan(i % 4) for i in range(4)]; guesses = [sc.guess(i % 4) for i in range(4)]
 for mode in a.modes.split(","):
-    for k in ("SOICP_MAP_DEFER", "SOICP_MAP_FAST"):
+    for k in ("SOICP_MAP_DEFER", "SOICP_MAP_FAST", "SOICP_PREFILTER_FAST", "SOICP_PREFILTER_STREAM"):
         os.environ.pop(k, None)
     os.environ.update(ENV[mode])
     slam = binding.LidarSlamGpu(device_id=0, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_iterations=5, lm_max_iterations=4,
@@ -30,7 +32,8 @@ for mode in a.modes.split(","):
     slam.add_surf_point_cloud(sc.map_points)
     slam.shift_map(sc.gt_pose(0)[:3])
     staged = mode.startswith("staged")
-    bufs = [slam.host_alloc_like(x) for x in scans] if staged else scans
+    # (node: the raw clouds sit in so_icp_host_alloc memory, like the message pool of INTEGRATION.md section 6; node_pageable / node_r3: numpy's)
+    bufs = [slam.host_alloc_like(x) for x in scans] if (staged or mode in ("node", "node_samequeue", "node_hostbuilt")) else scans
     times = []; pre = []; nf = 0
     t_all = time.perf_counter()
     for k in range(a.calls + 2):
@@ -43,7 +46,7 @@ for mode in a.modes.split(","):
                 slam.stage_scan(bufs[0])
             slam.stage_scan(bufs[(k + 1) % 4])
         if mode.startswith("node"):
-            d_scan, n_f, info = slam.prefilter_scan(scans[i], False, sc.plane_res / 2, sc.plane_res)
+            d_scan, n_f, info = slam.prefilter_scan(bufs[i], False, sc.plane_res / 2, sc.plane_res)
             t_pre = time.perf_counter() - t
             rc, pose, st = slam.localization_dev(True, guesses[i], d_scan, n_f, 0.1 * k)
             pre.append(t_pre); nf = n_f

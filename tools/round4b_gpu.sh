@@ -23,7 +23,7 @@ if [[ $ST == *t* ]]; then
   timeout 1500 python -m pytest tests -q -m gpu --durations=6 2>&1 | tail -120 > $O/pytest_gpu.log; tail -14 $O/pytest_gpu.log
 fi
 if [[ $ST == *l* ]]; then
-  timeout 400 python tools/localization_rate.py --calls 64 --modes default,hostbuilt,staged,staged_hostbuilt,node,node_hostbuilt,default 2>&1 | tail -8 | tee $O/localization_rate.txt
+  timeout 400 python tools/localization_rate.py --calls 64 --modes default,hostbuilt,staged,staged_hostbuilt,node,node_pageable,node_samequeue,node_hostbuilt,node_r3,node 2>&1 | tail -8 | tee $O/localization_rate.txt
 fi
 if [[ $ST == *p* ]]; then
   timeout 400 bash tools/localization_timeline.sh $TAG 2>&1 | tail -60
