@@ -370,6 +370,51 @@ def main():
         if world > 1:
             full.close()
 
+    # ---- Localization() per frame (rows f1 / f2 next to the path): registration + device-side map insert, on a context of its own
+    #      (the insert changes the map).  "raw_sweep": the 131 072-point scans themselves, the next one announced ahead
+    #      (so_icp_stage_scan); "node_order": what laserMapping does per frame -- so_icp_prefilter_scan (VoxelGrid at planeRes,
+    #      lmap.cpp:600-651) and Localization() on the filtered cloud (:250-263).
+    loc = None
+    if world == 1 and not args.no_secondary:
+        try:
+            ls = binding.LidarSlamGpu(rank=0, world_size=1, time_kernels=0, **mk)
+            ls.add_surf_point_cloud(sc.map_points)
+            ls.shift_map(sc.gt_pose(0)[:3])
+            bufs = [ls.host_alloc_like(x) for x in scans]
+            frames = 48
+
+            def run(node_order):
+                ts = []
+                for k in range(frames + 4):
+                    if k == 4:
+                        ls.map_size()  # (settles the insert in flight: the clock starts on an idle device)
+                        t_all = time.perf_counter()
+                    i = k % args.scans
+                    t = time.perf_counter()
+                    if node_order:
+                        d_f, n_f, _ = ls.prefilter_scan(bufs[i], False, sc.plane_res / 2, sc.plane_res)
+                        rc_l, _, _ = ls.localization_dev(True, guesses[i], d_f, n_f, 0.1 * k)
+                    else:
+                        if k == 0:
+                            ls.stage_scan(bufs[0])
+                        ls.stage_scan(bufs[(k + 1) % args.scans])
+                        rc_l, _, _ = ls.localization(True, guesses[i], bufs[i], 0.1 * k)
+                    ts.append(time.perf_counter() - t)
+                    assert rc_l == 0
+                ls.map_size()  # (the last insert included)
+                return 1e3 * (time.perf_counter() - t_all) / frames, 1e3 * float(np.median(ts[4:]))
+
+            raw_ms, raw_call = run(False)
+            node_ms, node_call = run(True)
+            built, handed_back = ls.map_insert_stats()
+            loc = {"raw_sweep_ms_per_frame": raw_ms, "raw_sweep_call_ms_median": raw_call, "node_order_ms_per_frame": node_ms,
+                   "node_order_call_ms_median": node_call, "frames": frames, "inserts_laid_out_by_the_device": built, "handed_back_to_the_host": handed_back,
+                   "note": "ms per frame = wall time of `frames` back-to-back frames incl. every map insert; call = prefilter (node order) + Localization() "
+                           "as the caller sees them (the insert completes behind the call)"}
+            ls.close()
+        except Exception as e:  # a secondary measurement must not cost the line
+            loc = {"unavailable": repr(e)}
+
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -525,6 +570,7 @@ def main():
                      "rest_ms_per_registration": max(ms_per_step - prof["knn_ms"] - prof["solve_ms"] - prof["binning_ms"], 0.0)}
                     if prof else None),
         "batch64": batch,
+        "localization": loc,
         "other_shard_mode": other_mode,
         "predicted_scaling": predicted,
     }

@@ -60,5 +60,6 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("value %.1f ms/step %.4f | entry_points %s | knn us %.2f frac %.4f | batch64 %s | parity %s" % (
     d["value"], d["ms_per_step"], {k: round(v, 1) for k, v in d["entry_points"].items() if k != "note"}, 1e3 * d["roofline"]["avg_launch_ms"],
     d["roofline"]["frac"], round((d.get("batch64") or {}).get("value", 0), 1), d.get("parity_vs_oracle_m_rad")))
+print("localization", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (d.get("localization") or {}).items() if k != "note"})
 PY
 fi
