@@ -874,18 +874,24 @@ __device__ __forceinline__ void leafhash_giant_groups(uint32_t first_leaf, uint3
       const float* src = tid < 64 ? sx : (tid < 128 ? sy : sz);
       float acc = 0.f;
       const uint32_t n16 = cnt & ~15u;
-      float4 cur[4], nxt[4];
+      float4 bufa[4], bufb[4];  // two register sets taking turns (no copies between them)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) cur[q] = n16 ? *reinterpret_cast<const float4*>(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (uint32_t j = 0; j < n16; j += 16) {
+      for (int q = 0; q < 4; ++q) bufa[q] = n16 ? *reinterpret_cast<const float4*>(src + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (uint32_t j = 0; j < n16; j += 32) {
         if (j + 16 < n16) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) nxt[q] = *reinterpret_cast<const float4*>(src + j + 16 + 4 * q);
+          for (int q = 0; q < 4; ++q) bufb[q] = *reinterpret_cast<const float4*>(src + j + 16 + 4 * q);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { acc += cur[q].x; acc += cur[q].y; acc += cur[q].z; acc += cur[q].w; }
+        for (int q = 0; q < 4; ++q) { acc += bufa[q].x; acc += bufa[q].y; acc += bufa[q].z; acc += bufa[q].w; }
+        if (j + 16 < n16) {
+          if (j + 32 < n16) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+            for (int q = 0; q < 4; ++q) bufa[q] = *reinterpret_cast<const float4*>(src + j + 32 + 4 * q);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { acc += bufb[q].x; acc += bufb[q].y; acc += bufb[q].z; acc += bufb[q].w; }
+        }
       }
       for (uint32_t j = n16; j < cnt; ++j) acc += src[j];
       if (lane == 0) sums[tid >> 6] = __float_as_uint(acc);
@@ -915,9 +921,13 @@ __global__ __launch_bounds__(kGiantThreads) void leafhash_centroids_kernel(const
   if (blockIdx.x < giant_blocks)
     leafhash_giant_groups(blockIdx.x, giant_blocks, gstart, gcount, members, wpts, leaf_keys, n_old, n_new, nhist, tt, nc, inv_cell, cent, keys2, giant_list,
                           giant_count, overflow, cc);
-  else if (blockIdx.x < giant_blocks + small_blocks)
-    leafhash_small_groups((blockIdx.x - giant_blocks) * blockDim.x + threadIdx.x, gstart, gcount, cursor, members, wpts, leaf_keys, n_old, tt, nc, inv_cell,
-                          cent, keys2, n_cent, cc);
+  else if (blockIdx.x < giant_blocks + small_blocks) {
+    // (four of the sixteen wavefronts work, the others end at once: 256 groups per workgroup spread the gathers over all the
+    //  compute units -- with 1 024 groups per workgroup half of them sat idle and this part took 19 us instead of 11)
+    if (threadIdx.x < 256u)
+      leafhash_small_groups((blockIdx.x - giant_blocks) * 256u + threadIdx.x, gstart, gcount, cursor, members, wpts, leaf_keys, n_old, tt, nc, inv_cell,
+                            cent, keys2, n_cent, cc);
+  }
   else
     leafhash_medium_groups(((blockIdx.x - giant_blocks - small_blocks) * blockDim.x + threadIdx.x) >> 6,
                            ((gridDim.x - giant_blocks - small_blocks) * blockDim.x) >> 6, threadIdx.x & 63, gstart, gcount, members, wpts, leaf_keys, n_old, tt,
@@ -1553,7 +1563,7 @@ static uint32_t* launch_first_stage_hashed(const MapInsertArgs& a, hipStream_t s
                      giant_list, a.d_n_cent + 4);
   hipLaunchKernelGGL(leafhash_place_kernel, grid_for(total, 256), dim3(256), 0, s, a.keys1, a.vals1, a.n_new, a.d_tt, a.ht_off, a.pos);
   const uint32_t max_medium = a.n_new / 16u + 1u, max_giant = a.n_new / 64u + 1u;
-  const uint32_t small_blocks = (a.n_new ? a.n_new + kGiantThreads - 1u : (uint32_t)kGiantThreads) / kGiantThreads;
+  const uint32_t small_blocks = (a.n_new ? a.n_new + 255u : 256u) / 256u;  // (256 groups per workgroup, see the kernel)
   const uint32_t medium_blocks = max_medium < 2048u ? (max_medium + 15u) / 16u : 128u, giant_blocks = max_giant < 512u ? max_giant : 512u;
   const size_t giant_lds = giant_lds_bytes(a.n_new);
   const uint32_t nhist = giant_hist_entries(a.n_new);
