@@ -1964,8 +1964,16 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   return SO_ICP_OK;
 }
 
+// The queue of the host-in / host-out steps around Localization() (pre-filter, de-skew, registered scan): they touch nothing the
+// map insert of the previous frame uses, so they need not wait behind it in the context's queue (SOICP_PREFILTER_STREAM=0: they do).
+static hipStream_t aux_stream(so_icp_ctx* c) {
+  if (!c->pf_own_stream) return c->stream;
+  if (!c->pf_stream && hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return c->stream; }
+  return c->pf_stream;
+}
+
 // featureExtraction::removePointDistortion, featureExtraction.cpp:223-314 (kernel: map_kernels.hip deskew_kernel)
-static int deskew_core(so_icp_ctx* c, void* d_points, size_t n, size_t stride, size_t time_off, double t0, const so_icp_stamped_pose* poses,
+static int deskew_core(so_icp_ctx* c, hipStream_t s, void* d_points, size_t n, size_t stride, size_t time_off, double t0, const so_icp_stamped_pose* poses,
                        size_t n_poses, int imu, const double T_i_l[7], so_icp_deskew_info* info) {
   static_assert(sizeof(so_icp_stamped_pose) == kStampedPoseDoubles * sizeof(double), "stamped pose = 8 doubles");
   const double* tab = reinterpret_cast<const double*>(poses);
@@ -1987,7 +1995,6 @@ static int deskew_core(so_icp_ctx* c, void* d_points, size_t n, size_t stride, s
     for (int k = 0; k < 3; ++k) info->t_w_original_l[k] = sensor.t[k];
   }
   if (!n) return SO_ICP_OK;
-  hipStream_t s = c->stream;
   std::vector<double> host_tab(tab, tab + n_poses * kStampedPoseDoubles);
   if (imu) for (size_t k = 0; k < n_poses; ++k) host_tab[k * 8 + 1] = host_tab[k * 8 + 2] = host_tab[k * 8 + 3] = 0.0;
   HIP_TRY(c, c->pf_small.reserve(host_tab.size() * sizeof(double) + 64));
@@ -2017,7 +2024,7 @@ int so_icp_deskew_scan_dev(so_icp_ctx* c, void* d_points, size_t n, size_t strid
   if (rc) return rc;
   NEED_DEVICE(c);
   HIP_TRY(c, hipSetDevice(c->cfg.device_id));
-  return deskew_core(c, d_points, n, stride, time_off, t0, poses, n_poses, imu, T_i_l, info);
+  return deskew_core(c, c->stream, d_points, n, stride, time_off, t0, poses, n_poses, imu, T_i_l, info);  // (the caller's device buffer: its queue)
 }
 
 int so_icp_deskew_scan(so_icp_ctx* c, void* points, size_t n, size_t stride, size_t time_off, double t0, const so_icp_stamped_pose* poses,
@@ -2026,14 +2033,15 @@ int so_icp_deskew_scan(so_icp_ctx* c, void* points, size_t n, size_t stride, siz
   if (rc) return rc;
   NEED_DEVICE(c);
   HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  hipStream_t s = aux_stream(c);
   if (n) {
     HIP_TRY(c, c->pf_in.reserve(n * stride + 64));
-    HIP_TRY(c, hipMemcpyAsync(c->pf_in.p, points, n * stride, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->pf_in.p, points, n * stride, hipMemcpyHostToDevice, s));
   }
-  rc = deskew_core(c, c->pf_in.p, n, stride, time_off, t0, poses, n_poses, imu, T_i_l, info);
+  rc = deskew_core(c, s, c->pf_in.p, n, stride, time_off, t0, poses, n_poses, imu, T_i_l, info);
   if (rc || !n) return rc;
-  HIP_TRY(c, hipMemcpyAsync(points, c->pf_in.p, n * stride, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpyAsync(points, c->pf_in.p, n * stride, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
   return SO_ICP_OK;
 }
 
@@ -2046,7 +2054,7 @@ int so_icp_transform_cloud(so_icp_ctx* c, void* points, size_t n, size_t stride,
   HIP_TRY(c, hipSetDevice(c->cfg.device_id));
   if (n_kept) *n_kept = 0;
   if (!n) return SO_ICP_OK;
-  hipStream_t s = c->stream;
+  hipStream_t s = aux_stream(c);
   HIP_TRY(c, c->pf_in.reserve(n * stride + 64));
   HIP_TRY(c, c->pf_flags.reserve(n + 64));
   HIP_TRY(c, c->pf_small.reserve(256));
@@ -2187,8 +2195,7 @@ int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stri
   // context's queue when Localization() returned) touches -- that insert's first kernel, the only reader of the previous filtered
   // cloud, had finished before Localization() returned.  On its own queue it runs beside the insert instead of behind it; the call
   // returns after its own read-back, so the registration that follows finds the filtered cloud complete.
-  if (c->pf_own_stream && !c->pf_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking));
-  hipStream_t s = c->pf_own_stream ? c->pf_stream : c->stream;
+  hipStream_t s = aux_stream(c);
   so_icp_prefilter_info li;
   std::memset(&li, 0, sizeof(li));
   li.line_res = line_res; li.plane_res = plane_res;
