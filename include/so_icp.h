@@ -303,7 +303,11 @@ int so_icp_download_scan(so_icp_ctx *ctx, const void *d_scan_xyz, size_t n, floa
  * Then pcl::VoxelGrid (leaf = planeRes: float leaf coordinates, centroids accumulated in float in input order, output in
  * ascending leaf index; "leaf size too small" passes the cloud through) and localMap.lineRes_/planeRes_ = the result
  * (lmap.cpp:648-649).  *d_filtered_out (packed float xyz, owned by the context, valid until the next call) feeds
- * so_icp_register_dev / so_icp_localization_dev without a host round trip. */
+ * so_icp_register_dev / so_icp_localization_dev without a host round trip.
+ * One enqueue, one read-back: the statistics are reduced, the resolution chosen and the leaf grid laid out on the device
+ * (only a statistic inside the rounding band of a threshold, or PCL's "leaf size too small" pass-through, goes through the
+ * host); the call runs on a queue of its own, beside the map insert the previous so_icp_localization left in the
+ * context's queue, and returns when the filtered cloud is complete. */
 typedef struct {
   double average_distance;
   int32_t count_far_points, increase_blind_radius;
