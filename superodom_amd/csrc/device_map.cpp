@@ -293,7 +293,7 @@ int DeviceMap::set_resolution(float line_res, float plane_res, std::string& err)
   return 0;
 }
 
-int DeviceMap::ensure_grid(size_t gn, std::string& err) {
+int DeviceMap::ensure_grid(size_t gn, std::string& err, bool library_scan) {
   if (gn > grid_cap_) {
     if (d_grid_) (void)hipFree(d_grid_);
     if (d_grid_scan_) (void)hipFree(d_grid_scan_);
@@ -302,7 +302,8 @@ int DeviceMap::ensure_grid(size_t gn, std::string& err) {
     DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_grid_scan_), gn * sizeof(uint32_t)));
     grid_cap_ = gn;
   }
-  if (temp_bytes_ < map_sort_temp_bytes(gn)) {  // the scan of the grids uses the sort's scratch buffer
+  // (a device-built round scans its grids with its own kernel: no scratch; sized for a whole round it would be ~100 MB)
+  if (library_scan && temp_bytes_ < map_sort_temp_bytes(gn)) {  // the scan of the grids uses the sort's scratch buffer
     if (d_temp_) (void)hipFree(d_temp_);
     d_temp_ = nullptr;
     temp_bytes_ = map_sort_temp_bytes(gn) + 256;
@@ -391,7 +392,7 @@ int DeviceMap::insert_fast(const float* d_in, size_t n, size_t stride_floats, co
     DM_TRY(hipMalloc(reinterpret_cast<void**>(&d_cube_of_), (n + 1024) * sizeof(int32_t)));
     new_cap_ = n + 1024;
   }
-  if (ensure_grid(per_round * ncell1_ + 1024, err)) return -2;
+  if (ensure_grid(per_round * ncell1_ + 1024, err, false)) return -2;
   if (ensure_leaf_table(n, err)) return -2;
   if (!block_clean_) { DM_TRY(hipMemsetAsync(d_small_, 0, kSmallWords * sizeof(uint32_t) + kMapNum, stream_)); block_clean_ = true; }
   if (!fast_clean_) {

@@ -83,7 +83,7 @@ class DeviceMap {
   void settle_quiet() const;
   int ensure_pool(int slots_needed, std::string& err);
   int ensure_work(size_t total, std::string& err);
-  int ensure_grid(size_t gn, std::string& err);
+  int ensure_grid(size_t gn, std::string& err, bool library_scan = true);
   int alloc_slot(int cube);
   hipStream_t stream_;
   int rank_ = 0, world_ = 1;
