@@ -61,6 +61,7 @@ class DeviceMap {
   // window (0 when deferred) or < 0.
   int add_scan_dev(const float* d_scan, size_t n, const double T[7], float* d_world, bool defer, std::string& err);
   bool defer_enabled() const { return defer_enabled_; }
+  bool insert_in_flight() const { return pending_.on; }  // a deferred insert has not been settled yet
   // completes a deferred insert: bookkeeping from the device's report, or -- when the device could not lay the round out --
   // the insert round by round.  Every member that reads or changes the bookkeeping calls it first.
   int settle(std::string& err);

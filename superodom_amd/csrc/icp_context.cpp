@@ -199,6 +199,7 @@ struct so_icp_ctx {
   VgDecision* h_pf = nullptr;         // pinned read-back of the decision
   size_t pf_temp_for = 0, pf_temp_need = 0;  // map_sort_temp_bytes(pf_temp_for) == pf_temp_need (the query costs two library calls)
   bool pf_fast = true;                // SOICP_PREFILTER_FAST=0: statistics read back, decided on the host, then the filter (rounds 1-3)
+  hipEvent_t ev_upload = nullptr;     // a scan uploaded through the auxiliary queue: the context's queue waits for it
   hipStream_t pf_stream = nullptr;    // the pre-filter's own queue: the next frame's upload + VoxelGrid run BESIDE the map insert the previous
   bool pf_own_stream = true;          // Localization() left in the context's queue (SOICP_PREFILTER_STREAM=0: behind it, in that queue)
   // Seam B scratch
@@ -873,13 +874,27 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
 
 // wait = false: the caller enqueues the scan's consumers on the same stream and does not return to ITS caller before they
 // have completed (so_icp_register), so the source buffer outlives the copy without a host-side wait here
+// The queue of the host-in / host-out steps around Localization() (pre-filter, de-skew, registered scan): they touch nothing the
+// map insert of the previous frame uses, so they need not wait behind it in the context's queue (SOICP_PREFILTER_STREAM=0: they do).
+static hipStream_t aux_stream(so_icp_ctx* c) {
+  if (!c->pf_own_stream) return c->stream;
+  if (!c->pf_stream && hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return c->stream; }
+  return c->pf_stream;
+}
+
 int upload_scan_impl(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, DevBuf& dst, bool wait = true) {
   if (stride_bytes == 0) stride_bytes = 12;
   if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
   HIP_TRY(c, dst.reserve((n + 64) * 12));
   if (!n) return SO_ICP_OK;
   if (stride_bytes == 12) {
-    HIP_TRY(c, hipMemcpyAsync(dst.p, xyz, n * 12, hipMemcpyHostToDevice, c->stream));
+    // The map insert of the previous Localization() may still be in the context's queue: the upload then goes through the
+    // auxiliary queue, beside it, and the context's queue waits for the copy's event (nothing in flight reads `dst`: the
+    // registration that used it has reported, the insert's only reader of it finished before that call returned).
+    hipStream_t s2 = (!wait && c->dmap && c->dmap->insert_in_flight()) ? aux_stream(c) : c->stream;
+    if (s2 != c->stream && !c->ev_upload && hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); s2 = c->stream; }
+    HIP_TRY(c, hipMemcpyAsync(dst.p, xyz, n * 12, hipMemcpyHostToDevice, s2));
+    if (s2 != c->stream) { HIP_TRY(c, hipEventRecord(c->ev_upload, s2)); HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_upload, 0)); }
     if (wait) HIP_TRY(c, hipStreamSynchronize(c->stream));
   } else {
     std::vector<float> packed(n * 3);
@@ -1323,6 +1338,7 @@ so_icp_ctx::~so_icp_ctx() {
   for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
   dmap.reset();  // (waits for a deferred insert on `stream`)
   if (pf_stream) { (void)hipStreamSynchronize(pf_stream); (void)hipStreamDestroy(pf_stream); }
+  if (ev_upload) (void)hipEventDestroy(ev_upload);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -1962,14 +1978,6 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   if (r) return r;
   c->last_time = time_laser_odometry;
   return SO_ICP_OK;
-}
-
-// The queue of the host-in / host-out steps around Localization() (pre-filter, de-skew, registered scan): they touch nothing the
-// map insert of the previous frame uses, so they need not wait behind it in the context's queue (SOICP_PREFILTER_STREAM=0: they do).
-static hipStream_t aux_stream(so_icp_ctx* c) {
-  if (!c->pf_own_stream) return c->stream;
-  if (!c->pf_stream && hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return c->stream; }
-  return c->pf_stream;
 }
 
 // featureExtraction::removePointDistortion, featureExtraction.cpp:223-314 (kernel: map_kernels.hip deskew_kernel)
