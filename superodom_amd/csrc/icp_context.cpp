@@ -280,6 +280,9 @@ struct so_icp_ctx {
   std::vector<HostRange> host_ranges;     // so_icp_host_register / so_icp_host_alloc (under stage_mu)
   bool stage_wait_on_host = false;        // SOICP_STAGE_WAIT=host: the registration thread waits for a DMA-staged copy itself (measurement aid)
   bool knn_pack = true;                   // SOICP_KNN_PACK=0: one chunk per wavefront throughout (round-3 work list)
+  bool knn_list_fits = false;             // the last registration's work list (normal + light chunks) fitted the k-NN grid one chunk per wavefront:
+                                          // packing four light chunks into a wavefront then only lengthens the longest wavefronts (a 13 k-point
+                                          // voxel-filtered scan: sweeps 20.5 + 18.6 -> 17.2 + 16.9 us unpacked); SOICP_KNN_PACK_SMALL=1 packs regardless
   int knn_pack_hold = 0;                  // registrations left without packing after one in which the packed near pass left > 3 % of
                                           // the queries to the exact per-lane scan (sparse map, far-off guess): then it is not a saving
   static constexpr int kBatchRoundsTracked = 16;
@@ -653,7 +656,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
   MatchParams mp = match_params(plane_res_now, c->ablate);
   mp.chunk_cap = (uint32_t)(c->d_chunks.cap / 4);
-  mp.pack_light = (c->knn_pack && c->knn_pack_hold == 0) ? 1 : 0;
+  static const bool pack_small = [] { const char* e = std::getenv("SOICP_KNN_PACK_SMALL"); return e && e[0] == '1'; }();
+  mp.pack_light = (c->knn_pack && c->knn_pack_hold == 0 && (pack_small || !c->knn_list_fits)) ? 1 : 0;
   mp.packed_leftover = &c->d_state->packed_leftover;
   if (c->knn_pack_hold > 0) --c->knn_pack_hold;
   if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
@@ -821,6 +825,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   c->h_state = c->h_ring[last & 1];
   const DevState& H = *c->h_state;
   if (mp.pack_light && (double)H.packed_leftover > 0.03 * (double)n * (double)std::max(H.n_iterations, 1)) c->knn_pack_hold = 32;
+  // (scans of a stream have one size: the list of this registration decides the packing of the next -- results do not depend on it)
+  c->knn_list_fits = ((H.bin_packed >> 21) & 0x1FFFFFull) + (H.bin_packed >> 42) <= (unsigned long long)kKnnBlocks * 4ull;
   fill_result(c, H, pose_in, st, pose_out, !c->batch_mode);
   st->time_elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_icp).count();  // :199-200
   if (timed) {  // keep only the launches that did real work (no-op launches after convergence are excluded)
