@@ -62,6 +62,20 @@ def _load_counters(name):
     return j, None
 
 
+class _stdout_to_stderr:
+    """gloo announces its connections on the process's stdout (fd 1); rank 0's JSON line must be the only thing there."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,15 +105,54 @@ def main():
                     help="where the HOST scan buffers of the timed loop live: pinned = so_icp_host_alloc (a node that keeps its feature clouds in a pinned "
                          "pool: DMA straight from them), registered = numpy memory pinned with so_icp_host_register, pageable = plain numpy memory (the "
                          "staged copies then go through the context's copy thread, which packs them into a pinned buffer first)")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent-contexts measurement")
+    ap.add_argument("--no-stock", action="store_true", help="skip the stock-operating-point measurement (config/os1_128.yaml, livox_mid360.yaml)")
+    ap.add_argument("--no-open-scene", action="store_true", help="skip the second perf scene (open hall, 0.5 m / 5 deg guesses)")
+    ap.add_argument("--dry-control-plane", action="store_true",
+                    help="N > 1 plumbing check without a GPU: spawn / join the ranks, rendezvous over gloo, barrier + max-over-ranks, rank 0 prints "
+                         "one JSON line -- what `bench.py --gpus N` does around the registrations (tests/test_bench_launch.py)")
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: become the launcher -- one rank per GPU through torch.distributed.run on
+        # 127.0.0.1, the same command line; rank 0's JSON line goes to our stdout unchanged.
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # hipIpc handles (peer exchange) and RCCL need dmabuf IPC on this driver
+        env.setdefault("OMP_NUM_THREADS", "1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+        args.gpus = world  # (started by a launcher with another rank count: the launcher decides)
+
+    if args.dry_control_plane:
+        import datetime
+        import torch
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            with _stdout_to_stderr():
+                dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+                dist_mod.barrier()
+            tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+            dist_mod.all_reduce(tt, op=dist_mod.ReduceOp.MAX)
+            top = float(tt.item())
+            dist_mod.barrier()
+            dist_mod.destroy_process_group()
+        else:
+            top = 1.0
+        if rank == 0:
+            print(json.dumps({"dry_control_plane": True, "n_gpus": world, "max_over_ranks_of_rank_plus_1": top}))
+        return
 
     from superodom_amd import binding, synth
 
@@ -110,12 +163,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # (every wait of the control plane is bounded: a rank that died must end the run, not hang it)
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
+        with _stdout_to_stderr():
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
+            dist.barrier()
 
     # ---------------- synthetic workload (seeded) ----------------
     sc = synth.Scene(args.workload)
     max_outer, lm_iters = args.max_outer, 4
-    device = int(os.environ.get("SOICP_BENCH_DEVICE", local_rank))
+    n_dev = max(binding.device_count(), 1)
+    device = int(os.environ.get("SOICP_BENCH_DEVICE", local_rank % n_dev))
+    ranks_per_device = world if "SOICP_BENCH_DEVICE" in os.environ else (world + n_dev - 1) // n_dev
+    if ranks_per_device > 1:
+        # development / first-run-proofing on a box with fewer GPUs than ranks: the ranks share devices.  RCCL refuses two ranks per
+        # device (the peer exchange carries the sums), and the persistent solve launches of the co-located ranks must fit the
+        # device together (one workgroup per compute unit each)
+        os.environ.setdefault("SOICP_BENCH_NO_RCCL", "1")
+        os.environ.setdefault("SOICP_SOLVE_WORKGROUPS", str(max(16, 200 // ranks_per_device)))
     mk = dict(device_id=device, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_iterations=max_outer, lm_max_iterations=lm_iters,
               max_surface_features=-1)
     def make_rank_context(shard_mode, time_kernels):
@@ -367,8 +430,93 @@ def main():
                  "parallelism": f"map replicated on {world} GPU(s), hypotheses split over the ranks; on a GPU the hypotheses advance together in batched kernels "
                                 "(one binning / k-NN / persistent solve launch per round over all of them, a workgroup group + LM controller per hypothesis), no collective",
                  "scaling": "strong"}
+        if world == 1:
+            # what a rank of an N-GPU node would run: 64 hypotheses split over N ranks are batches of 64 / N -- measured HERE, on one
+            # GPU, so that predicted_scaling.batch64_replicated_map[N] = N x rate(64 / N) is a number and not an extrapolation
+            by_size = {}
+            for B in (8, 16, 32):
+                try:
+                    full.register_batch(None, hyp[0][:B], d_scan=d_full[0][0], n=d_full[0][1])
+                    full.synchronize()
+                    t0 = time.perf_counter()
+                    n_b = 0
+                    for i in range(reps):
+                        for c0 in range(0, 64, B):
+                            full.register_batch(None, hyp[i][c0:c0 + B], d_scan=d_full[i][0], n=d_full[i][1])
+                            n_b += B
+                    full.synchronize()
+                    by_size[str(B)] = n_b / (time.perf_counter() - t0)
+                except Exception as e:  # noqa: BLE001
+                    by_size[str(B)] = {"error": repr(e)}
+            by_size["64"] = batch["value"]
+            batch["registrations_per_s_by_batch_size"] = by_size
         if world > 1:
             full.close()
+
+    # ---- concurrent contexts: 1 / 2 / 4 contexts on ONE device, each registering its own scans one after the other from its own host
+    #      thread and stream -- the single-GPU throughput over independent registrations (a node that tracks several sensors / maps),
+    #      beside the latency-chain number `value`.  The persistent solve launches of the contexts must be resident together:
+    #      each takes 200 / n workgroups (so_icp_config::solve_workgroups).
+    conc = None
+    if world == 1 and not args.no_secondary and not args.no_concurrent:
+        import threading
+        conc = {}
+        if True:
+            for n_ctx in (1, 2, 4):
+                ctxs = []
+                try:
+                    for c in range(n_ctx):
+                        cx = binding.LidarSlamGpu(rank=0, world_size=1, time_kernels=0, solve_workgroups=(200 // n_ctx if n_ctx > 1 else 0), **mk)
+                        cx.add_surf_point_cloud(sc.map_points)
+                        ctxs.append(cx)
+                    steps_c = max(args.steps, 16)
+                    plans = []
+                    for c, cx in enumerate(ctxs):
+                        dsc = [cx.upload_scan(s_) for s_ in scans]
+                        st_c = [binding.Stats() for _ in range(steps_c)]
+                        po_c = [np.zeros(7) for _ in range(steps_c)]
+                        calls = [cx.prepare_register_dev(dsc[(k + c) % args.scans][0], dsc[(k + c) % args.scans][1], g64[(k + c) % args.scans], st_c[k], po_c[k])
+                                 for k in range(steps_c)]
+                        plans.append((calls, st_c, po_c))
+                    gate = threading.Barrier(n_ctx + 1)
+                    rcs_c = [[0] * steps_c for _ in range(n_ctx)]
+
+                    def work(c):
+                        calls = plans[c][0]
+                        for k in range(min(8, steps_c)):
+                            calls[k]()
+                        ctxs[c].synchronize()
+                        gate.wait()
+                        for k in range(steps_c):
+                            rcs_c[c][k] = calls[k]()
+                        ctxs[c].synchronize()
+                        gate.wait()
+                    th = [threading.Thread(target=work, args=(c,)) for c in range(n_ctx)]
+                    for t_ in th:
+                        t_.start()
+                    gate.wait()
+                    t0 = time.perf_counter()
+                    gate.wait()
+                    dt_c = time.perf_counter() - t0
+                    for t_ in th:
+                        t_.join()
+                    flags_c = 0
+                    for c in range(n_ctx):
+                        assert all(r == 0 for r in rcs_c[c]), rcs_c[c]
+                        for s_ in plans[c][1]:
+                            flags_c |= s_.flags
+                    # same scans, same guesses as the timed loop: the poses must be the timed loop's poses (bit for bit when the
+                    # summation grid is the same; the reduced solve grid of n > 1 changes the order of the sums)
+                    dmax = max(max(synth.pose_error(plans[c][2][k], step_pose[(k + c) % args.scans])) for c in range(n_ctx) for k in range(min(steps_c, args.scans)))
+                    conc[str(n_ctx)] = {"registrations_per_s": n_ctx * steps_c / dt_c, "solve_workgroups_per_context": (200 // n_ctx if n_ctx > 1 else "one per compute unit"),
+                                        "stats_flags": int(flags_c), "max_pose_delta_vs_timed_loop_m_or_rad": dmax}
+                except Exception as e:  # noqa: BLE001
+                    conc[str(n_ctx)] = {"error": repr(e)}
+                finally:
+                    for cx in ctxs:
+                        cx.close()
+        conc["note"] = ("n contexts on one device, one host thread + stream each, resident scans, different scans in flight at the same time; "
+                        "stats_flags 0x1/0x2 = a persistent solve launch was abandoned (the contexts' launches did not become resident together)")
 
     # ---- Localization() per frame (rows f1 / f2 next to the path): registration + device-side map insert, on a context of its own
     #      (the insert changes the map).  "raw_sweep": the 131 072-point scans themselves, the next one announced ahead
@@ -414,6 +562,134 @@ def main():
             ls.close()
         except Exception as e:  # a secondary measurement must not cost the line
             loc = {"unavailable": repr(e)}
+
+    # ---- the stock operating point (what a drop-in user of the node runs): config/os1_128.yaml:26-28 -- max_iterations 5,
+    #      max_surface_features 2000, planeRes 0.2 -- in node order: so_icp_prefilter_scan (VoxelGrid at planeRes, lmap.cpp:600-651),
+    #      then the sampling rule of LS.cpp:346-359 inside the registration; and config/livox_mid360.yaml:26-28 (planeRes 0.1, 4000
+    #      features) on a 20 000-point stand-in sweep.  GPU times here; Oracle-A on one core + parity in the cpu_baseline leg.
+    stock = None
+    stock_cpu_jobs = []
+    if world == 1 and not args.no_secondary and not args.no_stock:
+        stock = {}
+
+        def stock_case(name, scene, host_scans, gs, plane_res, line_res, max_feat, cite):
+            cx = binding.LidarSlamGpu(rank=0, world_size=1, time_kernels=0, device_id=device, plane_res=plane_res, line_res=line_res,
+                                      max_iterations=5, lm_max_iterations=4, max_surface_features=max_feat)
+            try:
+                cx.add_surf_point_cloud(scene.map_points)
+                cx.shift_map(scene.gt_pose(0)[:3])
+                map_before = cx.export_map()
+                filt = []
+                for s_ in host_scans:
+                    d_f, n_f, _ = cx.prefilter_scan(s_, False, line_res, plane_res)
+                    filt.append(cx.download_scan(d_f, n_f))
+                d_filt = [cx.upload_scan(f) for f in filt]
+                ns = len(host_scans)
+                K = 96
+                st_k = [binding.Stats() for _ in range(K)]
+                po_k = [np.zeros(7) for _ in range(K)]
+                gk = [np.ascontiguousarray(g, dtype=np.float64) for g in gs]
+                calls = [cx.prepare_register_dev(d_filt[k % ns][0], d_filt[k % ns][1], gk[k % ns], st_k[k], po_k[k]) for k in range(K)]
+                for k in range(8):
+                    calls[k]()
+                cx.synchronize()
+                t0 = time.perf_counter()
+                for k in range(K):
+                    rc_ = calls[k]()
+                    assert rc_ == 0, (name, k, rc_)
+                cx.synchronize()
+                t_reg = (time.perf_counter() - t0) / K
+                # node order per frame: pre-filter + Localization() (registration + map insert), host buffers in pinned memory
+                bufs = [cx.host_alloc_like(x) for x in host_scans]
+                frames = 32
+                for k in range(frames + 4):
+                    if k == 4:
+                        cx.map_size()
+                        t0 = time.perf_counter()
+                    d_f, n_f, _ = cx.prefilter_scan(bufs[k % ns], False, line_res, plane_res)
+                    rc_l, _, _ = cx.localization_dev(True, gs[k % ns], d_f, n_f, 0.1 * k)
+                    assert rc_l == 0
+                cx.map_size()
+                t_frame = (time.perf_counter() - t0) / frames
+                sampled = int(sum(st_k[0].iterations[0].reject_hist))
+                stock[name] = {"config": cite, "plane_res": plane_res, "max_surface_features": max_feat, "max_iterations": 5,
+                               "raw_points": int(len(host_scans[0])), "filtered_points": int(len(filt[0])), "sampled_queries": sampled,
+                               "registration_ms": 1e3 * t_reg, "registrations_per_s": 1.0 / t_reg, "node_frame_ms": 1e3 * t_frame,
+                               "outer_iterations": sum(s_.n_iterations for s_ in st_k) / K,
+                               "lm_iterations": sum(s_.iterations[i].lm_iterations for s_ in st_k for i in range(s_.n_iterations)) / K,
+                               "note": "registration_ms = so_icp_register_dev on the pre-filtered resident cloud (sampling rule inside); node_frame_ms = "
+                                       "so_icp_prefilter_scan + so_icp_localization_dev incl. the map insert, back-to-back frames"}
+                stock_cpu_jobs.append((name, map_before, filt, gs, plane_res, max_feat, st_k[:ns], po_k[:ns]))
+            finally:
+                cx.close()
+        try:
+            stock_case("os1_128", sc, scans, guesses, sc.plane_res, sc.plane_res / 2, 2000, "config/os1_128.yaml:26-28")
+        except Exception as e:  # noqa: BLE001 -- a secondary measurement must not cost the line
+            stock["os1_128"] = {"unavailable": repr(e)}
+        try:
+            scl = synth.Scene("mid360_like")
+            stock_case("livox_mid360_like", scl, [np.ascontiguousarray(scl.scan(i), dtype=np.float32) for i in range(args.scans)],
+                       [scl.guess(i) for i in range(args.scans)], scl.plane_res, scl.plane_res / 2, 4000, "config/livox_mid360.yaml:26-28 (planeRes 0.1, 4000 features); "
+                       "synthetic 40 x 500 sweep standing in for the Mid-360 pattern")
+        except Exception as e:  # noqa: BLE001
+            stock["livox_mid360_like"] = {"unavailable": repr(e)}
+
+    # ---- second perf scene: an OPEN hall (1 m interior walls: the sweep reaches its 100 m range and touches nearly every occupied
+    #      cube: M_t ~ 1.9 M of the 2 M map points) registered from 0.5 m / 5 deg guesses (3 - 4 outer iterations) -- the other end of
+    #      the workload space from the headline's occluded rooms (M_t 0.42 M, 2 outer iterations)
+    open_scene = None
+    open_cpu_job = None
+    if world == 1 and not args.no_secondary and not args.no_open_scene:
+        try:
+            sco = synth.Scene("open_2m")
+            cx = binding.LidarSlamGpu(rank=0, world_size=1, time_kernels=1, device_id=device, plane_res=sco.plane_res, line_res=sco.plane_res / 2,
+                                      max_iterations=max_outer, lm_max_iterations=lm_iters, max_surface_features=-1)
+            n_map_o = cx.add_surf_point_cloud(sco.map_points)
+            ns = args.scans
+            o_scans = [cx.host_alloc_like(np.ascontiguousarray(sco.scan(i), dtype=np.float32)) for i in range(ns)]
+            o_guess = [np.ascontiguousarray(synth.perturb_pose(sco.gt_pose(i), 5000 + 64 * i, 0.5, 5.0), dtype=np.float64) for i in range(ns)]
+            K = max(args.steps, 24)
+            st_k = [binding.Stats() for _ in range(K)]
+            po_k = [np.zeros(7) for _ in range(K)]
+            calls = [cx.prepare_register(o_scans[k % ns], o_guess[k % ns], st_k[k], po_k[k]) for k in range(K)]
+            stg = [cx.prepare_stage_scan(o_scans[k % ns]) for k in range(K)]
+            for k in range(8):
+                cx.stage_scan(o_scans[k % ns]); cx.register(o_scans[k % ns], o_guess[k % ns])
+            cx.synchronize()
+            cx.reset_timing()
+            t0 = time.perf_counter()
+            stg[0]()
+            for k in range(K):
+                if k + 1 < K:
+                    stg[k + 1]()
+                rc_ = calls[k]()
+                assert rc_ == 0, (k, rc_, cx.last_error())
+            cx.synchronize()
+            t_o = (time.perf_counter() - t0) / K
+            tmo = cx.timing()
+            mko = np.floor((sco.map_points.astype(np.float64) + 25.0) / 50.0).astype(np.int64)
+            ck = lambda c: (c[:, 0] + 64) * 16384 + (c[:, 1] + 64) * 128 + (c[:, 2] + 64)
+            mt_o = []
+            for i in range(ns):
+                w_ = np.asarray(o_scans[i], np.float64) @ synth.quat_to_R(o_guess[i][3:]).T + o_guess[i][:3]
+                mt_o.append(int(np.isin(ck(mko), np.unique(ck(np.floor((w_ + 25.0) / 50.0).astype(np.int64)))).sum()))
+            knn_ms_o = tmo.knn_ms_total / max(tmo.knn_launches, 1)
+            b_o = 36.0 * len(o_scans[0]) + 12.0 * float(np.mean(mt_o))
+            errs_o = [synth.pose_error(po_k[i], sco.gt_pose(i)) for i in range(ns)]
+            open_scene = {"workload": f"open_2m: OS1-128 synthetic scan ({len(o_scans[0])} pts) vs {n_map_o}-pt map of an open hall, guesses +-0.5 m / +-5 deg per axis, staged entry",
+                          "value": 1.0 / t_o, "unit": "registrations/s", "ms_per_step": 1e3 * t_o, "steps": K,
+                          "outer_iterations_per_step": sum(s_.n_iterations for s_ in st_k) / K,
+                          "lm_iterations_per_step": sum(s_.iterations[i].lm_iterations for s_ in st_k for i in range(s_.n_iterations)) / K,
+                          "map_points_in_touched_cubes": float(np.mean(mt_o)), "knn_avg_launch_ms": knn_ms_o, "knn_launches_timed": int(tmo.knn_launches),
+                          "knn_algorithmic_bytes_per_launch": b_o, "knn_hbm_frac": (b_o / (knn_ms_o * 1e-3) / 1e9 / HBM_PEAK_GBS) if knn_ms_o > 0 else None,
+                          "pack_light": {"registrations_with_packed_light_chunks": int(tmo.knn_pack_registrations), "registrations": int(tmo.registrations),
+                                         "switched_off_by_leftover_rule": int(tmo.knn_pack_holds)},
+                          "stats_flags": int(np.bitwise_or.reduce([s_.flags for s_ in st_k])),
+                          "pose_error_vs_ground_truth_m_rad": [max(e[0] for e in errs_o), max(e[1] for e in errs_o)]}
+            open_cpu_job = (cx.export_map(), [np.array(x) for x in o_scans], o_guess, sco.plane_res, st_k[:ns], po_k[:ns])
+            cx.close()
+        except Exception as e:  # noqa: BLE001
+            open_scene = {"unavailable": repr(e)}
 
     if rank != 0:
         if dist is not None:
@@ -499,7 +775,12 @@ def main():
                                      "measured_on": "this run's profiling pass (N = %d)" % world},
                      "map_shards": {str(n): 1.0 / step_ms(n, "map") * 1e3 for n in (1, 2, 4, 8)} if world == 1 else None,
                      "query_split": {str(n): 1.0 / step_ms(n, "queries") * 1e3 for n in (1, 2, 4, 8)},
-                     "batch64_replicated_map": ({str(n): batch["value"] * n for n in (1, 2, 4, 8)} if (batch and world == 1) else None),
+                     # N ranks x the MEASURED one-GPU rate of a batch of 64 / N hypotheses (batch64.registrations_per_s_by_batch_size)
+                     "batch64_replicated_map": ({str(n): (n * batch["registrations_per_s_by_batch_size"][str(64 // n)]
+                                                          if isinstance(batch["registrations_per_s_by_batch_size"].get(str(64 // n)), float) else None)
+                                                 for n in (1, 2, 4, 8)} if (batch and world == 1 and "registrations_per_s_by_batch_size" in batch) else None),
+                     "batch64_8gpu_over_1gpu": ((8 * batch["registrations_per_s_by_batch_size"]["8"] / batch["value"])
+                                                if (batch and world == 1 and isinstance(batch.get("registrations_per_s_by_batch_size", {}).get("8"), float)) else None),
                      "note": "one registration is a latency chain of ~7 passes: sharding it cannot scale; throughput over independent registrations "
                              "(batch64: hypotheses split over the ranks, no collective) is what scales with N"}
 
@@ -571,6 +852,9 @@ def main():
                     if prof else None),
         "batch64": batch,
         "localization": loc,
+        "concurrent_contexts": conc,
+        "stock": stock,
+        "open_scene": open_scene,
         "other_shard_mode": other_mode,
         "predicted_scaling": predicted,
     }
@@ -645,6 +929,44 @@ def main():
             oracle_py.set_num_threads(1)
         except Exception as e:  # the number of record is the 1-thread baseline above
             out["cpu_baseline_all_cores"] = {"error": str(e)}
+        def oracle_check(map_xyz, h_scans, gs, plane_res, max_feat, g_stats, g_poses, n_check):
+            """Oracle-A on one core at the same configuration: (registrations/s, worst pose delta, counts / codes / histograms equal)"""
+            om2 = oracle_py.OracleMap(plane_res=plane_res)
+            om2.add_surf(map_xyz, raw=True)
+            om2.ensure_grids()
+            cfg2 = oracle_py.default_config(max_iterations=max_outer, lm_max_iterations=lm_iters, use_grid_knn=1, max_surface_features=max_feat)
+            w2, same2, t2 = (0.0, 0.0), True, 0.0
+            for i in range(n_check):
+                t0_ = time.perf_counter()
+                orc, opose, ost, _ = om2.register(h_scans[i], gs[i], cfg2)
+                t2 += time.perf_counter() - t0_
+                e = synth.pose_error(g_poses[i], opose)
+                w2 = (max(w2[0], e[0]), max(w2[1], e[1]))
+                g = g_stats[i]
+                ok2 = orc == 0 and g.n_iterations == ost.n_iterations
+                for it in range(min(g.n_iterations, ost.n_iterations)):
+                    a_, b_ = g.iterations[it], ost.iters[it]
+                    ok2 = ok2 and (a_.lm_iterations, a_.num_successful_steps, a_.termination, a_.num_surf_from_scan) == \
+                        (b_.lm_iterations, b_.num_successful_steps, b_.termination, b_.num_surf)
+                    ok2 = ok2 and list(a_.reject_hist) == list(b_.reject_hist) and list(a_.obs_hist) == list(b_.obs_hist)
+                same2 = same2 and bool(ok2)
+            return n_check / t2, [w2[0], w2[1]], same2
+        for (name, map_b, filt, gs_, pres, mfeat, g_st, g_po) in stock_cpu_jobs:
+            try:
+                rate, wpar, same2 = oracle_check(map_b, filt, gs_, pres, mfeat, g_st, g_po, len(filt))
+                stock[name].update({"cpu_oracle_a_1thread_registrations_per_s": rate, "cpu_oracle_a_1thread_ms": 1e3 / rate,
+                                    "parity_vs_oracle_m_rad": wpar, "parity_iteration_counts_and_histograms_equal": same2,
+                                    "speedup_vs_cpu_1thread": stock[name]["registrations_per_s"] / rate})
+            except Exception as e:  # noqa: BLE001
+                stock[name]["cpu_oracle_a"] = {"error": repr(e)}
+        if open_cpu_job is not None:
+            try:
+                map_b, h_sc, gs_, pres, g_st, g_po = open_cpu_job
+                rate, wpar, same2 = oracle_check(map_b, h_sc, gs_, pres, -1, g_st, g_po, min(2, len(h_sc)))
+                open_scene.update({"cpu_oracle_a_1thread_registrations_per_s": rate, "parity_vs_oracle_m_rad": wpar,
+                                   "parity_iteration_counts_and_histograms_equal": same2, "parity_scans_checked": min(2, len(h_sc))})
+            except Exception as e:  # noqa: BLE001
+                open_scene["cpu_oracle_a"] = {"error": repr(e)}
         out["parity_vs_oracle_m_rad"] = [worst[0], worst[1]]
         out["parity_iteration_counts_and_histograms_equal"] = stats_equal
         out["parity_scans_checked"] = min(n_cpu, len(poses))

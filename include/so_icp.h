@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SO_ICP_ABI_VERSION 2
+#define SO_ICP_ABI_VERSION 3 /* v3: the config, timing and prefilter-info structs grew (shard_mode, solve_workgroups, staging / packing counters, statistic_in_input_order) */
 
 /* LocalMap geometry, LM.h:131-138 */
 #define SO_ICP_MAP_W 21
@@ -87,7 +87,10 @@ typedef struct {
                                    their cell's owner (BASELINE configs[3]); SO_ICP_SHARD_QUERIES (1) = the map replicated on every
                                    rank, the scan's 64-point segments dealt round-robin to the ranks -- equal shares whatever the scene,
                                    no halo, no re-binning; the same 45-double exchange per evaluation in both */
-  int32_t reserved0;
+  int32_t solve_workgroups;     /* 0 = one workgroup of the persistent solve launch per compute unit (default); n >= 1: at most n -- the
+                                   launch needs ALL its workgroups resident at once, so contexts (or ranks) that share a device must
+                                   leave each other room: sum of the values <= compute units.  Results do not depend on it beyond the
+                                   order of the fp64 sums (SOICP_SOLVE_WORKGROUPS in the environment overrides it: test aid) */
 } so_icp_config;
 #define SO_ICP_SHARD_MAP 0
 #define SO_ICP_SHARD_QUERIES 1
@@ -157,6 +160,9 @@ typedef struct {
   /* packed light chunks of the k-NN sweep (time_kernels 2 + SOICP_ABLATE only): rows of 16 lanes with work, rows left to the
    * group passes because their block has more than 16 x-runs / keeps more than its quarter of the tile, candidates kept */
   int64_t knn_packed_rows, knn_packed_rows_too_many_runs, knn_packed_rows_tile_full, knn_packed_kept;
+  /* host adaptivity of the packing (every registration counts): registrations whose sweeps packed their light chunks, and how
+   * often a registration that left > 3 % of its queries to the exact scan switched the packing off for the next 32 */
+  int64_t knn_pack_registrations, knn_pack_holds;
 } so_icp_timing;
 
 /* -------- lifecycle ------------------------------------------------------------------------ */

@@ -21,7 +21,7 @@ class Config(C.Structure):
                 ("max_iterations", C.c_int32), ("lm_max_iterations", C.c_int32), ("max_surface_features", C.c_int32),
                 ("k", C.c_int32), ("tukey_variant", C.c_int32), ("time_kernels", C.c_int32),
                 ("line_res", C.c_float), ("plane_res", C.c_float), ("yaw_ratio", C.c_double),
-                ("velocity_failure_threshold", C.c_double), ("shard_mode", C.c_int32), ("reserved0", C.c_int32)]
+                ("velocity_failure_threshold", C.c_double), ("shard_mode", C.c_int32), ("solve_workgroups", C.c_int32)]
 
 
 class IterStats(C.Structure):
@@ -70,7 +70,7 @@ class Timing(C.Structure):
                 ("knn_group_passes", C.c_int64), ("knn_fallback_lanes", C.c_int64), ("knn_candidates_scanned", C.c_int64),
                 ("stage_wait_ms_total", C.c_double), ("staged_direct", C.c_int64), ("staged_copied", C.c_int64), ("stage_declined", C.c_int64),
                 ("knn_packed_rows", C.c_int64), ("knn_packed_rows_too_many_runs", C.c_int64), ("knn_packed_rows_tile_full", C.c_int64),
-                ("knn_packed_kept", C.c_int64)]
+                ("knn_packed_kept", C.c_int64), ("knn_pack_registrations", C.c_int64), ("knn_pack_holds", C.c_int64)]
 
 
 class Sums(C.Structure):

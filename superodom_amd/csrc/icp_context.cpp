@@ -824,7 +824,8 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   }
   c->h_state = c->h_ring[last & 1];
   const DevState& H = *c->h_state;
-  if (mp.pack_light && (double)H.packed_leftover > 0.03 * (double)n * (double)std::max(H.n_iterations, 1)) c->knn_pack_hold = 32;
+  if (mp.pack_light) c->timing.knn_pack_registrations++;
+  if (mp.pack_light && (double)H.packed_leftover > 0.03 * (double)n * (double)std::max(H.n_iterations, 1)) { c->knn_pack_hold = 32; c->timing.knn_pack_holds++; }
   // (scans of a stream have one size: the list of this registration decides the packing of the next -- results do not depend on it)
   c->knn_list_fits = ((H.bin_packed >> 21) & 0x1FFFFFull) + (H.bin_packed >> 42) <= (unsigned long long)kKnnBlocks * 4ull;
   fill_result(c, H, pose_in, st, pose_out, !c->batch_mode);
@@ -1413,7 +1414,8 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   {  // the persistent solve launch holds one workgroup per compute unit: never ask for more than the device has
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && cus > 0) c->n_cus = cus;
-    if (const char* ev = std::getenv("SOICP_SOLVE_WORKGROUPS")) { const int w = std::atoi(ev); if (w >= 1 && w < c->n_cus) c->n_cus = w; }  // leave compute units to others
+    if (cfg->solve_workgroups >= 1 && cfg->solve_workgroups < c->n_cus) c->n_cus = cfg->solve_workgroups;  // leave compute units to others
+    if (const char* ev = std::getenv("SOICP_SOLVE_WORKGROUPS")) { const int w = std::atoi(ev); if (w >= 1 && w < c->n_cus) c->n_cus = w; }
   }
   const size_t partial_bytes = std::max((size_t)kFitBlocksMax * kSumsStride * sizeof(double),
                                         (size_t)kFitBlocksMax * kRecordChunksMax * 16);  // partial sums / tagged records of solve_kernel

@@ -26,6 +26,12 @@ CONFIGS = {
     # small cases the CPU oracle finishes in seconds
     "tiny": dict(rings=16, azimuth=256, fov_deg=15.0, map_points=30_000, extent=14.0, spacing=7.0, plane_res=0.2),
     "small": dict(rings=32, azimuth=512, fov_deg=22.5, map_points=120_000, extent=30.0, spacing=10.0, plane_res=0.2),
+    # stand-in for config/livox_mid360.yaml (planeRes 0.1, max_surface_features 4000): a 20 000-point sweep on a ring x azimuth grid
+    # (the Mid-360's non-repetitive pattern is not modelled) in a 60 m x 60 m part of the same world, map at planeRes 0.1
+    "mid360_like": dict(rings=40, azimuth=500, fov_deg=26.0, map_points=400_000, extent=30.0, spacing=10.0, plane_res=0.1),
+    # second perf scene: an OPEN hall -- floor, ceiling, outer walls and 1 m high interior walls that occlude almost nothing, so
+    # the sweep reaches out to its 100 m range and touches nearly every occupied 50 m cube (M_t ~ the whole 2M-point map)
+    "open_2m": dict(rings=128, azimuth=1024, fov_deg=22.5, map_points=2_000_000, extent=95.0, spacing=9.0, plane_res=0.2, wall_height=1.0),
 }
 
 
@@ -35,7 +41,8 @@ CONFIGS = {
 class World:
     """A set of finite rectangles o + a*u + b*v, a,b in [0,1]."""
 
-    def __init__(self, extent=75.0, spacing=12.5, seed=1, z0=-1.5, z1=6.1):
+    def __init__(self, extent=75.0, spacing=12.5, seed=1, z0=-1.5, z1=6.1, wall_height=None):
+        """wall_height: height of the INTERIOR walls above the floor (None = floor to ceiling, with lintels above the doors)."""
         rng = np.random.default_rng(seed)
         E = float(extent)
         R = []
@@ -49,6 +56,8 @@ class World:
         for s in (-E, E):  # outer walls
             add([s, -E, z0], [0, 2 * E, 0], [0, 0, H])
             add([-E, s, z0], [2 * E, 0, 0], [0, 0, H])
+        if wall_height is not None:
+            H = float(wall_height)
         off = 3.7  # keeps every wall plane away from the world origin
         lines = [off + k * spacing for k in range(-int(2 * E / spacing) - 1, int(2 * E / spacing) + 2)]
         lines = [c for c in lines if -E + 1.0 < c < E - 1.0]
@@ -68,6 +77,8 @@ class World:
                             add([c, a, z0], [0, b - a, 0], [0, 0, H])
                         else:
                             add([a, c, z0], [b - a, 0, 0], [0, 0, H])
+                    if H <= 2.2:
+                        continue
                     # lintel above the door
                     if axis == 0:
                         add([c, g, z0 + 2.2], [0, door, 0], [0, 0, H - 2.2])
@@ -255,10 +266,10 @@ class Scene:
         cfg = dict(CONFIGS[name]); cfg.update(override)
         self.name, self.cfg = name, cfg
         self.plane_res = cfg["plane_res"]
-        self.world = World(extent=cfg["extent"], spacing=cfg["spacing"], seed=1)
+        self.world = World(extent=cfg["extent"], spacing=cfg["spacing"], seed=1, wall_height=cfg.get("wall_height"))
         self.dirs = lidar_dirs(cfg["rings"], cfg["azimuth"], cfg["fov_deg"])
         cache_dir = cache_dir or os.environ.get("SOICP_CACHE", "/tmp/soicp_cache")
-        key = "_".join(f"{k}{cfg[k]}" for k in ("map_points", "extent", "spacing", "plane_res"))
+        key = "_".join(f"{k}{cfg[k]}" for k in ("map_points", "extent", "spacing", "plane_res") + (("wall_height",) if "wall_height" in cfg else ()))
         path = os.path.join(cache_dir, f"map_{key}.npy")
         if os.path.exists(path):
             self.map_points = np.load(path)
