@@ -1725,7 +1725,69 @@ constexpr int kPartStride = SO_SOLVE_BLOCKS;  // partials[a][workgroup]: transpo
 static_assert(kEvalBlocks <= kPartStride && kFitBlocksMax <= kPartStride && kNAcc <= kSumsStride, "partials table");
 constexpr int kRedStride = kNAcc + 2;  // 31 doubles per record in LDS: 62-dword rows, so 32 consecutive rows start in 32 different bank pairs
 
-// sum 256 records of kNAcc doubles held in red[256][kRedStride]: thread (a, c) adds rows 32c..32c+31 of value a in
+// ---- first level of every reduction: the kNAcc accumulators of the 256 threads of a workgroup -> one record.
+// Round 5: in registers.  A reduce-scatter butterfly over the wavefront -- 32 values x 64 lanes -> lane L ends up with the
+// wavefront's total of value L >> 1 -- whose first two stages are gfx950's v_permlane32_swap / v_permlane16_swap (swap the
+// upper half / the odd rows of one register with the lower half / the even rows of another: after the swap ONE v_add_f64 has
+// summed value a over the two halves in the lower lanes and value b in the upper lanes, no selects), the in-row stages DPP moves
+// of the half each lane gives away (row_ror:8, row_half_mirror, quad_perm -- partner masks 8, 7, 2, 1 span the row), ~125 VALU
+// instructions, no LDS, no barrier; then the four wavefronts' totals meet in part[4][32] (one barrier).  The round-4 form staged
+// all 256 x 29 accumulators through 60 KB of LDS (1.3 - 1.8 us per pass by the in-kernel stamps) and is what kept a second
+// workgroup off the compute unit.  Fixed tree: identical bits on every launch, in every instantiation (single / BATCH virtual
+// workgroups / per-evaluation launches all come through here).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// (a, b) -> a summed over the lane pairs {L, L ^ 32} in lanes 0..31, b in lanes 32..63
+__device__ __forceinline__ double swap32_add(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// (a, b) -> a summed over {L, L ^ 16} in the even rows of 16 lanes, b in the odd rows
+__device__ __forceinline__ double swap16_add(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// in-row stage with partner L ^ mask (CTRL = the DPP pattern that reads that partner): lanes with `up` clear keep a, the others b
+template <int CTRL>
+__device__ __forceinline__ double row_stage_add(double a, double b, bool up) {
+  const double keep = up ? b : a, give = up ? a : b;
+  return keep + dpp_f64<CTRL>(give);
+}
+// lane L returns the wavefront's total of acc[L >> 1] (lanes with L >> 1 >= kNAcc: 0)
+__device__ __forceinline__ double wave_reduce_scatter(const double (&acc)[kNAcc]) {
+  static_assert(kNAcc > 16 && kNAcc <= 32, "butterfly over 32 value slots");
+  const int lane = (int)(threadIdx.x & 63u);
+  double u[16], w[8], x[4], y[2];
+#pragma unroll
+  for (int a = 0; a < 16; ++a) u[a] = swap32_add(acc[a], (a + 16 < kNAcc) ? acc[a + 16] : 0.0);   // lane bit 5 picks a / a + 16
+#pragma unroll
+  for (int a = 0; a < 8; ++a) w[a] = swap16_add(u[a], u[a + 8]);                                    // bit 4: a / a + 8
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) x[a] = row_stage_add<0x128>(w[a], w[a + 4], b3);                      // partner L ^ 8 (row_ror:8), bit 3: a / a + 4
+#pragma unroll
+  for (int a = 0; a < 2; ++a) y[a] = row_stage_add<0x141>(x[a], x[a + 2], b2);                      // partner L ^ 7 (row_half_mirror), bit 2: a / a + 2
+  const double z = row_stage_add<0x4E>(y[0], y[1], b1);                                             // partner L ^ 2 (quad_perm [2,3,0,1]), bit 1
+  return z + dpp_f64<0xB1>(z);                                                                      // partner L ^ 1 (quad_perm [1,0,3,2]): both lanes of the pair
+}
+// the workgroup's record: thread a < kNAcc returns the total of value a (the four wavefronts' totals added in wavefront order)
+__device__ __forceinline__ double wg_reduce(const double (&acc)[kNAcc], double (*part)[32], int tid) {
+  const double t = wave_reduce_scatter(acc);
+  const int lane = tid & 63, wave = tid >> 6;
+  if (!(lane & 1) && (lane >> 1) < kNAcc) part[wave][lane >> 1] = t;
+  __syncthreads();
+  double tot = 0;
+  if (tid < kNAcc) tot = ((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid];
+  return tot;
+}
+
+// second level (the per-evaluation launches): sum 256 records of kNAcc doubles held in red[256][kRedStride]: thread (a, c) adds rows 32c..32c+31 of value a in
 // order, then thread (a, 0) adds the 8 partial sums in order -- a fixed tree, identical on every launch.
 // Thread (a, c) belongs to wavefront c / 2 and so do the rows 32c..32c+31: when every thread has written ITS OWN row, a
 // wavefront reads only what it wrote itself -- the caller needs a wavefront-scope fence between the two, not a barrier.
@@ -2006,15 +2068,11 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     for (uint32_t q = 0, j; (j = query_of(vb, V, tid, q)) < n_kept; ++q) body(j, corr.status[j], nullptr, -1);
   }
   if (stamp) t_loop = wall_clock64();
-  // workgroup reduction through LDS (transposed: no serial shuffle chains), fixed order
-#pragma unroll
-  for (int a = 0; a < kNAcc; ++a) red[tid][a] = acc[a];
-  // (LDS serves a wavefront's accesses in order: the rows this wavefront reads below are the ones it has just written)
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  // BATCH: the group partials alternate between two buffers, so that ONE barrier per virtual workgroup (the one inside
-  // reduce_records) orders everything: a wavefront that writes buffer b again has passed the barrier of the virtual
+  // workgroup reduction in registers (wave_reduce_scatter), fixed order
+  // BATCH: the wavefront totals alternate between two buffers, so that ONE barrier per virtual workgroup (the one inside
+  // wg_reduce) orders everything: a wavefront that writes buffer b again has passed the barrier of the virtual
   // workgroup in between, which the threads that read b reach only after their reads
-  mine = reduce_records(red, (BATCH && (trip_ & 1u)) ? sh.part_odd : part, tid);
+  mine = wg_reduce(acc, (BATCH && (trip_ & 1u)) ? sh.part_odd : part, tid);
   if (PERSIST) {
     // Push model: the record of this workgroup for this pass is kNAcc chunks of 16 bytes {value (8), pass tag (4), one
     // histogram counter of the fit pass (4)}, each written with ONE sc1 dwordx4 store -- fire and forget: no drain, no
