@@ -1580,6 +1580,28 @@ struct LmCtl {       // LDS copy of the DevState fields the controller reads (pr
   int32_t lm_max, outer_iter, max_outer, pad;
 };
 
+// A solve has ended: T_w_lidar <- optimised pose, iteration statistics, termination rule of the outer loop (one thread).
+// Returns 1 when the registration is over too (the caller then stores the final normal equations).
+__device__ __forceinline__ int lm_solve_finished(DevState* st, const LmCtl& ctl, const double x[7], double count, int lm_iterations,
+                                                 int num_successful, int termination, double initial_cost, double x_cost, const LmSums& sums) {
+  for (int i = 0; i < 7; ++i) st->T[i] = x[i];
+  const int o = ctl.outer_iter;
+  DevIterStats& is = st->iters[o < 16 ? o : 15];
+  relative_motion(ctl.T, x, is.translation_norm, is.rotation_norm);
+  is.num_surf = (int32_t)count; is.lm_iterations = lm_iterations; is.num_successful = num_successful;
+  is.termination = termination; is.initial_cost = initial_cost; is.final_cost = x_cost;
+  for (int h = 0; h < 7; ++h) is.reject_hist[h] = (int32_t)sums.hist[h];
+  for (int h = 0; h < 9; ++h) is.obs_hist[h] = (int32_t)sums.hist[7 + h];
+  for (int i = 0; i < 7; ++i) is.pose_after[i] = x[i];
+  st->outer_iter = o + 1;
+  st->n_iterations = o + 1;
+  if (num_successful == 1 || o + 1 >= ctl.max_outer) {  // LidarSlam.cpp:141
+    st->reg_done = 1;
+    return 1;
+  }
+  return 0;
+}
+
 __device__ __forceinline__ int lm_control_regs(int slot, DevState* st, LmState& S, const LmSums& sums, const LmCtl& ctl, bool persist,
                                                int* reg_done_out = nullptr) {
   if (reg_done_out) *reg_done_out = 0;
@@ -1596,20 +1618,8 @@ __device__ __forceinline__ int lm_control_regs(int slot, DevState* st, LmState& 
 #endif
   if (!persist || !more) st->lm_more = more;
   if (more) return 1;
-  // solve finished: T_w_lidar <- optimised pose, iteration statistics, termination rule
-  for (int i = 0; i < 7; ++i) st->T[i] = S.x[i];
-  const int o = ctl.outer_iter;
-  DevIterStats& is = st->iters[o < 16 ? o : 15];
-  relative_motion(ctl.T, S.x, is.translation_norm, is.rotation_norm);
-  is.num_surf = (int32_t)S.count; is.lm_iterations = S.lm_iterations; is.num_successful = S.num_successful;
-  is.termination = S.termination; is.initial_cost = S.initial_cost; is.final_cost = S.x_cost;
-  for (int h = 0; h < 7; ++h) is.reject_hist[h] = (int32_t)sums.hist[h];
-  for (int h = 0; h < 9; ++h) is.obs_hist[h] = (int32_t)sums.hist[7 + h];
-  for (int i = 0; i < 7; ++i) is.pose_after[i] = S.x[i];
-  st->outer_iter = o + 1;
-  st->n_iterations = o + 1;
-  if (S.num_successful == 1 || o + 1 >= ctl.max_outer) {  // LidarSlam.cpp:141
-    st->reg_done = 1;
+  const int rd = lm_solve_finished(st, ctl, S.x, S.count, S.lm_iterations, S.num_successful, S.termination, S.initial_cost, S.x_cost, sums);
+  if (rd) {
     if (reg_done_out) *reg_done_out = 1;
     const bool have = S.count > 0;
     for (int i = 0; i < 36; ++i) st->JtJ[i] = have ? S.H[i] : 0.0;
@@ -1655,7 +1665,8 @@ __device__ SO_LM_INLINE int lm_control(int slot, DevState* st, LmState& S_lds, c
 #pragma unroll
     for (int j = i; j < 6; ++j) { S.H[6 * i + j] = S_lds.H[6 * i + j]; S.H[6 * j + i] = S.H[6 * i + j]; }
   }
-  S.x_cost = S_lds.x_cost; S.x_norm = S_lds.x_norm; S.radius = S_lds.radius; S.decrease_factor = S_lds.decrease_factor;
+  S.x_cost = S_lds.x_cost; S.x_norm = S_lds.x_norm; S.inv_radius = S_lds.inv_radius; S.decrease_factor = S_lds.decrease_factor;
+  S.inv_model_cost_change = S_lds.inv_model_cost_change; S.step_norm = S_lds.step_norm; S.cand_norm = S_lds.cand_norm;
   S.model_cost_change = S_lds.model_cost_change; S.initial_cost = S_lds.initial_cost; S.count = S_lds.count;
   S.iter = S_lds.iter; S.max_iter = S_lds.max_iter; S.reuse_diagonal = S_lds.reuse_diagonal; S.invalid_steps = S_lds.invalid_steps;
   S.num_successful = S_lds.num_successful; S.termination = S_lds.termination; S.done = S_lds.done; S.lm_iterations = S_lds.lm_iterations;
@@ -1678,7 +1689,8 @@ __device__ SO_LM_INLINE int lm_control(int slot, DevState* st, LmState& S_lds, c
 #pragma unroll
     for (int j = i; j < 6; ++j) { S_lds.H[6 * i + j] = S.H[6 * i + j]; S_lds.H[6 * j + i] = S.H[6 * i + j]; }
   }
-  S_lds.x_cost = S.x_cost; S_lds.x_norm = S.x_norm; S_lds.radius = S.radius; S_lds.decrease_factor = S.decrease_factor;
+  S_lds.x_cost = S.x_cost; S_lds.x_norm = S.x_norm; S_lds.inv_radius = S.inv_radius; S_lds.decrease_factor = S.decrease_factor;
+  S_lds.inv_model_cost_change = S.inv_model_cost_change; S_lds.step_norm = S.step_norm; S_lds.cand_norm = S.cand_norm;
   S_lds.model_cost_change = S.model_cost_change; S_lds.initial_cost = S.initial_cost; S_lds.count = S.count;
   S_lds.iter = S.iter; S_lds.max_iter = S.max_iter; S_lds.reuse_diagonal = S.reuse_diagonal; S_lds.invalid_steps = S.invalid_steps;
   S_lds.num_successful = S.num_successful; S_lds.termination = S.termination; S_lds.done = S.done; S_lds.lm_iterations = S.lm_iterations;
@@ -1686,6 +1698,237 @@ __device__ SO_LM_INLINE int lm_control(int slot, DevState* st, LmState& S_lds, c
   if (slot == 1) st->dbg[7] = wall_clock64();
 #endif
   return more_;
+}
+
+// ---- Round 5: the controller across the lanes of ONE wavefront (persistent solve, single registration).
+// The one-thread controller above is an instruction stream of ~750 fp64 operations and LDS moves on one lane -- 3.7 us per pass
+// (in-kernel stamps), 2.5 of them in front of the hand-off every other workgroup is waiting for.  Most of that stream is WIDE
+// work done element after element: ~70 state words in and out of LDS, 27 sums unpacked, 21 entries scaled twice, six
+// reciprocal-square-root scale factors in the first pass, eight hand-off chunks.  Here lane l < 36 owns element (l / 6, l % 6) of
+// H, lane 36 + j element j of g: unpacking, scaling and the damped matrix are one or two instructions for the whole wavefront,
+// the six Jacobi scale factors one sqrt + division, the hand-off one store.  What is a dependent chain -- the 6x6 Cholesky
+// (six pivots through rsqrt), the substitutions, the model cost change, the quaternion update -- stays the code of
+// lm_solver.h, run by every lane on the same (gathered) operands, so every element goes through the operations of the
+// one-thread controller in the same order: identical bits (the batched solve and the per-evaluation launches keep the
+// one-thread form; tests/test_gpu_configs.py compares them bit for bit).  The state's home is the LDS copy; what the next
+// lm_feed needs beyond the sums (lm_after_candidate) and the store-back run AFTER the hand-off has been published.
+__device__ __forceinline__ int lm_control_wave(int slot, DevState* st, LmState& S, const LmSums& sums, const LmCtl& ctl, double* gather /* LDS, >= 56 doubles */,
+                                               u4v* hand, unsigned long long want, double* pose_out, int* reg_done_out, int lane,
+                                               unsigned long long* dbg = nullptr) {
+  const bool is_mat = lane < 36, is_vec = lane >= 36 && lane < 42;
+  const int li = is_mat ? lane / 6 : 0, lj = is_mat ? lane - 6 * li : (is_vec ? lane - 36 : 0);
+  const int la = li < lj ? li : lj, lb = li < lj ? lj : li;          // (row, column) of the element's upper-triangle twin
+  const int tri = 6 * la - (la * (la - 1)) / 2 + (lb - la);           // its index in LmSums::JtJ
+  const bool is_diag = is_mat && li == lj;
+  // ---- uniform state (every lane holds the same value), element state (one per lane)
+  double x[7], cand[7];
+  double x_cost, x_norm, inv_radius, decrease_factor, mcc_state, initial_cost, count, inv_mcc, step_norm, cand_norm;
+  int iter, max_iter, reuse_diagonal, invalid_steps, num_successful, termination, done, lm_iterations;
+  double Hl = 0, gl = 0, diag_l = 0, sa = 1.0, sb = 1.0;              // H element / g element / diag (diagonal lanes) / scale[min(i,j)], scale[max(i,j)]
+  int more = 0;
+  bool propose = false;
+  if (slot == 0) {  // ---------------- lm_begin
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { x[i] = ctl.T[i]; cand[i] = x[i]; }
+    iter = 0; max_iter = ctl.lm_max; reuse_diagonal = 0; invalid_steps = 0; num_successful = 0; termination = 0; done = 0; lm_iterations = 0;
+    inv_radius = LmConst::kInitialInvRadius; decrease_factor = 2.0; mcc_state = 0; inv_mcc = 0; step_norm = 0; cand_norm = 0;
+    count = sums.count; x_cost = sums.cost; initial_cost = x_cost; x_norm = 0;
+    if (is_mat) Hl = sums.JtJ[tri];
+    if (is_vec) gl = sums.Jtr[lj];
+    if (!(count > 0)) { termination = 4; done = 1; }  // no residual blocks: nothing to minimise (scale 1, diag 0 go to the state below)
+    else {
+      // jacobi_scaling, fixed at iteration 0: 1 / (1 + sqrt(H_jj)) on the diagonal lanes, handed to the element lanes through the state
+      const double sc = 1.0 / (1.0 + sqrt(Hl));
+      if (is_diag) S.scale[li] = sc;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      sa = S.scale[is_vec ? lj : la]; sb = S.scale[lb];
+      double n2 = 0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) n2 = SO_FMA(x[i], x[i], n2);
+      x_norm = sqrt(n2);
+      propose = true;
+    }
+  } else {          // ---------------- lm_feed
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { x[i] = S.x[i]; cand[i] = S.cand[i]; }
+    x_cost = S.x_cost; x_norm = S.x_norm; inv_radius = S.inv_radius; decrease_factor = S.decrease_factor; mcc_state = S.model_cost_change;
+    initial_cost = S.initial_cost; count = S.count; inv_mcc = S.inv_model_cost_change; step_norm = S.step_norm; cand_norm = S.cand_norm;
+    iter = S.iter; max_iter = S.max_iter; reuse_diagonal = S.reuse_diagonal; invalid_steps = S.invalid_steps; num_successful = S.num_successful;
+    termination = S.termination; done = S.done; lm_iterations = S.lm_iterations;
+    if (is_mat) { Hl = S.H[lane]; sa = S.scale[la]; sb = S.scale[lb]; }
+    if (is_vec) { gl = S.g[lj]; sa = S.scale[lj]; }
+    if (is_diag) diag_l = S.diag[li];
+    if (!done) {
+      SO_LM_STAMP(dbg, 0);
+      const double cand_cost = sums.cost;
+      if (step_norm <= LmConst::kParameterTolerance * (x_norm + LmConst::kParameterTolerance)) { termination = 2; done = 1; }  // ParameterToleranceReached
+      else {
+        const double cost_change = x_cost - cand_cost;
+        if (fabs(cost_change) <= LmConst::kFunctionTolerance * x_cost) { termination = 1; done = 1; }  // FunctionToleranceReached
+        else {
+          const double rel = cost_change * inv_mcc;  // StepQuality
+          SO_LM_STAMP(dbg, 1);
+          if (rel > LmConst::kMinRelativeDecrease) {  // HandleSuccessfulStep
+#pragma unroll
+            for (int i = 0; i < 7; ++i) x[i] = cand[i];
+            x_norm = cand_norm; x_cost = cand_cost;
+            if (is_mat) Hl = sums.JtJ[tri];
+            if (is_vec) gl = sums.Jtr[lj];
+            num_successful++;
+            const double u = 2.0 * rel - 1.0;
+            double f = 1.0 - u * u * u;
+            if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+            inv_radius = inv_radius * f;
+            if (inv_radius < LmConst::kMinInvRadius) inv_radius = LmConst::kMinInvRadius;
+            decrease_factor = 2.0; reuse_diagonal = 0;
+            if (iter >= max_iter) { termination = 0; done = 1; }
+            else propose = true;  // (gradient test below)
+          } else {  // StepRejected
+            inv_radius = inv_radius * decrease_factor; decrease_factor *= 2.0; reuse_diagonal = 1;
+            propose = true;
+          }
+          SO_LM_STAMP(dbg, 2);
+        }
+      }
+    }
+  }
+  // gradient_max_norm <= gradient_tolerance after lm_begin / an accepted step (lm_gradient_converged: the fast exit on the lanes of
+  // g[0..2], the full test -- g gathered to every lane -- only when it does not decide)
+  if (propose && reuse_diagonal == 0) {
+    const double xi = lane == 36 ? x[0] : (lane == 37 ? x[1] : x[2]);
+    const bool big = lane >= 36 && lane < 39 && fabs(gl) > 1e-6 && fabs(xi) < 1e5;
+    if (__ballot(big) == 0ull) {
+      if (is_vec) gather[48 + lj] = gl;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      double gu[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) gu[i] = gather[48 + i];
+      if (lm_gradient_max_norm(x, gu) <= LmConst::kGradientTolerance) { termination = 3; done = 1; propose = false; }
+    }
+  }
+  // ---------------- lm_propose
+  double scale_u[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) scale_u[i] = 1.0;
+  if (propose) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) scale_u[i] = S.scale[i];
+  }
+  while (propose) {
+    if (iter >= max_iter) { termination = 0; done = 1; break; }                           // MaxSolverIterationsReached
+    if (inv_radius >= LmConst::kMaxInvRadius) { termination = 5; done = 1; break; }       // MinTrustRegionRadiusReached
+    iter++; lm_iterations = iter;
+    if (!reuse_diagonal) {
+      double v = Hl * sa * sa;  // (diagonal lanes: sa == sb == scale[j])
+      v = v < LmConst::kMinLmDiagonal ? LmConst::kMinLmDiagonal : v;
+      diag_l = v > LmConst::kMaxLmDiagonal ? LmConst::kMaxLmDiagonal : v;
+    }
+    const double Hs = Hl * sa * sb;                       // Hs = S H S
+    const double damp = diag_l * inv_radius;
+    const double Al = is_diag ? Hs + damp : Hs;           // + lm_diagonal^2 = diag / radius
+    if (is_mat) gather[lane] = Al;
+    if (is_diag) gather[42 + li] = Hs;
+    if (is_vec) gather[36 + lj] = gl * sa;                // gs = S g
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    double A[36], Hd[6], gs[6], y[6], step[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = gather[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { gs[i] = gather[36 + i]; Hd[i] = gather[42 + i]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next round of the loop rewrites the gather area)
+    SO_LM_STAMP(dbg, 3);
+    double Hu[36];  // Hs for the model cost change: the upper triangle of A is untouched by lm_chol6, the diagonal comes undamped
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      Hu[7 * i] = Hd[i];
+#pragma unroll
+      for (int j = i + 1; j < 6; ++j) Hu[6 * i + j] = A[6 * i + j];
+    }
+    const bool ok = lm_chol6(A, gs, y);
+    SO_LM_STAMP(dbg, 4);
+    reuse_diagonal = 1;
+    double mcc = 0;
+    if (ok) {
+      double sHs = 0, sg = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { step[i] = -y[i]; sg = SO_FMA(step[i], gs[i], sg); }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double r = 0;
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) r = SO_FMA(Hu[6 * i + j], step[j], r);
+        sHs = SO_FMA(step[i], SO_FMA(Hu[7 * i], step[i], 2.0 * r), sHs);
+      }
+      mcc = SO_FMA(-0.5, sHs, -sg);
+    }
+    if (!ok || !(mcc > 0.0)) {  // HandleInvalidStep
+      if (++invalid_steps >= LmConst::kMaxConsecutiveInvalidSteps) { termination = 5; done = 1; break; }
+      inv_radius *= 2.0;
+      continue;
+    }
+    SO_LM_STAMP(dbg, 5);
+    invalid_steps = 0;
+    mcc_state = mcc;
+    double delta[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) delta[i] = step[i] * scale_u[i];
+    pose_plus(x, delta, cand);
+    SO_LM_STAMP(dbg, 6);
+    more = 1;
+    break;
+  }
+  // ---------------- hand-off {next pose, more?}: one 16-byte chunk per lane 0..7
+  {
+    double hv = cand[0];
+    hv = lane == 1 ? cand[1] : hv; hv = lane == 2 ? cand[2] : hv; hv = lane == 3 ? cand[3] : hv;
+    hv = lane == 4 ? cand[4] : hv; hv = lane == 5 ? cand[5] : hv; hv = lane == 6 ? cand[6] : hv;
+    const unsigned long long val = lane == 7 ? (unsigned long long)more : (unsigned long long)__double_as_longlong(hv);
+    if (lane < 8) {
+      const u4v v = {(unsigned int)val, (unsigned int)(val >> 32), (unsigned int)want, (unsigned int)(want >> 32)};
+      store16_sc1(hand + lane, v);
+    }
+    if (lane < 7) pose_out[lane] = hv;
+  }
+  // ---------------- behind the hand-off: what the next lm_feed needs, the state back to its home
+  if (more) {  // lm_after_candidate
+    inv_mcc = 1.0 / mcc_state;
+    double sn = 0, n2 = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) sn = SO_FMA(x[i] - cand[i], x[i] - cand[i], sn);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) n2 = SO_FMA(cand[i], cand[i], n2);
+    step_norm = sqrt(sn); cand_norm = sqrt(n2);
+  }
+  if (is_mat) S.H[lane] = Hl;
+  if (is_vec) S.g[lj] = gl;
+  if (is_diag) S.diag[li] = diag_l;
+  if (slot == 0 && termination == 4 && lane < 6) S.scale[lane] = 1.0;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { S.x[i] = x[i]; S.cand[i] = cand[i]; }
+    S.x_cost = x_cost; S.x_norm = x_norm; S.inv_radius = inv_radius; S.decrease_factor = decrease_factor; S.model_cost_change = mcc_state;
+    S.initial_cost = initial_cost; S.count = count; S.inv_model_cost_change = inv_mcc; S.step_norm = step_norm; S.cand_norm = cand_norm;
+    S.iter = iter; S.max_iter = max_iter; S.reuse_diagonal = reuse_diagonal; S.invalid_steps = invalid_steps; S.num_successful = num_successful;
+    S.termination = termination; S.done = done; S.lm_iterations = lm_iterations;
+  }
+#ifdef SO_LM_STAMPS
+  if (slot == 1 && lane == 0) st->dbg[7] = wall_clock64();
+#endif
+  if (!more) {  // the solve is over
+    int rd = 0;
+    if (lane == 0) {
+      st->lm_more = 0;
+      rd = lm_solve_finished(st, ctl, x, count, lm_iterations, num_successful, termination, initial_cost, x_cost, sums);
+      *reg_done_out = rd;
+    }
+    rd = __builtin_amdgcn_readfirstlane(rd);
+    if (rd) {  // final normal equations: H and g as the state holds them, element by element
+      const bool have = count > 0;
+      if (is_mat) st->JtJ[lane] = have ? Hl : 0.0;
+      if (is_vec) st->Jtr[lj] = have ? gl : 0.0;
+    }
+  } else if (lane == 0) *reg_done_out = 0;
+  return more;
 }
 
 // threads [first, first+10) fetch the controller's inputs
@@ -2253,7 +2496,14 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
         sh_more = more_;
       }
     } else
-    if (tid == 0) sh_more = lm_control(slot, st, sh_S, sh_sums, sh_ctl, true, hand, want, sh.pose, &sh.reg_done);  // (publishes the hand-off)
+    if (tid < 64) {  // the controller's wavefront (publishes the hand-off)
+#ifdef SO_LM_STAMPS
+      const int more_ = lm_control_wave(slot, st, sh_S, sh_sums, sh_ctl, &sh.part_odd[0][0], hand, want, sh.pose, &sh.reg_done, tid, (slot == 1 && tid == 0) ? st->dbg : nullptr);
+#else
+      const int more_ = lm_control_wave(slot, st, sh_S, sh_sums, sh_ctl, &sh.part_odd[0][0], hand, want, sh.pose, &sh.reg_done, tid);
+#endif
+      if (tid == 0) sh_more = more_;
+    }
     __syncthreads();
     unsigned long long t_ctl = 0;
     if (stamp) t_ctl = wall_clock64();

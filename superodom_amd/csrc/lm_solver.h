@@ -34,17 +34,27 @@ struct LmSums {      // == so_icp_sums (include/so_icp.h), 45 doubles
   double hist[16];
 };
 
+// Round 5: the controller's serial chain carries no division any more.  Ceres keeps the trust-region radius and divides by it
+// (lm_diagonal = sqrt(diagonal / radius)), divides the cost change by the model cost change, and forms two norms when the
+// candidate's cost arrives.  Here the state holds the RECIPROCAL radius -- every update of the radius is a product (x 1/f on an
+// accepted step, x decrease_factor = a power of two on a rejected one, x 2 on an invalid one), so 1/radius is never formed --
+// and lm_propose, right after it has the candidate, forms 1 / model_cost_change, |x - cand| and |cand| (inputs of the NEXT
+// lm_feed's tolerance tests and step quality): on the device that work runs after the next pose has been handed to the other
+// workgroups, i.e. beside their evaluation pass instead of in front of it.  rel = cost_change x (1 / model_cost_change) differs
+// from the quotient by <= 1 ulp; it feeds the accept test (> 1e-3) and the radius factor only.
 struct LmState {
   double x[7], cand[7];
   double H[36], g[6];
   double scale[6], diag[6];
-  double x_cost, x_norm, radius, decrease_factor, model_cost_change, initial_cost, count;
+  double x_cost, x_norm, inv_radius, decrease_factor, model_cost_change, initial_cost, count;
+  double inv_model_cost_change, step_norm, cand_norm;  // formed by lm_propose with the candidate: 1 / model_cost_change, |x - cand|, |cand|
   int32_t iter, max_iter, reuse_diagonal, invalid_steps, num_successful, termination, done, lm_iterations;
 };
 
 // Ceres defaults in effect (solver.h, ceres 2.0.0)
 struct LmConst {
   static constexpr double kInitialRadius = 1e4, kMaxRadius = 1e16, kMinRadius = 1e-32;
+  static constexpr double kInitialInvRadius = 1e-4, kMinInvRadius = 1e-16 /* 1 / kMaxRadius */, kMaxInvRadius = 1e32 /* 1 / kMinRadius */;
   static constexpr double kMinRelativeDecrease = 1e-3, kMinLmDiagonal = 1e-6, kMaxLmDiagonal = 1e32;
   static constexpr double kFunctionTolerance = 1e-6, kGradientTolerance = 1e-10, kParameterTolerance = 1e-8;
   static constexpr int kMaxConsecutiveInvalidSteps = 5;
@@ -125,12 +135,25 @@ SO_HD bool lm_chol6(double A[36], const double b[6], double y[6]) {
   return spd;
 }
 
+// What the next lm_feed needs besides the candidate's sums (see LmState); on the device the caller has published the candidate
+// before this runs.
+SO_HD void lm_after_candidate(LmState& S) {
+  S.inv_model_cost_change = 1.0 / S.model_cost_change;
+  double sn = 0, n2 = 0;
+  SO_UNROLL
+  for (int i = 0; i < 7; ++i) sn = SO_FMA(S.x[i] - S.cand[i], S.x[i] - S.cand[i], sn);
+  SO_UNROLL
+  for (int i = 0; i < 7; ++i) n2 = SO_FMA(S.cand[i], S.cand[i], n2);
+  S.step_norm = sqrt(sn);
+  S.cand_norm = sqrt(n2);
+}
+
 // One pass of the while(FinalizeIterationAndCheckIfMinimizerCanContinue()) loop up to the point
 // where the candidate must be evaluated.  Returns 1 (evaluate S.cand) or 0 (solver finished).
 SO_HD int lm_propose(LmState& S, double next_pose[7], unsigned long long* dbg = nullptr) {
   for (;;) {
     if (S.iter >= S.max_iter) { S.termination = 0; S.done = 1; return 0; }           // MaxSolverIterationsReached
-    if (S.radius <= LmConst::kMinRadius) { S.termination = 5; S.done = 1; return 0; } // MinTrustRegionRadiusReached
+    if (S.inv_radius >= LmConst::kMaxInvRadius) { S.termination = 5; S.done = 1; return 0; } // MinTrustRegionRadiusReached
     S.iter++;
     S.lm_iterations = S.iter;
     // jacobian_ is column-scaled: Hs = S H S, gs = S g
@@ -143,7 +166,7 @@ SO_HD int lm_propose(LmState& S, double next_pose[7], unsigned long long* dbg = 
       }
     }
     double A[36], Hs[36], gs[6], y[6], step[6];
-    const double inv_radius = 1.0 / S.radius;  // one division for the six diagonal terms (the controller is a serial fp64 chain)
+    const double inv_radius = S.inv_radius;
     SO_UNROLL
     for (int i = 0; i < 6; ++i) {
       gs[i] = S.g[i] * S.scale[i];
@@ -177,7 +200,7 @@ SO_HD int lm_propose(LmState& S, double next_pose[7], unsigned long long* dbg = 
     }
     if (!ok || !(mcc > 0.0)) {  // HandleInvalidStep
       if (++S.invalid_steps >= LmConst::kMaxConsecutiveInvalidSteps) { S.termination = 5; S.done = 1; return 0; }
-      S.radius *= 0.5;
+      S.inv_radius *= 2.0;  // radius *= 0.5
       continue;
     }
     SO_LM_STAMP(dbg, 5);
@@ -190,6 +213,7 @@ SO_HD int lm_propose(LmState& S, double next_pose[7], unsigned long long* dbg = 
     SO_UNROLL
     for (int i = 0; i < 7; ++i) next_pose[i] = S.cand[i];
     SO_LM_STAMP(dbg, 6);
+    lm_after_candidate(S);
     return 1;
   }
 }
@@ -199,7 +223,8 @@ SO_HD int lm_begin(LmState& S, const double x0[7], const LmSums& sums, int max_i
   for (int i = 0; i < 7; ++i) { S.x[i] = x0[i]; S.cand[i] = x0[i]; }
   S.iter = 0; S.max_iter = max_iterations; S.reuse_diagonal = 0; S.invalid_steps = 0; S.num_successful = 0;
   S.termination = 0; S.done = 0; S.lm_iterations = 0;
-  S.radius = LmConst::kInitialRadius; S.decrease_factor = 2.0; S.model_cost_change = 0;
+  S.inv_radius = LmConst::kInitialInvRadius; S.decrease_factor = 2.0; S.model_cost_change = 0;
+  S.inv_model_cost_change = 0; S.step_norm = 0; S.cand_norm = 0;
   S.count = sums.count; S.x_cost = sums.cost; S.initial_cost = sums.cost;
   lm_unpack(sums, S.H, S.g);
   SO_UNROLL
@@ -220,31 +245,25 @@ SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7], unsigned 
   SO_LM_STAMP(dbg, 0);
   const double cand_cost = sums.cost;
   // ParameterToleranceReached
-  double sn = 0;
-  SO_UNROLL
-  for (int i = 0; i < 7; ++i) sn = SO_FMA(S.x[i] - S.cand[i], S.x[i] - S.cand[i], sn);
-  sn = sqrt(sn);
+  const double sn = S.step_norm;
   if (sn <= LmConst::kParameterTolerance * (S.x_norm + LmConst::kParameterTolerance)) { S.termination = 2; S.done = 1; return 0; }
   // FunctionToleranceReached
   const double cost_change = S.x_cost - cand_cost;
   if (fabs(cost_change) <= LmConst::kFunctionTolerance * S.x_cost) { S.termination = 1; S.done = 1; return 0; }
-  const double rel = cost_change / S.model_cost_change;  // TrustRegionStepEvaluator::StepQuality, monotonic
+  const double rel = cost_change * S.inv_model_cost_change;  // TrustRegionStepEvaluator::StepQuality, monotonic
   SO_LM_STAMP(dbg, 1);
   if (rel > LmConst::kMinRelativeDecrease) {             // HandleSuccessfulStep
     SO_UNROLL
     for (int i = 0; i < 7; ++i) S.x[i] = S.cand[i];
-    double n2 = 0;
-    SO_UNROLL
-    for (int i = 0; i < 7; ++i) n2 = SO_FMA(S.x[i], S.x[i], n2);
-    S.x_norm = sqrt(n2);
+    S.x_norm = S.cand_norm;
     S.x_cost = cand_cost;
     lm_unpack(sums, S.H, S.g);
     S.num_successful++;
     const double u = 2.0 * rel - 1.0;
     double f = 1.0 - u * u * u;  // LevenbergMarquardtStrategy::StepAccepted: 1 - pow(2 rho - 1, 3)
     if (f < 1.0 / 3.0) f = 1.0 / 3.0;
-    S.radius = S.radius / f;
-    if (S.radius > LmConst::kMaxRadius) S.radius = LmConst::kMaxRadius;
+    S.inv_radius = S.inv_radius * f;  // radius = radius / f
+    if (S.inv_radius < LmConst::kMinInvRadius) S.inv_radius = LmConst::kMinInvRadius;  // radius <= kMaxRadius
     S.decrease_factor = 2.0;
     S.reuse_diagonal = 0;
     // FinalizeIterationAndCheckIfMinimizerCanContinue tests MaxSolverIterationsReached before GradientToleranceReached
@@ -252,7 +271,7 @@ SO_HD int lm_feed(LmState& S, const LmSums& sums, double next_pose[7], unsigned 
     if (S.iter >= S.max_iter) { S.termination = 0; S.done = 1; return 0; }
     if (lm_gradient_converged(S.x, S.g)) { S.termination = 3; S.done = 1; return 0; }
   } else {  // HandleUnsuccessfulStep / StepRejected
-    S.radius = S.radius / S.decrease_factor;
+    S.inv_radius = S.inv_radius * S.decrease_factor;  // radius = radius / decrease_factor (a power of two: exact)
     S.decrease_factor *= 2.0;
     S.reuse_diagonal = 1;
   }
