@@ -105,6 +105,10 @@ def main():
                     help="where the HOST scan buffers of the timed loop live: pinned = so_icp_host_alloc (a node that keeps its feature clouds in a pinned "
                          "pool: DMA straight from them), registered = numpy memory pinned with so_icp_host_register, pageable = plain numpy memory (the "
                          "staged copies then go through the context's copy thread, which packs them into a pinned buffer first)")
+    ap.add_argument("--stage-protocol", default="steady", choices=["steady", "cold"],
+                    help="entry 'staged': steady = the clock starts with scan 0's copy done (announced behind the last warm-up registration) and covers "
+                         "K registrations + K copies (scans 1 .. K), the state of a node in the middle of a stream; cold = nothing announced when the "
+                         "clock starts (K copies, the first hidden by nothing)")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent-contexts measurement")
     ap.add_argument("--no-stock", action="store_true", help="skip the stock-operating-point measurement (config/os1_128.yaml, livox_mid360.yaml)")
     ap.add_argument("--no-open-scene", action="store_true", help="skip the second perf scene (open hall, 0.5 m / 5 deg guesses)")
@@ -251,17 +255,42 @@ def main():
             calls = [slam.prepare_register(scans[k % args.scans], g64[k % args.scans], stats[k], pose[k]) for k in range(steps)]
             stage = [slam.prepare_stage_scan(scans[k % args.scans]) for k in range(steps)] if entry == "staged" else None
         rcs = [0] * steps
-        for w in range(rewarm):
-            i = w % args.scans
-            if entry == "resident":
-                slam.register_dev(d_scans[i][0], d_scans[i][1], guesses[i], st)
-            else:
-                if entry == "staged":
-                    slam.stage_scan(scans[i])
-                slam.register(scans[i], guesses[i])
+        steady = bool(stage) and args.stage_protocol == "steady" and args.scans >= 2
+        if steady:
+            # Steady state of a node that registers a stream of sweeps: while scan k registers, scan k + 1 is on its way -- through the
+            # warm-up registrations and across the start of the clock alike.  The clock covers K registrations AND K copies: those of
+            # scans 1 .. K, the last one announced during the K-th registration for the registration that would follow -- what every
+            # window of K frames of the stream contains; the first timed scan's copy was the share of the window before (announced
+            # during the last warm-up registration, which enqueues it like any other).  `--stage-protocol cold` starts the clock with
+            # nothing announced: K copies inside, the first one hidden by nothing (the r01 - r04 protocol).
+            extra = slam.prepare_stage_scan(scans[steps % args.scans])
+            wi = [(w - rewarm) % args.scans for w in range(rewarm)]  # (ends on the scan before the first timed one: no buffer is announced twice)
+            if rewarm:
+                slam.stage_scan(scans[wi[0]])
+            for w in range(rewarm):
+                if w + 1 < rewarm:
+                    slam.stage_scan(scans[wi[w + 1]])
+                else:
+                    stage[0]()
+                slam.register(scans[wi[w]], guesses[wi[w]])
+            if not rewarm:
+                stage[0]()
+        else:
+            for w in range(rewarm):
+                i = w % args.scans
+                if entry == "resident":
+                    slam.register_dev(d_scans[i][0], d_scans[i][1], guesses[i], st)
+                else:
+                    if entry == "staged":
+                        slam.stage_scan(scans[i])
+                    slam.register(scans[i], guesses[i])
         barrier()
         t0 = time.perf_counter()
-        if stage:
+        if steady:
+            for k in range(steps):
+                (stage[k + 1] if k + 1 < steps else extra)()
+                rcs[k] = calls[k]()
+        elif stage:
             stage[0]()
             for k in range(steps):
                 if k + 1 < steps:
@@ -272,6 +301,8 @@ def main():
                 rcs[k] = calls[k]()
         slam.synchronize()
         t_local = time.perf_counter() - t0
+        if steady:
+            slam.stage_cancel(scans[steps % args.scans])  # (the copy announced for the registration after the clock)
         if dist is not None:
             dist.barrier()
         for k in range(steps):
@@ -834,7 +865,7 @@ def main():
                  "fixed_overhead_ms_per_step": ms_per_step - tm.host_ms_total / max(tm.registrations, 1),
                  "stage_wait_ms_per_step": tm.stage_wait_ms_total / max(tm.registrations, 1),
                  "staged_by_dma_from_registered_memory": int(tm.staged_direct), "staged_through_copy_thread": int(tm.staged_copied),
-                 "stage_declined": int(tm.stage_declined),
+                 "stage_declined": int(tm.stage_declined), "stage_protocol": (args.stage_protocol if args.entry == "staged" else None),
                  "scan_buffers": {"pinned": "pinned host memory (so_icp_host_alloc)", "registered": "registered host memory (so_icp_host_register)",
                                   "pageable": "pageable"}[args.scan_buffers],
                  "note": "c_abi = wall time inside the registration core (enqueue + wait + post-processing); stage_wait = host time the registrations "

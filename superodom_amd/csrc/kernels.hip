@@ -1830,20 +1830,16 @@ __device__ __forceinline__ int lm_control_wave(int slot, DevState* st, LmState& 
     if (is_diag) gather[42 + li] = Hs;
     if (is_vec) gather[36 + lj] = gl * sa;                // gs = S g
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    double A[36], Hd[6], gs[6], y[6], step[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = gather[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { gs[i] = gather[36 + i]; Hd[i] = gather[42 + i]; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next round of the loop rewrites the gather area)
-    SO_LM_STAMP(dbg, 3);
-    double Hu[36];  // Hs for the model cost change: the upper triangle of A is untouched by lm_chol6, the diagonal comes undamped
+    // (only the lower triangle travels into registers -- lm_chol6 reads nothing else --, and the model cost change reads Hs from
+    //  the gather area again)
+    double A[36], gs[6], y[6], step[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      Hu[7 * i] = Hd[i];
 #pragma unroll
-      for (int j = i + 1; j < 6; ++j) Hu[6 * i + j] = A[6 * i + j];
+      for (int j = 0; j <= i; ++j) A[6 * i + j] = gather[6 * i + j];
+      gs[i] = gather[36 + i];
     }
+    SO_LM_STAMP(dbg, 3);
     const bool ok = lm_chol6(A, gs, y);
     SO_LM_STAMP(dbg, 4);
     reuse_diagonal = 1;
@@ -1853,14 +1849,15 @@ __device__ __forceinline__ int lm_control_wave(int slot, DevState* st, LmState& 
 #pragma unroll
       for (int i = 0; i < 6; ++i) { step[i] = -y[i]; sg = SO_FMA(step[i], gs[i], sg); }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < 6; ++i) {  // Hs: off-diagonal entries = those of the damped matrix, the diagonal comes undamped (gather[42 + i])
         double r = 0;
 #pragma unroll
-        for (int j = i + 1; j < 6; ++j) r = SO_FMA(Hu[6 * i + j], step[j], r);
-        sHs = SO_FMA(step[i], SO_FMA(Hu[7 * i], step[i], 2.0 * r), sHs);
+        for (int j = i + 1; j < 6; ++j) r = SO_FMA(gather[6 * i + j], step[j], r);
+        sHs = SO_FMA(step[i], SO_FMA(gather[42 + i], step[i], 2.0 * r), sHs);
       }
       mcc = SO_FMA(-0.5, sHs, -sg);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next round of the loop rewrites the gather area)
     if (!ok || !(mcc > 0.0)) {  // HandleInvalidStep
       if (++invalid_steps >= LmConst::kMaxConsecutiveInvalidSteps) { termination = 5; done = 1; break; }
       inv_radius *= 2.0;
@@ -2084,7 +2081,9 @@ enum { kPassNotLast = 0, kPassMore = 1, kPassDone = 2, kPassSums = 3 };
 //         so the controller's workgroup adds the same numbers in the same order -- the sums, and with them every decision
 //         and the pose, are bit-identical to the single registration, whatever the number of real workgroups.
 struct WgSpan { uint32_t vb0, vb1, V; bool ctl; };
-template <bool FIT, bool PERSIST = false, bool PROF = false, bool BATCH = false>
+// PEER  : the instantiation with the peer exchange compiled in (sharded registration, N > 1); the single-device launches carry
+//         none of its index arithmetic and arguments
+template <bool FIT, bool PERSIST = false, bool PROF = false, bool BATCH = false, bool PEER = false>
 __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose, const float* __restrict__ spx,
                                          const float* __restrict__ spy, const float* __restrict__ spz,
                                          const CorrBuffers& corr, DevState* __restrict__ st, const EvalParams& ep,
@@ -2439,7 +2438,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       o[kNAcc + (tid - 32)] = (double)h;
     }
     __syncthreads();
-    if (ep.peer_world > 1) {
+    if (PEER && ep.peer_world > 1) {
       // ---- peer exchange: this rank's record to every rank's inbox, then everybody's records out of the own inbox.
       //      Double-buffered by the parity of the pass number: a rank can run at most one pass ahead of another (it
       //      needs that rank's record of the pass before), so a chunk is never overwritten before it was read.
@@ -2509,7 +2508,7 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
     if (stamp) t_ctl = wall_clock64();
     if (!sh_more) {  // the solve is over: histogram replicas cleared for the next outer iteration, state to memory, publish
       hist[tid] = 0; hist[256 + tid] = 0;
-      if (ep.peer_world > 1 && tid == 0) st->peer_seq = sh.peer_seq;
+      if (PEER && ep.peer_world > 1 && tid == 0) st->peer_seq = sh.peer_seq;
       if (tid < (int)(sizeof(LmState) / 8))
         __hip_atomic_store(reinterpret_cast<double*>(&st->S) + tid, reinterpret_cast<const double*>(&sh_S)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // (a solve that does not end the registration may leave the report to the next k-NN launch, see EvalParams)
@@ -2657,7 +2656,7 @@ __global__ __launch_bounds__(256, SO_SOLVE_BLOCKS / 256) void eval_kernel(int sl
 // Each stands in for an equal share of the bv.v_grid workgroups of the single-registration launch (eval_pass, WgSpan), so
 // the hypotheses advance independently of each other inside the one launch and every one of them reproduces the single
 // registration bit for bit.  The grid never exceeds the compute units (every workgroup resident).
-template <bool PROF, bool BATCH>
+template <bool PROF, bool BATCH, bool PEER = false>
 __global__ __launch_bounds__(256, BATCH ? 2 : 1) void solve_kernel(int lm_max, const float* __restrict__ spx, const float* __restrict__ spy,
                                                     const float* __restrict__ spz, CorrBuffers corr, DevState* __restrict__ st,
                                                     EvalParams ep, double* __restrict__ partials, uint32_t* __restrict__ ticket,
@@ -2694,7 +2693,7 @@ __global__ __launch_bounds__(256, BATCH ? 2 : 1) void solve_kernel(int lm_max, c
     sh.ctl.lm_max = st->lm_max; sh.ctl.outer_iter = st->outer_iter; sh.ctl.max_outer = st->max_outer;
   }
   const unsigned long long tag0 = (e0 + 1ull) << 5;  // pass tags: unique over launches (every launch advances the epoch) and passes (slot <= 16)
-  int code = eval_pass<true, true, PROF, BATCH>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0, &cache, hand, e0 + 1ull, span);
+  int code = eval_pass<true, true, PROF, BATCH, PEER>(0, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0, &cache, hand, e0 + 1ull, span);
   for (int slot = 1; slot <= lm_max; ++slot) {
     __syncthreads();
     const unsigned long long want = e0 + (unsigned long long)slot;
@@ -2724,7 +2723,7 @@ __global__ __launch_bounds__(256, BATCH ? 2 : 1) void solve_kernel(int lm_max, c
     if (sh.more != 1) return;  // solve ended (or timeout)
     pose = pose_from_array(sh.pose);
     __syncthreads();
-    code = eval_pass<false, true, PROF, BATCH>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0 + (unsigned long long)slot, &cache, hand, want + 1ull, span);
+    code = eval_pass<false, true, PROF, BATCH, PEER>(slot, 1, pose, spx, spy, spz, corr, st, ep, partials, ticket, hist, out, mpts, nbr5, mp, sh, tag0 + (unsigned long long)slot, &cache, hand, want + 1ull, span);
   }
 }
 
@@ -2913,7 +2912,8 @@ void launch_solve(int lm_max, const float* spx, const float* spy, const float* s
   // every workgroup must be resident for the whole launch (94 KB of LDS: one per compute unit)
   const uint32_t blocks = solve_grid(n_upper, max_blocks);
   const bool prof = ep.ablate != 0 || mp.ablate != 0;
-  auto* k = prof ? solve_kernel<true, false> : solve_kernel<false, false>;
+  auto* k = ep.peer_world > 1 ? (prof ? solve_kernel<true, false, true> : solve_kernel<false, false, true>)
+                              : (prof ? solve_kernel<true, false, false> : solve_kernel<false, false, false>);
   hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, s, lm_max, spx, spy, spz, corr, st, ep, partials, ticket, hist, sums, map.pts, nbr5, mp, kNoBatch);
 }
 uint32_t solve_batch_resident_blocks(uint32_t n_cus, int wg_per_cu) {

@@ -54,6 +54,9 @@ except Exception as e:
     print("no JSON line:", e)
 PY
 fi
+if [[ $ST == *p* ]]; then  # phase stamps of the production arithmetic (PROF instantiation, no controller stamps): fit + eval records
+  SOICP_ABLATE=128 python tools/eval_stamps.py 2>&1 | grep "^fit\|^eval" | tee $O/phase_stamps_fit_eval.txt
+fi
 if [[ $ST == *s* ]]; then
   bash tools/lm_stamps.sh 2>&1 | tail -45 | tee $O/phase_stamps.txt
   python -m superodom_amd.build --force > /dev/null 2>&1
