@@ -1147,22 +1147,11 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
       need_exact = true;  // (a row whose full-pass block has too many x-runs or keeps more than its quarter of the tile)
     }
   }
-  if constexpr (packed) {
-    // what the packed near pass could not finish -- a 5th neighbour beyond half a cell, a row with too many x-runs or kept
-    // candidates, a lane in another cube than its row -- goes to the exact per-lane scan of the 27 cells below (the group passes
-    // are not instantiated here: registers and code size).  The host watches the count and turns the packing off for sweeps
-    // where it is not rare.
-    unsigned long long left = __ballot(valid_q && c.slot >= 0 && !resolved);
-    if (left) __builtin_amdgcn_s_setprio(3);
-    if (left && lane == 0 && mp.packed_leftover) atomicAdd(leftover_ctr, (uint32_t)__popcll(left));
-    if (PROF) n_left_stat = (uint32_t)__popcll(left);
-    // One leftover query at a time, the WHOLE wavefront on it: the (clamped) 3 x 3 x 3 cells around the query -- every map point
-    // inside the gate ball lies there (one cell >= the gate radius) -- as <= 9 x-runs, their points dealt to the 64 lanes with
-    // the loads of a lane issued together, exact distances, lane-local top 5, five wavefront minima.  (The per-lane scan
-    // knn27() walks those ~300 points through dependent loads: 60 us for one lane, which ended the whole sweep.)
-    while (left) {
-      const int L = __ffsll((long long)left) - 1;
-      left &= left - 1ull;
+  // One query (lane L's) at a time, the WHOLE wavefront on it: the (clamped) 3 x 3 x 3 cells around the query -- every map point
+  // inside the gate ball lies there (one cell >= the gate radius) -- as <= 9 x-runs, their points dealt to the 64 lanes with
+  // the loads of a lane issued together, exact distances, lane-local top 5, five wavefront minima.  (The per-lane scan
+  // knn27() walks those ~300 points through dependent loads: 60 us for one lane, which ended the whole sweep.)
+  auto coop_exact_scan = [&](const int L) {
       const float sqx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), L)), sqy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), L));
       const float sqz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), L));
       const int sslot = __builtin_amdgcn_readlane(c.slot, L), scx = __builtin_amdgcn_readlane(c.cx, L);
@@ -1220,6 +1209,20 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
         top.b0 = m5[0]; top.b1 = m5[1]; top.b2 = m5[2]; top.b3 = m5[3]; top.b4 = m5[4];
         too_far_certain = false; resolved = true;
       }
+  };
+  if constexpr (packed) {
+    // what the packed near pass could not finish -- a 5th neighbour beyond half a cell, a row with too many x-runs or kept
+    // candidates, a lane in another cube than its row -- goes to the exact per-lane scan of the 27 cells below (the group passes
+    // are not instantiated here: registers and code size).  The host watches the count and turns the packing off for sweeps
+    // where it is not rare.
+    unsigned long long left = __ballot(valid_q && c.slot >= 0 && !resolved);
+    if (left) __builtin_amdgcn_s_setprio(3);
+    if (left && lane == 0 && mp.packed_leftover) atomicAdd(leftover_ctr, (uint32_t)__popcll(left));
+    if (PROF) n_left_stat = (uint32_t)__popcll(left);
+    while (left) {
+      const int L = __ffsll((long long)left) - 1;
+      left &= left - 1ull;
+      coop_exact_scan(L);
     }
   }
   if constexpr (!packed)
@@ -1501,17 +1504,23 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   __builtin_amdgcn_s_setprio(0);
   if (PROF && lane == 0) { atomicAdd(&lh[16], n_groups); atomicAdd(&lh[18], (int)(n_scanned >> 4)); atomicAdd(&lh[19], 1); }
 
+  if constexpr (!packed) {
+    // What the group passes left (8 near-equidistant candidates, a block with more than 2048 candidates): the same exact answer
+    // from the wave-cooperative scan -- round 5; the per-lane scan it replaces cost 60 us per lane and ended whole sweeps (open
+    // scene, 0.5 m / 5 degree guesses: one chunk of 85 us in a 50 us sweep)
+    unsigned long long left = __ballot(valid_q && (!split || lane < (split4 ? 16 : 32)) && c.slot >= 0 && (need_exact || !resolved));
+    if (PROF && left && lane == 0) atomicAdd(&lh[17], (int)__popcll(left));
+    while (left) {
+      const int L = __ffsll((long long)left) - 1;
+      left &= left - 1ull;
+      coop_exact_scan(L);
+    }
+  }
   if (valid_q && (!split || lane < (split4 ? 16 : 32))) {
     int status;
     if (c.slot < 0) {
       status = SO_MATCH_NOT_ENOUGH;  // LidarSlam.cpp:736-739
     } else {
-      if (need_exact || !resolved) {  // rare: exact per-lane scan of the 27 cells
-        if (PROF) atomicAdd(&lh[17], 1);
-        top.init();
-        too_far_certain = false;
-        knn27(map, c, qx, qy, qz, top);
-      }
       const float d2_4 = __uint_as_float((uint32_t)(top.b4 >> 32));
       if ((abl & 1) || too_far_certain || top.b4 == ~0ull || (double)d2_4 > (double)mp.sq_max_dist_f) {
         status = SO_MATCH_TOO_FAR;   // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
