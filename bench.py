@@ -818,7 +818,8 @@ def main():
     errs = [synth.pose_error(poses[i], sc.gt_pose(i)) for i in range(len(poses))]
     entry_text = {"staged": "so_icp_register on HOST scan buffers, the next scan announced with so_icp_stage_scan (DMA on the copy stream straight "
                             "from pinned caller memory, enqueued by the registration in flight; copy thread for pageable buffers): "
-                            "every scan's H2D copy is inside the timed region, overlapped with the previous registration",
+                            "every scan's H2D copy AND its spatial binning (scan_keys -> bin_offsets -> bin_place, enqueued behind the copy on the copy queue) "
+                            "are inside the timed region, overlapped with the previous registration",
                   "host": "so_icp_register on HOST scan buffers, copy then register (nothing overlapped)",
                   "resident": "so_icp_register_dev on scans uploaded BEFORE the timed region"}[args.entry]
     out = {
@@ -866,6 +867,9 @@ def main():
                  "stage_wait_ms_per_step": tm.stage_wait_ms_total / max(tm.registrations, 1),
                  "staged_by_dma_from_registered_memory": int(tm.staged_direct), "staged_through_copy_thread": int(tm.staged_copied),
                  "stage_declined": int(tm.stage_declined), "stage_protocol": (args.stage_protocol if args.entry == "staged" else None),
+                 # timed registrations whose scan had been spatially binned behind its DMA, on the copy queue, while the registration before
+                 # it ran (so_icp_stats::flags & SO_ICP_FLAG_BINNED_AHEAD; SOICP_PREBIN=0 disables): they start with their k-NN sweep
+                 "binned_ahead_timed_steps": int(sum(1 for s_ in step_stats if s_.flags & binding.FLAG_BINNED_AHEAD)),
                  "scan_buffers": {"pinned": "pinned host memory (so_icp_host_alloc)", "registered": "registered host memory (so_icp_host_register)",
                                   "pageable": "pageable"}[args.scan_buffers],
                  "note": "c_abi = wall time inside the registration core (enqueue + wait + post-processing); stage_wait = host time the registrations "

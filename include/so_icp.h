@@ -144,6 +144,8 @@ typedef struct {
 #define SO_ICP_FLAG_STAGED_SCAN 0x20u        /* the scan came from so_icp_stage_scan (upload overlapped with earlier work) */
 #define SO_ICP_FLAG_COPY_READBACK 0x40u      /* state read back with hipMemcpyAsync (SOICP_READBACK=copy) */
 #define SO_ICP_FLAG_QUERY_SPLIT 0x80u        /* world_size > 1 with SO_ICP_SHARD_QUERIES: map replicated, this rank registered its share of the scan */
+#define SO_ICP_FLAG_BINNED_AHEAD 0x100u      /* the staged scan had been spatially binned behind its copy, beside the registration before it
+                                                 (single device; SOICP_PREBIN=0 disables): this registration started with its k-NN sweep */
 
 /* average kernel durations since the last so_icp_reset_timing (HIP events on the context's stream) */
 typedef struct {

@@ -232,9 +232,11 @@ struct so_icp_ctx {
   int n_cus = 256;            // compute units of the device: upper bound of the persistent solve launch's workgroups
   int ablate = 0;             // SOICP_ABLATE (profiling / test switches), read at creation
   bool speculate = true;      // enqueue outer iteration i+1 before the report of i is in (SOICP_SPECULATE=0: wait first)
-  bool outer_events = true;   // an event behind the launch that reports an outer iteration is the watchdog of the host's wait for that report.
-                              // SOICP_OUTER_EVENTS=0: hipStreamQuery instead, no marker packet between the speculated k-NN sweep and the solve
-                              // behind it (round 4, A/B on one box: 5 811 / 5 784 with the events, 5 866 / 5 793 without -- noise; kept as it was)
+  // (round 5: no event and no stream query accompanies the host's wait for a report in the normal case.  An event record is a
+  //  marker packet, and so is what hipStreamQuery enqueues to learn whether the queue has drained: either one landed between the
+  //  speculated k-NN sweep and the solve launch enqueued behind it, where the command processor spent ~6 us on it -- the gap
+  //  every kernel trace of rounds 3-5 shows in front of the second solve.  The watchdog of that wait is now the clock: the queue
+  //  is queried only after kReportWatchdogMs without a report.)
   bool batch_mode = false;    // no kernel timing, tracker state read-only
   bool batch_single = false;  // batch on ONE lane: nothing runs next to it, the persistent solve launch is safe
   bool no_map_shift = false;  // so_icp_register_batch: hypotheses after the first keep the window of the first
@@ -267,9 +269,24 @@ struct so_icp_ctx {
     hipEvent_t ev = nullptr;             // direct path: end of the H2D copy on the copy stream
     bool ev_pending = false;             //   ... which may still be reading the caller's buffer
     bool deferred = false;               // direct path: announced, the copy is not enqueued yet (see stage_issue_deferred)
+    hipStream_t tail_stream = nullptr;   // direct path: the copy is enqueued there, what follows it (binning ahead, `ev`) not yet -- see stage_tail
     std::chrono::steady_clock::time_point t_announced;
     std::string err;
+    // binned ahead (stage_prebin): the scan's work list, built on the copy queue behind the copy while the registration before it runs
+    DevBuf pb_keys, pb_vals, pb_chunks, pb_binned, pb_ctr;
+    bool prebinned = false; uint32_t pb_chunk_cap = 0;
   } stage[kStageSlots];
+  // Binning ahead (round 5).  A scan announced with so_icp_stage_scan is hash-binned on the copy queue right behind its DMA, under the
+  // guess of the registration that enqueues the copy (the latest pose this context knows), so that its own registration starts
+  // with the k-NN sweep: scan_keys -> bin_offsets -> bin_place (three dependent launches, ~21 us of a 150 us registration) leave
+  // the registration's critical path and run beside the previous registration's solve, which keeps one wavefront per SIMD busy.
+  // Chunks binned under a pose one frame old stay spatially compact under the scan's own guess -- the k-NN kernel forms every
+  // chunk's candidate block from the queries' actual positions, as it does for the second sweep of any registration; results
+  // do not depend on the binning (exact per query, sums in scan order).  Single device, device-resident map only; SOICP_PREBIN=0
+  // switches it off.
+  bool prebin = true;
+  const double* prebin_pose = nullptr;    // non-null only while a registration that may bin ahead is enqueuing (its guess)
+  DevBuf d_pbin_key, d_pbin_cnt, d_pbin_off; uint32_t pbin_log2 = 0;
   StageSlot* stage_in_use = nullptr;  // the slot the current registration reads (released when the call returns)
   unsigned long long stage_seq = 0, stage_consumed_seq = 0;  // announcements so far / announcement number of the scan consumed last
   bool stage_quit = false, stage_started = false;
@@ -476,6 +493,9 @@ MatchParams match_params(float plane_res, int ablate) {
   mp.skip_near_pass = 0;
   mp.pack_light = 1;
   mp.packed_leftover = nullptr;
+  mp.begin = 0; mp.begin_max_surface_features = -1; mp.begin_n = 0;
+  mp.begin_args = RegBeginArgs{};
+  mp.begin_ctr = nullptr; mp.begin_state = nullptr;
   return mp;
 }
 EvalParams eval_params(float plane_res, int variant, int ablate) {
@@ -570,6 +590,7 @@ void fill_result(so_icp_ctx* c, const DevState& H, const double pose_in[7], so_i
 // finished -- no host round trip per evaluation.  One small read-back per outer iteration tells the host when to stop
 // enqueuing.
 void stage_issue_deferred(so_icp_ctx* c);  // (so_icp_stage_scan machinery, below)
+void stage_issue_deferred_copy(so_icp_ctx* c);
 constexpr int kRetryWithoutPersistentSolve = -1000;  // internal: never leaves register_core
 int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const double pose_in[7], double pose_out[7], so_icp_stats* st) {
   const auto t_begin = std::chrono::steady_clock::now();
@@ -627,7 +648,23 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   //      sampling rule, spatial sort (locality survives the small pose updates), chunk list + gather
   span_begin(c, 2, (uint32_t)n);
   BinTable bt{nullptr, nullptr, nullptr, 0};
-  if (n) {
+  // a scan that was binned ahead of this call (so_icp_stage_scan, so_icp_ctx::prebin): its work list is in the slot
+  const bool may_prebin = c->prebin && c->dmap && c->cfg.world_size <= 1 && !c->batch_mode && !c->borrow.on && !qsplit;
+  so_icp_ctx::StageSlot* pb = (may_prebin && n && c->scan_staged && c->stage_in_use && c->stage_in_use->prebinned && c->stage_in_use->n == n &&
+                               c->stage_in_use->dev.as<float>() == d_scan) ? c->stage_in_use : nullptr;
+  const float4* d_binned = c->d_binned.as<float4>();
+  const uint32_t* d_chunks = c->d_chunks.as<uint32_t>();
+  uint32_t chunk_cap = (uint32_t)(c->d_chunks.cap / 4);
+  // (the prologue rides on the first k-NN launch -- MatchParams::begin -- unless that is the instrumented instantiation, whose
+  //  statistics share the histogram block the prologue clears)
+  const bool begin_in_knn = pb && c->ablate == 0;
+  if (pb) {
+    if (!begin_in_knn)
+      launch_reg_begin_prebinned(ds, pose_in, max_outer, lm_max, c->d_hist, pb->pb_ctr.as<unsigned long long>(), c->d_status.as<uint8_t>(), (uint32_t)n,
+                                 c->cfg.max_surface_features, s);
+    d_binned = pb->pb_binned.as<float4>(); d_chunks = pb->pb_chunks.as<uint32_t>(); chunk_cap = pb->pb_chunk_cap;
+    st->flags |= SO_ICP_FLAG_BINNED_AHEAD;
+  } else if (n) {
     // hash binning: keys + per-key counts (scan_keys), bucket offsets + chunk list (bin_offsets), placement (bin_place).
     // The table has >= 2 slots per query; bin_offsets leaves it empty again.
     uint32_t lg = 16;
@@ -655,7 +692,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   HIP_TRY(c, hipGetLastError());  // a refused launch would otherwise surface as a 50 ms wait or "state was not published"
   const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
   MatchParams mp = match_params(plane_res_now, c->ablate);
-  mp.chunk_cap = (uint32_t)(c->d_chunks.cap / 4);
+  mp.chunk_cap = chunk_cap;
   static const bool pack_small = [] { const char* e = std::getenv("SOICP_KNN_PACK_SMALL"); return e && e[0] == '1'; }();
   mp.pack_light = (c->knn_pack && c->knn_pack_hold == 0 && (pack_small || !c->knn_list_fits)) ? 1 : 0;
   mp.packed_leftover = &c->d_state->packed_leftover;
@@ -732,8 +769,13 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
       ka = next_event(c); kb = next_event(c);
       if (ka && kb) c->spans.push_back(EventSpan{0, ka, kb, (uint32_t)n});
     }
-    launch_knn_plane(c->d_binned.as<float4>(),
-                     c->d_chunks.as<uint32_t>(), ds, c->view, mp, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s, ka, kb);
+    MatchParams mp_it = mp;
+    if (it == 0 && begin_in_knn) {
+      mp_it.begin = 1; mp_it.begin_args.max_outer = max_outer; mp_it.begin_args.lm_max = lm_max; mp_it.begin_max_surface_features = c->cfg.max_surface_features;
+      mp_it.begin_n = (uint32_t)n; std::memcpy(mp_it.begin_args.pose, pose_in, sizeof(mp_it.begin_args.pose));
+      mp_it.begin_ctr = pb->pb_ctr.as<unsigned long long>(); mp_it.begin_state = ds;
+    }
+    launch_knn_plane(d_binned, d_chunks, ds, c->view, mp_it, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s, ka, kb);
     if (c->cfg.time_kernels >= 2)  // kernel statistics of this sweep (profiling mode only)
       HIP_TRY(c, hipMemcpyAsync(c->h_hist + (size_t)it * kHistReplicas * kHistStride, c->d_hist,
                                 kHistReplicas * kHistStride * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -760,7 +802,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     if (!direct_rb) HIP_TRY(c, hipMemcpyAsync(c->h_ring[it & 1], ds, sizeof(DevState), hipMemcpyDeviceToHost, s));
     // (a deferred report is complete only after the NEXT k-NN launch: the event is recorded behind that one, see the loop)
     // (the pinned mirrors are polled; the event is the watchdog of that wait only where the stream itself cannot serve as one)
-    if (!deferred && (!direct_rb || c->outer_events)) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));
+    if (!direct_rb) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));
     HIP_TRY(c, hipGetLastError());
     return SO_ICP_OK;
   };
@@ -769,11 +811,16 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     if (!direct_rb) { HIP_TRY(c, hipEventSynchronize(c->ev_outer[it & 1])); return SO_ICP_OK; }
     volatile unsigned long long* seq = &c->h_ring[it & 1]->seq;
     const unsigned long long want = seq_base | (unsigned long long)(it + 1);
+    constexpr int kReportWatchdogMs = 5;  // (a registration lasts 0.15 ms; the waits inside a solve launch give up after 50 ms)
+    auto next_check = std::chrono::steady_clock::now() + std::chrono::milliseconds(kReportWatchdogMs);
     for (unsigned spin = 1;; ++spin) {
       if (*seq == want) break;
+      if ((spin & 0x3FFu) != 0) continue;
+      const auto now = std::chrono::steady_clock::now();
+      if (now < next_check) continue;
+      next_check = now + std::chrono::milliseconds(1);
       // watchdog: everything enqueued so far -- the launch that reports this iteration included -- has completed
-      // (hipStreamQuery: no marker packet in the queue; SOICP_OUTER_EVENTS=1: the event recorded behind that launch)
-      if ((spin & 0x3FFu) == 0 && (c->outer_events ? hipEventQuery(c->ev_outer[it & 1]) : hipStreamQuery(s)) != hipErrorNotReady) {
+      if (hipStreamQuery(s) != hipErrorNotReady) {
         (void)hipGetLastError();  // (hipErrorNotReady of the earlier polls, or the error the synchronize below reports)
         // the iteration's launches have all completed: either it was a no-op (converged earlier: cannot happen for the
         // iteration the host waits on) or a kernel failed -- report instead of spinning forever
@@ -810,12 +857,19 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // (every kernel consults DevState::reg_done) that drains while the host post-processes.
   // (SOICP_SPECULATE=0 enqueues nothing ahead: every launch of a profiled run is then a real one.)
   int last = 0;
-  if ((rc = enqueue_outer_a(0)) || (rc = enqueue_outer_b(0))) return rc;
+  if ((rc = enqueue_outer_a(0))) return rc;
+  // the NEXT scan's DMA goes out right behind this registration's first launch (the rest of what the copy queue does for that
+  // scan follows below, once the launches that are not urgent -- the first sweep lasts 20 us -- are in the queue as well)
+  if (!c->batch_mode && c->stage_issue_at == 1) stage_issue_deferred_copy(c);
+  if ((rc = enqueue_outer_b(0))) return rc;
   for (int it = 0;; ++it) {
     if (c->speculate && it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
-    if (defer_reports && it + 1 < max_outer && c->outer_events) HIP_TRY(c, hipEventRecord(c->ev_outer[it & 1], s));  // behind the launch that reports it
     // this registration's launches are in the queue and the host is about to idle: the moment for the NEXT scan's DMA
-    if (!c->batch_mode && ((it == 0 && c->stage_issue_at == 1) || (it == 1 && c->stage_issue_at == 2))) stage_issue_deferred(c);
+    if (!c->batch_mode && ((it == 0 && c->stage_issue_at == 1) || (it == 1 && c->stage_issue_at == 2))) {
+      c->prebin_pose = may_prebin ? pose_in : nullptr;  // (the next scan is binned behind its copy, under this registration's guess)
+      stage_issue_deferred(c);
+      c->prebin_pose = nullptr;
+    }
     if ((rc = await_outer(it))) return rc;
     last = it;
     if (c->h_ring[it & 1]->reg_done || it + 1 >= max_outer) break;
@@ -924,16 +978,63 @@ bool stage_any_queued(const so_icp_ctx* c) {
 // a registration ago)
 void stage_finish_direct(so_icp_ctx::StageSlot& sl) {
   sl.deferred = false;  // (a copy that was never enqueued reads nothing)
+  if (sl.tail_stream) {  // (a copy whose event was never recorded -- the registration that enqueued it failed in between: wait for the queue)
+    (void)hipStreamSynchronize(sl.tail_stream);
+    sl.tail_stream = nullptr; sl.prebinned = false; sl.ev_pending = false;
+  }
   if (sl.ev_pending) { (void)hipEventSynchronize(sl.ev); sl.ev_pending = false; }
 }
 // enqueue the DMA of a direct slot on the copy stream (under stage_mu)
-hipError_t stage_issue(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
+// bin the slot's scan on the copy queue, behind its copy (so_icp_ctx::prebin); a failure only means "not binned ahead"
+void stage_prebin(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
+  sl.prebinned = false;
+  const size_t n = sl.n;
+  if (!c->prebin || !c->prebin_pose || !n || n >= ((size_t)1 << 21)) return;
+  uint32_t lg = 16;
+  while ((1ull << lg) < 2 * (unsigned long long)n) ++lg;
+  const size_t m = n + 256, T = (size_t)1 << lg;
+  hipStream_t s = c->copy_stream;
+  bool ok = sl.pb_keys.reserve(m * 4) == hipSuccess && sl.pb_vals.reserve(m * 4) == hipSuccess && sl.pb_chunks.reserve(m * 4) == hipSuccess &&
+            sl.pb_binned.reserve(m * 16) == hipSuccess && sl.pb_ctr.reserve(64) == hipSuccess;
+  if (ok && c->pbin_log2 != lg) {  // (bin_offsets leaves the table empty again)
+    ok = c->d_pbin_key.reserve(T * 4) == hipSuccess && c->d_pbin_cnt.reserve(T * 4) == hipSuccess && c->d_pbin_off.reserve(T * 4) == hipSuccess &&
+         hipMemsetAsync(c->d_pbin_key.p, 0xFF, T * 4, s) == hipSuccess && hipMemsetAsync(c->d_pbin_cnt.p, 0, T * 4, s) == hipSuccess;
+    c->pbin_log2 = ok ? lg : 0;
+  }
+  if (!ok) { (void)hipGetLastError(); c->pbin_log2 = 0; return; }
+  const BinTable bt{c->d_pbin_key.as<uint32_t>(), c->d_pbin_cnt.as<uint32_t>(), c->d_pbin_off.as<uint32_t>(), lg};
+  sl.pb_chunk_cap = (uint32_t)(sl.pb_chunks.cap / 4);
+  launch_scan_keys(sl.dev.as<float>(), (uint32_t)n, c->d_state, c->prebin_pose, 0, 0, c->d_hist, c->view, c->cfg.max_surface_features, 0, 1,
+                   sl.pb_keys.as<uint32_t>(), sl.pb_vals.as<uint32_t>(), nullptr, bt, s, false, nullptr, 0, false, 0, sl.pb_ctr.as<unsigned long long>());
+  launch_bin_offsets(bt, sl.pb_chunks.as<uint32_t>(), sl.pb_chunk_cap, c->d_state, s, nullptr, 0, sl.pb_ctr.as<unsigned long long>());
+  launch_bin_place(bt, sl.dev.as<float>(), (uint32_t)n, sl.pb_keys.as<uint32_t>(), sl.pb_vals.as<uint32_t>(), sl.pb_binned.as<float4>(), s);
+  if (hipGetLastError() != hipSuccess) { c->pbin_log2 = 0; return; }  // (a refused launch may have left the table dirty: cleared before its next use)
+  sl.prebinned = true;
+}
+// The DMA of a direct slot in two steps (both under stage_mu): stage_issue_copy enqueues the copy, stage_tail what follows it on the
+// copy queue -- the binning ahead (only from inside a registration: so_icp_ctx::prebin_pose) and the event the consuming
+// registration waits for.  A registration in flight calls them apart (the copy right behind its first launch, the tail once its
+// other launches are in the queue: the copy is the long pole -- 34 us for a 131 072-point scan -- and the binning should land in
+// the shadow of the first solve, not beside the second sweep); everybody else calls stage_issue = both at once.
+hipError_t stage_issue_copy(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
   sl.deferred = false;
-  hipError_t e = hipMemcpyAsync(sl.dev.p, sl.src, sl.n * 12, hipMemcpyHostToDevice, c->copy_stream);
-  if (e == hipSuccess) e = hipEventRecord(sl.ev, c->copy_stream);
-  if (e == hipSuccess) { sl.ev_pending = true; return e; }
+  sl.prebinned = false;
+  const hipError_t e = hipMemcpyAsync(sl.dev.p, sl.src, sl.n * 12, hipMemcpyHostToDevice, c->copy_stream);
+  if (e == hipSuccess) { sl.tail_stream = c->copy_stream; return e; }
   sl.state = -1; sl.err = std::string("so_icp_stage_scan: ") + hipGetErrorString(e);
   return e;
+}
+hipError_t stage_tail(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
+  if (!sl.tail_stream) return hipSuccess;
+  stage_prebin(c, sl);
+  const hipError_t e = hipEventRecord(sl.ev, c->copy_stream);
+  if (e == hipSuccess) { sl.tail_stream = nullptr; sl.ev_pending = true; return e; }
+  stage_finish_direct(sl);  // (waits for the copy queue instead)
+  return hipSuccess;
+}
+hipError_t stage_issue(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
+  const hipError_t e = stage_issue_copy(c, sl);
+  return e == hipSuccess ? stage_tail(c, sl) : e;
 }
 // WHEN a DMA-staged scan travels.  A copy that is enqueued while the registration thread is enqueuing its launches slows
 // them down: the command processor fetches every dispatch packet and its arguments from host memory over the same PCIe link
@@ -944,7 +1045,15 @@ hipError_t stage_issue(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
 void stage_issue_deferred(so_icp_ctx* c) {
   if (!c->stage_started) return;
   std::lock_guard<std::mutex> lk(c->stage_mu);
-  for (so_icp_ctx::StageSlot& sl : c->stage) if (sl.state == 2 && sl.deferred) (void)stage_issue(c, sl);
+  for (so_icp_ctx::StageSlot& sl : c->stage) {
+    if (sl.state == 2 && sl.deferred) (void)stage_issue(c, sl);
+    else if (sl.state == 2 && sl.tail_stream) (void)stage_tail(c, sl);
+  }
+}
+void stage_issue_deferred_copy(so_icp_ctx* c) {  // (the registration in flight: copy now, stage_issue_deferred for the rest later)
+  if (!c->stage_started) return;
+  std::lock_guard<std::mutex> lk(c->stage_mu);
+  for (so_icp_ctx::StageSlot& sl : c->stage) if (sl.state == 2 && sl.deferred) (void)stage_issue_copy(c, sl);
 }
 bool host_range_registered(const so_icp_ctx* c, const void* p, size_t bytes) {
   const char* q = static_cast<const char*>(p);
@@ -1081,6 +1190,7 @@ const float* take_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t strid
       if (stage_issue(c, sl) != hipSuccess) { c->err = sl.err; *rc = SO_ICP_E_HIP; sl.src = nullptr; sl.state = 0; return nullptr; }
       sl.src = nullptr;
     }
+    if (sl.tail_stream) (void)stage_tail(c, sl);  // (no registration finished what it had begun: not binned ahead)
     if (sl.ev_pending && c->stage_wait_on_host) stage_finish_direct(sl);
     // (in a stream of registrations the copy ended long ago -- it was enqueued a registration earlier: then no barrier packet
     //  in front of this registration's first kernel either)
@@ -1321,7 +1431,7 @@ so_icp_ctx::~so_icp_ctx() {
     if (stage_thread.joinable()) stage_thread.join();
   }
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
-  for (StageSlot& sl : stage) { sl.dev.release(); if (sl.pinned) (void)hipHostFree(sl.pinned); if (sl.ev) (void)hipEventDestroy(sl.ev); }
+  for (StageSlot& sl : stage) { sl.dev.release(); for (DevBuf* b : {&sl.pb_keys, &sl.pb_vals, &sl.pb_chunks, &sl.pb_binned, &sl.pb_ctr}) b->release(); if (sl.pinned) (void)hipHostFree(sl.pinned); if (sl.ev) (void)hipEventDestroy(sl.ev); }
   for (const HostRange& r : host_ranges) { if (r.owned) (void)hipHostFree(const_cast<char*>(r.p)); else (void)hipHostUnregister(const_cast<char*>(r.p)); }
   for (int r = 0; r < 8; ++r) if (peer_opened[r] && peer_inbox[r]) (void)hipIpcCloseMemHandle(peer_inbox[r]);
   if (peer_own) (void)hipFree(peer_own);
@@ -1332,7 +1442,7 @@ so_icp_ctx::~so_icp_ctx() {
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_vals0, &d_chunks,
                     &d_binned, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist, &d_kdbg, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
-                    &pf_heads, &pf_temp, &pf_dec, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_counts, &d_sub})
+                    &pf_heads, &pf_temp, &pf_dec, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_pbin_key, &d_pbin_cnt, &d_pbin_off, &d_counts, &d_sub})
     b->release();
   for (DevBuf& b : resident_scans) b.release();
   d_state_buf.release();
@@ -1446,7 +1556,6 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
     return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if (const char* ev = std::getenv("SOICP_READBACK")) c->direct_readback = std::string(ev) != "copy";
   if (const char* ev = std::getenv("SOICP_SPECULATE")) c->speculate = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("SOICP_OUTER_EVENTS")) c->outer_events = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PREFILTER_FAST")) c->pf_fast = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PREFILTER_STREAM")) c->pf_own_stream = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_ABLATE")) c->ablate = std::atoi(ev);
@@ -1454,6 +1563,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_STAGE_WAIT")) c->stage_wait_on_host = std::string(ev) == "host";
   if (const char* ev = std::getenv("SOICP_KNN_PACK")) c->knn_pack = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_PREBIN")) c->prebin = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BATCH_CHAIN")) c->batch_chain = std::string(ev) != "0";
   if (const char* ev = std::getenv("SOICP_BATCH_REPORT")) c->batch_small_report = std::string(ev) != "full";
   if (const char* ev = std::getenv("SOICP_BATCH_ROUND0")) c->batch_round0_full = std::string(ev) != "near";

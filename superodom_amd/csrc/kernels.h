@@ -20,8 +20,11 @@ struct DevMapView {
   double inv_cell;
   int32_t origin[3];
   uint32_t n_points;
-  uint32_t n_slots;            // occupied cubes (tables); sort keys use slot ids n_slots / n_slots+1 for the two specials
+  uint32_t n_slots;            // occupied cubes (tables)
 };
+
+// registration prologue arguments (the guess and the loop bounds travel as kernel arguments; a batch reads them from memory)
+struct RegBeginArgs { double pose[7]; int32_t max_outer, lm_max; };
 
 struct MatchParams {
   float plane_res;        // localMap.planeRes_ (float member, LocalMap.h:761)
@@ -41,6 +44,15 @@ struct MatchParams {
   struct DevState* hring[2];
   unsigned long long seq_base;
   int32_t publish_prev;
+  // begin != 0: this launch is the FIRST kernel of a registration whose scan was binned ahead (so_icp_stage_scan): it carries the
+  // registration prologue itself -- one launch less on the path from the call to the first sweep, where the host's enqueue rate is
+  // the limit.  Every workgroup takes the pose, the loop state (iteration 0, not done) and the work-list counters from HERE instead
+  // of the state block; workgroup 0 writes the prologue into begin_state for the launches behind this one.
+  int32_t begin, begin_max_surface_features;
+  uint32_t begin_n;                        // points of the scan (the sampling rule's DROPPED status bytes are written by this launch)
+  RegBeginArgs begin_args;                 // guess + loop bounds
+  const unsigned long long* begin_ctr;     // work-list counters left by the binning
+  struct DevState* begin_state;
 };
 
 struct EvalParams {
@@ -129,8 +141,6 @@ constexpr int kArriveCounters = 16, kArriveStrideWords = 32, kHandoffWordOffset 
 constexpr int kSyncBytes = kHandoffWordOffset * 4 + 8 * 16;
 constexpr int kSumsStride = 48;      // doubles per partial record (45 used)
 constexpr int kRecordChunksMax = 40; // 16-byte chunks per workgroup record of the persistent solve (29 sums + 8 histogram pairs)
-// registration prologue arguments (the guess and the loop bounds travel as kernel arguments; a batch reads them from memory)
-struct RegBeginArgs { double pose[7]; int32_t max_outer, lm_max; };
 
 // so_icp_register_batch: B hypotheses (initial poses) of ONE scan advance in the same launches.  Every per-registration
 // array exists once per hypothesis with a common element stride; a launch serves the hypotheses listed in `active`
@@ -161,7 +171,8 @@ struct BinTable {
 // per query: table slot (0xFFFFFFFF = dropped) and rank inside its bucket
 // (bv / n_hyp: batched launch over the hypotheses bv->active[0 .. n_hyp), see BatchView; nullptr / 0 = one registration)
 void launch_bin_offsets(const BinTable& bt, uint32_t* d_chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s,
-                        const BatchView* bv = nullptr, uint32_t n_hyp = 0);
+                        const BatchView* bv = nullptr, uint32_t n_hyp = 0,
+                        unsigned long long* d_packed_ctr = nullptr /* a scan binned ahead of its registration: its own work-list counters */);
 // binned[pos] = {x, y, z, query index (bits)} of the query filed at position pos of its bucket
 void launch_bin_place(const BinTable& bt, const float* d_scan_xyz, uint32_t n, const uint32_t* d_qslot, const uint32_t* d_qrank,
                       float4* d_binned, hipStream_t s, const DevState* st_if_rebin = nullptr,
@@ -176,7 +187,13 @@ void launch_scan_keys(const float* d_scan_xyz, uint32_t n, DevState* st, const d
                       const BatchView* bv = nullptr, uint32_t n_hyp = 0,
                       bool qsplit = false /* N > 1 with the QUERIES split: d_scan is this rank's share (64-point segments rank, rank + world,
                                              ... of a scan of n_total points); every query is owned, the sampling rule uses the global index */,
-                      uint32_t n_total = 0);
+                      uint32_t n_total = 0,
+                      unsigned long long* d_prebin_ctr = nullptr /* binning AHEAD of the scan's registration (so_icp_stage_scan): no prologue, no status
+                                                                    bytes, `st` untouched; `pose` = the guess of the registration in flight */);
+// prologue of a registration whose scan was binned ahead: guess + loop bounds, the work-list counters out of *d_ctr, DROPPED status bytes
+// of the points the sampling rule leaves out
+void launch_reg_begin_prebinned(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* d_hist, const unsigned long long* d_ctr,
+                                uint8_t* d_status, uint32_t n, int max_surface_features, hipStream_t s);
 void launch_knn_plane(const float4* d_binned,
                       const uint32_t* d_chunk_start, const DevState* st, const DevMapView& map, const MatchParams& mp,
                       CorrBuffers corr, uint32_t* d_nbr5 /*5 canonical indices per query*/,

@@ -113,6 +113,30 @@ __global__ __launch_bounds__(512) void reg_begin_kernel(DevState* st, RegBeginAr
 }
 static_assert(kHistReplicas * kHistStride == 512, "reg_begin_kernel clears one histogram word per thread");
 
+// calculateSamplingRate / shouldProcessPoint (LidarSlam.cpp:346-359) for point gi of a scan of ntot points (0: rate 0, every point dropped)
+__device__ __forceinline__ bool sampling_keeps(uint32_t gi, uint32_t ntot, int max_surface_features) {
+  if (max_surface_features >= 0 && ntot > (uint32_t)max_surface_features) {
+    const double rate = 1.0 * max_surface_features / ntot;
+    const double rem = fmod((double)gi * rate, 1.0);
+    if (rem + 0.001 > rate) return false;
+  }
+  return true;
+}
+// Prologue of a registration whose scan was binned ahead (scan_keys_kernel with prebin_ctr, so_icp_stage_scan): the guess and the
+// loop bounds, the work-list counters the binning left in *ctr, and -- when the sampling rule drops points -- their status bytes
+// (the rule does not depend on the pose).  One launch instead of scan_keys -> bin_offsets -> bin_place on the registration's path.
+__global__ __launch_bounds__(256) void reg_begin_prebinned_kernel(DevState* st, RegBeginArgs a, int32_t* __restrict__ hist,
+                                                                  const unsigned long long* __restrict__ ctr, uint8_t* __restrict__ status,
+                                                                  uint32_t n, int max_surface_features) {
+  if (blockIdx.x == 0) {
+    hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
+    reg_begin_state(st, a, threadIdx.x);
+    if (threadIdx.x == 0) st->bin_packed = *ctr;  // (the same thread cleared it in reg_begin_state)
+  }
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !sampling_keeps(i, n, max_surface_features)) status[i] = SO_MATCH_DROPPED;
+}
+
 // (workgroup 0 also runs the registration prologue: one launch less per registration)
 template <bool BATCH>
 __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict__ scan, uint32_t n,
@@ -121,7 +145,7 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
                                                         int max_surface_features, int rank, int world,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                                         uint8_t* __restrict__ status, BinTable bt, int rebin, BatchView bv,
-                                                        int qsplit, uint32_t n_total) {
+                                                        int qsplit, uint32_t n_total, unsigned long long* __restrict__ prebin_ctr) {
   if (BATCH) {
     const uint32_t h = bv.active[blockIdx.y];
     st += h; hist += (size_t)h * (kHistReplicas * kHistStride);
@@ -132,7 +156,14 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   // rebin (sharded map, outer iteration >= 1): ownership and binning are re-derived under the CURRENT pose -- a query that
   // the pose update carried out of its owner's halo (1 degree at 50 m is more than a cell) is handed to its new owner, so
   // every rank searches only queries whose whole gate ball lies inside its shard.  No prologue; a no-op once converged.
-  if (rebin) {
+  // prebin_ctr (so_icp_stage_scan, single device): the scan is binned AHEAD of its registration, on the copy queue, beside the
+  // registration in flight -- under that registration's guess (`a.pose`; a chunk stays spatially compact under the small rigid
+  // motion to the scan's own guess, exactly like the second sweep of any registration, whose pose has moved since the binning).
+  // Nothing of the registration in flight is touched: no prologue, no status bytes, the work-list counters in *prebin_ctr;
+  // reg_begin_prebinned_kernel adopts them when the scan's own registration starts.
+  if (!BATCH && prebin_ctr) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *prebin_ctr = 0ull;  // (bin_offsets adds to it)
+  } else if (rebin) {
     if (st->reg_done) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->bin_packed = 0ull;  // (bin_offsets of this round adds to it)
   } else if (blockIdx.x == 0) {
@@ -142,12 +173,15 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Pose pose = pose_from_array(rebin ? st->T : (BATCH ? ab->pose : a.pose));
-  // key = (cube slot << 21) | Morton(half-cell: 7 bits per axis, low 3 bits = octant inside the map cell).  Two special
-  // "slots" follow the real cubes: n_slots = processed query whose cube is outside the window / has no tree
-  // (NOT_ENOUGH_NEIGHBORS), n_slots + 1 = query not sampled / not owned by this rank (dropped).  With more than 2046
-  // occupied cubes the slot does not fit above 21 cell bits: the key falls back to whole cells.
+  // key = (cube slot << 21) | Morton(half-cell: 7 bits per axis, low 3 bits = octant inside the map cell).  The two highest
+  // values of the slot field are special: slot_lim = processed query whose cube is outside the window / has no tree
+  // (NOT_ENOUGH_NEIGHBORS), slot_lim + 1 = query not sampled / not owned by this rank (dropped).  With more than 2046
+  // occupied cubes the slot does not fit above 21 cell bits: the key falls back to whole cells.  A key only GROUPS queries
+  // (every query is located again under the current pose by the k-NN sweep), so a real slot is clamped below the specials: a
+  // scan binned ahead of its registration may read a slot the map gained after `map` was snapshotted.
   const int cell_bits = (map.n_slots + 2u <= 2048u) ? 21 : 18;
-  const uint32_t kDropped = (map.n_slots + 1u) << cell_bits, kNoCube = map.n_slots << cell_bits;
+  const uint32_t slot_lim = (1u << (32 - cell_bits)) - 2u;
+  const uint32_t kDropped = (slot_lim + 1u) << cell_bits, kNoCube = slot_lim << cell_bits;
   uint32_t key = kDropped;
   bool process = true;
   // qsplit (N > 1, map replicated, QUERIES split): `scan` is this rank's share of the scan -- its 64-point segments rank, rank +
@@ -156,11 +190,7 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
   const uint32_t gi = qsplit ? ((((i >> 6) * (uint32_t)world + (uint32_t)rank) << 6) + (i & 63u)) : i;
   const uint32_t ntot = qsplit ? n_total : n;
   const bool own_all = qsplit || world <= 1;
-  if (max_surface_features >= 0 && ntot > (uint32_t)max_surface_features) {  // calculateSamplingRate / shouldProcessPoint (0: rate 0, every point dropped)
-    const double rate = 1.0 * max_surface_features / ntot;
-    const double rem = fmod((double)gi * rate, 1.0);
-    if (rem + 0.001 > rate) process = false;
-  }
+  if (!sampling_keeps(gi, ntot, max_surface_features)) process = false;
   if (process) {
     const float px = scan[3 * i], py = scan[3 * i + 1], pz = scan[3 * i + 2];
     double wx, wy, wz;
@@ -173,7 +203,8 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
     } else {
       int owner = rank;
       if (!own_all) owner = (int)(brick_hash(w[0], w[1], w[2], c.cx / kBrickCells, c.cy / kBrickCells, c.cz / kBrickCells) % (uint32_t)world);
-      if (owner == rank && cell_bits == 18) key = ((uint32_t)c.slot << 18) | morton3((uint32_t)c.cx, (uint32_t)c.cy, (uint32_t)c.cz);
+      const uint32_t kslot = min((uint32_t)c.slot, slot_lim - 1u);
+      if (owner == rank && cell_bits == 18) key = (kslot << 18) | morton3((uint32_t)c.cx, (uint32_t)c.cy, (uint32_t)c.cz);
       else if (owner == rank) {
         // Morton code of the HALF-cell: its three low bits are the octant of the cell the query sits in, so that a
         // chunk (one key) is one octant and the near pass of the k-NN kernel needs a 2x2x2 block of cells
@@ -183,11 +214,11 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
         int hz = (int)floor(((double)qz - mn2) * map.inv_cell * 2.0);
         hx = min(max(hx, 2 * c.cx), min(2 * c.cx + 1, hmax)); hy = min(max(hy, 2 * c.cy), min(2 * c.cy + 1, hmax));
         hz = min(max(hz, 2 * c.cz), min(2 * c.cz + 1, hmax));
-        key = ((uint32_t)c.slot << 21) | morton3((uint32_t)hx, (uint32_t)hy, (uint32_t)hz);
+        key = (kslot << 21) | morton3((uint32_t)hx, (uint32_t)hy, (uint32_t)hz);
       }
     }
   }
-  if (key == kDropped) status[i] = SO_MATCH_DROPPED;  // every other query gets its status from the k-NN sweep
+  if (key == kDropped && status) status[i] = SO_MATCH_DROPPED;  // every other query gets its status from the k-NN sweep
   // ---- hash binning: claim / find the key's table slot, then count the query in (one atomic per distinct key of the
   //      wavefront: consecutive scan points are neighbours in space, a wavefront holds a handful of keys)
   const bool kept = key != kDropped;
@@ -230,7 +261,8 @@ __global__ __launch_bounds__(256) void scan_keys_kernel(const float* __restrict_
 // grows from the top of the buffer downwards -- the k-NN kernel pairs light chunks so that all chunks run in one round.
 template <bool BATCH>
 __global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t* __restrict__ chunk_start, uint32_t chunk_cap,
-                                                           DevState* __restrict__ st, BatchView bv) {
+                                                           DevState* __restrict__ st, BatchView bv,
+                                                           unsigned long long* __restrict__ packed_ctr /* scan binned ahead: its own counters */) {
   __shared__ uint32_t wq[16], wc[16], wl[16], base_q, base_c, base_l;
   if (BATCH) {
     const uint32_t h = bv.active[blockIdx.y];
@@ -265,7 +297,7 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(BinTable bt, uint32_t
     }
     // one atomic for the three ranges (21 bits each: scans of fewer than 2^21 points, checked by the host)
     unsigned long long old = 0ull;
-    if (sq) old = atomicAdd(&st->bin_packed, (unsigned long long)sq | ((unsigned long long)sc << 21) | ((unsigned long long)sl << 42));
+    if (sq) old = atomicAdd((!BATCH && packed_ctr) ? packed_ctr : &st->bin_packed, (unsigned long long)sq | ((unsigned long long)sc << 21) | ((unsigned long long)sl << 42));
     base_q = (uint32_t)(old & 0x1FFFFFull); base_c = (uint32_t)((old >> 21) & 0x1FFFFFull); base_l = (uint32_t)(old >> 42);
   }
   __syncthreads();
@@ -772,7 +804,9 @@ constexpr uint32_t kPartTile = kTileCand / 4;  // candidates a packed chunk may 
 // PROF : the profiling / test-hook instantiation (per-wavefront stamps, SOICP_ABLATE switches, kernel statistics); the
 //        production instantiation carries none of it (the sweep is instruction-issue bound).
 // BATCH: so_icp_register_batch -- blockIdx.y picks the hypothesis, see BatchView.
-template <bool PROF, bool BATCH>
+// BEGIN: first launch of a registration whose scan was binned ahead (MatchParams::begin): an instantiation of its own, so that the
+//        others do not carry the prologue's arguments in their scalar registers (the kernel sits at its register budget).
+template <bool PROF, bool BATCH, bool BEGIN = false>
 __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restrict__ binned /* {x, y, z, query index} per binned position */,
                                                         const uint32_t* __restrict__ chunk_start,
                                                         const DevState* __restrict__ st,
@@ -792,12 +826,25 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   }
   uint32_t* const leftover_ctr = (BATCH && mp.packed_leftover)
       ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(mp.packed_leftover) + (size_t)bv.active[blockIdx.y] * sizeof(DevState)) : mp.packed_leftover;
-  if (st->reg_done) return;  // the registration already converged: this launch is a no-op
+  // (MatchParams::begin: first launch of a registration whose scan was binned ahead -- prologue, pose and counters from the arguments)
+  constexpr bool begin = BEGIN && !BATCH;
+  if (!begin && st->reg_done) return;  // the registration already converged: this launch is a no-op
   // the report of the previous outer iteration, left to this launch by its solve (MatchParams::publish_prev)
-  if (!BATCH && mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
+  if (!BATCH && !begin && mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
     publish_state_to(mp.hring[(st->outer_iter - 1) & 1], st, mp.seq_base | (unsigned long long)st->outer_iter, (int)threadIdx.x, 256);
   // the work-list counters of bin_offsets_kernel: kept queries | normal chunks << 21 | light chunks << 42
-  const unsigned long long pk = st->bin_packed;
+  const unsigned long long pk = begin ? *mp.begin_ctr : st->bin_packed;
+  if (begin) {
+    if (blockIdx.x == 0) {
+      hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
+      reg_begin_state(mp.begin_state, mp.begin_args, (int)threadIdx.x);
+      if (threadIdx.x == 0) mp.begin_state->bin_packed = pk;
+    }
+    // the sampling rule's DROPPED status bytes (the rule does not depend on the pose; every other query gets its status from the sweep)
+    if (mp.begin_max_surface_features >= 0 && mp.begin_n > (uint32_t)mp.begin_max_surface_features)
+      for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < mp.begin_n; i += gridDim.x * 256u)
+        if (!sampling_keeps(i, mp.begin_n, mp.begin_max_surface_features)) corr.status[i] = SO_MATCH_DROPPED;
+  }
   const uint32_t n_kept = (uint32_t)(pk & 0x1FFFFFull), n_normal = (uint32_t)((pk >> 21) & 0x1FFFFFull), n_light = (uint32_t)(pk >> 42);
   // Logical order of the work list: [first half of the light chunks][normal chunks][second half of the light chunks].
   // Wavefront w takes positions w, w + 4096, ...: with up to 8 192 chunks the wavefronts that get a second chunk are the
@@ -814,7 +861,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   const bool pack = SO_KNN_PACK && mp.pack_light && first_pass_is_near;
   const uint32_t n_packed = pack ? (n_light + 3u) >> 2 : 0u;
   const uint32_t n_chunks = n_normal + (pack ? n_packed : n_light), n_light1 = pack ? 0u : (n_light + 1u) >> 1;
-  const Pose pose = pose_from_array(st->T);
+  const Pose pose = pose_from_array(begin ? mp.begin_args.pose : st->T);
   if (PROF) {  // kernel statistics (group passes, fallback lanes, candidates scanned): profiling instantiation only
     if (threadIdx.x < 24) lh[threadIdx.x] = 0;
     __syncthreads();
@@ -1547,7 +1594,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
     if (SO_KNN_PACK && chunk < n_packed) do_item(std::true_type{}, chunk); else do_item(std::false_type{}, chunk);  // (n_packed = 0 unless `pack`)
   }
   if (stamp && lane_k == 0) {  // one record per wavefront, no atomics (they would perturb the measurement)
-    unsigned long long* d = mp.kdbg + ((size_t)(st->outer_iter & 1) * gridDim.x * 4 + blockIdx.x * 4 + wv) * 16;
+    unsigned long long* d = mp.kdbg + ((size_t)(begin ? 0 : (st->outer_iter & 1)) * gridDim.x * 4 + blockIdx.x * 4 + wv) * 16;
     d[0] = t_first; d[1] = wall_clock64();
     for (int i = 0; i < 5; ++i) d[2 + i] = acc[i];
     d[15] = clock64() - c_first;  // shader-clock ticks over the wavefront's life (d[1] - d[0] = the same span at 100 MHz)
@@ -2845,25 +2892,34 @@ void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_
 static const BatchView kNoBatch{nullptr, nullptr, 0, 0, 0, 0, 0, 0};
 void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist,
                       const DevMapView& map, int max_sf, int rank, int world, uint32_t* keys, uint32_t* vals, uint8_t* status,
-                      const BinTable& bin, hipStream_t s, bool rebin, const BatchView* bv, uint32_t n_hyp, bool qsplit, uint32_t n_total) {
+                      const BinTable& bin, hipStream_t s, bool rebin, const BatchView* bv, uint32_t n_hyp, bool qsplit, uint32_t n_total,
+                      unsigned long long* prebin_ctr) {
   RegBeginArgs a{};
   if (bv) {  // (the hypotheses' prologue arguments are in bv->begin)
     if (!n || !n_hyp) return;
     hipLaunchKernelGGL(scan_keys_kernel<true>, dim3((n + 255u) / 256u, n_hyp), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world,
-                       keys, vals, status, bin, 0, *bv, 0, n);
+                       keys, vals, status, bin, 0, *bv, 0, n, nullptr);
     return;
   }
-  if (!n) { if (!rebin) launch_reg_begin(st, pose, max_outer, lm_max, hist, s); return; }
+  if (!n) { if (!rebin && !prebin_ctr) launch_reg_begin(st, pose, max_outer, lm_max, hist, s); return; }
   for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
   a.max_outer = max_outer; a.lm_max = lm_max;
   hipLaunchKernelGGL(scan_keys_kernel<false>, grid_for(n, 256), dim3(256), 0, s, d_scan, n, st, a, hist, map, max_sf, rank, world, keys, vals, status,
-                     bin, rebin ? 1 : 0, kNoBatch, qsplit ? 1 : 0, qsplit ? n_total : n);
+                     bin, rebin ? 1 : 0, kNoBatch, qsplit ? 1 : 0, qsplit ? n_total : n, prebin_ctr);
+}
+void launch_reg_begin_prebinned(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist, const unsigned long long* ctr,
+                                uint8_t* status, uint32_t n, int max_sf, hipStream_t s) {
+  RegBeginArgs a;
+  for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
+  a.max_outer = max_outer; a.lm_max = lm_max;
+  const bool sampling = max_sf >= 0 && n > (uint32_t)max_sf;
+  hipLaunchKernelGGL(reg_begin_prebinned_kernel, sampling ? grid_for(n, 256) : dim3(1), dim3(256), 0, s, st, a, hist, ctr, status, sampling ? n : 0u, max_sf);
 }
 void launch_bin_offsets(const BinTable& bt, uint32_t* chunk_start, uint32_t chunk_cap, DevState* st, hipStream_t s, const BatchView* bv,
-                        uint32_t n_hyp) {
+                        uint32_t n_hyp, unsigned long long* packed_ctr) {
   const uint32_t gx = (1u << bt.log2_size) / 4096u;
-  if (bv) { if (n_hyp) hipLaunchKernelGGL(bin_offsets_kernel<true>, dim3(gx, n_hyp), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st, *bv); }
-  else hipLaunchKernelGGL(bin_offsets_kernel<false>, dim3(gx), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st, kNoBatch);
+  if (bv) { if (n_hyp) hipLaunchKernelGGL(bin_offsets_kernel<true>, dim3(gx, n_hyp), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st, *bv, nullptr); }
+  else hipLaunchKernelGGL(bin_offsets_kernel<false>, dim3(gx), dim3(1024), 0, s, bt, chunk_start, chunk_cap, st, kNoBatch, packed_ctr);
 }
 void launch_bin_place(const BinTable& bt, const float* d_scan, uint32_t n, const uint32_t* qslot, const uint32_t* qrank, float4* binned,
                       hipStream_t s, const DevState* st_if_rebin, const BatchView* bv, uint32_t n_hyp) {
@@ -2888,7 +2944,7 @@ void launch_knn_plane(const float4* binned,
   // The production instantiation carries no profiling code; SOICP_ABLATE != 0 selects the instrumented one.
   // Timing events ride on the kernel's own dispatch packet (no marker packets: separate hipEventRecord calls cost
   // ~3.7 us of stream time each, 8 % of a registration when every sweep is timed)
-  auto* k = mp.ablate ? knn_plane_kernel<true, false> : knn_plane_kernel<false, false>;
+  auto* k = mp.ablate ? knn_plane_kernel<true, false> : (mp.begin ? knn_plane_kernel<false, false, true> : knn_plane_kernel<false, false>);  // (the host never sets begin with ablate)
   if (ev_start && ev_stop)
     hipExtLaunchKernelGGL(k, dim3(kKnnBlocks), dim3(256), 0, s, ev_start, ev_stop, 0, binned,
                           chunk_start, st, map.pts, map.cell_start, map, mp, corr, nbr5, hist, kNoBatch);
