@@ -386,6 +386,17 @@ def main():
                 continue
             t_e, _, _ = timed_loop(entry, args.steps, rewarm=args.warmup)
             secondary[entry] = args.steps / t_e
+        if args.scan_buffers != "pageable" and world == 1:
+            # the protocol of rounds 1 - 3 beside the headline's: the same staged loop on PAGEABLE numpy buffers -- the copy
+            # thread packs and copies them, nothing is binned ahead
+            keep = scans
+            scans = [np.array(s_, dtype=np.float32, copy=True) for s_ in keep]
+            try:
+                timed_loop("staged", args.steps, rewarm=args.warmup)  # (untimed: the copy thread's pinned bounce buffers are allocated on first use)
+                t_e, st_pg, _ = timed_loop("staged", args.steps, rewarm=args.warmup)
+                secondary["staged_pageable_buffers"] = args.steps / t_e
+            finally:
+                scans = keep
     other_mode = None
     if world > 1 and not args.no_secondary:
         # the other way of splitting one registration over the ranks, same scans, same protocol (collective: every rank runs it)
@@ -847,7 +858,8 @@ def main():
                      "accepted_correspondences": accepted / args.steps, "stats_flags": int(flags),
                      "pose_error_vs_ground_truth_m_rad": [max(e[0] for e in errs), max(e[1] for e in errs)]},
         # the same registrations through the other entry points, `steps` each, after the timed region
-        "entry_points": {"note": "registrations/s; 'staged' and 'host' include the scan's H2D copy (1.5 MB), 'resident' does not",
+        "entry_points": {"note": "registrations/s; 'staged' and 'host' include the scan's H2D copy (1.5 MB), 'resident' does not; "
+                                 "'staged_pageable_buffers' = the staged loop on pageable numpy buffers (copy thread, nothing binned ahead: the r01 - r03 protocol)",
                          args.entry: value, **secondary},
         "roofline": {"bound": "hbm", "kernel": "knn_plane_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": tr_why or tr.get("source"),

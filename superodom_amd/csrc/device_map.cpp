@@ -203,16 +203,16 @@ int DeviceMap::upload_slot_table(std::string& err) {
   return 0;
 }
 
-bool DeviceMap::view(DevMapView& v, std::string& err) {
-  if (settle(err) < 0) return false;
-  if (ensure_pool(std::max<int>(1, (int)slot_cube_.size()), err)) return false;
-  if (upload_slot_table(err)) return false;
+int DeviceMap::view(DevMapView& v, std::string& err) {
+  if (const int rs = settle(err); rs < 0) return rs;  // (-1: a cube is full -- the caller's SO_ICP_E_NOMEM --, -2: device error)
+  if (ensure_pool(std::max<int>(1, (int)slot_cube_.size()), err)) return -2;
+  if (upload_slot_table(err)) return -2;
   v.pts = d_pool_; v.cell_start = d_cell_start_; v.cube_slot = d_cube_slot_;
   v.nc = nc_; v.ncell1 = ncell1_; v.inv_cell = 1.0 / cell_;
   v.origin[0] = origin_[0]; v.origin[1] = origin_[1]; v.origin[2] = origin_[2];
   v.n_points = (uint32_t)size_local();
   v.n_slots = (uint32_t)std::max<size_t>(1, slot_cube_.size());
-  return true;
+  return 0;
 }
 
 // planeRes decides the leaf of the voxel filter and the cell of the index.  The resident points keep their positions:
@@ -375,6 +375,7 @@ int DeviceMap::sync_meta(std::string& err) {
 
 int DeviceMap::insert_fast(const float* d_in, size_t n, size_t stride_floats, const double* T, float* d_world, bool defer, std::string& err) {
   if (!fast_enabled_ || !hash_grouping_ || world_ > 1 || slot_cube_.empty() || n >= (1u << 30)) return kNotFast;
+  if (slot_cube_.size() > (size_t)kMaxSlots) return kNotFast;  // (the device's per-slot tables hold kMaxSlots entries: the host lays such rounds out)
   if (skip_fast_ > 0) { --skip_fast_; return kNotFast; }
   if (nc_ <= 1 && ncell1_ <= 2) return kNotFast;  // (no resolution yet: the map is empty)
   const uint32_t lbits = leaf_bits(plane_res_);
@@ -449,12 +450,12 @@ void DeviceMap::settle_quiet() const {
   if (!pending_.on) return;
   DeviceMap* self = const_cast<DeviceMap*>(this);
   std::string e;
-  if (self->settle(e) < 0) self->deferred_err_ = e;
+  if (const int rc = self->settle(e); rc < 0) { self->deferred_err_ = e; self->deferred_rc_ = rc; }
 }
 
 int DeviceMap::settle(std::string& err) {
   if (!pending_.on) {
-    if (!deferred_err_.empty()) { err = deferred_err_; deferred_err_.clear(); return -2; }
+    if (!deferred_err_.empty()) { err = deferred_err_; deferred_err_.clear(); const int rc = deferred_rc_; deferred_rc_ = 0; return rc < 0 ? rc : -2; }
     return 0;
   }
   volatile unsigned long long* seq = &h_report_->seq;
@@ -477,15 +478,19 @@ int DeviceMap::settle(std::string& err) {
   std::memcpy(&R, h_report_, sizeof(R));
   if (R.halt == kFastHaltNone) {
     ++fast_inserts_;
+    // (the device has already moved ITS counts for every cube of the round: the host's copy follows for all of them, also when
+    //  one of them is reported as an error below -- a stale host count uploaded by the next sync_meta would undo the device's)
+    int bad = 0;
     for (uint32_t t = 0; t < R.n && t < (uint32_t)kMaxTouched; ++t) {
       const int cube = R.cube[t];
       const int s = (cube >= 0 && cube < kMapNum) ? cube_slot_[cube] : -1;
-      if (s < 0) { meta_dirty_ = true; err = "DeviceMap: the device reported a cube without a slot"; return -2; }
-      if (R.count[t] > kCapPerSlot) { meta_dirty_ = true; err = "DeviceMap: a 50 m cube exceeds the per-cube capacity of 1M points"; return -1; }
-      slot_count_[s] = R.count[t];
+      if (s < 0) { if (!bad) { bad = -2; err = "DeviceMap: the device reported a cube without a slot"; } continue; }
+      if (R.count[t] > kCapPerSlot && bad != -2) { bad = -1; err = "DeviceMap: a 50 m cube exceeds the per-cube capacity of 1M points"; }
+      slot_count_[s] = std::min<uint32_t>(R.count[t], kCapPerSlot);
       slot_res_[s] = ((R.dirty >> t) & 1u) ? -plane_res_ : plane_res_;  // (see add_surf_legacy)
     }
     est_old_ = R.n_old;
+    if (bad) { meta_dirty_ = true; return bad; }
     return (int)R.n_inside;
   }
   // the device could not lay the round out (or met a leaf the grouping kernels cannot sort): the map is unchanged, every

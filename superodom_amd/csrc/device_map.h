@@ -28,10 +28,9 @@ class DeviceMap {
     origin_[0] = 10; origin_[1] = 10; origin_[2] = 5; cube_slot_.assign(kMapNum, -1);
     const char* ev = std::getenv("SOICP_MAP_GROUPING");  // "sort": first stage of an insert by the stable radix sort (read per context)
     hash_grouping_ = !(ev && std::string(ev) == "sort");
-    ev = std::getenv("SOICP_MAP_FAST");   // "0": every insert round by round, laid out by the host (two read-backs per insert)
-    fast_enabled_ = !(ev && std::string(ev) == "0");
-    ev = std::getenv("SOICP_MAP_DEFER");  // "0": Localization() waits for the insert's report before it returns
-    defer_enabled_ = !(ev && std::string(ev) == "0");
+    ev = std::getenv("SOICP_MAP_FAST");   // "0": every insert round by round, laid out by the host (two read-backs per insert);
+    fast_enabled_ = !(ev && std::string(ev) == "0");   // "sync": laid out by the device, but Localization() waits for the insert's report
+    defer_enabled_ = !(ev && std::string(ev) == "sync");
   }
   ~DeviceMap();
   // changing planeRes rebuilds the cell tables over the resident points (they are re-filtered when an insert next touches
@@ -68,7 +67,7 @@ class DeviceMap {
   // (inserts laid out by the device / of those, the ones the host had to repeat round by round)
   void fast_stats(unsigned& inserts, unsigned& fallbacks) const { inserts = fast_inserts_; fallbacks = fast_fallbacks_; }
   size_t export_points(float* xyz, size_t cap, bool only_5x5, const int pos[3], std::string& err);
-  bool view(DevMapView& v, std::string& err);  // refreshes the device cube_slot table when the bookkeeping changed
+  int view(DevMapView& v, std::string& err);  // refreshes the device cube_slot table when the bookkeeping changed; 0, -1 (a cube is full), -2 (device error)
   // leaf keys hold 9 or 10 bits per axis (50 / planeRes + 4 leaves per cube axis must fit): planeRes >= 0.05
   bool supported_resolution(float plane_res) const { return plane_res >= 0.0499f; }
   static uint32_t leaf_bits(float leaf) { return (50.0f / leaf + 6.0f < 512.0f) ? 9u : 10u; }
@@ -130,7 +129,8 @@ class DeviceMap {
   size_t est_old_ = 0;        // old points of the last device-built round (sizes the next one's launches)
   int skip_fast_ = 0;         // inserts to go round by round after the device met a scan that needs several rounds
   unsigned fast_inserts_ = 0, fast_fallbacks_ = 0;
-  std::string deferred_err_;  // error of a settle() inside a const member: reported by the next call that can
+  int deferred_rc_ = 0;
+  std::string deferred_err_;  // error of a settle() inside a const member: reported (with its code) by the next call that can
 };
 
 }  // namespace soicp

@@ -201,7 +201,6 @@ struct so_icp_ctx {
   bool pf_fast = true;                // SOICP_PREFILTER_FAST=0: statistics read back, decided on the host, then the filter (rounds 1-3)
   hipEvent_t ev_upload = nullptr;     // a scan uploaded through the auxiliary queue: the context's queue waits for it
   hipStream_t pf_stream = nullptr;    // the pre-filter's own queue: the next frame's upload + VoxelGrid run BESIDE the map insert the previous
-  bool pf_own_stream = true;          // Localization() left in the context's queue (SOICP_PREFILTER_STREAM=0: behind it, in that queue)
   // Seam B scratch
   DevBuf d_q, d_nbr, d_d2, d_idx, d_found, d_fblist;
   // persistent LidarSLAM state
@@ -227,7 +226,7 @@ struct so_icp_ctx {
     }
   } batch;
   int batch_degrade = 0;  // 0: two solve workgroups per compute unit, 1: one (after a batched solve that was not co-resident, or
-                          // SOICP_BATCH_WG_PER_CU=1), 2: lanes = concurrent sequential registrations (SOICP_BATCH_MODE=lanes)
+                          // SOICP_BATCH_MODE=one_per_cu), 2: lanes = concurrent sequential registrations (SOICP_BATCH_MODE=lanes)
   bool no_map_shift_once = false;  // retry of a registration: keep the window of the first attempt
   int n_cus = 256;            // compute units of the device: upper bound of the persistent solve launch's workgroups
   int ablate = 0;             // SOICP_ABLATE (profiling / test switches), read at creation
@@ -295,20 +294,15 @@ struct so_icp_ctx {
   std::thread stage_thread; std::mutex stage_mu; std::condition_variable stage_cv;
   struct HostRange { const char* p; size_t bytes; bool owned; };
   std::vector<HostRange> host_ranges;     // so_icp_host_register / so_icp_host_alloc (under stage_mu)
-  bool stage_wait_on_host = false;        // SOICP_STAGE_WAIT=host: the registration thread waits for a DMA-staged copy itself (measurement aid)
   bool knn_pack = true;                   // SOICP_KNN_PACK=0: one chunk per wavefront throughout (round-3 work list)
   bool knn_list_fits = false;             // the last registration's work list (normal + light chunks) fitted the k-NN grid one chunk per wavefront:
                                           // packing four light chunks into a wavefront then only lengthens the longest wavefronts (a 13 k-point
-                                          // voxel-filtered scan: sweeps 20.5 + 18.6 -> 17.2 + 16.9 us unpacked); SOICP_KNN_PACK_SMALL=1 packs regardless
+                                          // voxel-filtered scan: sweeps 20.5 + 18.6 -> 17.2 + 16.9 us unpacked)
   int knn_pack_hold = 0;                  // registrations left without packing after one in which the packed near pass left > 3 % of
                                           // the queries to the exact per-lane scan (sparse map, far-off guess): then it is not a saving
   static constexpr int kBatchRoundsTracked = 16;
   float batch_survivors[kBatchRoundsTracked] = {};  // so_icp_register_batch: share of round r's list still active after it, last batch (chaining of rounds)
   bool batch_chain = true;                // (SOICP_BATCH_CHAIN=0: report + synchronisation after every round, as in round 3)
-  bool batch_small_report = true;         // (SOICP_BATCH_REPORT=full: the whole state blocks after every round, as in round 3)
-  bool batch_round0_full = true;          // so_icp_register_batch: round 0 starts with the full k-NN pass (SOICP_BATCH_ROUND0=near: the usual two passes)
-  int stage_issue_at = 1;                 // SOICP_STAGE_AT: 0 = a DMA copy is enqueued by the announcement itself; 1 = by the registration in
-                                          // flight once its launches are in the queue (default); 2 = after its second solve launch
   hipStream_t copy_stream = nullptr;
   bool retried = false;       // the current registration is the repeat of an abandoned one
   unsigned long long peer_timeout_ticks = 100000000ull;  // 1 s at 100 MHz: patience of a solve launch with the peer exchange (SOICP_PEER_TIMEOUT_MS)
@@ -447,7 +441,7 @@ int map_count_5x5(const so_icp_ctx* c, const int pos[3]) { return c->dmap ? c->d
 const int* map_origin(const so_icp_ctx* c) { return c->dmap ? c->dmap->origin() : c->map.origin(); }
 
 int upload_map(so_icp_ctx* c) {
-  if (c->dmap) return c->dmap->view(c->view, c->err) ? SO_ICP_OK : SO_ICP_E_HIP;
+  if (c->dmap) { const int rv = c->dmap->view(c->view, c->err); return rv == 0 ? SO_ICP_OK : (rv == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP); }
   if (c->uploaded_version == c->map.version()) return SO_ICP_OK;
   c->map.build_canonical(c->query_split ? 0 : c->cfg.rank, c->query_split ? 1 : c->cfg.world_size, c->cm);
   const CanonicalMap& m = c->cm;
@@ -693,8 +687,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   const float plane_res_now = c->borrow.on ? c->borrow.plane_res : map_plane_res(c);
   MatchParams mp = match_params(plane_res_now, c->ablate);
   mp.chunk_cap = chunk_cap;
-  static const bool pack_small = [] { const char* e = std::getenv("SOICP_KNN_PACK_SMALL"); return e && e[0] == '1'; }();
-  mp.pack_light = (c->knn_pack && c->knn_pack_hold == 0 && (pack_small || !c->knn_list_fits)) ? 1 : 0;
+  mp.pack_light = (c->knn_pack && c->knn_pack_hold == 0 && !c->knn_list_fits) ? 1 : 0;
   mp.packed_leftover = &c->d_state->packed_leftover;
   if (c->knn_pack_hold > 0) --c->knn_pack_hold;
   if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
@@ -860,12 +853,12 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   if ((rc = enqueue_outer_a(0))) return rc;
   // the NEXT scan's DMA goes out right behind this registration's first launch (the rest of what the copy queue does for that
   // scan follows below, once the launches that are not urgent -- the first sweep lasts 20 us -- are in the queue as well)
-  if (!c->batch_mode && c->stage_issue_at == 1) stage_issue_deferred_copy(c);
+  if (!c->batch_mode) stage_issue_deferred_copy(c);
   if ((rc = enqueue_outer_b(0))) return rc;
   for (int it = 0;; ++it) {
     if (c->speculate && it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
     // this registration's launches are in the queue and the host is about to idle: the moment for the NEXT scan's DMA
-    if (!c->batch_mode && ((it == 0 && c->stage_issue_at == 1) || (it == 1 && c->stage_issue_at == 2))) {
+    if (!c->batch_mode && it == 0) {
       c->prebin_pose = may_prebin ? pose_in : nullptr;  // (the next scan is binned behind its copy, under this registration's guess)
       stage_issue_deferred(c);
       c->prebin_pose = nullptr;
@@ -938,7 +931,6 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
 // The queue of the host-in / host-out steps around Localization() (pre-filter, de-skew, registered scan): they touch nothing the
 // map insert of the previous frame uses, so they need not wait behind it in the context's queue (SOICP_PREFILTER_STREAM=0: they do).
 static hipStream_t aux_stream(so_icp_ctx* c) {
-  if (!c->pf_own_stream) return c->stream;
   if (!c->pf_stream && hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return c->stream; }
   return c->pf_stream;
 }
@@ -1191,7 +1183,6 @@ const float* take_staged(so_icp_ctx* c, const float* xyz, size_t n, size_t strid
       sl.src = nullptr;
     }
     if (sl.tail_stream) (void)stage_tail(c, sl);  // (no registration finished what it had begun: not binned ahead)
-    if (sl.ev_pending && c->stage_wait_on_host) stage_finish_direct(sl);
     // (in a stream of registrations the copy ended long ago -- it was enqueued a registration earlier: then no barrier packet
     //  in front of this registration's first kernel either)
     if (sl.ev_pending && hipEventQuery(sl.ev) == hipSuccess) sl.ev_pending = false;
@@ -1362,7 +1353,7 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
     const int first = it;
     for (;;) {
       MatchParams mp_it = mp;
-      mp_it.skip_near_pass = (it == 0 && c->batch_round0_full) ? 1 : 0;
+      mp_it.skip_near_pass = it == 0 ? 1 : 0;  // round 0 starts with the full k-NN pass (hypotheses +-0.5 m / +-5 degrees off: the near pass certifies almost nothing)
       mp_it.pack_light = (c->knn_pack && !mp_it.skip_near_pass) ? 1 : 0;
       launch_knn_plane(b.binned.as<float4>(), b.chunks.as<uint32_t>(), ds, c->view, mp_it, corr,
                        b.nbr5.as<uint32_t>(), b.hist.as<int32_t>(), s, nullptr, nullptr, &bv, n_act);
@@ -1378,12 +1369,9 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
     // at a synchronisation point the host needs two words per hypothesis (outer_iter, reg_done); the whole state blocks (280 KB
     // for 64 hypotheses) are read once, after the last round
     static_assert(offsetof(DevState, reg_done) == offsetof(DevState, outer_iter) + 4, "the round report reads outer_iter and reg_done together");
-    if (c->batch_small_report)
-      HIP_TRY(c, hipMemcpy2DAsync(reinterpret_cast<char*>(b.h_states) + offsetof(DevState, outer_iter), sizeof(DevState),
-                                  reinterpret_cast<const char*>(ds) + offsetof(DevState, outer_iter), sizeof(DevState), 8, (size_t)B,
-                                  hipMemcpyDeviceToHost, s));
-    else
-      HIP_TRY(c, hipMemcpyAsync(b.h_states, ds, (size_t)B * sizeof(DevState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpy2DAsync(reinterpret_cast<char*>(b.h_states) + offsetof(DevState, outer_iter), sizeof(DevState),
+                                reinterpret_cast<const char*>(ds) + offsetof(DevState, outer_iter), sizeof(DevState), 8, (size_t)B,
+                                hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     std::vector<uint32_t> next;
     uint32_t alive_after[so_icp_ctx::kBatchRoundsTracked] = {};
@@ -1557,19 +1545,16 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_READBACK")) c->direct_readback = std::string(ev) != "copy";
   if (const char* ev = std::getenv("SOICP_SPECULATE")) c->speculate = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PREFILTER_FAST")) c->pf_fast = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("SOICP_PREFILTER_STREAM")) c->pf_own_stream = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_ABLATE")) c->ablate = std::atoi(ev);
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("SOICP_STAGE_WAIT")) c->stage_wait_on_host = std::string(ev) == "host";
   if (const char* ev = std::getenv("SOICP_KNN_PACK")) c->knn_pack = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PREBIN")) c->prebin = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BATCH_CHAIN")) c->batch_chain = std::string(ev) != "0";
-  if (const char* ev = std::getenv("SOICP_BATCH_REPORT")) c->batch_small_report = std::string(ev) != "full";
-  if (const char* ev = std::getenv("SOICP_BATCH_ROUND0")) c->batch_round0_full = std::string(ev) != "near";
-  if (const char* ev = std::getenv("SOICP_STAGE_AT")) { const int v = std::atoi(ev); if (v >= 0 && v <= 2) c->stage_issue_at = v; }
-  if (const char* ev = std::getenv("SOICP_BATCH_WG_PER_CU")) { if (std::atoi(ev) == 1) c->batch_degrade = 1; }  // (several processes on one device)
-  if (const char* ev = std::getenv("SOICP_BATCH_MODE")) { if (std::string(ev) == "lanes") c->batch_degrade = 2; }
+  if (const char* ev = std::getenv("SOICP_BATCH_MODE")) {  // "one_per_cu": one solve workgroup per compute unit (several processes on one device); "lanes"
+    if (std::string(ev) == "one_per_cu") c->batch_degrade = 1;
+    if (std::string(ev) == "lanes") c->batch_degrade = 2;
+  }
   const bool want_dmap = !(std::getenv("SOICP_HOST_MAP") && std::atoi(std::getenv("SOICP_HOST_MAP")));
   if (want_dmap) {  // world_size > 1: this rank's shard of the map, resident and updated on the device like the whole map is
     c->query_split = cfg->world_size > 1 && cfg->shard_mode == SO_ICP_SHARD_QUERIES;
@@ -1802,8 +1787,7 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
       HIP_TRY(c, sl.dev.reserve((n + 64) * 12));
       if (!sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
       sl.state = 2;
-      if (c->stage_issue_at == 0) { if (stage_issue(c, sl) != hipSuccess) { c->err = sl.err; sl.state = 0; return SO_ICP_E_HIP; } }
-      else { sl.deferred = true; sl.t_announced = std::chrono::steady_clock::now(); queued = true; }  // (the copy thread is the time-out)
+      sl.deferred = true; sl.t_announced = std::chrono::steady_clock::now(); queued = true;  // (the copy thread is the time-out)
       c->timing.staged_direct++;
     } else {
       sl.state = 1; queued = true;

@@ -1569,20 +1569,9 @@ static uint32_t* launch_first_stage_hashed(const MapInsertArgs& a, hipStream_t s
   const uint32_t nhist = giant_hist_entries(a.n_new);
   // (per launch, not once per process: the attribute belongs to the current device, and one process may drive several)
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(leafhash_centroids_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)giant_lds);
-  // (SOICP_MAP_SPLIT_CENTROIDS=1: the long leaves in a launch of their own behind the others, as rounds 2-3 had it)
-  static const bool split = [] { const char* e = std::getenv("SOICP_MAP_SPLIT_CENTROIDS"); return e && e[0] == '1'; }();
-  if (split) {
-    hipLaunchKernelGGL(leafhash_centroids_kernel, dim3(small_blocks + medium_blocks), dim3(kGiantThreads), giant_lds, s, a.heads, a.flags, cursor, a.pos, a.wpts,
-                       a.keys0, a.n_new, nhist, a.d_tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, giant_list, a.d_n_cent + 4,
-                       a.d_n_cent + 5, 0u, small_blocks, cc);
-    hipLaunchKernelGGL(leafhash_centroids_kernel, dim3(giant_blocks), dim3(kGiantThreads), giant_lds, s, a.heads, a.flags, cursor, a.pos, a.wpts,
-                       a.keys0, a.n_new, nhist, a.d_tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, giant_list, a.d_n_cent + 4,
-                       a.d_n_cent + 5, giant_blocks, 0u, cc);
-  } else {
-    hipLaunchKernelGGL(leafhash_centroids_kernel, dim3(giant_blocks + small_blocks + medium_blocks), dim3(kGiantThreads), giant_lds, s, a.heads, a.flags, cursor,
-                       a.pos, a.wpts, a.keys0, a.n_new, nhist, a.d_tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, giant_list,
-                       a.d_n_cent + 4, a.d_n_cent + 5, giant_blocks, small_blocks, cc);
-  }
+  hipLaunchKernelGGL(leafhash_centroids_kernel, dim3(giant_blocks + small_blocks + medium_blocks), dim3(kGiantThreads), giant_lds, s, a.heads, a.flags, cursor,
+                     a.pos, a.wpts, a.keys0, a.n_new, nhist, a.d_tt, a.nc, a.inv_cell, a.cent, keys2, a.d_n_cent, medium_list, a.d_n_cent + 6, giant_list,
+                     a.d_n_cent + 4, a.d_n_cent + 5, giant_blocks, small_blocks, cc);
   return keys2;
 }
 
@@ -1656,13 +1645,10 @@ void launch_map_insert_fast(const MapInsertArgs& a, const MapFastArgs& f, hipStr
   else
     hipLaunchKernelGGL(insert_front_kernel<false>, grid_for(f.n, 1024), dim3(1024), 0, s, f.d_in, f.n, f.stride_floats, f.pose, (float*)nullptr, f.origin[0],
                        f.origin[1], f.origin[2], const_cast<int32_t*>(a.d_cube_of), b);
-  // (SOICP_MAP_FUSE_COUNT=0: cell_count_kernel as its own launch, like the host-built rounds)
-  static const bool fuse_count = [] { const char* e = std::getenv("SOICP_MAP_FUSE_COUNT"); return !(e && e[0] == '0'); }();
-  uint32_t* keys2 = launch_first_stage_hashed(a, s, fuse_count);
+  uint32_t* keys2 = launch_first_stage_hashed(a, s, /*count_cells=*/true);  // (cell counting folded into the kernels that produce the centroids)
   const uint32_t total = (a.n_old_grid ? a.n_old_grid : a.n_old) + a.n_new;
   const uint32_t* halt = a.d_n_cent + 5;
   const uint32_t nblk = (a.ncell1 + kScanItems - 1u) / kScanItems;
-  if (!fuse_count) hipLaunchKernelGGL(cell_count_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.d_n_cent, a.ncell1, a.grid, a.vals1, halt);
   hipLaunchKernelGGL(cell_scan_table_kernel, dim3(nblk, (uint32_t)f.per_round), dim3(256), 0, s, a.grid, a.grid_scan, a.d_tt, a.cap, a.ncell1, a.cell_start,
                      a.d_counts, f.d_slot_count, halt, f.d_scan_state, f.d_tickets, nblk);
   hipLaunchKernelGGL(cell_place_kernel, grid_for(total, 256), dim3(256), 0, s, keys2, a.vals1, a.d_n_cent, a.grid_scan, a.cent, a.d_tt, a.ncell1,

@@ -194,7 +194,7 @@ def test_batch_with_hypotheses_that_fail_and_degenerate_inputs(oracle, gpu_slam_
     assert [int(r) for r in rcs] == [slam.register(none, p)[0] for p in poses[:3]] and ok == int((rcs == 0).sum())
 
 
-@pytest.mark.parametrize("env", [{"SOICP_BATCH_MODE": "lanes"}, {"SOICP_BATCH_WG_PER_CU": "1"}, {"SOICP_BATCH_CHAIN": "0"}])
+@pytest.mark.parametrize("env", [{"SOICP_BATCH_MODE": "lanes"}, {"SOICP_BATCH_MODE": "one_per_cu"}, {"SOICP_BATCH_CHAIN": "0"}])
 def test_batch_fallback_paths_give_the_same_bits(oracle, gpu_slam_factory, monkeypatch, env):
     """The degraded forms of so_icp_register_batch -- one solve workgroup per compute unit, and concurrent sequential
     registrations on worker contexts (what a device that cannot keep the batched solve resident falls back to) -- return the

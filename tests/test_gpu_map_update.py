@@ -359,13 +359,12 @@ def test_device_built_inserts_equal_host_built_ones(oracle, gpu_slam_factory, mo
 
 def test_localization_with_deferred_insert_equals_the_synchronous_one(gpu_slam_factory, monkeypatch):
     """Localization() returns once the insert's launches are enqueued (the bookkeeping is settled by whatever touches the
-    map next); SOICP_MAP_DEFER=0 waits for the insert's report, SOICP_MAP_FAST=0 lays every round out on the host.  The
+    map next); SOICP_MAP_FAST=sync waits for the insert's report, SOICP_MAP_FAST=0 lays every round out on the host.  The
     three give the same poses, the same map sizes after every frame and the same final map, bit for bit."""
     sc = synth.Scene("tiny")
     runs = []
-    for fast, defer in (("1", "1"), ("1", "0"), ("0", "0")):
+    for fast in ("1", "sync", "0"):
         monkeypatch.setenv("SOICP_MAP_FAST", fast)
-        monkeypatch.setenv("SOICP_MAP_DEFER", defer)
         slam = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=3)
         slam.add_surf_point_cloud(sc.map_points)
         slam.shift_map(sc.gt_pose(0)[:3])

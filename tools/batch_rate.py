@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[4] on one GPU: 64 pose hypotheses per scan (dt ~ U(-0.5, 0.5) m, dtheta ~ U(-5, 5) deg, SURVEY 8d
-seeds), one so_icp_register_batch call per scan, on the batched kernels (SOICP_BATCH_WG_PER_CU=1|2 limits the resident solve
+seeds), one so_icp_register_batch call per scan, on the batched kernels (SOICP_BATCH_MODE=one_per_cu limits the resident solve
 workgroups per compute unit).
 usage (GPU box): python tools/batch_rate.py [--hyp 64] [--scans 3]"""
 import argparse, os, sys, time
@@ -30,5 +30,5 @@ for i in range(a.scans + 1):
 errs = np.array(errs)
 print("batch mode %s, wg/cu %s: %d hypotheses/scan, %.2f ms per batch, %.0f registrations/s; returned ok %d; converged to < 1 cm: %d / %d; "
       "outer iterations per hypothesis: mean %.2f, histogram %s" % (
-          os.environ.get("SOICP_BATCH_MODE", "batched"), os.environ.get("SOICP_BATCH_WG_PER_CU", "auto"), a.hyp, 1e3 * tot_t / a.scans,
+          os.environ.get("SOICP_BATCH_MODE", "batched"), "-", a.hyp, 1e3 * tot_t / a.scans,
           a.hyp * a.scans / tot_t, tot_ok, int(np.sum(errs < 0.01)), len(errs), np.mean(outer), np.bincount(outer).tolist()))

@@ -2,7 +2,7 @@
 """Localization() end to end at BASELINE sizes (registration + device-side map insert): wall time per call.
 usage (GPU box): python tools/localization_rate.py [--calls 64] [--modes default,nodefer,hostbuilt]
   default    the insert is laid out by the device and completes behind the call (device_map.h: insert_fast / settle)
-  nodefer    SOICP_MAP_DEFER=0: the call waits for the insert's report
+  nodefer    SOICP_MAP_FAST=sync: the call waits for the insert's report
   hostbuilt  SOICP_MAP_FAST=0: every insert round laid out by the host (two read-backs per insert; rounds 1-3)
   staged     default switches, and the NEXT scan is announced before every call (so_icp_stage_scan, scans in so_icp_host_alloc memory):
              its upload runs beside the registration instead of behind the insert -- what a node does whose feature callback
@@ -19,12 +19,12 @@ a = ap.parse_args()
 # node / node_hostbuilt: what laserMapping does per frame (lmap.cpp:600-651, then :250-263): the surf cloud is voxel-filtered at
 # planeRes on the device (so_icp_prefilter_scan) and Localization() runs on the filtered cloud, which is also what is inserted
 # node_r3: the node order with this session's switches off (host-built insert rounds, host-decided pre-filter in the context's queue)
-ENV = {"node": {}, "node_pageable": {}, "node_samequeue": {"SOICP_PREFILTER_STREAM": "0"}, "node_hostbuilt": {"SOICP_MAP_FAST": "0"},
-       "node_r3": {"SOICP_MAP_FAST": "0", "SOICP_PREFILTER_FAST": "0", "SOICP_PREFILTER_STREAM": "0"}, "default": {}, "nodefer": {"SOICP_MAP_DEFER": "0"}, "hostbuilt": {"SOICP_MAP_FAST": "0"}, "staged": {}, "staged_hostbuilt": {"SOICP_MAP_FAST": "0"}}
+ENV = {"node": {}, "node_pageable": {}, "node_hostbuilt": {"SOICP_MAP_FAST": "0"},
+       "node_r3": {"SOICP_MAP_FAST": "0", "SOICP_PREFILTER_FAST": "0"}, "default": {}, "nodefer": {"SOICP_MAP_FAST": "sync"}, "hostbuilt": {"SOICP_MAP_FAST": "0"}, "staged": {}, "staged_hostbuilt": {"SOICP_MAP_FAST": "0"}}
 sc = synth.Scene("os1_128_2m")
 scans = [sc.scan(i % 4) for i in range(4)]; guesses = [sc.guess(i % 4) for i in range(4)]
 for mode in a.modes.split(","):
-    for k in ("SOICP_MAP_DEFER", "SOICP_MAP_FAST", "SOICP_PREFILTER_FAST", "SOICP_PREFILTER_STREAM"):
+    for k in ("SOICP_MAP_FAST", "SOICP_PREFILTER_FAST"):
         os.environ.pop(k, None)
     os.environ.update(ENV[mode])
     slam = binding.LidarSlamGpu(device_id=0, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_iterations=5, lm_max_iterations=4,
