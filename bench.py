@@ -190,9 +190,29 @@ def main():
         ctx = binding.LidarSlamGpu(rank=rank, world_size=world, time_kernels=time_kernels,
                                    shard_mode=binding.SHARD_QUERIES if shard_mode == "queries" else binding.SHARD_MAP, **mk)
         if world > 1 and not os.environ.get("SOICP_BENCH_NO_RCCL"):  # (NO_RCCL: development on a one-GPU box, where RCCL refuses two ranks per device)
-            uid = [binding.comm_unique_id() if rank == 0 else None]
+            # (collective and guarded: a rank whose communicator cannot be built must not leave the others inside ncclCommInitRank's
+            #  rendezvous without a word -- the peer exchange below can still carry the sums without RCCL)
+            import torch
+            try:
+                uid = [binding.comm_unique_id() if rank == 0 else None]
+                ok_uid = 1
+            except Exception as e:  # noqa: BLE001
+                print(f"rank {rank}: RCCL unavailable ({e})", file=sys.stderr)
+                uid, ok_uid = [None], 0
             dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(uid[0])
+            t_ok = torch.tensor([1 if (ok_uid and uid[0] is not None) else 0])
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            if bool(t_ok.item()):
+                try:
+                    ctx.comm_init(uid[0])
+                    good = 1
+                except Exception as e:  # noqa: BLE001
+                    print(f"rank {rank}: ncclCommInitRank failed ({e}); the run continues only if the peer exchange works", file=sys.stderr)
+                    good = 0
+                t_ok = torch.tensor([good])
+                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            if not bool(t_ok.item()):
+                os.environ["SOICP_BENCH_NO_RCCL"] = "1"  # (every rank took the same branch: the all-reduce above decided)
         on_peer = False
         if world > 1 and not os.environ.get("SOICP_BENCH_NO_PEER"):
             # peer exchange: the ranks' persistent solve launches trade their records through hipIpc-mapped inboxes instead of an
