@@ -231,8 +231,11 @@ int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t str
  * context's copy thread first.  A following so_icp_register / so_icp_localization with the SAME (scan_xyz, n, stride_bytes)
  * consumes the staged copy instead of uploading again (so_icp_stats::flags carries SO_ICP_FLAG_STAGED_SCAN); any other call
  * simply ignores it.  The caller's buffer must stay valid and unchanged until that call returns (a DMA copy reads it when the
- * registration in flight has its launches in the queue, or 300 us after the announcement, whichever comes first); to take a
+ * registration in flight has its first launch in the queue, or 300 us after the announcement, whichever comes first); to take a
  * staged buffer back without registering it, announce it again (the older copy is superseded) or call so_icp_stage_cancel.
+ * A DMA copy that a registration in flight enqueues is followed, on the copy stream, by the scan's spatial binning under that
+ * registration's guess (single device, device-resident map): the consuming registration then starts with its k-NN sweep
+ * (SO_ICP_FLAG_BINNED_AHEAD).  The binning only groups queries for the sweep -- results do not depend on it.
  * Three slots: two scans may be announced ahead of the one being registered; a further announcement returns
  * SO_ICP_STAGE_DECLINED (soft: that scan is uploaded by its own registration call).  Announcing a buffer again supersedes
  * its earlier copy; a copy announced BEFORE a scan that has been consumed since (a skipped frame) is never served and gives

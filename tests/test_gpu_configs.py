@@ -295,15 +295,16 @@ def test_staged_scan_is_the_same_registration(oracle, gpu_slam_factory, soicp, b
 def test_stats_flags_name_the_degraded_modes(oracle, gpu_slam_factory, soicp, monkeypatch):
     sc, slam, _ = _setup("tiny", oracle, gpu_slam_factory, max_iterations=3)
     scan, guess = sc.scan(0), sc.guess(0)
-    rc, _, st = slam.register(scan, guess)
+    rc, pose0, st = slam.register(scan, guess)
     assert rc == 0 and st.flags == 0, hex(st.flags)
     for env, flag in (({"SOICP_PERSISTENT": "0"}, soicp.FLAG_PER_EVAL_LAUNCHES),
                       ({"SOICP_HOST_MAP": "1"}, soicp.FLAG_HOST_MAP), ({"SOICP_READBACK": "copy"}, soicp.FLAG_COPY_READBACK)):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         _, alt, _ = _setup("tiny", oracle, gpu_slam_factory, max_iterations=3)
-        rc, _, s2 = alt.register(scan, guess)
+        rc, pose2, s2 = alt.register(scan, guess)
         assert rc == 0 and s2.flags == flag, (env, hex(s2.flags))
+        assert np.array_equal(pose2, pose0) and np.array_equal(np.array(s2.JtJ), np.array(st.JtJ)), (env, "a degraded mode is the same registration, bit for bit")
         for k in env:
             monkeypatch.delenv(k)
     # an abandoned persistent solve (test hook): the repeated registration is flagged, later ones carry the degraded mode
