@@ -9,6 +9,7 @@
 #include <stdexcept>
 
 #include "node_math.h"
+#include "pcd_io.h"
 
 namespace super_odometry_soicp {
 using namespace so_node_math;
@@ -125,6 +126,28 @@ void laserMapping::loadPriorMap(const float* xyz, size_t n, size_t stride_bytes)
   slam.localMap.addSurfPointCloud(prior);
   priorCloudMsg = to_ros_msg(prior);
   priorCloudMsg.header.frame_id = config_.WORLD_FRAME;
+}
+
+// initializationParam, laserMapping.cpp:163-173, with the file: utils::readPointCloud(config_.map_dir, laserCloudPrior)
+// (superodom_utils.cpp:16-33) -> addSurfPointCloud -> overall_map message; a file that cannot be read switches to mapping mode.
+bool laserMapping::loadPriorMap() {
+  if (!slam.localization_mode) return false;
+  std::vector<float> xyzi;
+  std::string err;
+  if (!so_pcd::read_xyzi(config_.map_dir, xyzi, err)) {
+    last_error = "Cannot read map file, switch to mapping mode: " + err;  // (:170-171)
+    slam.localization_mode = false;
+    return false;
+  }
+  PointCloud<Point> prior;
+  prior.points.resize(xyzi.size() / 4);
+  for (size_t i = 0; i < prior.points.size(); ++i) {
+    prior.points[i].x = xyzi[4 * i]; prior.points[i].y = xyzi[4 * i + 1]; prior.points[i].z = xyzi[4 * i + 2]; prior.points[i].intensity = xyzi[4 * i + 3];
+  }
+  slam.localMap.addSurfPointCloud(prior);
+  priorCloudMsg = to_ros_msg(prior);
+  priorCloudMsg.header.frame_id = config_.WORLD_FRAME;
+  return true;
 }
 
 void laserMapping::laserFeatureInfoHandler(const so_wire::LaserFeature& msgIn) {  // :250-263

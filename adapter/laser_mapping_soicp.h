@@ -60,7 +60,9 @@ class laserMapping {
   void laserFeatureInfoHandler(const so_wire::LaserFeature& msgIn);           // :250-263 (any thread)
   void laserFeatureInfoHandler(const uint8_t* cdr, size_t n);                 // the same, from a serialised message
   bool processOnce();  // one turn of process()'s loop (:768-793): false when checkDataAvailable() says no
-  // the prior map of localization mode (:161-171 reads a .pcd through PCL; here the caller hands the points over)
+  // the prior map of localization mode (:161-171): from config_.map_dir (a .pcd file: pcd_io.h restates the reader; false = the
+  // file could not be read and the node switched to mapping mode, like the reference), or handed over as points
+  bool loadPriorMap();
   void loadPriorMap(const float* xyz, size_t n, size_t stride_bytes);
 
   LidarSLAM slam;

@@ -59,6 +59,8 @@ int main(int argc, char** argv) {
       while ((k = fread(tmp, sizeof(float), 3 * 4096, pm)) > 0) xyz.insert(xyz.end(), tmp, tmp + k);
       fclose(pm);
       node.loadPriorMap(xyz.data(), xyz.size() / 3, 12);
+    } else if (cfg.localization_mode) {  // ... or the .pcd file the parameter file names (map_dir), as the reference does
+      if (!node.loadPriorMap()) fprintf(stderr, "%s\n", node.last_error.c_str());
     }
     std::vector<std::vector<uint8_t>> bag(n_msgs);
     for (int k = 0; k < n_msgs; ++k) {

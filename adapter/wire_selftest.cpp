@@ -9,6 +9,7 @@
 #include <string>
 
 #include "node_config.h"
+#include "pcd_io.h"
 #include "wire/cdr.h"
 
 using namespace so_wire;
@@ -153,7 +154,15 @@ int main(int argc, char** argv) {
              c.WORLD_FRAME.c_str(), c.SENSOR_FRAME.c_str(), c.ProjectName.c_str());
       return 0;
     }
-    fprintf(stderr, "usage: %s roundtrip <Type> in out | emit <Type> out | params <file.yaml>\n", argv[0]);
+    if (argc == 4 && !strcmp(argv[1], "pcd")) {  // the prior-map reader (pcd_io.h): file -> packed float32 {x, y, z, intensity}
+      std::vector<float> xyzi;
+      std::string err;
+      if (!so_pcd::read_xyzi(argv[2], xyzi, err)) { fprintf(stderr, "%s\n", err.c_str()); return 3; }
+      spit(argv[3], std::vector<uint8_t>(reinterpret_cast<const uint8_t*>(xyzi.data()), reinterpret_cast<const uint8_t*>(xyzi.data()) + xyzi.size() * 4));
+      printf("points=%zu\n", xyzi.size() / 4);
+      return 0;
+    }
+    fprintf(stderr, "usage: %s roundtrip <Type> in out | emit <Type> out | params <file.yaml> | pcd <file.pcd> out.f32\n", argv[0]);
     return 2;
   } catch (const std::exception& e) {
     fprintf(stderr, "wire_selftest: %s\n", e.what());

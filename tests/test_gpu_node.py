@@ -262,10 +262,12 @@ def test_node_shell_when_the_map_has_too_few_features(gpu_slam_factory, tmp_path
             assert [msgs[k][P + "uncertainty_" + a]["data"] for a in ("X", "Y", "Z", "roll", "pitch", "yaw")] == [0.0] * 6
 
 
-def test_node_shell_localization_mode_against_a_prior_map(tmp_path):
+@pytest.mark.parametrize("source", ["points", "pcd_file"])
+def test_node_shell_localization_mode_against_a_prior_map(tmp_path, source):
     """localization_mode (laserMapping.cpp:161-171, 305-313): the prior map is loaded before the first frame, the first pose comes
     from init_x .. init_yaw (tf2 setRPY), the map's frame is the world frame -- the poses must follow the ground truth of the
-    synthetic trajectory directly -- and the prior cloud goes out on /overall_map with every 20th frame."""
+    synthetic trajectory directly -- and the prior cloud goes out on /overall_map with every 20th frame.  The map arrives as
+    points, or -- like the reference -- as the .pcd file the parameter `map_dir` names (adapter/pcd_io.h)."""
     sc = synth.Scene("tiny")
     n_frames = 20
     frames = make_frames(sc, n_frames)
@@ -276,8 +278,19 @@ def test_node_shell_localization_mode_against_a_prior_map(tmp_path):
                       f"        mapping_plane_resolution: {sc.plane_res}\n        max_iterations: 4\n        max_surface_features: -1\n"
                       f"        auto_voxel_size: false\n        localization_mode: true\n        init_x: {float(g0[0])!r}\n        init_y: {float(g0[1])!r}\n"
                       f"        init_z: {float(g0[2])!r}\n        init_roll: {float(roll)!r}\n        init_pitch: {float(pitch)!r}\n        init_yaw: {float(yaw)!r}\n")
-    prior = tmp_path / "prior.f32"
-    np.ascontiguousarray(sc.map_points, np.float32).tofile(prior)
+    if source == "points":
+        prior = tmp_path / "prior.f32"
+        np.ascontiguousarray(sc.map_points, np.float32).tofile(prior)
+    else:
+        prior = None
+        pcd = tmp_path / "pointcloud_local.pcd"
+        mp = np.ascontiguousarray(sc.map_points, np.float32)
+        with open(pcd, "wb") as f:
+            f.write((f"# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+                     f"WIDTH {len(mp)}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {len(mp)}\nDATA binary\n").encode())
+            f.write(np.c_[mp, np.zeros(len(mp), np.float32)].astype("<f4").tobytes())
+        with open(params, "a") as f:
+            f.write(f'    map_dir: "{pcd}"\n')  # (declared at the node's top level, next to the laser_mapping_node block: laserMapping.cpp:183-203)
     pubs, failed, err = run_node(tmp_path, frames, 0.05, 0.05, 1, 7, params=params, prior=prior)
     assert failed == 0, err
     msgs, order = by_frame(pubs, n_frames)
