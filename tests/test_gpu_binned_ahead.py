@@ -47,10 +47,13 @@ def test_binned_ahead_bit_identical_to_plain_registration(oracle, soicp, gpu_sla
     # seven frames (1.2 m / 12 degrees: every far chunk straddles cells and cubes it was not binned for)
     for order in (list(range(n)), [0, 7, 1, 6, 2, 5, 3, 4]):
         got = _run_stream(slam, scans, guesses, order)
+        ahead = [bool(r[2].flags & soicp.FLAG_BINNED_AHEAD) for r in got]
+        # nobody was in flight to bin the first one; the others are binned by the registration before them -- unless that one took
+        # more than 300 us to reach the point where it enqueues the copy (then the copy thread did, without binning: a loaded host)
+        assert not ahead[0] and sum(ahead) >= len(order) - 3, (order, ahead)
         for k, i in enumerate(order):
             rc, pose, st = got[k]
             assert rc == 0 and (st.flags & soicp.FLAG_STAGED_SCAN)
-            assert bool(st.flags & soicp.FLAG_BINNED_AHEAD) == (k > 0), (order, k, hex(st.flags))  # (nobody was in flight to bin the first one)
             assert np.array_equal(pose, ref[i][1]), (order, k)
             assert np.array_equal(np.array(st.JtJ), np.array(ref[i][2].JtJ)) and np.array_equal(np.array(st.Jtr), np.array(ref[i][2].Jtr))
             assert _stats_tuple(st) == _stats_tuple(ref[i][2]), (order, k)
@@ -83,7 +86,7 @@ def test_binned_ahead_switch_and_pageable_buffers(soicp, gpu_slam_factory):
         scans = scans_np if mode == "pageable" else [slam.host_alloc_like(s) for s in scans_np]
         out[mode] = _run_stream(slam, scans, guesses, [0, 1, 2, 3])
         flags = [bool(r[2].flags & soicp.FLAG_BINNED_AHEAD) for r in out[mode]]
-        assert flags == ([False, True, True, True] if mode == "on" else [False] * 4), (mode, flags)
+        assert (not flags[0] and sum(flags) >= 2) if mode == "on" else flags == [False] * 4, (mode, flags)
         slam.close()
     for k in range(4):
         for mode in ("off", "pageable"):
@@ -113,7 +116,8 @@ def test_binned_ahead_through_localization_with_map_inserts(soicp, gpu_slam_fact
                 slam.stage_scan(scans[i + 1])
             res.append(slam.localization(True, sc.guess(i), scans[i], 0.1 * (i + 1)))
         out[mode] = (res, slam.export_map())
-        assert [bool(r[2].flags & soicp.FLAG_BINNED_AHEAD) for r in res] == ([False] + [True] * 5 if mode == "on" else [False] * 6)
+        ahead = [bool(r[2].flags & soicp.FLAG_BINNED_AHEAD) for r in res]
+        assert (not ahead[0] and sum(ahead) >= 3) if mode == "on" else ahead == [False] * 6, (mode, ahead)
         slam.close()
     for a, b in zip(out["on"][0], out["off"][0]):
         assert a[0] == b[0] and np.array_equal(a[1], b[1]) and _stats_tuple(a[2]) == _stats_tuple(b[2])
