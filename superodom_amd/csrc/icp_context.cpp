@@ -284,7 +284,6 @@ struct so_icp_ctx {
   // do not depend on the binning (exact per query, sums in scan order).  Single device, device-resident map only; SOICP_PREBIN=0
   // switches it off.
   bool prebin = true;
-  const double* prebin_pose = nullptr;    // non-null only while a registration that may bin ahead is enqueuing (its guess)
   DevBuf d_pbin_key, d_pbin_cnt, d_pbin_off; uint32_t pbin_log2 = 0;
   StageSlot* stage_in_use = nullptr;  // the slot the current registration reads (released when the call returns)
   unsigned long long stage_seq = 0, stage_consumed_seq = 0;  // announcements so far / announcement number of the scan consumed last
@@ -583,7 +582,7 @@ void fill_result(so_icp_ctx* c, const DevState& H, const double pose_in[7], so_i
 // and every kernel consults DevState (reg_done / lm_more) to turn itself into a no-op once the controller has
 // finished -- no host round trip per evaluation.  One small read-back per outer iteration tells the host when to stop
 // enqueuing.
-void stage_issue_deferred(so_icp_ctx* c);  // (so_icp_stage_scan machinery, below)
+void stage_issue_deferred(so_icp_ctx* c, const double* prebin_pose);  // (so_icp_stage_scan machinery, below)
 void stage_issue_deferred_copy(so_icp_ctx* c);
 constexpr int kRetryWithoutPersistentSolve = -1000;  // internal: never leaves register_core
 int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const double pose_in[7], double pose_out[7], so_icp_stats* st) {
@@ -859,9 +858,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     if (c->speculate && it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
     // this registration's launches are in the queue and the host is about to idle: the moment for the NEXT scan's DMA
     if (!c->batch_mode && it == 0) {
-      c->prebin_pose = may_prebin ? pose_in : nullptr;  // (the next scan is binned behind its copy, under this registration's guess)
-      stage_issue_deferred(c);
-      c->prebin_pose = nullptr;
+      stage_issue_deferred(c, may_prebin ? pose_in : nullptr);  // (the next scan is binned behind its copy, under this registration's guess)
     }
     if ((rc = await_outer(it))) return rc;
     last = it;
@@ -978,10 +975,10 @@ void stage_finish_direct(so_icp_ctx::StageSlot& sl) {
 }
 // enqueue the DMA of a direct slot on the copy stream (under stage_mu)
 // bin the slot's scan on the copy queue, behind its copy (so_icp_ctx::prebin); a failure only means "not binned ahead"
-void stage_prebin(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
+void stage_prebin(so_icp_ctx* c, so_icp_ctx::StageSlot& sl, const double* pose) {
   sl.prebinned = false;
   const size_t n = sl.n;
-  if (!c->prebin || !c->prebin_pose || !n || n >= ((size_t)1 << 21)) return;
+  if (!c->prebin || !pose || !n || n >= ((size_t)1 << 21)) return;
   uint32_t lg = 16;
   while ((1ull << lg) < 2 * (unsigned long long)n) ++lg;
   const size_t m = n + 256, T = (size_t)1 << lg;
@@ -996,7 +993,7 @@ void stage_prebin(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
   if (!ok) { (void)hipGetLastError(); c->pbin_log2 = 0; return; }
   const BinTable bt{c->d_pbin_key.as<uint32_t>(), c->d_pbin_cnt.as<uint32_t>(), c->d_pbin_off.as<uint32_t>(), lg};
   sl.pb_chunk_cap = (uint32_t)(sl.pb_chunks.cap / 4);
-  launch_scan_keys(sl.dev.as<float>(), (uint32_t)n, c->d_state, c->prebin_pose, 0, 0, c->d_hist, c->view, c->cfg.max_surface_features, 0, 1,
+  launch_scan_keys(sl.dev.as<float>(), (uint32_t)n, c->d_state, pose, 0, 0, c->d_hist, c->view, c->cfg.max_surface_features, 0, 1,
                    sl.pb_keys.as<uint32_t>(), sl.pb_vals.as<uint32_t>(), nullptr, bt, s, false, nullptr, 0, false, 0, sl.pb_ctr.as<unsigned long long>());
   launch_bin_offsets(bt, sl.pb_chunks.as<uint32_t>(), sl.pb_chunk_cap, c->d_state, s, nullptr, 0, sl.pb_ctr.as<unsigned long long>());
   launch_bin_place(bt, sl.dev.as<float>(), (uint32_t)n, sl.pb_keys.as<uint32_t>(), sl.pb_vals.as<uint32_t>(), sl.pb_binned.as<float4>(), s);
@@ -1004,7 +1001,8 @@ void stage_prebin(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
   sl.prebinned = true;
 }
 // The DMA of a direct slot in two steps (both under stage_mu): stage_issue_copy enqueues the copy, stage_tail what follows it on the
-// copy queue -- the binning ahead (only from inside a registration: so_icp_ctx::prebin_pose) and the event the consuming
+// copy queue -- the binning ahead (only when the REGISTRATION THREAD calls it from inside a registration, with that registration's
+// guess: `pose`; the copy thread and the announcing thread pass nullptr -- they must not read the context's map view) and the event the consuming
 // registration waits for.  A registration in flight calls them apart (the copy right behind its first launch, the tail once its
 // other launches are in the queue: the copy is the long pole -- 34 us for a 131 072-point scan -- and the binning should land in
 // the shadow of the first solve, not beside the second sweep); everybody else calls stage_issue = both at once.
@@ -1016,9 +1014,9 @@ hipError_t stage_issue_copy(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
   sl.state = -1; sl.err = std::string("so_icp_stage_scan: ") + hipGetErrorString(e);
   return e;
 }
-hipError_t stage_tail(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
+hipError_t stage_tail(so_icp_ctx* c, so_icp_ctx::StageSlot& sl, const double* pose = nullptr) {
   if (!sl.tail_stream) return hipSuccess;
-  stage_prebin(c, sl);
+  stage_prebin(c, sl, pose);
   const hipError_t e = hipEventRecord(sl.ev, c->copy_stream);
   if (e == hipSuccess) { sl.tail_stream = nullptr; sl.ev_pending = true; return e; }
   stage_finish_direct(sl);  // (waits for the copy queue instead)
@@ -1034,12 +1032,12 @@ hipError_t stage_issue(so_icp_ctx* c, so_icp_ctx::StageSlot& sl) {
 // right in front of the registration call, +0 with it started here).  So an announced copy waits for the registration in
 // flight to have its launches in the queue -- the host then idles for tens of microseconds, waiting for the first solve's
 // report -- and is enqueued from there.  Without a registration to piggy-back on, the copy thread enqueues it after 300 us.
-void stage_issue_deferred(so_icp_ctx* c) {
+void stage_issue_deferred(so_icp_ctx* c, const double* prebin_pose) {
   if (!c->stage_started) return;
   std::lock_guard<std::mutex> lk(c->stage_mu);
   for (so_icp_ctx::StageSlot& sl : c->stage) {
-    if (sl.state == 2 && sl.deferred) (void)stage_issue(c, sl);
-    else if (sl.state == 2 && sl.tail_stream) (void)stage_tail(c, sl);
+    if (sl.state == 2 && sl.deferred) { if (stage_issue_copy(c, sl) == hipSuccess) (void)stage_tail(c, sl, prebin_pose); }
+    else if (sl.state == 2 && sl.tail_stream) (void)stage_tail(c, sl, prebin_pose);
   }
 }
 void stage_issue_deferred_copy(so_icp_ctx* c) {  // (the registration in flight: copy now, stage_issue_deferred for the rest later)
@@ -1781,6 +1779,7 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
     so_icp_ctx::StageSlot& sl = *pick;
     stage_finish_direct(sl);  // (an evicted copy must have left its caller's buffer)
     sl.src = xyz; sl.n = n; sl.stride = stride_bytes; sl.err.clear(); sl.seq = ++c->stage_seq; sl.ev_pending = false;
+    sl.prebinned = false;  // (the slot's work list belongs to the scan it held before)
     if (stride_bytes == 12 && n && host_range_registered(c, xyz, n * 12)) {
       // registered (pinned) host memory, packed xyz: no pack, no copy thread -- the DMA reads the caller's buffer itself
       sl.state = 0;  // (until the copy is enqueued: an error below leaves the slot empty)

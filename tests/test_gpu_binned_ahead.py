@@ -57,6 +57,15 @@ def test_binned_ahead_bit_identical_to_plain_registration(oracle, soicp, gpu_sla
             assert np.array_equal(pose, ref[i][1]), (order, k)
             assert np.array_equal(np.array(st.JtJ), np.array(ref[i][2].JtJ)) and np.array_equal(np.array(st.Jtr), np.array(ref[i][2].Jtr))
             assert _stats_tuple(st) == _stats_tuple(ref[i][2]), (order, k)
+    # the same slots again, now with scans from PAGEABLE memory (copy thread, nothing binned ahead): a slot's work list must not
+    # outlive the scan it was built for (the slots still hold the lists of the pinned scans above, same sizes)
+    pageable = [np.array(s_, dtype=np.float32, copy=True) for s_ in scans]
+    order = [3, 1, 4, 0, 2, 6]
+    got = _run_stream(slam, pageable, guesses, order)
+    for k, i in enumerate(order):
+        rc, pose, st = got[k]
+        assert rc == 0 and (st.flags & soicp.FLAG_STAGED_SCAN) and not (st.flags & soicp.FLAG_BINNED_AHEAD), (k, hex(st.flags))
+        assert np.array_equal(pose, ref[i][1]) and _stats_tuple(st) == _stats_tuple(ref[i][2]), ("pageable after pinned", k)
     # ... and the oracle agrees with what both paths produced
     om = oracle.OracleMap(plane_res=sc.plane_res)
     om.add_surf(slam.export_map(), raw=True)
