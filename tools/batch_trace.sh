@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/${1:-trace}; mkdir -p $OUT
-rm -rf /tmp/bt && rocprofv3 --kernel-trace --output-format csv -d /tmp/bt -- python $R/tools/batch_rate.py --scans 1 > /tmp/bt.log 2>&1
+rm -rf /tmp/bt && rocprofv3 --kernel-trace --output-format csv -d /tmp/bt -- python $R/tools/batch_rate.py --scans 1 --hyp ${2:-64} > /tmp/bt.log 2>&1
 f=$(find /tmp/bt -name "*kernel_trace.csv" | head -1)
 python - $f <<'PY' | tee $OUT/batch_timeline.txt
 import csv, sys
