@@ -837,6 +837,9 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   if (begin) {
     if (blockIdx.x == 0) {
       hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
+      // (the prologue also clears DevState::packed_leftover, which the packed wavefronts of THIS launch add to -- after their near
+      //  pass, several dependent memory round trips into their lives, whereas workgroup 0 is dispatched first and does this in its
+      //  first instructions; the counter only feeds the host's packing heuristic, never a result)
       reg_begin_state(mp.begin_state, mp.begin_args, (int)threadIdx.x);
       if (threadIdx.x == 0) mp.begin_state->bin_packed = pk;
     }
