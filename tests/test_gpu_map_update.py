@@ -409,3 +409,34 @@ def test_prefilter_decided_on_the_device_equals_the_host_decided_one(oracle, gpu
         assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (a[1:], b[1:])
     assert {round(r[5], 3) for r in outs[0]} == {0.2, 0.4, 0.8}, "the three clouds should exercise the three choices"
     assert np.array_equal(outs[0][6][0], oracle.voxel_grid(clouds[3], outs[0][6][5]))
+
+
+def test_front_kernel_hand_off_with_every_workgroup_touching_every_cube(gpu_slam_factory, monkeypatch):
+    """the last-workgroup hand-off of insert_front_kernel exchanges the touched-cube lists through relaxed device-scope
+    atomics only (no fences: DESIGN 3b).  Stress it where a lost cube would show: clouds whose points are interleaved at random over
+    25 cubes (5 x 5 blocks of 50 m), so that EVERY workgroup of the front kernel tallies every cube (the 8-entry LDS tally
+    overflows into direct atomics) and the last workgroup lays out a round of 25 cubes -- forty inserts in a row, each compared
+    bit for bit with the same insert laid out by the host (SOICP_MAP_FAST=0).  A cube missing from a round would drop its points."""
+    rng = np.random.default_rng(2025)
+    clouds = []
+    for _ in range(40):
+        n = int(rng.integers(20_000, 60_000))
+        xy = rng.uniform(-124.0, 124.0, (n, 2))
+        z = rng.normal(0.0, 0.02, n) + 0.3 * np.sin(xy[:, 0] / 9.0)
+        clouds.append(np.c_[xy, z].astype(np.float32)[rng.permutation(n)])
+    exports, stats = [], []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("SOICP_MAP_FAST", fast)
+        slam = gpu_slam_factory(plane_res=0.4, line_res=0.2)
+        out = []
+        for step, pts in enumerate(clouds):
+            slam.add_surf_point_cloud(pts)
+            if step % 4 == 3 or step < 2:
+                out.append(slam.export_map())
+        out.append(slam.export_map())
+        exports.append(out)
+        stats.append(slam.map_insert_stats())
+        slam.close()
+    for k, (a, b) in enumerate(zip(*exports)):
+        assert np.array_equal(a, b), f"export {k}: device-built and host-built rounds left different maps"
+    assert stats[0][0] >= 35 and stats[1] == (0, 0), stats  # (the first insert creates the cubes' slots on the host; the rest are laid out by the device)
