@@ -290,6 +290,8 @@ struct so_icp_ctx {
   bool stage_quit = false, stage_started = false;
   std::atomic<int> stage_pending{0};      // queued slots the copy thread has not picked up yet
   std::atomic<bool> stage_parked{false};  // the copy thread sleeps on stage_cv (it spins for a while after every job first)
+  std::atomic<bool> stage_timed{false};   // ... in the TIMED wait for a DMA-staged scan's 300 us: it looks at the slots again by itself when that
+                                          // runs out, so another DMA announcement need not wake it (a futex call on the announcing thread's path)
   std::thread stage_thread; std::mutex stage_mu; std::condition_variable stage_cv;
   struct HostRange { const char* p; size_t bytes; bool owned; };
   std::vector<HostRange> host_ranges;     // so_icp_host_register / so_icp_host_alloc (under stage_mu)
@@ -1072,9 +1074,11 @@ void stage_worker(so_icp_ctx* c) {
         }
         if (waiting) {
           c->stage_pending.store(0, std::memory_order_relaxed);
+          c->stage_timed.store(true);
           c->stage_parked.store(true);
           c->stage_cv.wait_until(lk, deadline, [&] { return c->stage_quit || stage_any_queued(c); });
           c->stage_parked.store(false);
+          c->stage_timed.store(false);
           continue;
         }
       }
@@ -1746,7 +1750,7 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
   NEED_DEVICE(c);
   if (stride_bytes == 0) stride_bytes = 12;
   if (stride_bytes % 4 && stride_bytes != SIZE_MAX) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
-  bool queued = false;
+  bool queued = false, dma_only = false;
   {
     // (this entry point may be called from ANOTHER thread than the registration calls -- the node's feature callback --,
     //  so everything it touches lives under stage_mu)
@@ -1786,7 +1790,7 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
       HIP_TRY(c, sl.dev.reserve((n + 64) * 12));
       if (!sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
       sl.state = 2;
-      sl.deferred = true; sl.t_announced = std::chrono::steady_clock::now(); queued = true;  // (the copy thread is the time-out)
+      sl.deferred = true; sl.t_announced = std::chrono::steady_clock::now(); queued = true; dma_only = true;  // (the copy thread is the time-out)
       c->timing.staged_direct++;
     } else {
       sl.state = 1; queued = true;
@@ -1795,7 +1799,9 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
   }
   if (queued) {
     c->stage_pending.fetch_add(1, std::memory_order_release);
-    if (c->stage_parked.load()) c->stage_cv.notify_all();
+    // (a copy thread in its timed wait re-reads the slots when the time is up -- at most 300 us from now, the patience a DMA
+    //  announcement is entitled to anyway: no wake-up for it; a scan for the copy thread itself, or a thread parked for good, is woken)
+    if (c->stage_parked.load() && !(dma_only && c->stage_timed.load())) c->stage_cv.notify_all();
   }
   return SO_ICP_OK;
 }
