@@ -443,6 +443,29 @@ def main():
             slam.peer_enable(peer)
         except Exception as e:  # noqa: BLE001
             other_mode = {"shard_mode": om_name, "error": str(e)}
+    # N > 1: what N independent registration STREAMS deliver (one robot / one sensor per GPU: map replicated, every rank registers its own
+    # scans through the staged entry, no exchange at all) -- the weak-scaling figure beside `value`, which shards ONE registration
+    independent = None
+    if world > 1 and not args.no_secondary:
+        try:
+            slam.peer_enable(False)
+            solo = binding.LidarSlamGpu(rank=0, world_size=1, time_kernels=0, **mk)
+            solo.add_surf_point_cloud(sc.map_points)
+            keep = scans
+            scans = [solo.host_alloc_like(np.asarray(s_)) for s_ in keep]
+            try:
+                timed_loop("staged", args.steps, rewarm=args.warmup, slam=solo)  # (untimed: buffers, clocks)
+                t_s, st_s, _ = timed_loop("staged", args.steps, rewarm=args.warmup, slam=solo)  # (max over the ranks, barrier on both sides)
+            finally:
+                scans = keep
+            independent = {"value": world * args.steps / t_s, "unit": "registrations/s (all ranks together)", "per_rank": args.steps / t_s,
+                           "scaling": "weak", "binned_ahead_steps_rank0": int(sum(1 for s_ in st_s if s_.flags & binding.FLAG_BINNED_AHEAD)),
+                           "note": "N independent streams, one per rank, each on the whole map: every rank times the same K registrations, the "
+                                   "slowest rank's time counts"}
+            solo.close()
+            slam.peer_enable(peer)
+        except Exception as e:  # noqa: BLE001 -- a secondary measurement must not cost the line
+            independent = {"error": str(e)}
     prof = None
     if not args.no_kernel_events and not args.no_profile_pass:
         # kernel split of a registration: every launch bracketed by events (would cost ~25 us per registration inside the
@@ -923,6 +946,7 @@ def main():
         "stock": stock,
         "open_scene": open_scene,
         "other_shard_mode": other_mode,
+        "independent_streams": independent,
         "predicted_scaling": predicted,
     }
 
