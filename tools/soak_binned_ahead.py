@@ -13,9 +13,10 @@ import oracle_py as oracle  # noqa: E402
 from superodom_amd import binding, synth  # noqa: E402
 
 ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60.0); ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--scenes", default="tiny,small", help="comma-separated synth scenes (os1_128_2m = the configuration of record; the oracle is skipped there)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
-scenes = {name: synth.Scene(name) for name in ("tiny", "small")}
+scenes = {name: synth.Scene(name) for name in a.scenes.split(",")}
 
 
 def key(st, status):
@@ -64,7 +65,7 @@ while time.time() < t_end:
             n_bad += 1
             print("MISMATCH", dict(scene=name, stream=ids, k=k, n=len(scans[k]), max_it=max_it, msf=msf, rc=(rc, ref[k][0]), flags=hex(st.flags),
                                    err=synth.pose_error(pose, ref[k][1])), flush=True)
-    if n_streams % 4 == 0:
+    if n_streams % 4 == 0 and len(sc.map_points) <= 500_000:
         om = oracle.OracleMap(plane_res=sc.plane_res); om.add_surf(slam.export_map(), raw=True)
         cfg = oracle.default_config(max_iterations=max_it, max_surface_features=msf)
         for k in (0, len(scans) - 1):
