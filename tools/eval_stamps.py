@@ -24,18 +24,29 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="os1_128_2m")
     ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--scan", type=int, default=0, help="scan (and guess) of the trajectory registered by the plain loop")
+    ap.add_argument("--staged", action="store_true", help="the bench's stream: four scans in rotation, each announced during the registration before it "
+                                                           "(so_icp_stage_scan from pinned memory) -- the sweeps then run on chunks binned AHEAD, under the previous guess")
     a = ap.parse_args()
     sc = synth.Scene(a.workload)
     slam = binding.LidarSlamGpu(device_id=0, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_iterations=5,
                                 lm_max_iterations=4, max_surface_features=-1)
     slam.add_surf_point_cloud(sc.map_points)
-    d = slam.upload_scan(sc.scan(0))
+    d = slam.upload_scan(sc.scan(a.scan))
     st = binding.Stats()
     acc = np.zeros((2, 8))
     lm_stamps = os.environ.get("SOICP_LM_STAMPS")  # library built with -DSO_LM_STAMPS: dbg[0..7] = clocks inside the controller (slot 1)
     lm_acc = np.zeros(7)
+    host = [slam.host_alloc_like(np.ascontiguousarray(sc.scan(i), dtype=np.float32)) for i in range(4)] if a.staged else None
+    if a.staged:
+        slam.stage_scan(host[0])
     for r in range(a.reps + 2):
-        slam.register_dev(d[0], d[1], sc.guess(0), st)
+        if a.staged:  # (the last registration of the loop is scan (reps + 1) % 4, binned under the guess of the one before)
+            slam.stage_scan(host[(r + 1) % 4])
+            _, _, st = slam.register(host[r % 4], sc.guess(r % 4))
+            ahead = bool(st.flags & binding.FLAG_BINNED_AHEAD)
+        else:
+            slam.register_dev(d[0], d[1], sc.guess(a.scan), st)
         s = slam.debug_stamps().astype(np.float64) * 0.01  # 100 MHz -> us
         if r >= 2 and lm_stamps:
             lm_acc += np.diff(slam.debug_stamps().astype(np.float64)[0:8]) * 0.01
@@ -43,6 +54,8 @@ def main():
             acc[0] += s[0:8]
             acc[1] += s[8:16]
     acc /= a.reps
+    if a.staged:
+        print('last registration binned ahead:', ahead)
     if lm_stamps:
         print("controller phases (us):", dict(zip(["feed:tolerances+rel", "feed:accept+unpack+gradient", "propose:scale+Hs", "cholesky+solve", "model change",
                                                     "pose_plus", "store back"], np.round(lm_acc / a.reps, 2))))
