@@ -146,6 +146,8 @@ typedef struct {
 #define SO_ICP_FLAG_QUERY_SPLIT 0x80u        /* world_size > 1 with SO_ICP_SHARD_QUERIES: map replicated, this rank registered its share of the scan */
 #define SO_ICP_FLAG_BINNED_AHEAD 0x100u      /* the staged scan had been spatially binned behind its copy, beside the registration before it
                                                  (single device; SOICP_PREBIN=0 disables): this registration started with its k-NN sweep */
+#define SO_ICP_FLAG_QUERY_WAVES 0x200u       /* small scan (<= 4 096 kept queries, e.g. max_surface_features 2000 / 4000 of the stock configurations): no
+                                                 binning, every kept query searched by a wavefront of its own (SOICP_QUERY_WAVES=0 disables): identical results */
 
 /* average kernel durations since the last so_icp_reset_timing (HIP events on the context's stream) */
 typedef struct {

@@ -45,6 +45,7 @@ class Stats(C.Structure):
 FLAG_PER_EVAL_LAUNCHES, FLAG_RETRIED, FLAG_HOST_MAP, FLAG_SORT_BINNING, FLAG_SHARDED, FLAG_STAGED_SCAN, FLAG_COPY_READBACK = 1, 2, 4, 8, 16, 32, 64
 FLAG_QUERY_SPLIT = 128
 FLAG_BINNED_AHEAD = 256
+FLAG_QUERY_WAVES = 512
 
 
 class RegistrationError(C.Structure):

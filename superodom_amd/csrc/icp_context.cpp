@@ -295,6 +295,7 @@ struct so_icp_ctx {
   std::thread stage_thread; std::mutex stage_mu; std::condition_variable stage_cv;
   struct HostRange { const char* p; size_t bytes; bool owned; };
   std::vector<HostRange> host_ranges;     // so_icp_host_register / so_icp_host_alloc (under stage_mu)
+  bool query_waves = true;                // SOICP_QUERY_WAVES=0: a small scan (<= 4 096 kept queries) is binned and swept in chunks like a large one
   bool knn_pack = true;                   // SOICP_KNN_PACK=0: one chunk per wavefront throughout (round-3 work list)
   bool knn_list_fits = false;             // the last registration's work list (normal + light chunks) fitted the k-NN grid one chunk per wavefront:
                                           // packing four light chunks into a wavefront then only lengthens the longest wavefronts (a 13 k-point
@@ -653,7 +654,16 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   // (the prologue rides on the first k-NN launch -- MatchParams::begin -- unless that is the instrumented instantiation, whose
   //  statistics share the histogram block the prologue clears)
   const bool begin_in_knn = pb && c->ablate == 0;
-  if (pb) {
+  // A SMALL scan -- the stock operating point of the node: max_surface_features 2000 / 4000 of a pre-filtered cloud -- is not binned at all:
+  // every kept query gets a wavefront of its own (knn_query_wave_kernel), the prologue rides on the first sweep.  Single device,
+  // single registration; the instrumented build keeps the chunked sweep (its stamps describe that kernel).
+  const int max_sf_cfg = c->cfg.max_surface_features;
+  const size_t kept_upper = (max_sf_cfg >= 0 && n > (size_t)max_sf_cfg) ? (size_t)max_sf_cfg + 2 : n;  // (the rule keeps ~ rate * n points)
+  const bool query_waves = c->query_waves && n && kept_upper <= kQueryWaveMaxKept && c->cfg.world_size <= 1 && !c->batch_mode && !c->borrow.on &&
+                           !qsplit && c->ablate == 0;
+  if (query_waves) {
+    st->flags |= SO_ICP_FLAG_QUERY_WAVES;
+  } else if (pb) {
     if (!begin_in_knn)
       launch_reg_begin_prebinned(ds, pose_in, max_outer, lm_max, c->d_hist, pb->pb_ctr.as<unsigned long long>(), c->d_status.as<uint8_t>(), (uint32_t)n,
                                  c->cfg.max_surface_features, s);
@@ -764,12 +774,16 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
       if (ka && kb) c->spans.push_back(EventSpan{0, ka, kb, (uint32_t)n});
     }
     MatchParams mp_it = mp;
-    if (it == 0 && begin_in_knn) {
+    if (it == 0 && begin_in_knn && !query_waves) {
       mp_it.begin = 1; mp_it.begin_args.max_outer = max_outer; mp_it.begin_args.lm_max = lm_max; mp_it.begin_max_surface_features = c->cfg.max_surface_features;
       mp_it.begin_n = (uint32_t)n; std::memcpy(mp_it.begin_args.pose, pose_in, sizeof(mp_it.begin_args.pose));
       mp_it.begin_ctr = pb->pb_ctr.as<unsigned long long>(); mp_it.begin_state = ds;
     }
-    launch_knn_plane(d_binned, d_chunks, ds, c->view, mp_it, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s, ka, kb);
+    if (query_waves)
+      launch_knn_query_waves(d_scan, (uint32_t)n, ds, pose_in, max_outer, lm_max, it == 0, c->d_hist, c->view, mp, c->cfg.max_surface_features,
+                             c->d_status.as<uint8_t>(), c->d_nbr5.as<uint32_t>(), s, ka, kb);
+    else
+      launch_knn_plane(d_binned, d_chunks, ds, c->view, mp_it, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s, ka, kb);
     if (c->cfg.time_kernels >= 2)  // kernel statistics of this sweep (profiling mode only)
       HIP_TRY(c, hipMemcpyAsync(c->h_hist + (size_t)it * kHistReplicas * kHistStride, c->d_hist,
                                 kHistReplicas * kHistStride * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -860,7 +874,7 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
     if (c->speculate && it + 1 < max_outer && (rc = enqueue_outer_a(it + 1))) return rc;
     // this registration's launches are in the queue and the host is about to idle: the moment for the NEXT scan's DMA
     if (!c->batch_mode && it == 0) {
-      stage_issue_deferred(c, may_prebin ? pose_in : nullptr);  // (the next scan is binned behind its copy, under this registration's guess)
+      stage_issue_deferred(c, (may_prebin && !query_waves) ? pose_in : nullptr);  // (the next scan is binned behind its copy, under this registration's guess; a stream of small scans is not binned at all)
     }
     if ((rc = await_outer(it))) return rc;
     last = it;
@@ -1551,6 +1565,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_PEER_TIMEOUT_MS")) { const long ms = std::atol(ev); if (ms >= 1 && ms <= 60000) c->peer_timeout_ticks = (unsigned long long)ms * 100000ull; }
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_KNN_PACK")) c->knn_pack = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_QUERY_WAVES")) c->query_waves = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PREBIN")) c->prebin = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BATCH_CHAIN")) c->batch_chain = std::string(ev) != "0";
   if (const char* ev = std::getenv("SOICP_BATCH_MODE")) {  // "one_per_cu": one solve workgroup per compute unit (several processes on one device); "lanes"

@@ -200,6 +200,13 @@ void launch_knn_plane(const float4* d_binned,
                       int32_t* d_hist /*kHistReplicas*kHistStride*/, hipStream_t s, hipEvent_t ev_start = nullptr,
                       hipEvent_t ev_stop = nullptr /* timing events attached to the dispatch itself */,
                       const BatchView* bv = nullptr, uint32_t n_hyp = 0);
+// The sweep of a SMALL scan: one wavefront per scan point, no binning launches, no chunk list (knn_query_wave_kernel).  begin: first
+// launch of the registration -- carries the prologue (guess + loop bounds from the arguments) and the DROPPED status bytes of the
+// sampling rule.  Leaves what launch_knn_plane leaves: a status byte per processed query, five canonical indices where PENDING.
+constexpr uint32_t kQueryWaveMaxKept = 4096;  // kept queries up to which every query gets a wavefront of its own (all resident at once)
+void launch_knn_query_waves(const float* d_scan_xyz, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, bool begin,
+                            int32_t* d_hist, const DevMapView& map, const MatchParams& mp, int max_surface_features, uint8_t* d_status,
+                            uint32_t* d_nbr5, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr,
                  DevState* st, const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist,
                  LmSums* d_sums, const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper,

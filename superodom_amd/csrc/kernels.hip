@@ -1612,6 +1612,120 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// knn_query_wave_kernel -- the sweep of a SMALL scan (round 6): one WAVEFRONT per scan point, no binning at all.
+//
+// The stock operating point of the node (config/os1_128.yaml:26-28, livox_mid360.yaml:26-28: max_surface_features 2000 / 4000 of a
+// pre-filtered cloud of 9 - 13 k points) keeps a few thousand queries.  The chunked sweep above is built for 131 072 of them: three
+// binning launches the host cannot enqueue as fast as the device finishes them (21 us), then wavefronts that serve 27 queries each
+// through six dependent memory round trips -- 60 workgroups' worth of work on a 256-unit chip.  With <= 4 096 kept queries every
+// query can have a wavefront of its own, all resident at once: sampling rule (LidarSlam.cpp:346-359), world transform (:397-398),
+// cube + cell (LocalMap.h:488-507), then the (clamped) 3 x 3 x 3 cells around the query -- every map point inside the gate ball lies
+// there, one cell >= the gate radius -- as <= 9 x-runs dealt to the 64 lanes, exact distances (octree.h:93-102), lane-local top 5,
+// five wavefront minima, distance gate (LidarSlam.cpp:741).  Four dependent round trips, no binning launches, no chunk list; the
+// same exact lists (ties by canonical index) and the same status bytes + neighbour lists as knn_plane_kernel leaves for the fit pass.
+// BEGIN: first launch of a registration -- the prologue rides on it (workgroup 0), the pose comes from the kernel arguments, and the
+//        points the sampling rule drops get their DROPPED status bytes.
+// ------------------------------------------------------------------------------------------------
+template <bool BEGIN>
+__global__ __launch_bounds__(256) void knn_query_wave_kernel(const float* __restrict__ scan, uint32_t n, const DevState* __restrict__ st, DevState* st_begin,
+                                                             RegBeginArgs a, int32_t* __restrict__ hist, const float4* __restrict__ mpts,
+                                                             const uint32_t* __restrict__ mcell_start, DevMapView map, MatchParams mp, int max_surface_features,
+                                                             uint8_t* __restrict__ status, uint32_t* __restrict__ nbr5) {
+  __shared__ uint32_t rowtab[4][2][20];  // per wavefront: exclusive candidate offsets [17] and first canonical index [16] of the nine x-runs
+  if (BEGIN) {
+    if (blockIdx.x == 0) {
+      hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
+      reg_begin_state(st_begin, a, (int)threadIdx.x);
+    }
+  } else {
+    if (st->reg_done) return;  // the registration already converged: this launch is a no-op
+    // the report of the previous outer iteration, left to this launch by its solve (MatchParams::publish_prev)
+    if (mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
+      publish_state_to(mp.hring[(st->outer_iter - 1) & 1], st, mp.seq_base | (unsigned long long)st->outer_iter, (int)threadIdx.x, 256);
+  }
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t i = blockIdx.x * 4u + (uint32_t)wv;  // this wavefront's scan point
+  if (i >= n) return;
+  if (!sampling_keeps(i, n, max_surface_features)) {
+    if (BEGIN && lane == 0) status[i] = SO_MATCH_DROPPED;  // (the rule does not depend on the pose: once per registration)
+    return;
+  }
+  const Pose pose = pose_from_array(BEGIN ? a.pose : st->T);
+  double pw[3];
+  quat_rotate<double>(pose.q, (double)scan[3 * i], (double)scan[3 * i + 1], (double)scan[3 * i + 2], pw[0], pw[1], pw[2]);  // LidarSlam.cpp:397-398
+  pw[0] += pose.t[0]; pw[1] += pose.t[1]; pw[2] += pose.t[2];
+  const float qx = (float)pw[0], qy = (float)pw[1], qz = (float)pw[2];                                                        // LidarSlam.cpp:728-731
+  const CellRef c = locate(map, qx, qy, qz);
+  if (c.slot < 0) {  // outside the window / no tree: LidarSlam.cpp:736-739
+    if (lane == 0) __builtin_nontemporal_store((uint8_t)SO_MATCH_NOT_ENOUGH, &status[i]);
+    return;
+  }
+  uint32_t* rowoff = rowtab[wv][0];
+  uint32_t* rowbeg = rowtab[wv][1];
+  const int nc = map.nc;
+  const int x0 = c.cx > 0 ? c.cx - 1 : 0, x1 = c.cx < nc - 1 ? c.cx + 1 : nc - 1;
+  uint32_t vb = 0, vl = 0;
+  if (lane < 9) {
+    const int y = c.cy + (lane % 3) - 1, z = c.cz + (lane / 3) - 1;
+    if (y >= 0 && y < nc && z >= 0 && z < nc) {
+      const uint32_t* row = mcell_start + (size_t)c.slot * map.ncell1 + ((size_t)z * nc + y) * nc;
+      vb = row[x0]; vl = row[x1 + 1] - vb;
+    }
+  }
+  uint32_t inc = vl;  // inclusive scan over lanes 0..15 (the nine runs sit in the first row of 16 lanes)
+  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);
+  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);
+  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);
+  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 15);
+  if (lane < 16) { rowoff[lane] = lane < 9 ? inc - vl : total; rowbeg[lane] = vb; }
+  if (lane == 0) rowoff[16] = total;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  Top5 loc;
+  loc.init();
+  for (uint32_t t0 = 0; t0 < total; t0 += 256u) {  // four loads of a lane in flight: a block of <= 256 points is one round trip
+    float ax_[4], ay_[4], az_[4];
+    uint32_t cn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
+      cn[u] = 0xFFFFFFFFu; ax_[u] = ay_[u] = az_[u] = 0.f;
+      if (t < total) {
+        int r = 0;
+#pragma unroll
+        for (int step = 8; step >= 1; step >>= 1) r = (r + step < 16 && rowoff[r + step] <= t) ? r + step : r;
+        cn[u] = rowbeg[r] + (t - rowoff[r]);
+        const float4 p = mpts[cn[u]];
+        ax_[u] = p.x; ay_[u] = p.y; az_[u] = p.z;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (cn[u] != 0xFFFFFFFFu) loc.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, ax_[u], ay_[u], az_[u])) << 32) | cn[u]);
+  }
+  unsigned long long m5[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    m5[t] = wave_min_u64(loc.b0);
+    if (loc.b0 == m5[t] && m5[t] != ~0ull) { loc.b0 = loc.b1; loc.b1 = loc.b2; loc.b2 = loc.b3; loc.b3 = loc.b4; loc.b4 = ~0ull; }  // (keys are unique)
+  }
+  if (lane == 0) {
+    const float d2_4 = __uint_as_float((uint32_t)(m5[4] >> 32));
+    int stq = SO_MATCH_PENDING;  // five neighbours inside the gate: the plane fit runs in slot 0 of the solve
+    if (m5[4] == ~0ull || (double)d2_4 > (double)mp.sq_max_dist_f) stq = SO_MATCH_TOO_FAR;  // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
+    else {
+      uint32_t* o = nbr5 + (size_t)5 * i;
+      __builtin_nontemporal_store((uint32_t)m5[0], o); __builtin_nontemporal_store((uint32_t)m5[1], o + 1);
+      __builtin_nontemporal_store((uint32_t)m5[2], o + 2); __builtin_nontemporal_store((uint32_t)m5[3], o + 3);
+      __builtin_nontemporal_store((uint32_t)m5[4], o + 4);
+    }
+    __builtin_nontemporal_store((uint8_t)stq, &status[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LM evaluation: fused cost + J^T J + J^T r
 // ------------------------------------------------------------------------------------------------
 constexpr int kNAcc = 29;  // cost, count, Jtr[6], JtJ[21]
@@ -2954,6 +3068,19 @@ void launch_knn_plane(const float4* binned,
   else
     hipLaunchKernelGGL(k, dim3(kKnnBlocks), dim3(256), 0, s, binned, chunk_start, st, map.pts,
                        map.cell_start, map, mp, corr, nbr5, hist, kNoBatch);
+}
+void launch_knn_query_waves(const float* d_scan, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, bool begin, int32_t* hist,
+                            const DevMapView& map, const MatchParams& mp, int max_sf, uint8_t* status, uint32_t* nbr5, hipStream_t s,
+                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (!n) return;
+  RegBeginArgs a{};
+  if (begin) { for (int i = 0; i < 7; ++i) a.pose[i] = pose[i]; a.max_outer = max_outer; a.lm_max = lm_max; }
+  auto* k = begin ? knn_query_wave_kernel<true> : knn_query_wave_kernel<false>;
+  const dim3 grid((n + 3u) / 4u);
+  if (ev_start && ev_stop)
+    hipExtLaunchKernelGGL(k, grid, dim3(256), 0, s, ev_start, ev_stop, 0, d_scan, n, st, st, a, hist, map.pts, map.cell_start, map, mp, max_sf, status, nbr5);
+  else
+    hipLaunchKernelGGL(k, grid, dim3(256), 0, s, d_scan, n, st, st, a, hist, map.pts, map.cell_start, map, mp, max_sf, status, nbr5);
 }
 uint32_t solve_grid(uint32_t n_upper, uint32_t max_blocks) {
   uint32_t blocks = (n_upper + 255u) / 256u;

@@ -13,6 +13,13 @@ from superodom_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _chunked_sweep_for_small_scans(monkeypatch):
+    """The scans of these scenes keep <= 4 096 queries, which round 6 sweeps with one wavefront per query and does not bin at all
+    (SO_ICP_FLAG_QUERY_WAVES, tests/test_gpu_query_waves.py).  This file is about the binned path: switch that off (read at so_icp_create)."""
+    monkeypatch.setenv("SOICP_QUERY_WAVES", "0")
+
+
 def _stats_tuple(st):
     out = [st.n_iterations]
     for it in range(st.n_iterations):

@@ -296,14 +296,15 @@ def test_stats_flags_name_the_degraded_modes(oracle, gpu_slam_factory, soicp, mo
     sc, slam, _ = _setup("tiny", oracle, gpu_slam_factory, max_iterations=3)
     scan, guess = sc.scan(0), sc.guess(0)
     rc, pose0, st = slam.register(scan, guess)
-    assert rc == 0 and st.flags == 0, hex(st.flags)
+    QW = soicp.FLAG_QUERY_WAVES  # (a 4 096-point scan: one wavefront per query, no binning -- not a degraded mode, tests/test_gpu_query_waves.py)
+    assert rc == 0 and st.flags == QW, hex(st.flags)
     for env, flag in (({"SOICP_PERSISTENT": "0"}, soicp.FLAG_PER_EVAL_LAUNCHES),
                       ({"SOICP_HOST_MAP": "1"}, soicp.FLAG_HOST_MAP), ({"SOICP_READBACK": "copy"}, soicp.FLAG_COPY_READBACK)):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         _, alt, _ = _setup("tiny", oracle, gpu_slam_factory, max_iterations=3)
         rc, pose2, s2 = alt.register(scan, guess)
-        assert rc == 0 and s2.flags == flag, (env, hex(s2.flags))
+        assert rc == 0 and s2.flags == (flag | QW), (env, hex(s2.flags))
         assert np.array_equal(pose2, pose0) and np.array_equal(np.array(s2.JtJ), np.array(st.JtJ)), (env, "a degraded mode is the same registration, bit for bit")
         for k in env:
             monkeypatch.delenv(k)

@@ -1,0 +1,131 @@
+"""-m gpu: the sweep of a SMALL scan -- one wavefront per kept query, no binning (knn_query_wave_kernel, round 6;
+so_icp_stats::flags & SO_ICP_FLAG_QUERY_WAVES) -- against the chunked sweep of the same scan (SOICP_QUERY_WAVES=0) and against the oracle.
+
+Both sweeps are exact 5-NN searches (LocalMap.h:481-525, octree.h:93-102; ties by canonical index), so everything downstream must be
+IDENTICAL: status bytes, histograms, iteration counts, termination codes and the bits of the pose.  The operating points are the
+stock ones of the node (config/os1_128.yaml:26-28: max_surface_features 2000; livox_mid360.yaml:26-28: 4000) plus the edges of
+the switch (a scan of exactly 4 096 points without sampling, one point more, an empty cube, queries outside the window)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import pose_close
+from superodom_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(make, soicp, **cfg):
+    """Two contexts on the same device: the default (query waves for small scans) and the chunked sweep throughout."""
+    a = make(**cfg)
+    old = os.environ.get("SOICP_QUERY_WAVES")
+    os.environ["SOICP_QUERY_WAVES"] = "0"  # (read when the context is created)
+    try:
+        b = make(**cfg)
+    finally:
+        if old is None:
+            del os.environ["SOICP_QUERY_WAVES"]
+        else:
+            os.environ["SOICP_QUERY_WAVES"] = old
+    return a, b
+
+
+def _same(sa, sb):
+    assert sa.n_iterations == sb.n_iterations
+    for it in range(sa.n_iterations):
+        x, y = sa.iterations[it], sb.iterations[it]
+        assert (x.lm_iterations, x.num_successful_steps, x.termination, x.num_surf_from_scan) == \
+               (y.lm_iterations, y.num_successful_steps, y.termination, y.num_surf_from_scan)
+        assert list(x.reject_hist) == list(y.reject_hist) and list(x.obs_hist) == list(y.obs_hist)
+        assert x.initial_cost == y.initial_cost and x.final_cost == y.final_cost
+        assert np.array_equal(np.array(x.pose_after), np.array(y.pose_after))
+    assert np.array_equal(np.array(sa.JtJ), np.array(sb.JtJ)) and np.array_equal(np.array(sa.Jtr), np.array(sb.Jtr))
+
+
+@pytest.mark.parametrize("scene,max_feat,scan_ids", [("small", 2000, [0, 3, 7]), ("small", 4000, [1, 5]), ("tiny", -1, [0, 5, 11]), ("tiny", 1500, [2])])
+def test_query_wave_sweep_equals_the_chunked_sweep_and_the_oracle(oracle, soicp, gpu_slam_factory, scene, max_feat, scan_ids):
+    sc = synth.Scene(scene)
+    a, b = _pair(gpu_slam_factory, soicp, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=max_feat, max_iterations=5)
+    for s in (a, b):
+        s.add_surf_point_cloud(sc.map_points)
+    om = oracle.OracleMap(plane_res=sc.plane_res)
+    om.add_surf(a.export_map(), raw=True)
+    for i in scan_ids:
+        scan, guess = sc.scan(i), sc.guess(i)
+        ra, pa, sa = a.register(scan, guess)
+        ma = a.match_status(len(scan))
+        rb, pb, sb = b.register(scan, guess)
+        mb = b.match_status(len(scan))
+        assert ra == rb == 0
+        assert sa.flags & soicp.FLAG_QUERY_WAVES, hex(sa.flags)
+        assert not (sb.flags & soicp.FLAG_QUERY_WAVES), hex(sb.flags)
+        assert np.array_equal(pa, pb), "the two sweeps must give the same bits"
+        assert np.array_equal(ma, mb), "MatchingResult of every query"
+        _same(sa, sb)
+        orc, opose, ost, _ = om.register(scan, guess, oracle.default_config(max_iterations=5, max_surface_features=max_feat))
+        assert orc == 0 and sa.n_iterations == ost.n_iterations
+        for it in range(sa.n_iterations):
+            assert list(sa.iterations[it].reject_hist) == list(ost.iters[it].reject_hist)
+            assert list(sa.iterations[it].obs_hist) == list(ost.iters[it].obs_hist)
+            assert sa.iterations[it].lm_iterations == ost.iters[it].lm_iterations
+        ok, dt, dr = pose_close(pa, opose, 1e-8, 1e-8)
+        assert ok, (dt, dr)
+    a.close(); b.close()
+
+
+def test_the_switch_is_at_4096_kept_queries_and_resident_scans_take_it_too(oracle, soicp, gpu_slam_factory):
+    sc = synth.Scene("small")
+    a, b = _pair(gpu_slam_factory, soicp, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=4)
+    for s in (a, b):
+        s.add_surf_point_cloud(sc.map_points)
+    full = sc.scan(4)
+    assert len(full) > 4097
+    for n, expect in ((4096, True), (4097, False), (1, True), (63, True)):
+        scan = np.ascontiguousarray(full[:n])
+        ra, pa, sa = a.register(scan, sc.guess(4))
+        rb, pb, sb = b.register(scan, sc.guess(4))
+        assert ra == rb == 0
+        assert bool(sa.flags & soicp.FLAG_QUERY_WAVES) == expect, (n, hex(sa.flags))
+        assert np.array_equal(pa, pb), n
+        _same(sa, sb)
+    # resident scan (so_icp_register_dev), the entry the node's pre-filter hands its cloud to
+    scan = np.ascontiguousarray(full[:3000])
+    d = a.upload_scan(scan)
+    rc, pose, st = a.register_dev(d[0], d[1], sc.guess(4))
+    assert rc == 0
+    rb, pb, sb = b.register(scan, sc.guess(4))
+    assert st.flags & soicp.FLAG_QUERY_WAVES and np.array_equal(pose, pb)
+    _same(st, sb)
+    a.close(); b.close()
+
+
+def test_queries_outside_the_window_in_empty_cubes_and_far_from_the_map(oracle, soicp, gpu_slam_factory):
+    # NOT_ENOUGH_NEIGHBORS (no cube / no tree, LidarSlam.cpp:736-739) and TOO_FAR (:741-744, incl. cubes with < 5 points) from the
+    # query-wave sweep: a scan whose points reach beyond the map and beyond the 21 x 21 x 11 window
+    sc = synth.Scene("tiny")
+    a, b = _pair(gpu_slam_factory, soicp, plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=3)
+    extra = np.array([[70.0, 3.0, 0.5], [71.0, 3.5, 0.6], [72.0, 2.0, 0.1]], np.float32)  # a cube with three points
+    for s in (a, b):
+        s.add_surf_point_cloud(np.concatenate([sc.map_points, extra]))
+    om = oracle.OracleMap(plane_res=sc.plane_res)
+    om.add_surf(a.export_map(), raw=True)
+    rng = np.random.default_rng(5)
+    scan = sc.scan(3).copy()
+    scan[::37] *= 40.0          # far outside the map, some outside the window
+    scan[5::41] += np.array([70.0, 3.0, 0.0], np.float32)  # into the sparse cube
+    scan = scan[rng.permutation(len(scan))].astype(np.float32)
+    ra, pa, sa = a.register(scan, sc.guess(3))
+    ma = a.match_status(len(scan))
+    rb, pb, sb = b.register(scan, sc.guess(3))
+    mb = b.match_status(len(scan))
+    assert ra == rb == 0 and (sa.flags & soicp.FLAG_QUERY_WAVES)
+    assert np.array_equal(ma, mb) and np.array_equal(pa, pb)
+    _same(sa, sb)
+    h = list(sa.iterations[0].reject_hist)
+    assert h[1] > 0 and h[2] > 0, h  # both rejections occur
+    orc, opose, ost, _ = om.register(scan, sc.guess(3), oracle.default_config(max_iterations=3))
+    assert list(sa.iterations[0].reject_hist) == list(ost.iters[0].reject_hist)
+    ok, dt, dr = pose_close(pa, opose, 1e-8, 1e-8)
+    assert ok, (dt, dr)
+    a.close(); b.close()
