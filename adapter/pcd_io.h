@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -24,6 +25,21 @@ struct Header {
   size_t width = 0, height = 1, points = 0, point_size = 0, data_offset = 0;
   std::string data;  // ascii | binary | binary_compressed
 };
+
+// a header number: decimal digits only, bounded -- a malformed or hostile file must end in `false` (the node then switches to
+// mapping mode, laserMapping.cpp:165-171), never in an exception out of loadPriorMap()
+inline bool parse_count(const std::string& tok, size_t max, size_t& out) {
+  if (tok.empty() || tok.size() > 19) return false;
+  size_t v = 0;
+  for (char ch : tok) {
+    if (ch < '0' || ch > '9') return false;
+    v = v * 10 + (size_t)(ch - '0');
+  }
+  if (v > max) return false;
+  out = v;
+  return true;
+}
+constexpr size_t kMaxPoints = (size_t)1 << 32;  // (a prior map of 4 G points is 64 GB of xyzi: beyond anything the node could hold)
 
 inline bool parse_header(const std::vector<uint8_t>& buf, Header& h, std::string& err) {
   size_t pos = 0;
@@ -46,9 +62,11 @@ inline bool parse_header(const std::vector<uint8_t>& buf, Header& h, std::string
     else if (key == "SIZE") sizes = v;
     else if (key == "TYPE") types = v;
     else if (key == "COUNT") counts = v;
-    else if (key == "WIDTH" && !v.empty()) h.width = std::stoull(v[0]);
-    else if (key == "HEIGHT" && !v.empty()) h.height = std::stoull(v[0]);
-    else if (key == "POINTS" && !v.empty()) { h.points = std::stoull(v[0]); have_points = true; }
+    else if ((key == "WIDTH" || key == "HEIGHT" || key == "POINTS") && !v.empty()) {
+      size_t val = 0;
+      if (!parse_count(v[0], kMaxPoints, val)) { err = "PCD header: bad " + key + " '" + v[0] + "'"; return false; }
+      if (key == "WIDTH") h.width = val; else if (key == "HEIGHT") h.height = val; else { h.points = val; have_points = true; }
+    }
     else if (key == "DATA" && !v.empty()) { h.data = v[0]; h.data_offset = pos; break; }
     else { err = "PCD header: unknown entry '" + key + "'"; return false; }
   }
@@ -58,7 +76,11 @@ inline bool parse_header(const std::vector<uint8_t>& buf, Header& h, std::string
   size_t off = 0;
   for (size_t i = 0; i < names.size(); ++i) {
     Field f;
-    f.name = names[i]; f.size = std::stoi(sizes[i]); f.type = types[i].empty() ? 'F' : types[i][0]; f.count = counts.empty() ? 1 : std::stoi(counts[i]);
+    size_t fsize = 0, fcount = 1;
+    if (!parse_count(sizes[i], 8, fsize) || (!counts.empty() && !parse_count(counts[i], 1u << 20, fcount))) {
+      err = "PCD header: bad SIZE / COUNT of field '" + names[i] + "'"; return false;
+    }
+    f.name = names[i]; f.size = (int)fsize; f.type = types[i].empty() ? 'F' : types[i][0]; f.count = (int)fcount;
     if (!(f.size == 1 || f.size == 2 || f.size == 4 || f.size == 8) || f.count < 0 || !(f.type == 'F' || f.type == 'I' || f.type == 'U')) {
       err = "PCD header: unsupported SIZE / TYPE / COUNT of field '" + f.name + "'"; return false;
     }
@@ -67,7 +89,12 @@ inline bool parse_header(const std::vector<uint8_t>& buf, Header& h, std::string
     h.fields.push_back(f);
   }
   h.point_size = off;
-  if (!have_points) h.points = h.width * h.height;
+  if (off == 0 || off > ((size_t)1 << 30)) { err = "PCD header: point size out of range"; return false; }
+  if (!have_points) {
+    if (h.height != 0 && h.width > kMaxPoints / h.height) { err = "PCD header: WIDTH x HEIGHT out of range"; return false; }
+    h.points = h.width * h.height;
+  }
+  if (h.points > kMaxPoints) { err = "PCD header: POINTS out of range"; return false; }
   return true;
 }
 
@@ -121,9 +148,23 @@ inline bool read_xyzi(const std::string& path, std::vector<float>& xyzi, std::st
   if (ix < 0 || iy < 0 || iz < 0) { err = "PCD file without x / y / z fields: " + path; return false; }
   for (int k : {ix, iy, iz}) if (h.fields[k].count != 1) { err = "PCD file: x / y / z with COUNT != 1"; return false; }
   const size_t n = h.points;
-  xyzi.assign(4 * n, 0.f);
   const uint8_t* body = buf.data() + h.data_offset;
   const size_t body_len = buf.size() - h.data_offset;
+  // the body length bounds the number of points BEFORE anything is allocated for them (POINTS is untrusted: h.point_size * n
+  // cannot overflow -- both factors are bounded by parse_header -- and an ascii point takes at least two bytes per field)
+  size_t n_fields_flat = 0;
+  for (const Field& fd : h.fields) n_fields_flat += (size_t)fd.count;
+  if (h.data == "binary" && h.point_size * n > body_len) { err = "PCD binary body shorter than POINTS x point size"; return false; }
+  if (h.data == "ascii" && n_fields_flat > 0 && n > body_len / (2 * n_fields_flat) + 1) { err = "PCD ascii body shorter than POINTS"; return false; }
+  if (h.data == "binary_compressed") {
+    if (body_len < 8) { err = "PCD binary_compressed body too short"; return false; }
+    uint32_t usize0;
+    std::memcpy(&usize0, body + 4, 4);
+    if ((size_t)usize0 != h.point_size * n) { err = "PCD binary_compressed: sizes do not match the header"; return false; }
+  }
+  try {
+    xyzi.assign(4 * n, 0.f);
+  } catch (const std::exception&) { err = "PCD file: no memory for " + std::to_string(n) + " points"; return false; }
   if (h.data == "ascii") {
     std::istringstream is(std::string(reinterpret_cast<const char*>(body), body_len));
     for (size_t p = 0; p < n; ++p) {
@@ -146,7 +187,7 @@ inline bool read_xyzi(const std::string& path, std::vector<float>& xyzi, std::st
     uint32_t csize, usize;
     std::memcpy(&csize, body, 4); std::memcpy(&usize, body + 4, 4);
     if ((size_t)csize + 8 > body_len || (size_t)usize != h.point_size * n) { err = "PCD binary_compressed: sizes do not match the header"; return false; }
-    soa.resize(usize);
+    try { soa.resize(usize); } catch (const std::exception&) { err = "PCD binary_compressed: no memory for the decompressed body"; return false; }
     if (!lzf_decompress(body + 8, csize, soa.data(), usize)) { err = "PCD binary_compressed: corrupt LZF stream"; return false; }
     body = soa.data();
     structure_of_arrays = true;

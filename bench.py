@@ -260,7 +260,7 @@ def main():
 
     g64 = [np.ascontiguousarray(g, dtype=np.float64) for g in guesses]
 
-    def timed_loop(entry, steps, rewarm=0, slam=slam):
+    def timed_loop(entry, steps, rewarm=0, slam=slam, protocol=None):
         """`steps` registrations through one entry point, only C calls between the two clock reads (arguments pre-built).
         rewarm: untimed registrations run right before the clock starts, after the argument lists are built -- the W warm-up
         steps of the contract leave the device idle for the milliseconds Python needs to build them, and the first
@@ -275,7 +275,7 @@ def main():
             calls = [slam.prepare_register(scans[k % args.scans], g64[k % args.scans], stats[k], pose[k]) for k in range(steps)]
             stage = [slam.prepare_stage_scan(scans[k % args.scans]) for k in range(steps)] if entry == "staged" else None
         rcs = [0] * steps
-        steady = bool(stage) and args.stage_protocol == "steady" and args.scans >= 2
+        steady = bool(stage) and (protocol or args.stage_protocol) == "steady" and args.scans >= 2
         if steady:
             # Steady state of a node that registers a stream of sweeps: while scan k registers, scan k + 1 is on its way -- through the
             # warm-up registrations and across the start of the clock alike.  The clock covers K registrations AND K copies: those of
@@ -406,6 +406,12 @@ def main():
                 continue
             t_e, _, _ = timed_loop(entry, args.steps, rewarm=args.warmup)
             secondary[entry] = args.steps / t_e
+        if args.entry == "staged" and args.scans >= 2:
+            # the staged loop under the OTHER start-of-clock protocol: `value` of r01 - r04 was measured with nothing announced
+            # when the clock starts ("cold"), r05 on with the stream crossing the clock start ("steady") -- both are in every line
+            other_protocol = "cold" if args.stage_protocol == "steady" else "steady"
+            t_e, _, _ = timed_loop("staged", args.steps, rewarm=args.warmup, protocol=other_protocol)
+            secondary["staged_%s_protocol" % other_protocol] = args.steps / t_e
         if args.scan_buffers != "pageable" and world == 1:
             # the protocol of rounds 1 - 3 beside the headline's: the same staged loop on PAGEABLE numpy buffers -- the copy
             # thread packs and copies them, nothing is binned ahead
@@ -902,7 +908,9 @@ def main():
                      "pose_error_vs_ground_truth_m_rad": [max(e[0] for e in errs), max(e[1] for e in errs)]},
         # the same registrations through the other entry points, `steps` each, after the timed region
         "entry_points": {"note": "registrations/s; 'staged' and 'host' include the scan's H2D copy (1.5 MB), 'resident' does not; "
-                                 "'staged_pageable_buffers' = the staged loop on pageable numpy buffers (copy thread, nothing binned ahead: the r01 - r03 protocol)",
+                                 "'staged_pageable_buffers' = the staged loop on pageable numpy buffers (copy thread, nothing binned ahead: the r01 - r03 protocol); "
+                                 "'staged_cold_protocol' / 'staged_steady_protocol' = the staged loop under the start-of-clock protocol `value` was NOT measured with "
+                                 "(host.stage_protocol names the one it was: 'cold' = nothing announced when the clock starts, r01 - r04; 'steady' = the stream crosses the clock start, r05 on)",
                          args.entry: value, **secondary},
         "roofline": {"bound": "hbm", "kernel": "knn_plane_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": tr_why or tr.get("source"),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SO_ICP_ABI_VERSION 3 /* v3: the config, timing and prefilter-info structs grew (shard_mode, solve_workgroups, staging / packing counters, statistic_in_input_order) */
+#define SO_ICP_ABI_VERSION 4 /* v4: so_icp_register_sequence; so_icp_timing grew (seq_chained, seq_chain_breaks).  v3: the config, timing and prefilter-info structs grew (shard_mode, solve_workgroups, staging / packing counters, statistic_in_input_order) */
 
 /* LocalMap geometry, LM.h:131-138 */
 #define SO_ICP_MAP_W 21
@@ -149,6 +149,9 @@ typedef struct {
 #define SO_ICP_FLAG_QUERY_WAVES 0x200u       /* small scan (<= 4 096 kept queries, e.g. max_surface_features 2000 / 4000 of the stock configurations): no
                                                  binning, every kept query searched by a wavefront of its own (SOICP_QUERY_WAVES=0 disables): identical results */
 
+#define SO_ICP_FLAG_CHAINED 0x400u           /* so_icp_register_sequence: this registration's launches were enqueued behind the registration before it, before
+                                                 that one had reported; its guess (guesses_out) was formed on the device */
+
 /* average kernel durations since the last so_icp_reset_timing (HIP events on the context's stream) */
 typedef struct {
   double knn_ms_total;   int64_t knn_launches;   int64_t knn_queries;   int64_t knn_map_points;
@@ -167,6 +170,9 @@ typedef struct {
   /* host adaptivity of the packing (every registration counts): registrations whose sweeps packed their light chunks, and how
    * often a registration that left > 3 % of its queries to the exact scan switched the packing off for the next 32 */
   int64_t knn_pack_registrations, knn_pack_holds;
+  /* so_icp_register_sequence: registrations whose launches were enqueued behind the registration before them (SO_ICP_FLAG_CHAINED), and how
+   * often a registration needed more outer iterations than were enqueued ahead (the chained registration behind it then started again) */
+  int64_t seq_chained, seq_chain_breaks;
 } so_icp_timing;
 
 /* -------- lifecycle ------------------------------------------------------------------------ */
@@ -225,6 +231,26 @@ int so_icp_knn_surf(so_icp_ctx *ctx, const float *q_xyz, size_t nq, int k,
  * the scan into the map (so_icp_localization does).  prev uncertainty comes from the previous call. */
 int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t stride_bytes,
                     const double pose_in[7], double pose_out[7], so_icp_stats *stats);
+/* A RUN of scans whose guesses chain (a node working off a backlog of feature clouds in localization mode; a log replayed at full
+ * speed): guess_0 = pose0, guess_k = T_(k-1) o delta_k -- T_(k-1) the pose registration k-1 ended with, delta_k the motion prediction
+ * between the two scans in the sensor frame: what laserMapping::selectPosePrediction (lmap.cpp:345-372) does with the LIO / VIO /
+ * IMU predictions, `T_w_lidar = T_w_lidar * prediction` (Twist::operator*, utils/Twist.h:181-185): t = t + R(q) dt, q = normalize(q dq).
+ * Equivalent to `count` calls of so_icp_register (so_icp_register_dev with scans_on_device) from guesses_out[k], bit for bit.  What it
+ * buys: the launches of registration k+1 are enqueued BEHIND those of registration k before k has reported -- the guess is formed on
+ * the device --, so the device does not idle for the host's turn-around between two calls (~11 us of a 140 us registration), and
+ * scan k+1 is copied and binned beside registration k under the predicted guess.  A registration that turns out to need more outer
+ * iterations than were enqueued ahead is finished the ordinary way and the one behind it starts again (so_icp_timing::seq_chain_breaks).
+ * The map is NOT updated in between (localization mode, LS.cpp:60-80 `if (!localization_mode)`): use so_icp_localization per scan when it must be.
+ * scans[k]: host pointers (packed or strided xyz; memory from so_icp_host_alloc / so_icp_host_register is copied by DMA) or, with
+ * scans_on_device, device pointers to packed xyz.  deltas: count x 7 {dx, dy, dz, qx, qy, qz, qw}, row 0 unused.  poses_out: count x 7;
+ * guesses_out (count x 7, nullable): the guess each registration started from; stats (count, nullable); n_done (nullable): registrations
+ * completed -- on an error or SO_ICP_NOT_ENOUGH_MAP_FEATURES the run stops at that scan and its code is returned.
+ * The chained path needs a single device, the device-resident map and yaw_ratio 0 (every stock configuration: MannualYawCorrection,
+ * LS.cpp:891-913, is then the identity up to rounding, and the chain continues from the optimised pose itself,
+ * stats[k].iterations[last].pose_after); otherwise -- or with SOICP_SEQ_CHAIN=0 -- the registrations run one after the other, same results. */
+int so_icp_register_sequence(so_icp_ctx *ctx, int count, const void *const *scans, const size_t *n_points, size_t stride_bytes,
+                             int scans_on_device, const double pose0[7], const double *deltas, double *poses_out, double *guesses_out,
+                             so_icp_stats *stats, int *n_done);
 /* Announce the NEXT scan: the host buffer travels to HBM on the context's copy stream while the caller goes on (typically:
  * while the previous so_icp_register is still running -- the node's feature callback, lmap.cpp:21-25, has the cloud long
  * before process() reaches it).  Packed xyz (stride 12) inside a buffer pinned with so_icp_host_register is read by DMA

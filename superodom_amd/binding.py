@@ -46,6 +46,7 @@ FLAG_PER_EVAL_LAUNCHES, FLAG_RETRIED, FLAG_HOST_MAP, FLAG_SORT_BINNING, FLAG_SHA
 FLAG_QUERY_SPLIT = 128
 FLAG_BINNED_AHEAD = 256
 FLAG_QUERY_WAVES = 512
+FLAG_CHAINED = 1024
 
 
 class RegistrationError(C.Structure):
@@ -72,7 +73,8 @@ class Timing(C.Structure):
                 ("knn_group_passes", C.c_int64), ("knn_fallback_lanes", C.c_int64), ("knn_candidates_scanned", C.c_int64),
                 ("stage_wait_ms_total", C.c_double), ("staged_direct", C.c_int64), ("staged_copied", C.c_int64), ("stage_declined", C.c_int64),
                 ("knn_packed_rows", C.c_int64), ("knn_packed_rows_too_many_runs", C.c_int64), ("knn_packed_rows_tile_full", C.c_int64),
-                ("knn_packed_kept", C.c_int64), ("knn_pack_registrations", C.c_int64), ("knn_pack_holds", C.c_int64)]
+                ("knn_packed_kept", C.c_int64), ("knn_pack_registrations", C.c_int64), ("knn_pack_holds", C.c_int64),
+                ("seq_chained", C.c_int64), ("seq_chain_breaks", C.c_int64)]
 
 
 class Sums(C.Structure):
@@ -93,7 +95,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
             "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram",
             "so_icp_host_register", "so_icp_host_unregister", "so_icp_host_alloc", "so_icp_host_free", "so_icp_device_count", "so_icp_stage_cancel",
-            "so_icp_map_insert_stats"]
+            "so_icp_map_insert_stats", "so_icp_register_sequence"]
 
 _lib = None
 
@@ -128,6 +130,7 @@ def load():
     L.so_icp_knn_surf.argtypes = [vp, f32p, C.c_size_t, C.c_int, f32p, f32p, i32p, u8p]
     L.so_icp_register.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, f64p, C.POINTER(Stats)]
     L.so_icp_register_dev.argtypes = [vp, vp, C.c_size_t, f64p, f64p, C.POINTER(Stats)]
+    L.so_icp_register_sequence.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, f64p, f64p, f64p, f64p, C.POINTER(Stats), i32p]
     L.so_icp_upload_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.so_icp_free_scan.argtypes = [vp, vp]
     L.so_icp_localization.argtypes = [vp, C.c_int, f64p, f32p, C.c_size_t, C.c_size_t, C.c_double, f64p, C.POINTER(Stats)]
@@ -363,6 +366,32 @@ class LidarSlamGpu:
         assert pose_in.dtype == np.float64 and pose_in.flags.c_contiguous and pose_out.dtype == np.float64 and pose_out.flags.c_contiguous
         fn, args = self.L.so_icp_register_dev, (self.h, d_scan, n, pose_in.ctypes.data_as(_F64P), pose_out.ctypes.data_as(_F64P), C.byref(stats))
         return lambda: fn(*args)
+
+    def prepare_register_sequence(self, scans, pose0, deltas, on_device=False):
+        """so_icp_register_sequence with pre-built arguments.  scans: contiguous float32 (n, 3) host arrays, or (device pointer, n) pairs
+        with on_device.  deltas: (count, 7), row 0 unused.  Returns (call, poses_out (count, 7), guesses_out (count, 7), stats array, n_done):
+        call() performs the C call and returns its code."""
+        count = len(scans)
+        ptrs = (C.c_void_p * count)(); ns = (C.c_size_t * count)()
+        for k, sc in enumerate(scans):
+            if on_device:
+                ptrs[k], ns[k] = sc[0], sc[1]
+            else:
+                assert isinstance(sc, np.ndarray) and sc.dtype == np.float32 and sc.flags.c_contiguous
+                ptrs[k], ns[k] = sc.ctypes.data, len(sc)
+        pose0 = np.ascontiguousarray(pose0, dtype=np.float64); deltas = np.ascontiguousarray(deltas, dtype=np.float64).reshape(count, 7)
+        out = np.zeros((count, 7)); guesses = np.zeros((count, 7)); st = (Stats * count)(); n_done = C.c_int32(0)
+        fn, args = self.L.so_icp_register_sequence, (self.h, count, ptrs, ns, 12, 1 if on_device else 0, pose0.ctypes.data_as(_F64P),
+                                                     deltas.ctypes.data_as(_F64P), out.ctypes.data_as(_F64P), guesses.ctypes.data_as(_F64P), st, C.byref(n_done))
+        keep = (ptrs, ns, pose0, deltas, scans)
+        return (lambda: fn(*args)), out, guesses, st, n_done, keep
+
+    def register_sequence(self, scans, pose0, deltas, on_device=False):
+        call, out, guesses, st, n_done, _keep = self.prepare_register_sequence(scans, pose0, deltas, on_device)
+        rc = call()
+        if rc < 0:
+            self._check(rc)
+        return rc, out, guesses, list(st), n_done.value
 
     def register_batch(self, scan, poses_in, d_scan=None, n=None):
         """Same scan, many initial poses (so_icp_register_batch).  scan: host array, or None with (d_scan, n) from upload_scan.

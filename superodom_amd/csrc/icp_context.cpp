@@ -186,8 +186,10 @@ struct so_icp_ctx {
   LmSums* d_sums = nullptr; double* d_partials = nullptr;
   LmSums* h_sums = nullptr; uint32_t* h_u32 = nullptr;  // pinned
   DevBuf d_state_buf; DevState* d_state = nullptr; DevState* h_state = nullptr;  // device-resident registration state + the pinned mirror read last
-  DevState* h_ring[2] = {nullptr, nullptr}; hipEvent_t ev_outer[2] = {nullptr, nullptr};  // per-outer-iteration read-backs (double-buffered)
-  DevState* d_ring[2] = {nullptr, nullptr};  // device-side addresses of the pinned mirrors
+  // per-outer-iteration read-backs (double-buffered); mirrors 2, 3: the second pair of so_icp_register_sequence, whose chained
+  // registrations alternate between the pairs (the next registration starts reporting before the host has read the last report of this one)
+  DevState* h_ring[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_outer[2] = {nullptr, nullptr};
+  DevState* d_ring[4] = {nullptr, nullptr, nullptr, nullptr};  // device-side addresses of the pinned mirrors
   bool direct_readback = true; unsigned long long reg_counter = 0;
   bool persistent_solve = true;  // SOICP_PERSISTENT=0: one launch per evaluation
   unsigned long long solve_launches = 0;  // persistent solve launches so far (EvalParams::epoch_base)
@@ -295,11 +297,19 @@ struct so_icp_ctx {
   std::thread stage_thread; std::mutex stage_mu; std::condition_variable stage_cv;
   struct HostRange { const char* p; size_t bytes; bool owned; };
   std::vector<HostRange> host_ranges;     // so_icp_host_register / so_icp_host_alloc (under stage_mu)
+  // so_icp_register_sequence: a copy / binning queue and three scan slots of its own (nothing shared with so_icp_stage_scan's
+  // slots and thread), the iterations pre-enqueued per registration, DevState::done_count as of the last report
+  hipStream_t seq_stream = nullptr;
+  StageSlot seq_slot[kStageSlots];
+  DevBuf d_sbin_key, d_sbin_cnt, d_sbin_off; uint32_t sbin_log2 = 0;
+  int seq_depth = 2; uint32_t done_count_seen = 0;
+  bool seq_chain = true;                  // SOICP_SEQ_CHAIN=0: so_icp_register_sequence runs one registration after the other (same results)
   bool query_waves = true;                // SOICP_QUERY_WAVES=0: a small scan (<= 4 096 kept queries) is binned and swept in chunks like a large one
   bool knn_pack = true;                   // SOICP_KNN_PACK=0: one chunk per wavefront throughout (round-3 work list)
   bool knn_list_fits = false;             // the last registration's work list (normal + light chunks) fitted the k-NN grid one chunk per wavefront:
                                           // packing four light chunks into a wavefront then only lengthens the longest wavefronts (a 13 k-point
                                           // voxel-filtered scan: sweeps 20.5 + 18.6 -> 17.2 + 16.9 us unpacked)
+  uint32_t packed_leftover_seen = 0;      // DevState::packed_leftover (a running count) as of the last report
   int knn_pack_hold = 0;                  // registrations left without packing after one in which the packed near pass left > 3 % of
                                           // the queries to the exact per-lane scan (sparse map, far-off guess): then it is not a saving
   static constexpr int kBatchRoundsTracked = 16;
@@ -492,6 +502,7 @@ MatchParams match_params(float plane_res, int ablate) {
   mp.begin = 0; mp.begin_max_surface_features = -1; mp.begin_n = 0;
   mp.begin_args = RegBeginArgs{};
   mp.begin_ctr = nullptr; mp.begin_state = nullptr;
+  mp.chain_expect = 0;
   return mp;
 }
 EvalParams eval_params(float plane_res, int variant, int ablate) {
@@ -504,6 +515,8 @@ EvalParams eval_params(float plane_res, int variant, int ablate) {
   ep.seq_base = 0;
   ep.n_queries = 0; ep.q_stride = 1;
   ep.defer_publish = 0;
+  ep.chain_expect = 0; ep.chain_next = 0;
+  for (double& d : ep.chain_delta) d = 0;
   ep.epoch_base = 0;
   for (void*& p : ep.peer_inbox) p = nullptr;
   ep.peer_rank = 0; ep.peer_world = 0;
@@ -885,9 +898,13 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   c->h_state = c->h_ring[last & 1];
   const DevState& H = *c->h_state;
   if (mp.pack_light) c->timing.knn_pack_registrations++;
-  if (mp.pack_light && (double)H.packed_leftover > 0.03 * (double)n * (double)std::max(H.n_iterations, 1)) { c->knn_pack_hold = 32; c->timing.knn_pack_holds++; }
+  // (the device's count runs on from registration to registration -- nothing on the device clears it beside the sweeps that add to it)
+  const uint32_t packed_left = H.packed_leftover >= c->packed_leftover_seen ? H.packed_leftover - c->packed_leftover_seen : H.packed_leftover;
+  c->packed_leftover_seen = H.packed_leftover;
+  if (mp.pack_light && (double)packed_left > 0.03 * (double)n * (double)std::max(H.n_iterations, 1)) { c->knn_pack_hold = 32; c->timing.knn_pack_holds++; }
   // (scans of a stream have one size: the list of this registration decides the packing of the next -- results do not depend on it)
   c->knn_list_fits = ((H.bin_packed >> 21) & 0x1FFFFFull) + (H.bin_packed >> 42) <= (unsigned long long)kKnnBlocks * 4ull;
+  if (!c->batch_mode && !c->borrow.on) c->done_count_seen = H.done_count;  // (registrations completed on the context's state block: so_icp_register_sequence)
   fill_result(c, H, pose_in, st, pose_out, !c->batch_mode);
   st->time_elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_icp).count();  // :199-200
   if (timed) {  // keep only the launches that did real work (no-op launches after convergence are excluded)
@@ -942,7 +959,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
 // wait = false: the caller enqueues the scan's consumers on the same stream and does not return to ITS caller before they
 // have completed (so_icp_register), so the source buffer outlives the copy without a host-side wait here
 // The queue of the host-in / host-out steps around Localization() (pre-filter, de-skew, registered scan): they touch nothing the
-// map insert of the previous frame uses, so they need not wait behind it in the context's queue (SOICP_PREFILTER_STREAM=0: they do).
+// map insert of the previous frame uses, so they need not wait behind it in the context's queue.
 static hipStream_t aux_stream(so_icp_ctx* c) {
   if (!c->pf_stream && hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return c->stream; }
   return c->pf_stream;
@@ -990,20 +1007,38 @@ void stage_finish_direct(so_icp_ctx::StageSlot& sl) {
   if (sl.ev_pending) { (void)hipEventSynchronize(sl.ev); sl.ev_pending = false; }
 }
 // enqueue the DMA of a direct slot on the copy stream (under stage_mu)
-// bin the slot's scan on the copy queue, behind its copy (so_icp_ctx::prebin); a failure only means "not binned ahead"
+// the buffers stage_prebin needs for a scan of n points, reserved by the ANNOUNCING thread (so_icp_stage_scan, under stage_mu) next to the
+// slot's scan buffer: a hipMalloc / hipFree is a device-wide synchronisation and must not sit in a registration's critical path,
+// where stage_prebin runs.  A failure only means "not binned ahead".
+static inline uint32_t prebin_table_log2(size_t n) {
+  uint32_t lg = 16;
+  while ((1ull << lg) < 2 * (unsigned long long)n) ++lg;
+  return lg;
+}
+void stage_prebin_reserve(so_icp_ctx* c, so_icp_ctx::StageSlot& sl, size_t n) {
+  if (!c->prebin || !n || n >= ((size_t)1 << 21)) return;
+  const size_t m = n + 256, T = (size_t)1 << prebin_table_log2(n);
+  bool ok = sl.pb_keys.reserve(m * 4) == hipSuccess && sl.pb_vals.reserve(m * 4) == hipSuccess && sl.pb_chunks.reserve(m * 4) == hipSuccess &&
+            sl.pb_binned.reserve(m * 16) == hipSuccess && sl.pb_ctr.reserve(64) == hipSuccess;
+  if (ok && (c->d_pbin_key.cap < T * 4 || c->d_pbin_cnt.cap < T * 4 || c->d_pbin_off.cap < T * 4)) {
+    c->pbin_log2 = 0;  // (a table that moves is cleared again before its next use)
+    ok = c->d_pbin_key.reserve(T * 4) == hipSuccess && c->d_pbin_cnt.reserve(T * 4) == hipSuccess && c->d_pbin_off.reserve(T * 4) == hipSuccess;
+  }
+  if (!ok) (void)hipGetLastError();
+}
+// bin the slot's scan on the copy queue, behind its copy (so_icp_ctx::prebin); a failure only means "not binned ahead".  Runs on the
+// registration thread, inside a registration: allocates nothing -- a scan whose buffers were not reserved at its announcement is not binned ahead
 void stage_prebin(so_icp_ctx* c, so_icp_ctx::StageSlot& sl, const double* pose) {
   sl.prebinned = false;
   const size_t n = sl.n;
   if (!c->prebin || !pose || !n || n >= ((size_t)1 << 21)) return;
-  uint32_t lg = 16;
-  while ((1ull << lg) < 2 * (unsigned long long)n) ++lg;
+  const uint32_t lg = prebin_table_log2(n);
   const size_t m = n + 256, T = (size_t)1 << lg;
   hipStream_t s = c->copy_stream;
-  bool ok = sl.pb_keys.reserve(m * 4) == hipSuccess && sl.pb_vals.reserve(m * 4) == hipSuccess && sl.pb_chunks.reserve(m * 4) == hipSuccess &&
-            sl.pb_binned.reserve(m * 16) == hipSuccess && sl.pb_ctr.reserve(64) == hipSuccess;
+  bool ok = sl.pb_keys.cap >= m * 4 && sl.pb_vals.cap >= m * 4 && sl.pb_chunks.cap >= m * 4 && sl.pb_binned.cap >= m * 16 && sl.pb_ctr.cap >= 64 &&
+            c->d_pbin_key.cap >= T * 4 && c->d_pbin_cnt.cap >= T * 4 && c->d_pbin_off.cap >= T * 4;
   if (ok && c->pbin_log2 != lg) {  // (bin_offsets leaves the table empty again)
-    ok = c->d_pbin_key.reserve(T * 4) == hipSuccess && c->d_pbin_cnt.reserve(T * 4) == hipSuccess && c->d_pbin_off.reserve(T * 4) == hipSuccess &&
-         hipMemsetAsync(c->d_pbin_key.p, 0xFF, T * 4, s) == hipSuccess && hipMemsetAsync(c->d_pbin_cnt.p, 0, T * 4, s) == hipSuccess;
+    ok = hipMemsetAsync(c->d_pbin_key.p, 0xFF, T * 4, s) == hipSuccess && hipMemsetAsync(c->d_pbin_cnt.p, 0, T * 4, s) == hipSuccess;
     c->pbin_log2 = ok ? lg : 0;
   }
   if (!ok) { (void)hipGetLastError(); c->pbin_log2 = 0; return; }
@@ -1435,6 +1470,10 @@ so_icp_ctx::~so_icp_ctx() {
     if (stage_thread.joinable()) stage_thread.join();
   }
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+  if (seq_stream) (void)hipStreamSynchronize(seq_stream);
+  for (StageSlot& sl : seq_slot) { sl.dev.release(); for (DevBuf* b : {&sl.pb_keys, &sl.pb_vals, &sl.pb_chunks, &sl.pb_binned, &sl.pb_ctr}) b->release(); if (sl.ev) (void)hipEventDestroy(sl.ev); }
+  for (DevBuf* b : {&d_sbin_key, &d_sbin_cnt, &d_sbin_off}) b->release();
+  if (seq_stream) (void)hipStreamDestroy(seq_stream);
   for (StageSlot& sl : stage) { sl.dev.release(); for (DevBuf* b : {&sl.pb_keys, &sl.pb_vals, &sl.pb_chunks, &sl.pb_binned, &sl.pb_ctr}) b->release(); if (sl.pinned) (void)hipHostFree(sl.pinned); if (sl.ev) (void)hipEventDestroy(sl.ev); }
   for (const HostRange& r : host_ranges) { if (r.owned) (void)hipHostFree(const_cast<char*>(r.p)); else (void)hipHostUnregister(const_cast<char*>(r.p)); }
   for (int r = 0; r < 8; ++r) if (peer_opened[r] && peer_inbox[r]) (void)hipIpcCloseMemHandle(peer_inbox[r]);
@@ -1548,12 +1587,12 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if ((e = c->d_state_buf.reserve(sizeof(DevState))) != hipSuccess) return bail(std::string("hipMalloc: ") + hipGetErrorString(e));
   if ((e = hipMemset(c->d_state_buf.p, 0, sizeof(DevState))) != hipSuccess) return bail(std::string("hipMemset: ") + hipGetErrorString(e));
   c->d_state = c->d_state_buf.as<DevState>();
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 4; ++i) {
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ring[i]), sizeof(DevState), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
       return bail(std::string("hipHostMalloc: ") + hipGetErrorString(e));
     std::memset(c->h_ring[i], 0, sizeof(DevState));
     if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_ring[i]), c->h_ring[i], 0)) != hipSuccess) return bail(std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
-    if ((e = hipEventCreateWithFlags(&c->ev_outer[i], hipEventDisableTiming)) != hipSuccess) return bail(std::string("hipEventCreate: ") + hipGetErrorString(e));
+    if (i < 2 && (e = hipEventCreateWithFlags(&c->ev_outer[i], hipEventDisableTiming)) != hipSuccess) return bail(std::string("hipEventCreate: ") + hipGetErrorString(e));
   }
   c->h_state = c->h_ring[0];
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_hist), (size_t)SO_ICP_MAX_OUTER * kHistReplicas * kHistStride * sizeof(int32_t))) != hipSuccess)
@@ -1567,6 +1606,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_KNN_PACK")) c->knn_pack = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_QUERY_WAVES")) c->query_waves = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PREBIN")) c->prebin = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_SEQ_CHAIN")) c->seq_chain = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BATCH_CHAIN")) c->batch_chain = std::string(ev) != "0";
   if (const char* ev = std::getenv("SOICP_BATCH_MODE")) {  // "one_per_cu": one solve workgroup per compute unit (several processes on one device); "lanes"
     if (std::string(ev) == "one_per_cu") c->batch_degrade = 1;
@@ -1760,6 +1800,338 @@ int so_icp_register(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_byt
   return rc;
 }
 
+// ---- so_icp_register_sequence ---------------------------------------------------------------------------------------------
+// A run of scans whose guesses chain: guess_0 = pose0, guess_k = T_(k-1) o delta_k, T_(k-1) = the pose registration k-1 ended with
+// (laserMapping.cpp:345-372: T_w_lidar = T_w_lidar * prediction; pose_compose, so_math.h).  Between two so_icp_register calls of a
+// stream the device idles for ~11 us: the host reads the last report, returns, is called again and enqueues the first launch of the
+// next registration.  Here the NEXT registration's launches are in the queue before the current one has
+// reported: the guess is formed on the device, by the solve that ends the registration in front (DevState::T_chain) -- provided the
+// registration in front of it was over by then (DevState::done_count): a registration gets `seq_depth` outer iterations enqueued
+// ahead (what the last one needed); one that needs more makes the launches behind it no-ops, the host finishes it with further
+// launches and starts the next one again, unchained.  Every registration is the one so_icp_register runs from guesses_out[k]: same
+// kernels, same arguments, same sums -- identical bits (tests/test_gpu_sequence.py).
+// Chained path: single device, device-resident map, persistent solve, direct read-back, yaw_ratio 0 (the stock configurations:
+// MannualYawCorrection, LidarSlam.cpp:891-913, is then the identity up to rounding; the chain starts from the optimised pose itself,
+// iterations[last].pose_after); everything else -- and SOICP_SEQ_CHAIN=0 -- runs the registrations one after the other with guesses
+// composed on the host by the same arithmetic.
+namespace {
+struct SeqRun {
+  const float* d_scan = nullptr; size_t n = 0;
+  so_icp_ctx::StageSlot* slot = nullptr;   // host scan (its HBM copy) and / or the work list binned ahead; nullptr: resident scan swept by query waves
+  bool query_waves = false, binned = false, enqueued = false, chained = false, needs_event = false;
+  uint32_t chain_expect = 0;
+  double guess[7];                          // exact for an unchained start, the host's prediction for a chained one
+  int pos[3] = {0, 0, 0}; int count_5x5 = 0;
+  unsigned long long seq_base = 0; int ring = 0; int enq_iters = 0;
+  MatchParams mp; EvalParams ep;
+  const float4* d_binned = nullptr; const uint32_t* d_chunks = nullptr;
+};
+inline bool cube_stable(const so_icp_ctx* c, const double t[3], double margin) {
+  // the window would not roll for a pose here (LocalMap.h:169-287: the sensor's block stays >= 3 blocks from the border), and no
+  // pose within `margin` of it lies in another block: placing the window for the PREDICTED guess is placing it for the actual one
+  const int* o = map_origin(c);
+  const int dim[3] = {kMapW, kMapH, kMapD};
+  for (int a = 0; a < 3; ++a) {
+    const int lo = cube_coord(t[a] - margin, o[a]), hi = cube_coord(t[a] + margin, o[a]);
+    if (lo != hi || lo < 3 || lo >= dim[a] - 3) return false;
+  }
+  return true;
+}
+}  // namespace
+
+int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans, const size_t* n_points, size_t stride_bytes, int scans_on_device,
+                             const double pose0[7], const double* deltas, double* poses_out, double* guesses_out, so_icp_stats* stats, int* n_done) {
+  if (n_done) *n_done = 0;
+  if (!c || count < 0 || (count && (!scans || !n_points || !pose0 || !poses_out)) || (count > 1 && !deltas)) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  if (stride_bytes == 0) stride_bytes = 12;
+  for (int k = 0; k < count; ++k) if (!scans[k] && n_points[k]) return SO_ICP_E_INVALID;
+  std::vector<so_icp_stats> local_stats;
+  if (!stats) { local_stats.resize((size_t)count); stats = local_stats.data(); }
+  const bool fast = c->seq_chain && c->dmap && c->cfg.world_size <= 1 && !c->batch_mode && !c->borrow.on && c->persistent_solve && c->direct_readback &&
+                    c->speculate && c->ablate == 0 && c->cfg.time_kernels == 0 && c->cfg.yaw_ratio == 0.0 && !c->comm && !c->group && !c->query_split &&
+                    (scans_on_device || stride_bytes == 12) && count > 1;
+  // the pose the chain continues from: the optimised pose of the registration, before MannualYawCorrection (fill_result)
+  auto chain_from = [&](int k, double T[7]) {
+    const so_icp_stats& s = stats[k];
+    if (s.n_iterations > 0) std::memcpy(T, s.iterations[std::min(s.n_iterations, SO_ICP_MAX_OUTER) - 1].pose_after, 7 * sizeof(double));
+    else std::memcpy(T, poses_out + 7 * (size_t)k, 7 * sizeof(double));
+  };
+  auto run_plain = [&](int k, const double guess[7]) -> int {  // one registration through the ordinary entry points
+    if (guesses_out) std::memcpy(guesses_out + 7 * (size_t)k, guess, 7 * sizeof(double));
+    return scans_on_device ? so_icp_register_dev(c, scans[k], n_points[k], guess, poses_out + 7 * (size_t)k, &stats[k])
+                           : so_icp_register(c, static_cast<const float*>(scans[k]), n_points[k], stride_bytes, guess, poses_out + 7 * (size_t)k, &stats[k]);
+  };
+  if (!fast) {
+    double guess[7];
+    std::memcpy(guess, pose0, sizeof(guess));
+    for (int k = 0; k < count; ++k) {
+      if (k) { double T[7]; chain_from(k - 1, T); pose_compose(T, deltas + 7 * (size_t)k, guess); }
+      const int rc = run_plain(k, guess);
+      if (rc) return rc;
+      if (n_done) *n_done = k + 1;
+    }
+    return SO_ICP_OK;
+  }
+
+  // ---------------- chained path
+  hipStream_t s = c->stream;
+  if (!c->seq_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->seq_stream, hipStreamNonBlocking));
+  struct Drain {  // an early return must not leave copies reading the caller's buffers, nor launches of this call in the queue
+    so_icp_ctx* c; bool ok = false;
+    ~Drain() { if (!ok) { (void)hipStreamSynchronize(c->seq_stream); (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); } }
+  } drain{c};
+  size_t n_max = 0;
+  for (int k = 0; k < count; ++k) {
+    if (n_points[k] >= ((size_t)1 << 21)) return fail(c, SO_ICP_E_UNSUPPORTED, "scan of 2^21 points or more: the work-list counters hold 21 bits each (chunk descriptors 26)");
+    n_max = std::max(n_max, n_points[k]);
+  }
+  { const int rc = reserve_scan_buffers(c, n_max); if (rc) return rc; }  // (once, for the longest scan: nothing is re-allocated under a registration in flight)
+  { const int rc = upload_map(c); if (rc) return rc; }                   // (the binning ahead of scan 0 reads the map view before the first prepare())
+  const int max_outer = std::min(c->cfg.max_iterations > 0 ? c->cfg.max_iterations : 4, SO_ICP_MAX_OUTER);
+  const int lm_max = std::min(c->cfg.lm_max_iterations > 0 ? c->cfg.lm_max_iterations : 4, 16);
+  const int max_sf = c->cfg.max_surface_features;
+  DevState* ds = c->d_state;
+  CorrBuffers corr{c->d_nd.as<double4>(), c->d_coeff.as<double>(), c->d_status.as<uint8_t>()};
+  std::vector<SeqRun> runs((size_t)count);
+  for (int k = 0; k < count; ++k) {
+    SeqRun& r = runs[(size_t)k];
+    r.n = n_points[k];
+    const size_t kept_upper = (max_sf >= 0 && r.n > (size_t)max_sf) ? (size_t)max_sf + 2 : r.n;
+    r.query_waves = c->query_waves && r.n && kept_upper <= kQueryWaveMaxKept;
+    r.ring = (k & 1) * 2;
+    if (!scans_on_device || !r.query_waves) r.slot = &c->seq_slot[k % so_icp_ctx::kStageSlots];
+  }
+  // the scan's way to HBM and its work list, on the sequence's own queue: copy (host scans), scan_keys -> bin_offsets -> bin_place under
+  // `pose` (scans swept in chunks), one event.  Slot k % 3: its last user, scan k - 3, was collected before scan k - 1 was enqueued.
+  auto stage_scan = [&](int k, const double pose[7]) -> int {
+    SeqRun& r = runs[(size_t)k];
+    r.d_scan = static_cast<const float*>(scans[k]);
+    r.binned = false; r.needs_event = false;
+    if (!r.slot || !r.n) { if (!scans_on_device) r.d_scan = nullptr; return SO_ICP_OK; }
+    so_icp_ctx::StageSlot& sl = *r.slot;
+    if (!sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (!scans_on_device) {
+      HIP_TRY(c, sl.dev.reserve((r.n + 64) * 12));
+      HIP_TRY(c, hipMemcpyAsync(sl.dev.p, scans[k], r.n * 12, hipMemcpyHostToDevice, c->seq_stream));
+      r.d_scan = sl.dev.as<float>();
+      r.needs_event = true;
+    }
+    if (!r.query_waves) {
+      if (!c->prebin) return SO_ICP_OK;  // (binned by the registration itself: never chained)
+      const uint32_t lg = prebin_table_log2(r.n);
+      const size_t m = r.n + 256, T = (size_t)1 << lg;
+      HIP_TRY(c, sl.pb_keys.reserve(m * 4)); HIP_TRY(c, sl.pb_vals.reserve(m * 4)); HIP_TRY(c, sl.pb_chunks.reserve(m * 4));
+      HIP_TRY(c, sl.pb_binned.reserve(m * 16)); HIP_TRY(c, sl.pb_ctr.reserve(64));
+      if (c->d_sbin_key.cap < T * 4 || c->sbin_log2 != lg) {
+        HIP_TRY(c, c->d_sbin_key.reserve(T * 4)); HIP_TRY(c, c->d_sbin_cnt.reserve(T * 4)); HIP_TRY(c, c->d_sbin_off.reserve(T * 4));
+        HIP_TRY(c, hipMemsetAsync(c->d_sbin_key.p, 0xFF, T * 4, c->seq_stream)); HIP_TRY(c, hipMemsetAsync(c->d_sbin_cnt.p, 0, T * 4, c->seq_stream));
+        c->sbin_log2 = lg;
+      }
+      const BinTable bt{c->d_sbin_key.as<uint32_t>(), c->d_sbin_cnt.as<uint32_t>(), c->d_sbin_off.as<uint32_t>(), lg};
+      sl.pb_chunk_cap = (uint32_t)(sl.pb_chunks.cap / 4);
+      launch_scan_keys(r.d_scan, (uint32_t)r.n, ds, pose, 0, 0, c->d_hist, c->view, max_sf, 0, 1, sl.pb_keys.as<uint32_t>(), sl.pb_vals.as<uint32_t>(), nullptr,
+                       bt, c->seq_stream, false, nullptr, 0, false, 0, sl.pb_ctr.as<unsigned long long>());
+      launch_bin_offsets(bt, sl.pb_chunks.as<uint32_t>(), sl.pb_chunk_cap, ds, c->seq_stream, nullptr, 0, sl.pb_ctr.as<unsigned long long>());
+      launch_bin_place(bt, r.d_scan, (uint32_t)r.n, sl.pb_keys.as<uint32_t>(), sl.pb_vals.as<uint32_t>(), sl.pb_binned.as<float4>(), c->seq_stream);
+      if (hipGetLastError() != hipSuccess) { c->sbin_log2 = 0; return fail(c, SO_ICP_E_HIP, "so_icp_register_sequence: the binning launches were refused"); }
+      r.binned = true; r.needs_event = true;
+      r.d_binned = sl.pb_binned.as<float4>(); r.d_chunks = sl.pb_chunks.as<uint32_t>();
+    }
+    if (r.needs_event) HIP_TRY(c, hipEventRecord(sl.ev, c->seq_stream));
+    return SO_ICP_OK;
+  };
+  // host side of a registration's start (register_core_once): window, map view, parameters.  false + rc == 0: cannot be started this way
+  auto prepare = [&](int k, const double guess[7], bool chained, int* rc_out) -> bool {
+    SeqRun& r = runs[(size_t)k];
+    *rc_out = SO_ICP_OK;
+    std::memcpy(r.guess, guess, sizeof(r.guess));
+    if (!r.query_waves && !r.binned) return false;
+    if (!c->no_map_shift) {
+      if (chained && !cube_stable(c, guess, 1.0)) return false;
+      map_shift(c, guess, r.pos); std::memcpy(c->last_pos, r.pos, sizeof(r.pos));
+    } else std::memcpy(r.pos, c->last_pos, sizeof(r.pos));
+    r.count_5x5 = map_count_5x5(c, r.pos);
+    if (!(r.count_5x5 > 50)) { if (!chained) *rc_out = SO_ICP_NOT_ENOUGH_MAP_FEATURES; return false; }  // LidarSlam.cpp:113-116
+    if ((*rc_out = upload_map(c))) return false;
+    const float plane_res_now = map_plane_res(c);
+    r.mp = match_params(plane_res_now, 0);
+    r.mp.chunk_cap = r.binned ? r.slot->pb_chunk_cap : 0;
+    r.mp.pack_light = (c->knn_pack && c->knn_pack_hold == 0 && !c->knn_list_fits) ? 1 : 0;
+    r.mp.packed_leftover = &ds->packed_leftover;
+    if (c->knn_pack_hold > 0) --c->knn_pack_hold;
+    r.ep = eval_params(plane_res_now, c->cfg.tukey_variant, 0);
+    r.seq_base = (++c->reg_counter) << 8;
+    r.ep.hring[0] = c->d_ring[r.ring]; r.ep.hring[1] = c->d_ring[r.ring + 1]; r.ep.seq_base = r.seq_base;
+    r.ep.n_queries = (uint32_t)r.n; r.ep.q_stride = 3; r.ep.defer_publish = 0;
+    r.mp.hring[0] = r.ep.hring[0]; r.mp.hring[1] = r.ep.hring[1]; r.mp.seq_base = r.seq_base; r.mp.publish_prev = 0;
+    r.chained = chained;
+    r.chain_expect = chained ? c->done_count_seen + 1u : 0u;  // (exactly the registration in front of this one completes in between)
+    r.mp.chain_expect = r.chain_expect; r.ep.chain_expect = r.chain_expect;
+    return true;
+  };
+  // outer iterations [it0, it1) of run k into the queue; `last_publishes`: the solve of it1 - 1 reports by itself (nothing of this
+  // registration is enqueued behind it yet), the others leave their report to the sweep behind them (EvalParams::defer_publish)
+  auto enqueue = [&](int k, int it0, int it1) -> int {
+    SeqRun& r = runs[(size_t)k];
+    if (it0 == 0 && r.needs_event) HIP_TRY(c, hipStreamWaitEvent(s, r.slot->ev, 0));
+    for (int it = it0; it < it1; ++it) {
+      MatchParams mp_it = r.mp;
+      mp_it.publish_prev = (it > it0) ? 1 : 0;  // (the solve in front of this sweep deferred its report)
+      if (r.query_waves) {
+        launch_knn_query_waves(r.d_scan, (uint32_t)r.n, ds, r.guess, max_outer, lm_max, it == 0, c->d_hist, c->view, mp_it, max_sf, c->d_status.as<uint8_t>(),
+                               c->d_nbr5.as<uint32_t>(), s, nullptr, nullptr, it == 0 ? r.chain_expect : 0u);
+      } else {
+        if (it == 0) {
+          mp_it.begin = 1; mp_it.begin_args.max_outer = max_outer; mp_it.begin_args.lm_max = lm_max; mp_it.begin_max_surface_features = max_sf;
+          mp_it.begin_n = (uint32_t)r.n; std::memcpy(mp_it.begin_args.pose, r.guess, sizeof(mp_it.begin_args.pose));
+          mp_it.begin_args.chain_expect = r.chain_expect; mp_it.begin_args.pad = 0;
+          mp_it.begin_ctr = r.slot->pb_ctr.as<unsigned long long>(); mp_it.begin_state = ds;
+        }
+        launch_knn_plane(r.d_binned, r.d_chunks, ds, c->view, mp_it, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s);
+      }
+      EvalParams ep_it = r.ep;
+      ep_it.defer_publish = (it + 1 < it1) ? 1 : 0;
+      ep_it.epoch_base = (++c->solve_launches) << 5;
+      if (k + 1 < count) { ep_it.chain_next = 1; std::memcpy(ep_it.chain_delta, deltas + 7 * (size_t)(k + 1), sizeof(ep_it.chain_delta)); }  // (whichever solve ends this registration forms the next guess)
+      launch_solve(lm_max, r.d_scan, r.d_scan + 1, r.d_scan + 2, corr, ds, ep_it, c->d_partials, c->d_ticket, c->d_hist, c->d_sums, c->view,
+                   c->d_nbr5.as<uint32_t>(), r.mp, (uint32_t)r.n, (uint32_t)c->n_cus, s);
+    }
+    HIP_TRY(c, hipGetLastError());
+    r.enq_iters = it1; r.enqueued = true;
+    return SO_ICP_OK;
+  };
+  auto await = [&](int k, int it) -> int {
+    SeqRun& r = runs[(size_t)k];
+    volatile unsigned long long* seq = &c->h_ring[r.ring + (it & 1)]->seq;
+    const unsigned long long want = r.seq_base | (unsigned long long)(it + 1);
+    auto next_check = std::chrono::steady_clock::now() + std::chrono::milliseconds(5);
+    for (unsigned spin = 1;; ++spin) {
+      if (*seq == want) break;
+      if ((spin & 0x3FFu) != 0) continue;
+      const auto now = std::chrono::steady_clock::now();
+      if (now < next_check) continue;
+      next_check = now + std::chrono::milliseconds(1);
+      if (hipStreamQuery(s) != hipErrorNotReady) {  // everything enqueued has completed and the report is not there
+        (void)hipGetLastError();
+        if (*seq == want) break;
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (*seq == want) break;
+        return fail(c, SO_ICP_E_HIP, "so_icp_register_sequence: registration state was not published by the device");
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return SO_ICP_OK;
+  };
+  const int depth0 = std::max(1, std::min(c->seq_depth, max_outer));
+  int rc = SO_ICP_OK;
+  // scan 0: an ordinary start from pose0
+  if ((rc = stage_scan(0, pose0))) return rc;
+  bool started = prepare(0, pose0, false, &rc);
+  if (rc) return rc;
+  if (started && (rc = enqueue(0, 0, depth0))) return rc;
+  for (int k = 0; k < count; ++k) {
+    SeqRun& r = runs[(size_t)k];
+    so_icp_stats* st = &stats[k];
+    double* pose_out = poses_out + 7 * (size_t)k;
+    if (!started) {
+      // this scan cannot be started from here (an empty scan, too little map, a window about to roll, ...): the ordinary entry point,
+      // from the guess the chain arithmetic gives -- same results, and the next scan starts a new chain
+      double guess[7];
+      if (k == 0) std::memcpy(guess, pose0, sizeof(guess)); else { double T[7]; chain_from(k - 1, T); pose_compose(T, deltas + 7 * (size_t)k, guess); }
+      if ((rc = hipStreamSynchronize(c->seq_stream)) != hipSuccess) return fail(c, SO_ICP_E_HIP, "so_icp_register_sequence: copy queue");
+      if ((rc = run_plain(k, guess))) return rc;
+    } else {
+      const auto t_icp = std::chrono::steady_clock::now();
+      // the NEXT scan: on its way to HBM, binned under the host's prediction of its guess, and -- the point of this entry -- its
+      // registration enqueued behind this one's launches
+      bool next_started = false;
+      if (k + 1 < count) {
+        double pred[7];
+        pose_compose(r.guess, deltas + 7 * (size_t)(k + 1), pred);  // (this registration will move r.guess by centimetres: good enough to bin under and to place the window)
+        if ((rc = stage_scan(k + 1, pred))) return rc;
+        int prc = 0;
+        next_started = prepare(k + 1, pred, true, &prc);
+        if (prc) return prc;
+        if (next_started && (rc = enqueue(k + 1, 0, std::max(1, std::min(c->seq_depth, max_outer))))) return rc;
+      }
+      // this registration's reports
+      int last = 0;
+      for (int it = 0;; ++it) {
+        if ((rc = await(k, it))) return rc;
+        last = it;
+        if (c->h_ring[r.ring + (it & 1)]->reg_done || it + 1 >= max_outer) break;
+        if (it + 1 >= r.enq_iters) {
+          // it needs more outer iterations than were enqueued ahead: the chained registration behind it has found it unfinished
+          // and turned itself off (DevState::done_count); one iteration at a time from here, the next scan starts again afterwards
+          if (next_started) { next_started = false; runs[(size_t)k + 1].enqueued = false; c->timing.seq_chain_breaks++; }
+          if ((rc = enqueue(k, it + 1, it + 2))) return rc;
+        }
+      }
+      const DevState& H = *c->h_ring[r.ring + (last & 1)];
+      c->h_state = c->h_ring[r.ring + (last & 1)];
+      std::memset(st, 0, sizeof(*st));
+      st->flags = (r.slot && !scans_on_device ? SO_ICP_FLAG_STAGED_SCAN : 0u) | (r.binned ? SO_ICP_FLAG_BINNED_AHEAD : 0u) |
+                  (r.query_waves ? SO_ICP_FLAG_QUERY_WAVES : 0u) | (r.chained ? SO_ICP_FLAG_CHAINED : 0u);
+      if (c->have_hist) uncertainty_from_hist(c->prev_obs_hist, st->uncertainty);  // LidarSlam.cpp:47
+      st->pos_in_localmap[0] = r.pos[0]; st->pos_in_localmap[1] = r.pos[1]; st->pos_in_localmap[2] = r.pos[2];
+      st->laser_cloud_surf_from_map_num = r.count_5x5;
+      st->laser_cloud_surf_stack_num = (int32_t)r.n;
+      st->startup_count = c->startup_count;
+      double guess[7];
+      std::memcpy(guess, H.pose_in, sizeof(guess));  // (what the device formed for a chained registration; the host's own argument otherwise)
+      if (guesses_out) std::memcpy(guesses_out + 7 * (size_t)k, guess, sizeof(guess));
+      const uint32_t packed_left = H.packed_leftover >= c->packed_leftover_seen ? H.packed_leftover - c->packed_leftover_seen : H.packed_leftover;
+      c->packed_leftover_seen = H.packed_leftover;
+      if (r.mp.pack_light) c->timing.knn_pack_registrations++;
+      if (r.mp.pack_light && (double)packed_left > 0.03 * (double)r.n * (double)std::max(H.n_iterations, 1)) { c->knn_pack_hold = 32; c->timing.knn_pack_holds++; }
+      if (!r.query_waves) c->knn_list_fits = ((H.bin_packed >> 21) & 0x1FFFFFull) + (H.bin_packed >> 42) <= (unsigned long long)kKnnBlocks * 4ull;
+      c->done_count_seen = H.done_count;
+      c->seq_depth = std::max(1, H.n_iterations);
+      fill_result(c, H, guess, st, pose_out, true);
+      st->time_elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_icp).count();
+      c->timing.registrations++;
+      if (r.chained) {
+        c->timing.seq_chained++;
+        // the window was placed for the predicted guess: the actual one must lie in the same block (cube_stable saw to it)
+        const int* o = map_origin(c);
+        if (cube_coord(guess[0], o[0]) != r.pos[0] || cube_coord(guess[1], o[1]) != r.pos[1] || cube_coord(guess[2], o[2]) != r.pos[2])
+          return fail(c, SO_ICP_E_HIP, "so_icp_register_sequence: a chained guess left the map block its window was placed for");
+      }
+      if (k + 1 < count && !next_started && !runs[(size_t)k + 1].enqueued) {
+        // an ordinary start of the next scan, from the exact guess (after a broken chain: its copy and work list are where they were)
+        SeqRun& nx = runs[(size_t)k + 1];
+        double T[7], g[7];
+        chain_from(k, T); pose_compose(T, deltas + 7 * (size_t)(k + 1), g);
+        int prc = 0;
+        next_started = prepare(k + 1, g, false, &prc);
+        if (prc && prc != SO_ICP_NOT_ENOUGH_MAP_FEATURES) return prc;
+        if (next_started && (rc = enqueue(k + 1, 0, std::max(1, std::min(c->seq_depth, max_outer))))) return rc;
+        (void)nx;
+      }
+      started = next_started;
+      if (n_done) *n_done = k + 1;
+      continue;
+    }
+    // (after a plain registration: the next scan starts a chain of its own)
+    if (n_done) *n_done = k + 1;
+    started = false;
+    if (k + 1 < count) {
+      double T[7], g[7];
+      chain_from(k, T); pose_compose(T, deltas + 7 * (size_t)(k + 1), g);
+      if ((rc = stage_scan(k + 1, g))) return rc;
+      int prc = 0;
+      started = prepare(k + 1, g, false, &prc);
+      if (prc && prc != SO_ICP_NOT_ENOUGH_MAP_FEATURES) return prc;
+      if (started && (rc = enqueue(k + 1, 0, std::max(1, std::min(c->seq_depth, max_outer))))) return rc;
+    }
+  }
+  c->scan_staged = false;
+  drain.ok = true;
+  return SO_ICP_OK;
+}
+
 int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes) {
   if (!c || (!xyz && n)) return SO_ICP_E_INVALID;
   NEED_DEVICE(c);
@@ -1803,6 +2175,7 @@ int so_icp_stage_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_b
       // registered (pinned) host memory, packed xyz: no pack, no copy thread -- the DMA reads the caller's buffer itself
       sl.state = 0;  // (until the copy is enqueued: an error below leaves the slot empty)
       HIP_TRY(c, sl.dev.reserve((n + 64) * 12));
+      stage_prebin_reserve(c, sl, n);  // (what the binning ahead of this scan will need: allocated here, off the registration's path)
       if (!sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
       sl.state = 2;
       sl.deferred = true; sl.t_announced = std::chrono::steady_clock::now(); queued = true; dma_only = true;  // (the copy thread is the time-out)
@@ -2063,7 +2436,7 @@ int so_icp_localization(so_icp_ctx* c, int initialization, const double T_in[7],
   };
   auto transform_and_add_dev = [&](const float* d_scan, const double T[7]) -> int {  // same, entirely on the device
     // (one launch transforms the scan, finds every point's cube and lays the insert round out on the device; the insert is
-    //  enqueued without a read-back and -- unless SOICP_MAP_DEFER=0 -- completes behind this call: device_map.h, settle)
+    //  enqueued without a read-back and -- unless SOICP_MAP_FAST=sync -- completes behind this call: device_map.h, settle)
     if (const int rs = c->dmap->settle(c->err); rs < 0) return rs == -1 ? SO_ICP_E_NOMEM : SO_ICP_E_HIP;  // (before d_world may be re-allocated)
     HIP_TRY(c, c->d_world.reserve((n + 64) * 12));
     const int r = c->dmap->add_scan_dev(d_scan, n, T, c->d_world.as<float>(), c->dmap->defer_enabled() && !c->dmap->sharded(), c->err);

@@ -24,7 +24,11 @@ struct DevMapView {
 };
 
 // registration prologue arguments (the guess and the loop bounds travel as kernel arguments; a batch reads them from memory)
-struct RegBeginArgs { double pose[7]; int32_t max_outer, lm_max; };
+// chain_expect != 0 (so_icp_register_sequence): the guess was formed ON THE DEVICE by the last solve of the registration before,
+// DevState::T_chain = its result o the delta that solve carried (EvalParams::chain_delta; pose_compose, so_math.h), and the launch is
+// valid only if exactly chain_expect registrations have completed on this state block (DevState::done_count) -- it was enqueued behind
+// the launches of the registration before, which may turn out to need more.
+struct RegBeginArgs { double pose[7]; int32_t max_outer, lm_max; uint32_t chain_expect, pad; };
 
 struct MatchParams {
   float plane_res;        // localMap.planeRes_ (float member, LocalMap.h:761)
@@ -39,6 +43,8 @@ struct MatchParams {
   int32_t skip_near_pass; // 1: the sweep starts with the FULL pass (gate radius).  Round 0 of a batch of hypotheses +-0.5 m / +-5 degrees
                           // off: the near pass (half a cell) certifies almost nothing there and its scan is wasted (exact either way)
   uint32_t chunk_cap;     // entries of the chunk list buffer: LIGHT chunks (<= 16 queries) are listed from its top downwards
+  uint32_t chain_expect;  // != 0: a launch of a CHAINED registration (enqueued before the registration in front of it had reported): a no-op
+                          // unless DevState::done_count == chain_expect, i.e. unless that registration really was over when this one began
   // deferred report: when the solve of outer iteration i-1 left the publication of its state block to the k-NN launch of
   // iteration i (EvalParams::defer_publish), that launch's first workgroup writes it to hring[(i-1) & 1] (see EvalParams)
   struct DevState* hring[2];
@@ -70,6 +76,11 @@ struct EvalParams {
   // 1: a solve that does NOT end the registration leaves the publication to the next k-NN launch (already enqueued by the
   // host): the L2 write-back + system fence + PCIe stores (2.7 us) then overlap that sweep instead of delaying it
   int32_t defer_publish;
+  uint32_t chain_expect;  // see MatchParams::chain_expect
+  // chain_next != 0: a chained registration may follow this one (so_icp_register_sequence): the solve that ends the registration leaves
+  // DevState::T_chain = result o chain_delta, the guess the first launch of the next registration starts from
+  int32_t chain_next;
+  double chain_delta[7];
   // persistent solve: epoch base of the launch (hand-off epochs and pass tags count up from it; strictly increasing per context)
   unsigned long long epoch_base;
   // Peer exchange (sharded map, persistent solve): every rank's inbox is mapped into this process (hipIpc, or the plain
@@ -110,7 +121,7 @@ struct DevState {
   int32_t max_outer, lm_max, pad0, pad1;
   // device-side control
   int32_t outer_iter, reg_done, lm_more, n_iterations;
-  uint32_t packed_leftover;  // k-NN sweeps of this registration: queries of packed light chunks that the packed near pass could not finish (exact per-lane scan)
+  uint32_t packed_leftover;  // k-NN sweeps since the context was created (a running count: the host takes differences): queries of packed light chunks that the packed near pass could not finish (exact per-lane scan)
   uint32_t pad2[3];
   // work-list counters of the hash binning in ONE word (kept queries | normal chunks << 21 | light chunks (<= 16 queries,
   // listed separately) << 42), so that a workgroup of bin_offsets_kernel reserves its three ranges with one atomic round trip
@@ -120,6 +131,12 @@ struct DevState {
   LmState S;
   double JtJ[36], Jtr[6];
   DevIterStats iters[16];
+  // chained registrations (so_icp_register_sequence): the pose the LAST completed registration ended with and the number of registrations
+  // completed on this block -- written when a registration ends, never by a prologue, so that the first launch of a chained
+  // registration (whose workgroup 0 rewrites the fields above) can read both from every workgroup
+  double T_final[7];
+  double T_chain[7];     // T_final o the delta the ending solve carried (EvalParams::chain_delta)
+  uint32_t done_count, pad3;
   unsigned long long peer_seq;  // peer exchange: passes exchanged so far by this context (tag and double-buffer parity; equal on all ranks)
   unsigned long long dbg[16];  // profiling aid (SOICP_ABLATE bit 7): wall-clock stamps of the last evaluation's phases
   unsigned long long seq;      // host mirror only: publication word (see EvalParams::hring), written last
@@ -206,7 +223,8 @@ void launch_knn_plane(const float4* d_binned,
 constexpr uint32_t kQueryWaveMaxKept = 4096;  // kept queries up to which every query gets a wavefront of its own (all resident at once)
 void launch_knn_query_waves(const float* d_scan_xyz, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, bool begin,
                             int32_t* d_hist, const DevMapView& map, const MatchParams& mp, int max_surface_features, uint8_t* d_status,
-                            uint32_t* d_nbr5, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                            uint32_t* d_nbr5, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                            uint32_t chain_expect = 0 /* begin launch of a chained registration: the guess is DevState::T_chain (RegBeginArgs) */);
 void launch_eval(int slot, bool fuse_lm, const float* spx, const float* spy, const float* spz, const CorrBuffers& corr,
                  DevState* st, const EvalParams& ep, double* d_partials, uint32_t* d_ticket, int32_t* d_hist,
                  LmSums* d_sums, const DevMapView& map, const uint32_t* d_nbr5, const MatchParams& mp, uint32_t n_upper,

@@ -97,13 +97,19 @@ __device__ __forceinline__ CellRef locate(const DevMapView& m, float qx, float q
 // (kernels.h: BatchView).  The single-registration instantiations compile to the code they were before.
 
 // registration prologue: pose <- host-provided guess (kernel arguments: no H2D copy), counters and histograms cleared
+// (the guess: a.pose, or for a chained registration DevState::T_chain, which no prologue writes)
 __device__ __forceinline__ void reg_begin_state(DevState* st, const RegBeginArgs& a, int tid) {
-  if (tid < 7) { st->pose_in[tid] = a.pose[tid]; st->T[tid] = a.pose[tid]; st->eval_pose[tid] = a.pose[tid]; }
+  if (tid < 7) {
+    double v = a.pose[tid];
+    if (a.chain_expect) v = st->T_chain[tid];
+    st->pose_in[tid] = v; st->T[tid] = v; st->eval_pose[tid] = v;
+  }
   if (tid == 0) {
     st->max_outer = a.max_outer; st->lm_max = a.lm_max;
     st->outer_iter = 0; st->reg_done = 0; st->lm_more = 0; st->n_iterations = 0;
     st->bin_packed = 0ull;
-    st->packed_leftover = 0u;
+    // (DevState::packed_leftover is NOT cleared here: when the prologue rides on the first k-NN launch, that launch's packed wavefronts add
+    //  to it, and a clear ordered only by dispatch order could lose counts from run to run -- ADVICE r05.  It runs on; the host takes differences.)
   }
 }
 // stand-alone prologue (empty scan: scan_keys_kernel, which normally carries it, is not launched)
@@ -806,7 +812,9 @@ constexpr uint32_t kPartTile = kTileCand / 4;  // candidates a packed chunk may 
 // BATCH: so_icp_register_batch -- blockIdx.y picks the hypothesis, see BatchView.
 // BEGIN: first launch of a registration whose scan was binned ahead (MatchParams::begin): an instantiation of its own, so that the
 //        others do not carry the prologue's arguments in their scalar registers (the kernel sits at its register budget).
-template <bool PROF, bool BATCH, bool BEGIN = false>
+// BEGIN: 0 = a sweep behind the registration's prologue; 1 = first launch of a registration whose scan was binned ahead (MatchParams::begin);
+//        2 = that, for a CHAINED registration (RegBeginArgs::chain_expect): the guess comes from DevState::T_chain
+template <bool PROF, bool BATCH, int BEGIN = 0>
 __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restrict__ binned /* {x, y, z, query index} per binned position */,
                                                         const uint32_t* __restrict__ chunk_start,
                                                         const DevState* __restrict__ st,
@@ -827,8 +835,16 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   uint32_t* const leftover_ctr = (BATCH && mp.packed_leftover)
       ? reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(mp.packed_leftover) + (size_t)bv.active[blockIdx.y] * sizeof(DevState)) : mp.packed_leftover;
   // (MatchParams::begin: first launch of a registration whose scan was binned ahead -- prologue, pose and counters from the arguments)
-  constexpr bool begin = BEGIN && !BATCH;
+  constexpr bool begin = BEGIN != 0 && !BATCH;
+  constexpr bool chained_begin = BEGIN == 2 && !BATCH;
   if (!begin && st->reg_done) return;  // the registration already converged: this launch is a no-op
+  if (!BATCH && mp.chain_expect && st->done_count != mp.chain_expect) return;  // chained registration whose predecessor was not over: no-op
+  // BEGIN launch of a chained registration: valid only if the registration in front of it was over, and its guess is what that one's
+  // last solve left in DevState::T_chain (= its result o the delta it carried: EvalParams::chain_delta) -- fields no prologue writes,
+  // read like any other launch reads st->T
+  // (an instantiation of its own: selecting between the two sources at run time cost this kernel, which has no register to spare, 60 - 368
+  //  bytes of scratch in every form that was tried)
+  if (chained_begin && st->done_count != mp.begin_args.chain_expect) return;
   // the report of the previous outer iteration, left to this launch by its solve (MatchParams::publish_prev)
   if (!BATCH && !begin && mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
     publish_state_to(mp.hring[(st->outer_iter - 1) & 1], st, mp.seq_base | (unsigned long long)st->outer_iter, (int)threadIdx.x, 256);
@@ -837,9 +853,6 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   if (begin) {
     if (blockIdx.x == 0) {
       hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
-      // (the prologue also clears DevState::packed_leftover, which the packed wavefronts of THIS launch add to -- after their near
-      //  pass, several dependent memory round trips into their lives, whereas workgroup 0 is dispatched first and does this in its
-      //  first instructions; the counter only feeds the host's packing heuristic, never a result)
       reg_begin_state(mp.begin_state, mp.begin_args, (int)threadIdx.x);
       if (threadIdx.x == 0) mp.begin_state->bin_packed = pk;
     }
@@ -864,7 +877,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   const bool pack = SO_KNN_PACK && mp.pack_light && first_pass_is_near;
   const uint32_t n_packed = pack ? (n_light + 3u) >> 2 : 0u;
   const uint32_t n_chunks = n_normal + (pack ? n_packed : n_light), n_light1 = pack ? 0u : (n_light + 1u) >> 1;
-  const Pose pose = pose_from_array(begin ? mp.begin_args.pose : st->T);
+  const Pose pose = pose_from_array(chained_begin ? st->T_chain : (begin ? mp.begin_args.pose : st->T));
   if (PROF) {  // kernel statistics (group passes, fallback lanes, candidates scanned): profiling instantiation only
     if (threadIdx.x < 24) lh[threadIdx.x] = 0;
     __syncthreads();
@@ -1626,13 +1639,41 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
 // BEGIN: first launch of a registration -- the prologue rides on it (workgroup 0), the pose comes from the kernel arguments, and the
 //        points the sampling rule drops get their DROPPED status bytes.
 // ------------------------------------------------------------------------------------------------
+// first scan point of wavefront k's share: a monotone function of k, evaluated identically by wavefronts k and k + 1, so the shares
+// [first(k), first(k + 1)) partition the scan whatever the rounding does
+__device__ __forceinline__ uint32_t query_wave_first(uint32_t k, uint32_t n, double per_wave) {
+  if (per_wave <= 1.0) return k < n ? k : n;  // (no sampling: wavefront k owns point k)
+  const double f = ceil((double)k * per_wave);
+  return f < (double)n ? (uint32_t)f : n;
+}
+// DISPATCH (round 6, second step): under the sampling rule only ~max_surface_features of the n points are searched (1 993 of 13 275 at
+// the stock operating point), and a wavefront per POINT spent 4 us of every sweep -- searching or not -- on dispatching 3 300
+// workgroups that mostly return at once.  The rule keeps point i iff frac(i * rate) + 0.001 <= rate (LidarSlam.cpp:353-359): about
+// one point in every run of 1 / rate.  Wavefront k therefore owns the points [first(k), first(k + 1)), first(k) = ceil(k / rate):
+// its lanes apply the rule -- the reference's own fp64 test, not a closed form -- to one point each and the wavefront searches the
+// points that pass, one after the other (one, as a rule; none or two where the rounding of i * rate falls that way: the shares
+// partition the scan, so the set of searched points is exactly the rule's).  ~max_surface_features wavefronts instead of n.
 template <bool BEGIN>
-__global__ __launch_bounds__(256) void knn_query_wave_kernel(const float* __restrict__ scan, uint32_t n, const DevState* __restrict__ st, DevState* st_begin,
+__global__ __launch_bounds__(256) void knn_query_wave_kernel(const float* __restrict__ scan, uint32_t n, uint32_t n_waves, double per_wave,
+                                                             const DevState* __restrict__ st, DevState* st_begin,
                                                              RegBeginArgs a, int32_t* __restrict__ hist, const float4* __restrict__ mpts,
                                                              const uint32_t* __restrict__ mcell_start, DevMapView map, MatchParams mp, int max_surface_features,
                                                              uint8_t* __restrict__ status, uint32_t* __restrict__ nbr5) {
   __shared__ uint32_t rowtab[4][2][20];  // per wavefront: exclusive candidate offsets [17] and first canonical index [16] of the nine x-runs
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t k = blockIdx.x * 4u + (uint32_t)wv;  // this wavefront's share of the scan
+  const uint32_t i_lo = query_wave_first(k, n, per_wave), i_hi = k < n_waves ? query_wave_first(k + 1u, n, per_wave) : i_lo;
+  // every lane's own point of the share and the pose are requested BEFORE the "already converged?" word of the state block is
+  // looked at: one memory round trip for the three instead of two (a sweep is five dependent round trips and little else)
+  const uint32_t il0 = i_lo + (uint32_t)lane < n ? i_lo + (uint32_t)lane : n - 1u;
+  float sx = scan[3 * il0], sy = scan[3 * il0 + 1], sz = scan[3 * il0 + 2];
+  double T7[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) T7[t] = BEGIN ? (a.chain_expect ? st->T_chain[t] : a.pose[t]) : st->T[t];
+  if (mp.chain_expect && st->done_count != mp.chain_expect) return;  // chained registration whose predecessor was not over: no-op
   if (BEGIN) {
+    if (a.chain_expect && st->done_count != a.chain_expect) return;  // (its guess: what the last solve of the registration in front left in T_chain)
     if (blockIdx.x == 0) {
       hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
       reg_begin_state(st_begin, a, (int)threadIdx.x);
@@ -1643,85 +1684,94 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(const float* __rest
     if (mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
       publish_state_to(mp.hring[(st->outer_iter - 1) & 1], st, mp.seq_base | (unsigned long long)st->outer_iter, (int)threadIdx.x, 256);
   }
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t i = blockIdx.x * 4u + (uint32_t)wv;  // this wavefront's scan point
-  if (i >= n) return;
-  if (!sampling_keeps(i, n, max_surface_features)) {
-    if (BEGIN && lane == 0) status[i] = SO_MATCH_DROPPED;  // (the rule does not depend on the pose: once per registration)
-    return;
-  }
-  const Pose pose = pose_from_array(BEGIN ? a.pose : st->T);
-  double pw[3];
-  quat_rotate<double>(pose.q, (double)scan[3 * i], (double)scan[3 * i + 1], (double)scan[3 * i + 2], pw[0], pw[1], pw[2]);  // LidarSlam.cpp:397-398
-  pw[0] += pose.t[0]; pw[1] += pose.t[1]; pw[2] += pose.t[2];
-  const float qx = (float)pw[0], qy = (float)pw[1], qz = (float)pw[2];                                                        // LidarSlam.cpp:728-731
-  const CellRef c = locate(map, qx, qy, qz);
-  if (c.slot < 0) {  // outside the window / no tree: LidarSlam.cpp:736-739
-    if (lane == 0) __builtin_nontemporal_store((uint8_t)SO_MATCH_NOT_ENOUGH, &status[i]);
-    return;
-  }
+  if (i_lo >= i_hi) return;
+  const Pose pose = pose_from_array(T7);
   uint32_t* rowoff = rowtab[wv][0];
   uint32_t* rowbeg = rowtab[wv][1];
   const int nc = map.nc;
-  const int x0 = c.cx > 0 ? c.cx - 1 : 0, x1 = c.cx < nc - 1 ? c.cx + 1 : nc - 1;
-  uint32_t vb = 0, vl = 0;
-  if (lane < 9) {
-    const int y = c.cy + (lane % 3) - 1, z = c.cz + (lane / 3) - 1;
-    if (y >= 0 && y < nc && z >= 0 && z < nc) {
-      const uint32_t* row = mcell_start + (size_t)c.slot * map.ncell1 + ((size_t)z * nc + y) * nc;
-      vb = row[x0]; vl = row[x1 + 1] - vb;
-    }
-  }
-  uint32_t inc = vl;  // inclusive scan over lanes 0..15 (the nine runs sit in the first row of 16 lanes)
-  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);
-  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);
-  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);
-  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 15);
-  if (lane < 16) { rowoff[lane] = lane < 9 ? inc - vl : total; rowbeg[lane] = vb; }
-  if (lane == 0) rowoff[16] = total;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  Top5 loc;
-  loc.init();
-  for (uint32_t t0 = 0; t0 < total; t0 += 256u) {  // four loads of a lane in flight: a block of <= 256 points is one round trip
-    float ax_[4], ay_[4], az_[4];
-    uint32_t cn[4];
+  for (uint32_t base = i_lo; base < i_hi; base += 64u) {  // (one trip unless n / max_surface_features > 64)
+    const uint32_t il = base + (uint32_t)lane;
+    if (base != i_lo) { const uint32_t ic = il < n ? il : n - 1u; sx = scan[3 * ic]; sy = scan[3 * ic + 1]; sz = scan[3 * ic + 2]; }
+    const bool keep = il < i_hi && sampling_keeps(il, n, max_surface_features);
+    if (BEGIN && il < i_hi && !keep) status[il] = SO_MATCH_DROPPED;  // (the rule does not depend on the pose: once per registration)
+    unsigned long long todo = __ballot(keep);
+    while (todo) {
+      const int li = __builtin_ctzll(todo);  // wavefront-uniform: the lane that holds the next point of the share the rule keeps
+      const uint32_t i = base + (uint32_t)li;
+      todo &= todo - 1ull;
+      const float fx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sx), li));
+      const float fy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sy), li));
+      const float fz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sz), li));
+      double pw[3];
+      quat_rotate<double>(pose.q, (double)fx, (double)fy, (double)fz, pw[0], pw[1], pw[2]);  // LidarSlam.cpp:397-398
+      pw[0] += pose.t[0]; pw[1] += pose.t[1]; pw[2] += pose.t[2];
+      const float qx = (float)pw[0], qy = (float)pw[1], qz = (float)pw[2];                   // LidarSlam.cpp:728-731
+      const CellRef c = locate(map, qx, qy, qz);
+      if (c.slot < 0) {  // outside the window / no tree: LidarSlam.cpp:736-739
+        if (lane == 0) __builtin_nontemporal_store((uint8_t)SO_MATCH_NOT_ENOUGH, &status[i]);
+        continue;
+      }
+      const int x0 = c.cx > 0 ? c.cx - 1 : 0, x1 = c.cx < nc - 1 ? c.cx + 1 : nc - 1;
+      uint32_t vb = 0, vl = 0;
+      if (lane < 9) {
+        const int y = c.cy + (lane % 3) - 1, z = c.cz + (lane / 3) - 1;
+        if (y >= 0 && y < nc && z >= 0 && z < nc) {
+          const uint32_t* row = mcell_start + (size_t)c.slot * map.ncell1 + ((size_t)z * nc + y) * nc;
+          vb = row[x0]; vl = row[x1 + 1] - vb;
+        }
+      }
+      uint32_t inc = vl;  // inclusive scan over lanes 0..15 (the nine runs sit in the first row of 16 lanes)
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 15);
+      __builtin_amdgcn_wave_barrier();  // (a second point of the share: the table of the first has been read by every lane)
+      if (lane < 16) { rowoff[lane] = lane < 9 ? inc - vl : total; rowbeg[lane] = vb; }
+      if (lane == 0) rowoff[16] = total;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      Top5 loc;
+      loc.init();
+      for (uint32_t t0 = 0; t0 < total; t0 += 256u) {  // four loads of a lane in flight: a block of <= 256 points is one round trip
+        float ax_[4], ay_[4], az_[4];
+        uint32_t cn[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
-      cn[u] = 0xFFFFFFFFu; ax_[u] = ay_[u] = az_[u] = 0.f;
-      if (t < total) {
-        int r = 0;
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
+          cn[u] = 0xFFFFFFFFu; ax_[u] = ay_[u] = az_[u] = 0.f;
+          if (t < total) {
+            int r = 0;
 #pragma unroll
-        for (int step = 8; step >= 1; step >>= 1) r = (r + step < 16 && rowoff[r + step] <= t) ? r + step : r;
-        cn[u] = rowbeg[r] + (t - rowoff[r]);
-        const float4 p = mpts[cn[u]];
-        ax_[u] = p.x; ay_[u] = p.y; az_[u] = p.z;
+            for (int step = 8; step >= 1; step >>= 1) r = (r + step < 16 && rowoff[r + step] <= t) ? r + step : r;
+            cn[u] = rowbeg[r] + (t - rowoff[r]);
+            const float4 p = mpts[cn[u]];
+            ax_[u] = p.x; ay_[u] = p.y; az_[u] = p.z;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (cn[u] != 0xFFFFFFFFu) loc.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, ax_[u], ay_[u], az_[u])) << 32) | cn[u]);
+      }
+      unsigned long long m5[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        m5[t] = wave_min_u64(loc.b0);
+        if (loc.b0 == m5[t] && m5[t] != ~0ull) { loc.b0 = loc.b1; loc.b1 = loc.b2; loc.b2 = loc.b3; loc.b3 = loc.b4; loc.b4 = ~0ull; }  // (keys are unique)
+      }
+      if (lane == 0) {
+        const float d2_4 = __uint_as_float((uint32_t)(m5[4] >> 32));
+        int stq = SO_MATCH_PENDING;  // five neighbours inside the gate: the plane fit runs in slot 0 of the solve
+        if (m5[4] == ~0ull || (double)d2_4 > (double)mp.sq_max_dist_f) stq = SO_MATCH_TOO_FAR;  // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
+        else {
+          uint32_t* o = nbr5 + (size_t)5 * i;
+          __builtin_nontemporal_store((uint32_t)m5[0], o); __builtin_nontemporal_store((uint32_t)m5[1], o + 1);
+          __builtin_nontemporal_store((uint32_t)m5[2], o + 2); __builtin_nontemporal_store((uint32_t)m5[3], o + 3);
+          __builtin_nontemporal_store((uint32_t)m5[4], o + 4);
+        }
+        __builtin_nontemporal_store((uint8_t)stq, &status[i]);
       }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (cn[u] != 0xFFFFFFFFu) loc.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, ax_[u], ay_[u], az_[u])) << 32) | cn[u]);
-  }
-  unsigned long long m5[5];
-#pragma unroll
-  for (int t = 0; t < 5; ++t) {
-    m5[t] = wave_min_u64(loc.b0);
-    if (loc.b0 == m5[t] && m5[t] != ~0ull) { loc.b0 = loc.b1; loc.b1 = loc.b2; loc.b2 = loc.b3; loc.b3 = loc.b4; loc.b4 = ~0ull; }  // (keys are unique)
-  }
-  if (lane == 0) {
-    const float d2_4 = __uint_as_float((uint32_t)(m5[4] >> 32));
-    int stq = SO_MATCH_PENDING;  // five neighbours inside the gate: the plane fit runs in slot 0 of the solve
-    if (m5[4] == ~0ull || (double)d2_4 > (double)mp.sq_max_dist_f) stq = SO_MATCH_TOO_FAR;  // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
-    else {
-      uint32_t* o = nbr5 + (size_t)5 * i;
-      __builtin_nontemporal_store((uint32_t)m5[0], o); __builtin_nontemporal_store((uint32_t)m5[1], o + 1);
-      __builtin_nontemporal_store((uint32_t)m5[2], o + 2); __builtin_nontemporal_store((uint32_t)m5[3], o + 3);
-      __builtin_nontemporal_store((uint32_t)m5[4], o + 4);
-    }
-    __builtin_nontemporal_store((uint8_t)stq, &status[i]);
   }
 }
 
@@ -1770,6 +1820,8 @@ __device__ __forceinline__ int lm_solve_finished(DevState* st, const LmCtl& ctl,
   st->n_iterations = o + 1;
   if (num_successful == 1 || o + 1 >= ctl.max_outer) {  // LidarSlam.cpp:141
     st->reg_done = 1;
+    for (int i = 0; i < 7; ++i) st->T_final[i] = x[i];  // (what a chained registration behind this one starts from)
+    st->done_count = st->done_count + 1u;
     return 1;
   }
   return 0;
@@ -2684,6 +2736,13 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       if (PEER && ep.peer_world > 1 && tid == 0) st->peer_seq = sh.peer_seq;
       if (tid < (int)(sizeof(LmState) / 8))
         __hip_atomic_store(reinterpret_cast<double*>(&st->S) + tid, reinterpret_cast<const double*>(&sh_S)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the guess of a chained registration behind this one (so_icp_register_sequence): this result o the delta the launch carries
+      if (!BATCH && ep.chain_next && sh.reg_done && tid == 0) {
+        double tf[7], nx[7];
+        for (int i = 0; i < 7; ++i) tf[i] = sh_S.x[i];  // (= DevState::T_final)
+        pose_compose(tf, ep.chain_delta, nx);
+        for (int i = 0; i < 7; ++i) st->T_chain[i] = nx[i];
+      }
       // (a solve that does not end the registration may leave the report to the next k-NN launch, see EvalParams)
       if (!ep.defer_publish || sh.reg_done) publish_state(st, ep, sh_ctl.outer_iter, tid, 256);
     }
@@ -2850,6 +2909,7 @@ __global__ __launch_bounds__(256, BATCH ? 2 : 1) void solve_kernel(int lm_max, c
     span.ctl = sub == 0;
   }
   if (st->reg_done) return;
+  if (!BATCH && ep.chain_expect && st->done_count != ep.chain_expect) return;  // chained registration whose predecessor was not over: no-op
   const int tid = threadIdx.x;
   // hand-off record: 8 chunks of 16 bytes {value, epoch}, each written / read with ONE sc1 dwordx4 access (atomic as a
   // unit), so a reader that sees the expected epoch in a chunk has that chunk's value: no second round trip, no
@@ -3061,7 +3121,8 @@ void launch_knn_plane(const float4* binned,
   // The production instantiation carries no profiling code; SOICP_ABLATE != 0 selects the instrumented one.
   // Timing events ride on the kernel's own dispatch packet (no marker packets: separate hipEventRecord calls cost
   // ~3.7 us of stream time each, 8 % of a registration when every sweep is timed)
-  auto* k = mp.ablate ? knn_plane_kernel<true, false> : (mp.begin ? knn_plane_kernel<false, false, true> : knn_plane_kernel<false, false>);  // (the host never sets begin with ablate)
+  auto* k = mp.ablate ? knn_plane_kernel<true, false>
+                      : (mp.begin ? (mp.begin_args.chain_expect ? knn_plane_kernel<false, false, 2> : knn_plane_kernel<false, false, 1>) : knn_plane_kernel<false, false>);  // (the host never sets begin with ablate)
   if (ev_start && ev_stop)
     hipExtLaunchKernelGGL(k, dim3(kKnnBlocks), dim3(256), 0, s, ev_start, ev_stop, 0, binned,
                           chunk_start, st, map.pts, map.cell_start, map, mp, corr, nbr5, hist, kNoBatch);
@@ -3071,16 +3132,21 @@ void launch_knn_plane(const float4* binned,
 }
 void launch_knn_query_waves(const float* d_scan, uint32_t n, DevState* st, const double pose[7], int max_outer, int lm_max, bool begin, int32_t* hist,
                             const DevMapView& map, const MatchParams& mp, int max_sf, uint8_t* status, uint32_t* nbr5, hipStream_t s,
-                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+                            hipEvent_t ev_start, hipEvent_t ev_stop, uint32_t chain_expect) {
   if (!n) return;
   RegBeginArgs a{};
   if (begin) { for (int i = 0; i < 7; ++i) a.pose[i] = pose[i]; a.max_outer = max_outer; a.lm_max = lm_max; }
+  if (begin) a.chain_expect = chain_expect;
+  // one wavefront per run of points the sampling rule keeps about one of (knn_query_wave_kernel); max_surface_features == 0 keeps nothing
+  const bool sampled = max_sf > 0 && n > (uint32_t)max_sf;
+  const double per_wave = sampled ? (double)n / (double)max_sf : 1.0;
+  const uint32_t n_waves = sampled ? (uint32_t)max_sf + 1u : n;  // first(max_sf) = ceil(max_sf * (n / max_sf)) >= n - 1: the last share is short or empty
   auto* k = begin ? knn_query_wave_kernel<true> : knn_query_wave_kernel<false>;
-  const dim3 grid((n + 3u) / 4u);
+  const dim3 grid((n_waves + 3u) / 4u);
   if (ev_start && ev_stop)
-    hipExtLaunchKernelGGL(k, grid, dim3(256), 0, s, ev_start, ev_stop, 0, d_scan, n, st, st, a, hist, map.pts, map.cell_start, map, mp, max_sf, status, nbr5);
+    hipExtLaunchKernelGGL(k, grid, dim3(256), 0, s, ev_start, ev_stop, 0, d_scan, n, n_waves, per_wave, st, st, a, hist, map.pts, map.cell_start, map, mp, max_sf, status, nbr5);
   else
-    hipLaunchKernelGGL(k, grid, dim3(256), 0, s, d_scan, n, st, st, a, hist, map.pts, map.cell_start, map, mp, max_sf, status, nbr5);
+    hipLaunchKernelGGL(k, grid, dim3(256), 0, s, d_scan, n, n_waves, per_wave, st, st, a, hist, map.pts, map.cell_start, map, mp, max_sf, status, nbr5);
 }
 uint32_t solve_grid(uint32_t n_upper, uint32_t max_blocks) {
   uint32_t blocks = (n_upper + 255u) / 256u;

@@ -76,6 +76,20 @@ SO_HD void pose_plus(const double x[7], const double d[6], double o[7]) {
   o[3] = q[0] * inv; o[4] = q[1] * inv; o[5] = q[2] * inv; o[6] = q[3] * inv;
 }
 
+// a o d: the pose a followed by the relative motion d expressed in a's frame -- what `T_w_lidar = T_w_lidar * prediction`
+// (laserMapping.cpp:345-372, Twist::operator*, utils/Twist.h:181-185) computes, here without Eigen's detour through the 4x4 affine
+// matrix: t = a.t + R(a.q) d.t, q = normalize(a.q (x) d.q).  Only + - * / sqrt, unfused (-ffp-contract=off on both sides): the host and the
+// device form the same bits (so_icp_register_sequence composes the guess of a chained registration on the device).
+SO_HD void pose_compose(const double a[7], const double d[7], double o[7]) {
+  double rx, ry, rz;
+  quat_rotate<double>(a + 3, d[0], d[1], d[2], rx, ry, rz);
+  o[0] = a[0] + rx; o[1] = a[1] + ry; o[2] = a[2] + rz;
+  double q[4];
+  quat_mul(a + 3, d + 3, q);
+  const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  o[3] = q[0] / nrm; o[4] = q[1] / nrm; o[5] = q[2] / nrm; o[6] = q[3] / nrm;
+}
+
 // (a^-1 * b).pos.norm() and 2*atan2(|vec|, w): LidarSlam.cpp:201-208, 246-249 (Twist.h:172-185).
 SO_HD void relative_motion(const double a[7], const double b[7], double& tn, double& rn) {
   const double qi[4] = {-a[3], -a[4], -a[5], a[6]};

@@ -198,6 +198,35 @@ def perturb_pose(pose, seed, dt=0.10, dth_deg=1.0):
     return np.concatenate([pose[:3] + d, q / np.linalg.norm(q)])
 
 
+def pose_compose(a, d):
+    """a o d, operation by operation as soicp::pose_compose (csrc/so_math.h) evaluates it in IEEE double -- the guess of a chained
+    registration (so_icp_register_sequence): t = a.t + R(a.q) d.t (Eigen's _transformVector form), q = normalize(a.q (x) d.q)."""
+    a = [float(v) for v in a]; d = [float(v) for v in d]
+    q0, q1, q2, q3 = a[3], a[4], a[5], a[6]
+    vx, vy, vz = d[0], d[1], d[2]
+    ux = q1 * vz - q2 * vy; uy = q2 * vx - q0 * vz; uz = q0 * vy - q1 * vx
+    ux += ux; uy += uy; uz += uz
+    ox = vx + q3 * ux + (q1 * uz - q2 * uy)
+    oy = vy + q3 * uy + (q2 * ux - q0 * uz)
+    oz = vz + q3 * uz + (q0 * uy - q1 * ux)
+    b0, b1, b2, b3 = d[3], d[4], d[5], d[6]
+    w = q3 * b3 - q0 * b0 - q1 * b1 - q2 * b2
+    x = q3 * b0 + q0 * b3 + q1 * b2 - q2 * b1
+    y = q3 * b1 + q1 * b3 + q2 * b0 - q0 * b2
+    z = q3 * b2 + q2 * b3 + q0 * b1 - q1 * b0
+    nrm = float(np.sqrt(np.float64(x * x + y * y + z * z + w * w)))
+    return np.array([a[0] + ox, a[1] + oy, a[2] + oz, x / nrm, y / nrm, z / nrm, w / nrm])
+
+
+def pose_between(a, b):
+    """the motion d with a o d ~ b (a^-1 o b): what an odometry source predicts between two scans, in the frame of the first"""
+    qa = np.asarray(a[3:], float) / np.linalg.norm(a[3:])
+    qi = np.array([-qa[0], -qa[1], -qa[2], qa[3]])
+    dt = quat_to_R(qi) @ (np.asarray(b[:3], float) - np.asarray(a[:3], float))
+    dq = quat_mul(qi, np.asarray(b[3:], float))
+    return np.concatenate([dt, dq / np.linalg.norm(dq)])
+
+
 def pose_error(a, b):
     """(translation distance, rotation angle) between two poses."""
     dt = float(np.linalg.norm(np.asarray(a[:3]) - np.asarray(b[:3])))

@@ -111,9 +111,14 @@ DEGENERATE_RECTS = {
                       ([-24, -6.3, -1.5], [48, 0, 0], [0, 0, 5.6]), ([-24, 5.9, -1.5], [48, 0, 0], [0, 0, 5.6])],
     # two parallel walls: only the translation along their normal and the two rotations that tilt them are observable
     "two_walls": [([-20, -6.3, -1.5], [40, 0, 0], [0, 0, 7.5]), ([-20, 5.9, -1.5], [40, 0, 0], [0, 0, 7.5])],
+    # a room corner AT THE WORLD ORIGIN: floor z = 0 and the walls x = 0, y = 0 all contain the origin, where the reference's plane
+    # parameterisation A x = -1 (LidarSlam.cpp:798-816) is ill conditioned (|x| = 1 / offset; only the 1 cm noise keeps it finite).
+    # Well conditioned as a registration (three orthogonal planes): every pose component is observable.
+    "origin_corner": [([0, 0, 0], [24, 0, 0], [0, 24, 0]), ([0, 0, 0], [0, 24, 0], [0, 0, 8]), ([0, 0, 0], [24, 0, 0], [0, 0, 8])],
 }
 # rows of the 6-vector [dt_x, dt_y, dt_z, rotvec_x, rotvec_y, rotvec_z] (world frame) the scene DOES constrain
-DEGENERATE_OBSERVABLE = {"floor_only": [2, 3, 4], "open_corridor": [1, 2, 3, 4, 5], "two_walls": [1, 3, 5]}
+DEGENERATE_OBSERVABLE = {"floor_only": [2, 3, 4], "open_corridor": [1, 2, 3, 4, 5], "two_walls": [1, 3, 5], "origin_corner": [0, 1, 2, 3, 4, 5]}
+DEGENERATE_SENSOR_OFFSET = {"origin_corner": [5.3, 4.9, 1.8]}  # (the sensor stands inside the corner, 2 m above the floor)
 
 
 class DegenerateScene:
@@ -132,7 +137,8 @@ class DegenerateScene:
         self.observable = DEGENERATE_OBSERVABLE[name]
 
     def gt_pose(self, i):
-        return np.concatenate([[0.7 + 0.5 * i, -0.9 + 0.3 * i, 0.2], synth.quat_from_rotvec(np.array([0.02, -0.03, 0.4 + 0.3 * i]))])
+        off = np.array(DEGENERATE_SENSOR_OFFSET.get(self.name, [0, 0, 0]), float)
+        return np.concatenate([off + [0.7 + 0.5 * i, -0.9 + 0.3 * i, 0.2], synth.quat_from_rotvec(np.array([0.02, -0.03, 0.4 + 0.3 * i]))])
 
     def scan(self, i):
         return synth.raycast(self.world, self.gt_pose(i), self.dirs, seed=60 + i, sigma=self.sigma)

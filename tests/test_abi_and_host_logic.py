@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(soicp):
     for name in declared:
         assert hasattr(L, name), f"libsoicp.so does not export {name}"
     assert sorted(declared) == sorted(soicp.EXPORTED), "binding.EXPORTED must list exactly the header's functions"
-    assert L.so_icp_abi_version() == 3
+    assert L.so_icp_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header(soicp, tmp_path):

@@ -45,3 +45,36 @@ def test_hip_path_on_rank_deficient_geometry(oracle, gpu_slam_factory, name, sig
         assert np.allclose(H, Ho, rtol=1e-9, atol=1e-9 * np.abs(Ho).max())
         assert obs <= 1e-8, (name, i, d6)
         assert dt <= 1e-4 and dr <= 1e-4, (name, i, dt, dr)
+
+
+def test_hip_path_on_planes_through_the_world_origin(oracle, gpu_slam_factory):
+    """LidarSlam.cpp:798-816 parameterises a plane as A x = -1: for a plane through the WORLD origin |x| = 1 / offset
+    diverges and the reference's pivoted QR works on a badly scaled system.  The product solves the same least-squares problem in
+    closed form on the centred scatter (plane_fit.h).  A room corner at the origin -- floor z = 0, walls x = 0 and y = 0, 1 cm noise --
+    makes EVERY correspondence such a plane: MatchingResult of every query, histograms, iteration counts and termination codes
+    equal Oracle-A's, poses <= 1e-8 (host-side twin: tests/test_plane_fit_host.py::test_planes_through_the_world_origin)."""
+    sc = DegenerateScene("origin_corner", sigma=0.01)
+    slam = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5)
+    assert slam.add_surf_point_cloud(sc.map_points) == len(sc.map_points)
+    om = oracle.OracleMap(plane_res=sc.plane_res)
+    om.add_surf(slam.export_map(), raw=True)
+    for i in range(3):
+        scan, guess = sc.scan(i), sc.guess(i)
+        rc, pose, st = slam.register(scan, guess)
+        status = slam.match_status(len(scan)).copy()
+        orc, opose, ost, corrs = om.register(scan, guess, oracle.default_config(max_iterations=5), want_corrs=True)
+        assert rc == orc == 0 and st.n_iterations == ost.n_iterations
+        for it in range(st.n_iterations):
+            a, b = st.iterations[it], ost.iters[it]
+            assert (a.lm_iterations, a.num_successful_steps, a.termination, a.num_surf_from_scan) == \
+                (b.lm_iterations, b.num_successful_steps, b.termination, b.num_surf), (i, it)
+            assert list(a.reject_hist) == list(b.reject_hist) and list(a.obs_hist) == list(b.obs_hist)
+            assert abs(a.final_cost - b.final_cost) <= 1e-9 * max(1.0, abs(b.final_cost))
+        assert np.array_equal(status, corrs["status"]), "MatchingResult of the last outer iteration, query by query"
+        ok = corrs["status"] == 0
+        assert ok.sum() > 0.5 * len(scan)
+        # the planes really pass (almost) through the origin: offsets of the accepted planes are millimetres, |x| = 1 / d in the hundreds
+        assert np.median(np.abs(corrs["d"][ok])) < 0.02, np.median(np.abs(corrs["d"][ok]))
+        dt, dr = synth.pose_error(pose, opose)
+        print(f"origin_corner scan {i}: {int(ok.sum())} accepted planes, median |d| {np.median(np.abs(corrs['d'][ok])):.4f} m | pose vs oracle {dt:.2e} m {dr:.2e} rad")
+        assert dt <= 1e-8 and dr <= 1e-8, (i, dt, dr)

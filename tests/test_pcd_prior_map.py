@@ -117,3 +117,21 @@ def test_pcd_reader_refuses_what_it_cannot_read(tmp_path):
                         struct.pack("<II", 3, 24) + bytes([0xE0, 0x05, 0x00]))
     r = subprocess.run([TOOL, "pcd", str(corrupt), out], capture_output=True, text=True)
     assert r.returncode == 3 and "LZF" in r.stderr
+    # hostile / malformed headers: every one of them must come back as "cannot read" -- exit code 3, the path on which
+    # the node switches to mapping mode (laserMapping.cpp:165-171) -- never as an uncaught exception (abort, exit code 134)
+    head = b"VERSION 0.7\nFIELDS x y z\nSIZE %s\nTYPE F F F\nCOUNT %s\nWIDTH %s\nHEIGHT %s\nPOINTS %s\nDATA %s\n"
+    cases = {
+        "points_not_a_number": head % (b"4 4 4", b"1 1 1", b"2", b"1", b"two", b"binary") + b"\0" * 24,
+        "points_negative": head % (b"4 4 4", b"1 1 1", b"2", b"1", b"-2", b"binary") + b"\0" * 24,
+        "points_huge_binary": head % (b"4 4 4", b"1 1 1", b"2", b"1", b"18446744073709551615", b"binary") + b"\0" * 24,
+        "points_huge_ascii": head % (b"4 4 4", b"1 1 1", b"2", b"1", b"4000000000", b"ascii") + b"1 2 3\n4 5 6\n",
+        "points_huge_compressed": head % (b"4 4 4", b"1 1 1", b"2", b"1", b"4000000000", b"binary_compressed") + struct.pack("<II", 3, 24) + bytes([0, 1, 2]),
+        "width_times_height_overflows": (b"VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 4294967296\nHEIGHT 4294967296\nDATA binary\n" + b"\0" * 24),
+        "size_not_a_number": head % (b"4 x 4", b"1 1 1", b"2", b"1", b"2", b"binary") + b"\0" * 24,
+        "count_out_of_range": head % (b"4 4 4", b"1 99999999999999999999 1", b"2", b"1", b"2", b"binary") + b"\0" * 24,
+    }
+    for name, blob in cases.items():
+        f = tmp_path / (name + ".pcd")
+        f.write_bytes(blob)
+        r = subprocess.run([TOOL, "pcd", str(f), out], capture_output=True, text=True)
+        assert r.returncode == 3 and "PCD" in r.stderr, (name, r.returncode, r.stderr[-200:])

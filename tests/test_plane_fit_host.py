@@ -171,3 +171,64 @@ def test_observability_short_cut_equals_the_arithmetic_as_written(pf):
         assert np.array_equal(s0, s1) and np.array_equal(nd0, nd1) and np.array_equal(c0, c1)
         assert (s0 == 0).sum() > 5000
         assert np.array_equal(o0, o1), np.flatnonzero((o0 != o1).any(1))[:10]
+
+
+def _oracle_fit(L, P, pw, plane_res):
+    """what orc_plane_match (oracle/so_oracle.c, LidarSlam.cpp:749-844) does behind the neighbour search, on given clusters:
+    PCA gate with the oracle's Jacobi eigen-solver, the 5x3 plane by column-pivoted Householder QR, inlier gate; -> status, n, d"""
+    import ctypes as C
+    f64p = C.POINTER(C.c_double)
+    n = len(P)
+    st = np.zeros(n, np.int32); nd = np.zeros((n, 4))
+    pr = np.float32(plane_res)
+    for t in range(n):
+        A = P[t].astype(np.float64)
+        mean = A.sum(0) / 5.0
+        c = A - mean
+        S = np.zeros((3, 3))
+        for j in range(5):
+            S += np.outer(c[j], c[j])
+        ev = np.zeros(3); V = np.zeros(9)
+        L.orc_eig3_sym(np.ascontiguousarray(S).ctypes.data_as(f64p), ev.ctypes.data_as(f64p), V.ctypes.data_as(f64p))
+        if ev[0] < 1e-6 or ev[1] / ev[2] < 0.1:
+            st[t] = 3; continue
+        x = np.zeros(3)
+        if not L.orc_plane_ls5(np.ascontiguousarray(A).ctypes.data_as(f64p), x.ctypes.data_as(f64p)):
+            st[t] = 4; continue
+        nrm = np.sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2])
+        d = 1.0 / nrm; nn = x / nrm
+        dist = np.abs(A @ nn + d)
+        if (dist > float(pr) / 2.0).any():
+            st[t] = 5; continue
+        nd[t, :3] = nn; nd[t, 3] = d
+    return st, nd
+
+
+def test_planes_through_the_world_origin(oracle, pf):
+    """LidarSlam.cpp:798-816 fits A x = -1: for a plane through the world origin |x| = 1 / offset diverges.  Clusters on planes with
+    offsets <= 1e-3 / <= 0.05 / <= 0.5 m (and 5 - 60 m as the control), the product's closed form against the oracle's pivoted QR:
+    MatchingResult equal, planes within 1e-9 (measured <= 3e-10 at the small offsets; the control stays below 1e-10)."""
+    import ctypes as C
+    L = oracle.lib()
+    L.orc_eig3_sym.restype = None
+    L.orc_plane_ls5.restype = C.c_int
+    rng = np.random.default_rng(12)
+    for lo, hi, tol in ((0.0, 1e-3, 1e-9), (0.0, 0.05, 1e-9), (0.0, 0.5, 1e-9), (5.0, 60.0, 1e-10)):
+        n = 4000
+        P = np.zeros((n, 5, 3), np.float32)
+        for t in range(n):
+            nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+            off = rng.uniform(lo, hi) * rng.choice([-1.0, 1.0])
+            u = np.cross(nrm, [0.3, 0.5, 0.8]); u /= np.linalg.norm(u); v = np.cross(nrm, u)
+            ctr = nrm * off + u * rng.uniform(-40, 40) + v * rng.uniform(-40, 40)
+            P[t] = (ctr + np.outer(rng.uniform(-0.35, 0.35, 5), u) + np.outer(rng.uniform(-0.35, 0.35, 5), v)
+                    + np.outer(rng.normal(0, 0.01, 5), nrm)).astype(np.float32)
+        pw = P.mean(1).astype(np.float64) + rng.normal(0, 0.05, (n, 3))
+        status, nd, _, _ = pf(P.reshape(-1, 15), pw, IDENTITY, 0.2)
+        ost, ond = _oracle_fit(L, P, pw, 0.2)
+        assert np.array_equal(status, ost), (lo, hi, np.flatnonzero(status != ost)[:10])
+        ok = status == 0
+        assert ok.sum() > 2000, (lo, hi, int(ok.sum()))
+        worst = np.abs(nd[ok] - ond[ok]).max()
+        print(f"plane offsets {lo} .. {hi} m: {int(ok.sum())} accepted, max |plane - oracle plane| {worst:.2e}")
+        assert worst < tol, (lo, hi, worst)
