@@ -412,6 +412,39 @@ def main():
             other_protocol = "cold" if args.stage_protocol == "steady" else "steady"
             t_e, _, _ = timed_loop("staged", args.steps, rewarm=args.warmup, protocol=other_protocol)
             secondary["staged_%s_protocol" % other_protocol] = args.steps / t_e
+        if world == 1 and args.scans >= 2:
+            # `steps` registrations as ONE so_icp_register_sequence call (round 6): the guesses chain on the device, guess_k = T_(k-1) o delta_k
+            # with delta_k = gt(k-1)^-1 o guesses[k] (an odometry prediction that lands where the headline's guesses are, up to the
+            # millimetres registration k - 1 ends from its ground truth), the launches of registration k + 1 are enqueued behind those of k
+            # before k has reported, scan k + 1 is copied and binned beside registration k.  Same scans, every copy and binning launch
+            # inside the clock.  The first chained registrations are repeated through so_icp_register from the guesses the run reports:
+            # equal bits.
+            try:
+                S_ = args.scans
+                seq_scans = [scans[k % S_] for k in range(args.steps)]
+                seq_d = np.zeros((args.steps, 7)); seq_d[:, 6] = 1.0
+                for k in range(1, args.steps):
+                    seq_d[k] = synth.pose_between(sc.gt_pose((k - 1) % S_), guesses[k % S_])
+                for rep in range(2):  # (the first run is the warm-up: buffers of the sequence path are allocated on first use)
+                    call, seq_out, seq_g, seq_st, seq_n, _keep = slam.prepare_register_sequence(seq_scans, g64[0], seq_d)
+                    slam.synchronize()
+                    t0 = time.perf_counter()
+                    rc_ = call()
+                    slam.synchronize()
+                    t_seq = time.perf_counter() - t0
+                    assert rc_ == 0 and seq_n.value == args.steps, (rc_, seq_n.value, slam.last_error())
+                n_ch = sum(1 for s_ in seq_st if s_.flags & binding.FLAG_CHAINED)
+                same = True
+                for k in range(min(args.steps, 6)):
+                    rc_p, pose_p, st_p = slam.register(seq_scans[k], seq_g[k])
+                    same = same and rc_p == 0 and bool(np.array_equal(pose_p, seq_out[k])) and st_p.n_iterations == seq_st[k].n_iterations
+                secondary["chained"] = args.steps / t_seq
+                secondary["chained_detail"] = {"registrations": args.steps, "chained": n_ch,
+                                               "outer_iterations_per_step": sum(s_.n_iterations for s_ in seq_st) / args.steps,
+                                               "equal_bits_with_so_icp_register_from_the_reported_guesses": bool(same),
+                                               "guess_offset_from_the_headline_guesses_m": float(max(np.linalg.norm(seq_g[k][:3] - guesses[k % S_][:3]) for k in range(args.steps)))}
+            except Exception as e:  # noqa: BLE001 -- a secondary measurement must not cost the line
+                secondary["chained_detail"] = {"unavailable": repr(e)}
         if args.scan_buffers != "pageable" and world == 1:
             # the protocol of rounds 1 - 3 beside the headline's: the same staged loop on PAGEABLE numpy buffers -- the copy
             # thread packs and copies them, nothing is binned ahead
@@ -909,7 +942,8 @@ def main():
         # the same registrations through the other entry points, `steps` each, after the timed region
         "entry_points": {"note": "registrations/s; 'staged' and 'host' include the scan's H2D copy (1.5 MB), 'resident' does not; "
                                  "'staged_pageable_buffers' = the staged loop on pageable numpy buffers (copy thread, nothing binned ahead: the r01 - r03 protocol); "
-                                 "'staged_cold_protocol' / 'staged_steady_protocol' = the staged loop under the start-of-clock protocol `value` was NOT measured with "
+                                 "'chained' = the same registrations as ONE so_icp_register_sequence call (guesses chained on the device, the next registration enqueued behind "
+                                 "the current one: no host turn-around between registrations; chained_detail); 'staged_cold_protocol' / 'staged_steady_protocol' = the staged loop under the start-of-clock protocol `value` was NOT measured with "
                                  "(host.stage_protocol names the one it was: 'cold' = nothing announced when the clock starts, r01 - r04; 'steady' = the stream crosses the clock start, r05 on)",
                          args.entry: value, **secondary},
         "roofline": {"bound": "hbm", "kernel": "knn_plane_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

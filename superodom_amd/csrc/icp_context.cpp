@@ -302,6 +302,7 @@ struct so_icp_ctx {
   hipStream_t seq_stream = nullptr;
   StageSlot seq_slot[kStageSlots];
   DevBuf d_sbin_key, d_sbin_cnt, d_sbin_off; uint32_t sbin_log2 = 0;
+  DevBuf d_seq_flag; uint32_t seq_flag_value = 0;  // "scan in place" word of the sequence's copy / binning queue (MatchParams::begin_flag)
   int seq_depth = 2; uint32_t done_count_seen = 0;
   bool seq_chain = true;                  // SOICP_SEQ_CHAIN=0: so_icp_register_sequence runs one registration after the other (same results)
   bool query_waves = true;                // SOICP_QUERY_WAVES=0: a small scan (<= 4 096 kept queries) is binned and swept in chunks like a large one
@@ -502,6 +503,7 @@ MatchParams match_params(float plane_res, int ablate) {
   mp.begin = 0; mp.begin_max_surface_features = -1; mp.begin_n = 0;
   mp.begin_args = RegBeginArgs{};
   mp.begin_ctr = nullptr; mp.begin_state = nullptr;
+  mp.begin_flag = nullptr; mp.begin_flag_want = 0;
   mp.chain_expect = 0;
   return mp;
 }
@@ -1472,7 +1474,7 @@ so_icp_ctx::~so_icp_ctx() {
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   if (seq_stream) (void)hipStreamSynchronize(seq_stream);
   for (StageSlot& sl : seq_slot) { sl.dev.release(); for (DevBuf* b : {&sl.pb_keys, &sl.pb_vals, &sl.pb_chunks, &sl.pb_binned, &sl.pb_ctr}) b->release(); if (sl.ev) (void)hipEventDestroy(sl.ev); }
-  for (DevBuf* b : {&d_sbin_key, &d_sbin_cnt, &d_sbin_off}) b->release();
+  for (DevBuf* b : {&d_sbin_key, &d_sbin_cnt, &d_sbin_off, &d_seq_flag}) b->release();
   if (seq_stream) (void)hipStreamDestroy(seq_stream);
   for (StageSlot& sl : stage) { sl.dev.release(); for (DevBuf* b : {&sl.pb_keys, &sl.pb_vals, &sl.pb_chunks, &sl.pb_binned, &sl.pb_ctr}) b->release(); if (sl.pinned) (void)hipHostFree(sl.pinned); if (sl.ev) (void)hipEventDestroy(sl.ev); }
   for (const HostRange& r : host_ranges) { if (r.owned) (void)hipHostFree(const_cast<char*>(r.p)); else (void)hipHostUnregister(const_cast<char*>(r.p)); }
@@ -1819,6 +1821,7 @@ struct SeqRun {
   const float* d_scan = nullptr; size_t n = 0;
   so_icp_ctx::StageSlot* slot = nullptr;   // host scan (its HBM copy) and / or the work list binned ahead; nullptr: resident scan swept by query waves
   bool query_waves = false, binned = false, enqueued = false, chained = false, needs_event = false;
+  uint32_t flag_value = 0;                  // what the sequence's queue stores into its flag word behind this scan's copy and binning
   uint32_t chain_expect = 0;
   double guess[7];                          // exact for an unchained start, the host's prediction for a chained one
   int pos[3] = {0, 0, 0}; int count_5x5 = 0;
@@ -1878,6 +1881,7 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
   // ---------------- chained path
   hipStream_t s = c->stream;
   if (!c->seq_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->seq_stream, hipStreamNonBlocking));
+  if (!c->d_seq_flag.p) { HIP_TRY(c, c->d_seq_flag.reserve(64)); HIP_TRY(c, hipMemset(c->d_seq_flag.p, 0, 64)); c->seq_flag_value = 0; }
   struct Drain {  // an early return must not leave copies reading the caller's buffers, nor launches of this call in the queue
     so_icp_ctx* c; bool ok = false;
     ~Drain() { if (!ok) { (void)hipStreamSynchronize(c->seq_stream); (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); } }
@@ -1939,7 +1943,11 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
       r.binned = true; r.needs_event = true;
       r.d_binned = sl.pb_binned.as<float4>(); r.d_chunks = sl.pb_chunks.as<uint32_t>();
     }
-    if (r.needs_event) HIP_TRY(c, hipEventRecord(sl.ev, c->seq_stream));
+    if (r.needs_event) {
+      r.flag_value = ++c->seq_flag_value;
+      launch_stream_flag(c->d_seq_flag.as<uint32_t>(), r.flag_value, c->seq_stream);  // (a chained start waits for this on the device ...)
+      HIP_TRY(c, hipEventRecord(sl.ev, c->seq_stream));                                // (... an ordinary start through the queue)
+    }
     return SO_ICP_OK;
   };
   // host side of a registration's start (register_core_once): window, map view, parameters.  false + rc == 0: cannot be started this way
@@ -1975,10 +1983,13 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
   // registration is enqueued behind it yet), the others leave their report to the sweep behind them (EvalParams::defer_publish)
   auto enqueue = [&](int k, int it0, int it1) -> int {
     SeqRun& r = runs[(size_t)k];
-    if (it0 == 0 && r.needs_event) HIP_TRY(c, hipStreamWaitEvent(s, r.slot->ev, 0));
+    // scan and work list come from the other queue.  Ordinary start: the queue waits for that queue's event.  Chained start: no barrier
+    // packet between two registrations -- the first launch itself waits for the flag behind the scan's binning (MatchParams::begin_flag)
+    if (it0 == 0 && r.needs_event && !r.chain_expect) HIP_TRY(c, hipStreamWaitEvent(s, r.slot->ev, 0));
     for (int it = it0; it < it1; ++it) {
       MatchParams mp_it = r.mp;
       mp_it.publish_prev = (it > it0) ? 1 : 0;  // (the solve in front of this sweep deferred its report)
+      if (it == 0 && r.needs_event && r.chain_expect) { mp_it.begin_flag = c->d_seq_flag.as<uint32_t>(); mp_it.begin_flag_want = r.flag_value; }
       if (r.query_waves) {
         launch_knn_query_waves(r.d_scan, (uint32_t)r.n, ds, r.guess, max_outer, lm_max, it == 0, c->d_hist, c->view, mp_it, max_sf, c->d_status.as<uint8_t>(),
                                c->d_nbr5.as<uint32_t>(), s, nullptr, nullptr, it == 0 ? r.chain_expect : 0u);

@@ -6,5 +6,5 @@ for cfg in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.read())
 k=d['kernels']
-print('%-40s' % '$cfg', 'value %.0f resident %.0f ratio %.3f host %.0f | knn %.1f solve %.1f bin %.1f | batch64 %.0f' % (d['value'], d['entry_points']['resident'], d['value']/d['entry_points']['resident'], d['entry_points']['host'], 1e3*k['knn_ms_per_registration'], 1e3*k['solve_ms_per_registration'], 1e3*k['binning_ms_per_registration'], d['batch64']['value']))"
+print('%-40s' % '$cfg', 'value %.0f resident %.0f ratio %.3f host %.0f chained %.0f | knn %.1f solve %.1f bin %.1f | batch64 %.0f' % (d['value'], d['entry_points']['resident'], d['value']/d['entry_points']['resident'], d['entry_points']['host'], d['entry_points'].get('chained', 0), 1e3*k['knn_ms_per_registration'], 1e3*k['solve_ms_per_registration'], 1e3*k['binning_ms_per_registration'], d['batch64']['value']))"
 done; done
