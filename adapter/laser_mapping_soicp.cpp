@@ -325,6 +325,27 @@ void laserMapping::updatePoseAndPublish() {  // :729-765
   timeLaserOdometryPrev = timeLaserOdometry;
 }
 
+// laser_cloud_surround / laser_cloud_map (:437-462): `pcl::toROSMsg(localMap.get...LocalMap())` -- here the device gathers the cloud as
+// pcl::PointXYZI records straight into the payload area of the serialised message, which is assembled in a pinned buffer: no point cloud
+// object, no to_ros_msg copy, no serialisation copy (round 5 measured 9 ms for one laser_cloud_map of the `small` scene through those).
+void laserMapping::publishMapCloud(const std::string& topic, bool only_5x5, const so_wire::Time& stamp) {
+  if (!out_) return;
+  const size_t n = slam.localMap.exportRecords(nullptr, 0, only_5x5, slam.pos_in_localmap);
+  so_wire::PointCloud2 meta = to_ros_msg(PointCloud<Point>());
+  meta.width = (uint32_t)n; meta.row_step = meta.point_step * meta.width;
+  meta.header.stamp = stamp; meta.header.frame_id = config_.WORLD_FRAME;
+  const size_t payload = n * sizeof(Point);
+  const std::vector<uint8_t> prefix = so_wire::cloud_prefix(meta, payload);
+  uint8_t* buf = slam.PinnedScratch(0, prefix.size() + payload + 1);
+  std::memcpy(buf, prefix.data(), prefix.size());
+  const size_t got = slam.localMap.exportRecords(buf + prefix.size(), n, only_5x5, slam.pos_in_localmap);
+  if (got != n) throw std::runtime_error("publishMapCloud: the map changed between the count and the export");
+  buf[prefix.size() + payload] = meta.is_dense ? 1 : 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  out_->publish_bytes(topic, "sensor_msgs/msg/PointCloud2", buf, prefix.size() + payload + 1);
+  phase_seconds[7] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 void laserMapping::publishTopic() {  // :415-597
   const std::string& P = config_.ProjectName;
   const so_wire::Time stamp = stamp_from_seconds(timeLaserOdometry);
@@ -338,39 +359,49 @@ void laserMapping::publishTopic() {  // :415-597
   }
   publish(P + "/prediction_source", "std_msgs/msg/String", src);
 
-  if (frameCount % 5 == 0 && config_.debug_view_enabled) {  // :437-447
-    so_wire::PointCloud2 m = to_ros_msg(slam.localMap.get5x5LocalMap(slam.pos_in_localmap));
-    m.header.stamp = stamp; m.header.frame_id = config_.WORLD_FRAME;
-    publish(P + "/laser_cloud_surround", "sensor_msgs/msg/PointCloud2", m);
-  }
+  auto t_sub = std::chrono::steady_clock::now();
+  auto lap_sub = [&](int k) { const auto now = std::chrono::steady_clock::now(); phase_seconds[k] += std::chrono::duration<double>(now - t_sub).count(); t_sub = now; };
+  if (frameCount % 5 == 0 && config_.debug_view_enabled) publishMapCloud(P + "/laser_cloud_surround", true, stamp);  // :437-447
   if (frameCount % 20 == 0) {  // :449-462
-    so_wire::PointCloud2 m = to_ros_msg(slam.localMap.getAllLocalMap());
-    m.header.stamp = stamp; m.header.frame_id = config_.WORLD_FRAME;
-    publish(P + "/laser_cloud_map", "sensor_msgs/msg/PointCloud2", m);
+    publishMapCloud(P + "/laser_cloud_map", false, stamp);
     if (slam.localization_mode) { priorCloudMsg.header.stamp = stamp; publish(P + "/overall_map", "sensor_msgs/msg/PointCloud2", priorCloudMsg); }
   }
 
+  lap_sub(5);
   {  // registered scan (:464-493): the full-resolution cloud in the world frame, points within 0.1 m of the origin dropped.
      // Written straight into the message payload (pcl::PointXYZI records), no intermediate cloud.
     const size_t n = (size_t)fullRes_.width * fullRes_.height;
     so_wire::PointCloud2 m = to_ros_msg(PointCloud<Point>());
     size_t kept = 0;
+    bool published_in_place = false;
     const XyzLayout L0 = n ? xyz_layout(fullRes_) : XyzLayout{0, 0, 0, 0, false, false};
-    // (below ~32 k points the two PCIe copies cost what the host loop costs: 20 ns a point; SOICP_NODE_DEVICE_TRANSFORM_MIN moves the threshold)
-    static const size_t device_min = std::getenv("SOICP_NODE_DEVICE_TRANSFORM_MIN") ? (size_t)std::atol(std::getenv("SOICP_NODE_DEVICE_TRANSFORM_MIN")) : 32768;
-    if (n >= device_min && n && fullRes_.point_step == sizeof(Point) && L0.contiguous && L0.off_x == 0 && L0.has_intensity && L0.off_intensity == 16) {
-      // the message already holds pcl::PointXYZI records: transformed on the device in place (so_icp_transform_cloud), the
-      // rare dropped points squeezed out here
-      m.data.assign(fullRes_.data.begin(), fullRes_.data.begin() + n * sizeof(Point));
+    // (the host loop costs ~13 ns a point, the device path ~40 us flat now that both of its copies are DMA transfers: break-even near 3 000 points;
+    //  SOICP_NODE_DEVICE_TRANSFORM_MIN moves the threshold)
+    static const size_t device_min = std::getenv("SOICP_NODE_DEVICE_TRANSFORM_MIN") ? (size_t)std::atol(std::getenv("SOICP_NODE_DEVICE_TRANSFORM_MIN")) : 4096;
+    if (n >= device_min && n && out_ && fullRes_.point_step == sizeof(Point) && L0.contiguous && L0.off_x == 0 && L0.has_intensity && L0.off_intensity == 16) {
+      // the message already holds pcl::PointXYZI records: they go into the payload area of the outgoing message -- assembled in a pinned
+      // buffer, so that both copies of so_icp_transform_cloud are DMA transfers --, are transformed there by the device, and the rare
+      // dropped points are squeezed out in place.  (The serialised prefix has the same length whatever the point count.)
+      so_wire::PointCloud2 meta = to_ros_msg(PointCloud<Point>());
+      meta.header.stamp = stamp; meta.header.frame_id = config_.WORLD_FRAME;
+      const size_t psize = so_wire::cloud_prefix(meta, 0).size();
+      uint8_t* buf = slam.PinnedScratch(1, psize + n * sizeof(Point) + 1);
+      std::memcpy(buf + psize, fullRes_.data.data(), n * sizeof(Point));
       Transformd Tw; Tw.rot = q_w_curr; Tw.pos = t_w_curr;
       std::vector<uint8_t> keep;
-      kept = slam.TransformCloud(m.data.data(), n, sizeof(Point), Tw, keep);
+      kept = slam.TransformCloud(buf + psize, n, sizeof(Point), Tw, keep);
       if (kept != n) {
-        Point* rec = reinterpret_cast<Point*>(m.data.data());
         size_t o = 0;
-        for (size_t i = 0; i < n; ++i) if (keep[i]) rec[o++] = rec[i];
-        m.data.resize(kept * sizeof(Point));
+        for (size_t i = 0; i < n; ++i) if (keep[i]) { if (o != i) std::memcpy(buf + psize + o * sizeof(Point), buf + psize + i * sizeof(Point), sizeof(Point)); ++o; }
       }
+      meta.width = (uint32_t)kept; meta.row_step = meta.point_step * meta.width;
+      const std::vector<uint8_t> prefix = so_wire::cloud_prefix(meta, kept * sizeof(Point));
+      std::memcpy(buf, prefix.data(), psize);
+      buf[psize + kept * sizeof(Point)] = meta.is_dense ? 1 : 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      out_->publish_bytes(P + "/registered_scan", "sensor_msgs/msg/PointCloud2", buf, psize + kept * sizeof(Point) + 1);
+      phase_seconds[7] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      published_in_place = true;
     } else if (n) {
       const XyzLayout L = L0;
       m.data.resize(n * sizeof(Point));
@@ -390,8 +421,9 @@ void laserMapping::publishTopic() {  // :415-597
     }
     m.width = (uint32_t)kept; m.row_step = m.point_step * m.width;
     m.header.stamp = stamp; m.header.frame_id = config_.WORLD_FRAME;
-    publish(P + "/registered_scan", "sensor_msgs/msg/PointCloud2", m);
+    if (!published_in_place) publish(P + "/registered_scan", "sensor_msgs/msg/PointCloud2", m);
   }
+  lap_sub(6);
 
   so_wire::Odometry odomAftMapped;  // :504-525
   odomAftMapped.header.frame_id = config_.WORLD_FRAME;

@@ -49,6 +49,11 @@ class Outbox {
  public:
   virtual ~Outbox() = default;
   virtual void publish(const std::string& topic, const std::string& type, std::vector<uint8_t>&& cdr) = 0;
+  // a message assembled in a buffer the node keeps (pinned memory the device wrote the payload into): a bridge that can send from a
+  // pointer (rcl_serialized_message_t wraps one) overrides this and saves the copy
+  virtual void publish_bytes(const std::string& topic, const std::string& type, const uint8_t* cdr, size_t n) {
+    publish(topic, type, std::vector<uint8_t>(cdr, cdr + n));
+  }
 };
 
 class laserMapping {
@@ -67,7 +72,9 @@ class laserMapping {
 
   LidarSLAM slam;
   PredictionSource prediction_source = PredictionSource::IMU_ORIENTATION;
-  double phase_seconds[5] = {0, 0, 0, 0, 0};  // accumulated wall time: extract, initial guess, adjustVoxelSize, Localization, publish
+  // accumulated wall time: extract, initial guess, adjustVoxelSize, Localization, publish; then, inside publish: the map clouds (every 5th /
+  // 20th frame), the registered scan, everything that went through the outbox (serialisation + the bridge's own time)
+  double phase_seconds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int frames_failed = 0;           // frames whose processing threw (process() logs and continues, :788-790)
   std::string last_error;
 
@@ -91,8 +98,13 @@ class laserMapping {
   void updatePoseAndPublish();
   void publishTopic();
   template <typename M> void publish(const std::string& topic, const char* type, const M& m) {
-    if (out_) out_->publish(topic, type, so_wire::serialize(m));
+    if (!out_) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    out_->publish(topic, type, so_wire::serialize(m));
+    phase_seconds[7] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
+  // laser_cloud_map / laser_cloud_surround: the map cloud gathered by the device straight into the message (so_icp_map_export_records)
+  void publishMapCloud(const std::string& topic, bool only_5x5, const so_wire::Time& stamp);
 
   NodeConfig config_;
   Outbox* out_;

@@ -46,6 +46,13 @@ PointCloud<Point> LocalMapFacade::export_points(int only_5x5, const int pos[3]) 
   for (size_t i = 0; i < n; ++i) { out.points[i].x = xyz[3 * i]; out.points[i].y = xyz[3 * i + 1]; out.points[i].z = xyz[3 * i + 2]; }
   return out;
 }
+size_t LocalMapFacade::exportRecords(void* out, size_t cap_points, bool only_5x5, const Vector3i& p) {
+  if (!*ctx_) return 0;
+  const int pos[3] = {p.x(), p.y(), p.z()};
+  size_t n = 0;
+  if (so_icp_map_export_records(*ctx_, out, sizeof(Point), cap_points, &n, only_5x5 ? 1 : 0, pos) < 0) throw std::runtime_error(so_icp_last_error(*ctx_));
+  return n;
+}
 PointCloud<Point> LocalMapFacade::get5x5LocalMap(const Vector3i& p) { const int pos[3] = {p.x(), p.y(), p.z()}; return export_points(1, pos); }
 PointCloud<Point> LocalMapFacade::getAllLocalMap() { const int pos[3] = {0, 0, 0}; return export_points(0, pos); }
 
@@ -128,6 +135,21 @@ size_t LidarSLAM::TransformCloud(void* points, size_t n, size_t stride_bytes, co
   if (so_icp_transform_cloud(gpu_, points, n, stride_bytes, Tw, keep.data(), &kept) < 0)
     throw std::runtime_error(std::string("so_icp_transform_cloud: ") + so_icp_last_error(gpu_));
   return kept;
+}
+
+uint8_t* LidarSLAM::PinnedScratch(int which, size_t bytes) {
+  ensure_context();
+  if ((size_t)which >= scratch_.size()) scratch_.resize((size_t)which + 1);
+  Scratch& sc = scratch_[(size_t)which];
+  if (sc.cap < bytes) {
+    if (sc.p) so_icp_host_free(gpu_, sc.p);
+    sc.p = nullptr; sc.cap = 0;
+    void* p = nullptr;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (so_icp_host_alloc(gpu_, want, &p) < 0) throw std::runtime_error(std::string("so_icp_host_alloc: ") + so_icp_last_error(gpu_));
+    sc.p = static_cast<uint8_t*>(p); sc.cap = want;
+  }
+  return sc.p;
 }
 
 void LidarSLAM::LocalizationPrefiltered(bool initialization, PredictionSource, Transformd position, const void* d_planner_xyz, size_t n_planner,

@@ -46,6 +46,9 @@ class LocalMapFacade {
   void addSurfPointCloud(const PointCloud<Point>& cloud);               // LocalMap.h:591 (localization mode: prior map)
   PointCloud<Point> get5x5LocalMap(const Vector3i& pos_in_localmap);    // LocalMap.h:646-688
   PointCloud<Point> getAllLocalMap();
+  // the same clouds as pcl::PointXYZI records written where the caller says -- the payload area of the PointCloud2 message being assembled
+  // (so_icp_map_export_records: one gather on the device, one copy); out == nullptr: the number of points
+  size_t exportRecords(void* out, size_t cap_points, bool only_5x5, const Vector3i& pos_in_localmap);
  private:
   friend class LidarSLAM;
   PointCloud<Point> export_points(int only_5x5, const int pos[3]);
@@ -80,6 +83,9 @@ class LidarSLAM {
   // utils::pointAssociateToMap over a cloud (the registered scan of laserMapping::publishTopic, laserMapping.cpp:464-493) on the
   // device: records with float x y z at 0 4 8 rewritten in place, keep[i] = the node publishes point i
   size_t TransformCloud(void* points, size_t n, size_t stride_bytes, const Transformd& T, std::vector<uint8_t>& keep);
+  // A message buffer of at least `bytes` in pinned host memory (so_icp_host_alloc): copies between it and the device are DMA transfers.
+  // One buffer per `which` (0, 1, ...), grown on demand, valid until the next call with the same index or the context's end.
+  uint8_t* PinnedScratch(int which, size_t bytes);
   void LocalizationPrefiltered(bool initialization, PredictionSource predictodom, Transformd T_w_lidar_in, const void* d_planner_xyz,
                                size_t n_planner, int32_t n_edge_points, double timeLaserOdometry);
 
@@ -109,6 +115,8 @@ class LidarSLAM {
   void push_knobs();
   void read_back(int32_t n_edge_points, const double T_out[7], double timeLaserOdometry);
   so_icp_ctx* gpu_ = nullptr;
+  struct Scratch { uint8_t* p = nullptr; size_t cap = 0; };
+  std::vector<Scratch> scratch_;
 };
 
 }  // namespace super_odometry_soicp

@@ -25,7 +25,10 @@ struct Recorder : Outbox {
   FILE* f = nullptr;
   uint32_t frame = 0;
   void publish(const std::string& topic, const std::string& type, std::vector<uint8_t>&& cdr) override {
-    wr<uint32_t>(f, frame); wr_blob(f, topic.data(), topic.size()); wr_blob(f, type.data(), type.size()); wr_blob(f, cdr.data(), cdr.size());
+    publish_bytes(topic, type, cdr.data(), cdr.size());
+  }
+  void publish_bytes(const std::string& topic, const std::string& type, const uint8_t* cdr, size_t n) override {  // (a bridge that sends from a pointer)
+    wr<uint32_t>(f, frame); wr_blob(f, topic.data(), topic.size()); wr_blob(f, type.data(), type.size()); wr_blob(f, cdr, n);
   }
 };
 
@@ -78,9 +81,10 @@ int main(int argc, char** argv) {
     }
     if (n_msgs > 1) {
       fprintf(stderr, "node_driver: %d frames, %.3f ms per frame (deserialise + guess + prefilter + Localization + publish)", n_msgs - 1, 1e3 * busy / (n_msgs - 1));
-      const char* names[5] = {"extract", "guess", "adjustVoxelSize", "Localization", "publish"};
+      const char* names[8] = {"extract", "guess", "adjustVoxelSize", "Localization", "publish", "[publish: map clouds", "registered scan", "outbox (serialise + bridge)"};
       fprintf(stderr, " | of which");
-      for (int k = 0; k < 5; ++k) fprintf(stderr, " %s %.3f", names[k], 1e3 * node.phase_seconds[k] / (n_msgs - 1));
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.3f", names[k], 1e3 * node.phase_seconds[k] / (n_msgs - 1));
+      fprintf(stderr, "]");
       fprintf(stderr, "\n");
     }
     wr<uint32_t>(rec.f, 0xFFFFFFFFu); wr<int32_t>(rec.f, node.frames_failed); wr_blob(rec.f, node.last_error.data(), node.last_error.size());

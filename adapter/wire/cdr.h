@@ -211,6 +211,18 @@ inline void get(CdrReader& r, LaserFeature& m) {
 }
 
 template <typename M> std::vector<uint8_t> serialize(const M& m) { CdrWriter w; put(w, m); return w.take(); }
+// A PointCloud2 whose payload is produced IN PLACE (a device copy lands in the message, no intermediate cloud): the serialised message of
+// `meta` (data empty, width / row_step already those of the final message) up to and including the length word of `data`, for a payload
+// of payload_bytes.  The caller writes the payload behind it and one more byte: is_dense.  (put(PointCloud2) above ends with
+// [uint32 length][bytes][bool]: bytes need no alignment, the bool none either.)
+inline std::vector<uint8_t> cloud_prefix(const PointCloud2& meta, size_t payload_bytes) {
+  if (!meta.data.empty()) throw std::runtime_error("cloud_prefix: the meta message must not carry a payload");
+  std::vector<uint8_t> b = serialize(meta);
+  b.pop_back();  // is_dense
+  const uint32_t len = (uint32_t)payload_bytes;
+  std::memcpy(b.data() + b.size() - 4, &len, 4);
+  return b;
+}
 template <typename M> M deserialize(const uint8_t* p, size_t n) { CdrReader r(p, n); M m; get(r, m); return m; }
 template <typename M> M deserialize(const std::vector<uint8_t>& b) { return deserialize<M>(b.data(), b.size()); }
 

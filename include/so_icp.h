@@ -208,6 +208,11 @@ int so_icp_map_add_surf(so_icp_ctx *ctx, const float *xyz, size_t n, size_t stri
 int so_icp_map_count_5x5(so_icp_ctx *ctx, const int pos[3], int *n_edge, int *n_surf);  /* get5x5LocalMapFeatureSize, LM.h:292-318 */
 /* getAllLocalMap / get5x5LocalMap (LM.h:646-688): points in the canonical (device) order */
 int so_icp_map_export(so_icp_ctx *ctx, float *xyz, size_t cap_points, size_t *n_out, int only_5x5, const int pos[3]);
+/* The same points as RECORDS of stride_bytes (float x, y, z first, the remaining bytes zero -- stride 32: pcl::PointXYZI with intensity 0,
+ * what pcl::toROSMsg puts into the laser_cloud_map / laser_cloud_surround messages, lmap.cpp:437-462), written straight to `out`: the
+ * payload area of the message being assembled.  One gather, one copy (DMA when `out` lies in so_icp_host_alloc / _register memory), one
+ * synchronisation -- so_icp_map_export makes a round trip per occupied cube.  out == NULL (or more points than cap_points): the count only. */
+int so_icp_map_export_records(so_icp_ctx *ctx, void *out, size_t stride_bytes, size_t cap_points, size_t *n_out, int only_5x5, const int pos[3]);
 int so_icp_map_size(so_icp_ctx *ctx, size_t *n_points, size_t *n_points_this_rank);
 int so_icp_map_clear(so_icp_ctx *ctx);
 int so_icp_map_get_origin(so_icp_ctx *ctx, int origin_out[3]);

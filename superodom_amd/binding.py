@@ -95,7 +95,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
             "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram",
             "so_icp_host_register", "so_icp_host_unregister", "so_icp_host_alloc", "so_icp_host_free", "so_icp_device_count", "so_icp_stage_cancel",
-            "so_icp_map_insert_stats", "so_icp_register_sequence"]
+            "so_icp_map_insert_stats", "so_icp_register_sequence", "so_icp_map_export_records"]
 
 _lib = None
 
@@ -124,6 +124,7 @@ def load():
     L.so_icp_map_count_5x5.argtypes = [vp, i32p, i32p, i32p]
     L.so_icp_map_export.argtypes = [vp, f32p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, i32p]
     L.so_icp_map_size.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.so_icp_map_export_records.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.c_int, i32p]
     L.so_icp_map_clear.argtypes = [vp]
     L.so_icp_map_insert_stats.argtypes = [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     L.so_icp_map_get_origin.argtypes = [vp, i32p]
@@ -266,6 +267,18 @@ class LidarSlamGpu:
         self._check(self.L.so_icp_map_export(self.h, _p(out, C.c_float), n, C.byref(m), int(only_5x5),
                                              None if posa is None else _p(posa, C.c_int32)))
         return out[:m.value].copy()
+
+    def export_map_records(self, stride=32, only_5x5=False, pos=None, out=None):
+        """so_icp_map_export_records: the map as records of `stride` bytes (x, y, z floats first, rest zero) -> uint8 array (n, stride)"""
+        posa = None if pos is None else np.ascontiguousarray(pos, dtype=np.int32)
+        pp = None if posa is None else _p(posa, C.c_int32)
+        m = C.c_size_t()
+        self._check(self.L.so_icp_map_export_records(self.h, None, stride, 0, C.byref(m), int(only_5x5), pp))
+        n = m.value
+        buf = out if out is not None else np.zeros((max(n, 1), stride), np.uint8)
+        assert buf.nbytes >= n * stride
+        self._check(self.L.so_icp_map_export_records(self.h, buf.ctypes.data_as(C.c_void_p), stride, n, C.byref(m), int(only_5x5), pp))
+        return buf.reshape(-1)[:m.value * stride].reshape(m.value, stride)
 
     def clear_map(self):
         self._check(self.L.so_icp_map_clear(self.h))

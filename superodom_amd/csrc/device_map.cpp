@@ -770,4 +770,37 @@ size_t DeviceMap::export_points(float* xyz, size_t cap, bool only_5x5, const int
   return n;
 }
 
+size_t DeviceMap::export_records(void* out, size_t stride, size_t cap, bool only_5x5, const int pos[3], std::string& err) {
+  if (settle(err) < 0) return 0;
+  std::vector<std::pair<int, uint32_t>> todo;  // (slot, count) in ascending cube index: the order of export_points
+  size_t n = 0;
+  for (int cube = 0; cube < kMapNum; ++cube) {
+    const int s = cube_slot_[cube];
+    if (s < 0 || slot_count_[s] == 0) continue;
+    if (only_5x5) {
+      const int ci = cube % kMapW, cj = (cube / kMapW) % kMapH, ck = cube / (kMapW * kMapH);
+      if (std::abs(ci - pos[0]) > 2 || std::abs(cj - pos[1]) > 2 || std::abs(ck - pos[2]) > 1) continue;
+    }
+    todo.emplace_back(s, slot_count_[s]);
+    n += slot_count_[s];
+  }
+  if (!out || n > cap || !n) return n;
+  const size_t words = n * (stride / 4);
+  if (words > stage_cap_) {  // (the staging buffer of export_points, counted in 32-bit words)
+    if (d_stage_) (void)hipFree(d_stage_);
+    d_stage_ = nullptr; stage_cap_ = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&d_stage_), (words + 1024) * sizeof(float)) != hipSuccess) { err = "DeviceMap: export staging alloc failed"; return 0; }
+    stage_cap_ = words + 1024;
+  }
+  size_t at = 0;
+  for (const auto& sc : todo) {
+    launch_gather_export_records(d_pool_, kCapPerSlot, (uint32_t)sc.first, sc.second, reinterpret_cast<uint32_t*>(d_stage_) + at * (stride / 4), (uint32_t)(stride / 4), stream_);
+    at += sc.second;
+  }
+  if (hipMemcpyAsync(out, d_stage_, n * stride, hipMemcpyDeviceToHost, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess) {
+    err = "DeviceMap: export copy failed"; return 0;
+  }
+  return n;
+}
+
 }  // namespace soicp

@@ -67,6 +67,9 @@ class DeviceMap {
   // (inserts laid out by the device / of those, the ones the host had to repeat round by round)
   void fast_stats(unsigned& inserts, unsigned& fallbacks) const { inserts = fast_inserts_; fallbacks = fast_fallbacks_; }
   size_t export_points(float* xyz, size_t cap, bool only_5x5, const int pos[3], std::string& err);
+  // the same points as records of `stride` bytes (x, y, z floats first, the rest zero), every cube gathered into ONE staging buffer, ONE
+  // copy to `out` (pinned memory: by DMA), ONE synchronisation; out == nullptr: the count only
+  size_t export_records(void* out, size_t stride, size_t cap, bool only_5x5, const int pos[3], std::string& err);
   int view(DevMapView& v, std::string& err);  // refreshes the device cube_slot table when the bookkeeping changed; 0, -1 (a cube is full), -2 (device error)
   // leaf keys hold 9 or 10 bits per axis (50 / planeRes + 4 leaves per cube axis must fit): planeRes >= 0.05
   bool supported_resolution(float plane_res) const { return plane_res >= 0.0499f; }

@@ -199,6 +199,7 @@ struct so_icp_ctx {
   DevBuf pf_in, pf_out, pf_small, pf_w, pf_s, pf_k0, pf_k1, pf_v0, pf_v1, pf_flags, pf_pos, pf_heads, pf_temp;  // so_icp_prefilter_scan
   DevBuf pf_dec;                      // {counters[16], VgDecision, partial statistics}: the pre-filter decided on the device
   VgDecision* h_pf = nullptr;         // pinned read-back of the decision
+  uint32_t* h_pf_kept = nullptr;      // pinned: so_icp_transform_cloud's count of kept points
   size_t pf_temp_for = 0, pf_temp_need = 0;  // map_sort_temp_bytes(pf_temp_for) == pf_temp_need (the query costs two library calls)
   bool pf_fast = true;                // SOICP_PREFILTER_FAST=0: statistics read back, decided on the host, then the filter (rounds 1-3)
   hipEvent_t ev_upload = nullptr;     // a scan uploaded through the auxiliary queue: the context's queue waits for it
@@ -1497,6 +1498,7 @@ so_icp_ctx::~so_icp_ctx() {
   if (h_sums) (void)hipHostFree(h_sums);
   if (h_u32) (void)hipHostFree(h_u32);
   if (h_pf) (void)hipHostFree(h_pf);
+  if (h_pf_kept) (void)hipHostFree(h_pf_kept);
   for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
   dmap.reset();  // (waits for a deferred insert on `stream`)
   if (pf_stream) { (void)hipStreamSynchronize(pf_stream); (void)hipStreamDestroy(pf_stream); }
@@ -1708,6 +1710,28 @@ int so_icp_map_export(so_icp_ctx* c, float* xyz, size_t cap, size_t* n_out, int 
   if (c->dmap) HIP_TRY(c, hipSetDevice(c->cfg.device_id));
   const size_t n = c->dmap ? c->dmap->export_points(xyz, cap, only_5x5 != 0, pos ? pos : zero, c->err)
                            : c->map.export_points(xyz, cap, only_5x5 != 0, pos ? pos : zero);
+  if (n_out) *n_out = n;
+  return SO_ICP_OK;
+}
+int so_icp_map_export_records(so_icp_ctx* c, void* out, size_t stride_bytes, size_t cap, size_t* n_out, int only_5x5, const int pos[3]) {
+  if (!c || (only_5x5 && !pos)) return SO_ICP_E_INVALID;
+  if (stride_bytes < 12 || stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "records: float x y z at 0 4 8, stride a multiple of 4");
+  const int zero[3] = {0, 0, 0};
+  size_t n = 0;
+  if (c->dmap) {
+    HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+    c->err.clear();
+    n = c->dmap->export_records(out, stride_bytes, cap, only_5x5 != 0, pos ? pos : zero, c->err);
+    if (!c->err.empty()) return SO_ICP_E_HIP;
+  } else {  // host-side map (sharded ranks, host-only contexts): through the packed export
+    n = c->map.export_points(nullptr, 0, only_5x5 != 0, pos ? pos : zero);
+    if (out && n <= cap && n) {
+      std::vector<float> xyz(3 * n);
+      c->map.export_points(xyz.data(), n, only_5x5 != 0, pos ? pos : zero);
+      std::memset(out, 0, n * stride_bytes);
+      for (size_t i = 0; i < n; ++i) std::memcpy(static_cast<char*>(out) + i * stride_bytes, &xyz[3 * i], 12);
+    }
+  }
   if (n_out) *n_out = n;
   return SO_ICP_OK;
 }
@@ -2572,15 +2596,22 @@ int so_icp_transform_cloud(so_icp_ctx* c, void* points, size_t n, size_t stride,
   HIP_TRY(c, c->pf_in.reserve(n * stride + 64));
   HIP_TRY(c, c->pf_flags.reserve(n + 64));
   HIP_TRY(c, c->pf_small.reserve(256));
+  if (!c->h_pf_kept) HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_pf_kept), 64));
   HIP_TRY(c, hipMemcpyAsync(c->pf_in.p, points, n * stride, hipMemcpyHostToDevice, s));
   HIP_TRY(c, hipMemsetAsync(c->pf_small.p, 0, 8, s));
   launch_transform_cloud(c->pf_in.as<uint8_t>(), (uint32_t)n, (uint32_t)stride, pose_from_array(T), c->pf_flags.as<uint8_t>(), c->pf_small.as<uint32_t>(), s);
   HIP_TRY(c, hipGetLastError());
-  uint32_t kept = 0;
+  // the records and the count first (the count through a pinned word: a copy to pageable memory is staged and synchronised by the
+  // runtime); the flags only when a point was dropped -- points within 0.1 m of the world origin, next to never (lmap.cpp:476) --: a
+  // caller's std::vector of flags is pageable memory, and its copy cost as much as the records'
   HIP_TRY(c, hipMemcpyAsync(points, c->pf_in.p, n * stride, hipMemcpyDeviceToHost, s));
-  HIP_TRY(c, hipMemcpyAsync(&kept, c->pf_small.p, 4, hipMemcpyDeviceToHost, s));
-  if (keep) HIP_TRY(c, hipMemcpyAsync(keep, c->pf_flags.p, n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipMemcpyAsync(c->h_pf_kept, c->pf_small.p, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
+  const uint32_t kept = *c->h_pf_kept;
+  if (keep) {
+    if (kept == (uint32_t)n) std::memset(keep, 1, n);
+    else { HIP_TRY(c, hipMemcpyAsync(keep, c->pf_flags.p, n, hipMemcpyDeviceToHost, s)); HIP_TRY(c, hipStreamSynchronize(s)); }
+  }
   if (n_kept) *n_kept = kept;
   return SO_ICP_OK;
 }

@@ -150,6 +150,7 @@ void launch_map_retable(const MapInsertArgs& a, hipStream_t s);  // resolution c
 void launch_shard_select(const float* d_xyz, uint32_t n, const MapTouched& tt, float inv_leaf, int nc, double inv_cell, int rank, int world,
                          float4* pool_slot, uint32_t cap, uint32_t* d_counters, hipStream_t s);
 void launch_gather_export(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, float* d_out, hipStream_t s);
+void launch_gather_export_records(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, uint32_t* d_out_words, uint32_t stride_words, hipStream_t s);
 // pointAssociateToMap over a cloud (registered scan of the node): records rewritten in place, keep flags, number kept
 void launch_transform_cloud(uint8_t* d_pts, uint32_t n, uint32_t stride, const Pose& pose, uint8_t* d_keep, uint32_t* d_n_kept /* zeroed */, hipStream_t s);
 // removePointDistortion: records of `stride` bytes (float x y z at 0 4 8, float time at time_off), rewritten in place

@@ -942,6 +942,21 @@ __global__ __launch_bounds__(256) void gather_export_kernel(const float4* __rest
   out_xyz[3 * i] = p.x; out_xyz[3 * i + 1] = p.y; out_xyz[3 * i + 2] = p.z;
 }
 
+// the same gather into RECORDS of stride_words 32-bit words -- float x, y, z at words 0..2, the rest zero (pcl::PointXYZI: 8 words, intensity 0):
+// the payload of a sensor_msgs/PointCloud2 as the node publishes its map clouds (laserMapping.cpp:437-462), written where the message is
+__global__ __launch_bounds__(256) void gather_export_records_kernel(const float4* __restrict__ pool, uint32_t cap, uint32_t slot, uint32_t count,
+                                                                    uint32_t* __restrict__ out_words, uint32_t stride_words) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per output WORD: coalesced stores whatever the record size
+  const uint32_t i = t / stride_words, w = t - i * stride_words;
+  if (i >= count) return;
+  uint32_t v = 0u;
+  if (w < 3u) {
+    const float4 p = pool[(size_t)slot * cap + i];
+    v = __float_as_uint(w == 0u ? p.x : (w == 1u ? p.y : p.z));
+  }
+  out_words[t] = v;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
@@ -1148,13 +1163,18 @@ __global__ __launch_bounds__(1024) void insert_front_kernel(const float* __restr
   // The last workgroup to get here lays out the round.  All it takes from the others are the per-cube counters and the list
   // of touched cubes, which are only ever touched by device-scope atomics (read-modify-write here, atomic loads below) whose
   // results are consumed: they have been performed when their thread reaches the barrier, and the ticket is taken behind
-  // the barrier.  No fence: a release fence in every wavefront writes the L2 back 2 048 times (measured: 40 us); cube_of and
-  // the world points are read by later launches only.
+  // the barrier -- with release semantics (below); cube_of and the world points are read by later launches only.
   if (threadIdx.x < kTally && s_tkey[threadIdx.x] >= 0) front_count(b, s_tkey[threadIdx.x], s_tval[threadIdx.x]);
   __syncthreads();
-  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(b.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+  // Round 6: the hand-off as the HIP memory model wants it -- every workgroup RELEASES with its ticket, the last one ACQUIRES.  Rounds 4 - 5
+  // ran it with relaxed operations only (sound on gfx950, where a device-scope read-modify-write whose result is consumed has been
+  // performed before its thread goes on, but outside the model); measured on the 131 072-point insert (128 workgroups, one release each):
+  // Localization() 0.266 - 0.270 -> 0.269 - 0.278 ms per frame, node order 0.321 - 0.332 -> 0.330 - 0.337 (profiles/r06/ab_front_release_acquire.txt).
+  // (A release in every WAVEFRONT -- 2 048 L2 write-backs -- was 40 us: the tally above is per workgroup for that reason too.)
+  if (threadIdx.x == 0) last = __hip_atomic_fetch_add(b.ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
   __syncthreads();
   if (!last) return;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   if (threadIdx.x < 64) {
     const uint32_t n_t = __hip_atomic_load(b.touched_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t h = n_t > (uint32_t)b.per_round ? (uint32_t)kFastHaltMultiRound : 0u;  // (per_round <= kMaxTouched < kTouchedCap)
@@ -1822,6 +1842,11 @@ void launch_transform_cloud(uint8_t* d_pts, uint32_t n, uint32_t stride, const P
   hipLaunchKernelGGL(transform_cloud_kernel, grid_for(n, 256), dim3(256), 0, s, d_pts, n, stride, pose, d_keep, d_n_kept);
 }
 
+void launch_gather_export_records(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, uint32_t* d_out_words, uint32_t stride_words, hipStream_t s) {
+  if (!count) return;
+  const uint64_t words = (uint64_t)count * stride_words;
+  hipLaunchKernelGGL(gather_export_records_kernel, dim3((uint32_t)((words + 255u) / 256u)), dim3(256), 0, s, pool, cap, slot, count, d_out_words, stride_words);
+}
 void launch_gather_export(const float4* pool, uint32_t cap, uint32_t slot, uint32_t count, float* d_out, hipStream_t s) {
   if (!count) return;
   hipLaunchKernelGGL(gather_export_kernel, grid_for(count, 256), dim3(256), 0, s, pool, cap, slot, count, d_out);

@@ -440,3 +440,31 @@ def test_front_kernel_hand_off_with_every_workgroup_touching_every_cube(gpu_slam
     for k, (a, b) in enumerate(zip(*exports)):
         assert np.array_equal(a, b), f"export {k}: device-built and host-built rounds left different maps"
     assert stats[0][0] >= 35 and stats[1] == (0, 0), stats  # (the first insert creates the cubes' slots on the host; the rest are laid out by the device)
+
+
+def test_map_export_as_records_equals_the_packed_export(gpu_slam_factory):
+    """so_icp_map_export_records (round 6): the map clouds the node publishes (getAllLocalMap / get5x5LocalMap, LM.h:646-688 -> pcl::toROSMsg,
+    lmap.cpp:437-462) written as pcl::PointXYZI records where the message is assembled -- the same points in the same order as
+    so_icp_map_export, x y z in the first three floats, every other byte zero; into pageable and into pinned memory; 5x5 subset; other strides."""
+    sc = synth.Scene("small")
+    slam = gpu_slam_factory(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=3)
+    slam.add_surf_point_cloud(sc.map_points)
+    slam.shift_map(sc.gt_pose(0)[:3])
+    xyz = slam.export_map()
+    assert len(xyz) > 10000
+    for stride in (32, 12, 16):
+        rec = slam.export_map_records(stride)
+        assert rec.shape == (len(xyz), stride)
+        f = np.ascontiguousarray(rec).view(np.float32).reshape(len(xyz), stride // 4)
+        assert np.array_equal(f[:, :3], xyz)
+        assert not rec[:, 12:].any()
+    pinned = slam.host_alloc_like(np.zeros((len(xyz) + 3, 32), np.uint8))
+    pinned[...] = 0xAB
+    rec = slam.export_map_records(32, out=pinned)
+    assert np.array_equal(np.ascontiguousarray(rec).view(np.float32).reshape(-1, 8)[:, :3], xyz)
+    assert (pinned[len(xyz):] == 0xAB).all(), "nothing is written behind the last record"
+    pos = [10, 10, 5]
+    sub = slam.export_map(only_5x5=True, pos=pos)
+    rec5 = slam.export_map_records(32, only_5x5=True, pos=pos)
+    assert len(sub) > 0 and np.array_equal(np.ascontiguousarray(rec5).view(np.float32).reshape(-1, 8)[:, :3], sub)
+    slam.close()

@@ -54,7 +54,7 @@ def main():
           f"(table upload + kernel + counter read-back), CPU restatement 1 core {cpu_ms:.1f} ms")
 
     sc = synth.Scene("small")
-    n_frames = 24
+    n_frames = int(os.environ.get("F4_FRAMES", "24"))
     with tempfile.TemporaryDirectory() as tmp:
         fin, fout = os.path.join(tmp, "bag.bin"), os.path.join(tmp, "out.bin")
         with open(fin, "wb") as f:
@@ -72,7 +72,7 @@ def main():
                 m["cloud_realsense"] = cdr_py.cloud_msg(np.zeros((0, 3)), stamp=stamp)
                 raw = cdr_py.encode("LaserFeature", m)
                 f.write(struct.pack("<I", len(raw))); f.write(raw)
-        r = subprocess.run([os.path.join(ROOT, "adapter", "node_driver"), fin, fout], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([os.path.join(ROOT, "adapter", os.environ.get("F4_DRIVER", "node_driver")), fin, fout], capture_output=True, text=True, timeout=600)
         print(f"node shell, scene small ({len(scan)} surf points per frame, full-resolution cloud of the same size): {r.stderr.strip()} rc={r.returncode}")
 
 
