@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="os1_128_2m")
     ap.add_argument("--scans", type=int, default=4, help="distinct synthetic scans cycled through the steps")
-    ap.add_argument("--entry", default="staged", choices=["staged", "host", "resident"],
+    ap.add_argument("--entry", default="auto", choices=["auto", "chained", "staged", "host", "resident"],
                     help="entry point of the TIMED loop: staged = so_icp_register with the next scan announced by so_icp_stage_scan "
                          "(default, PCIe inside the clock, overlapped); host = so_icp_register alone (copy, then register); "
                          "resident = so_icp_register_dev on scans uploaded before the clock (profiling runs)")
@@ -259,12 +259,55 @@ def main():
         return float(tt.item())
 
     g64 = [np.ascontiguousarray(g, dtype=np.float64) for g in guesses]
+    if args.entry == "auto":
+        # N = 1: the K timed steps are ONE so_icp_register_sequence call (round 6) -- the stream entry: guesses chained on the device, no host
+        # turn-around between registrations; every copy and binning launch inside the clock.  N > 1: the staged loop of single calls (r05).
+        args.entry = "chained" if (world == 1 and args.scans >= 2) else "staged"
+    # the chained entry's motion predictions: delta_k = gt(k-1)^-1 o guesses[k] -- an odometry source that lands where the independent
+    # guesses of the other entries are, up to the millimetres by which registration k - 1 ends off its ground truth
+    def seq_args(steps):
+        S_ = args.scans
+        d_ = np.zeros((steps, 7)); d_[:, 6] = 1.0
+        for k in range(1, steps):
+            d_[k] = synth.pose_between(sc.gt_pose((k - 1) % S_), guesses[k % S_])
+        return [scans[k % S_] for k in range(steps)], d_
+    step_guess = {}  # timed step -> the guess it started from (chained: formed on the device), for the oracle's parity check
 
     def timed_loop(entry, steps, rewarm=0, slam=slam, protocol=None):
         """`steps` registrations through one entry point, only C calls between the two clock reads (arguments pre-built).
         rewarm: untimed registrations run right before the clock starts, after the argument lists are built -- the W warm-up
         steps of the contract leave the device idle for the milliseconds Python needs to build them, and the first
         registrations after an idle period run on a device that is still raising its clocks."""
+        if entry == "chained":
+            seq_scans, seq_d = seq_args(steps)
+            call, seq_out, seq_g, seq_st, seq_n, _keep = slam.prepare_register_sequence(seq_scans, g64[0], seq_d)
+            steady = (protocol or args.stage_protocol) == "steady"
+            if steady and rewarm >= 2:
+                # Steady state of a stream worked off in calls of K scans: the scan that starts a call was copied and binned beside the last
+                # registration of the call before (so_icp_sequence_announce_next) -- here: of the untimed warm-up call --, and the timed call
+                # does the same for the scan behind its own last one: K copies and K binnings inside the clock, like the staged entry's steady
+                # protocol.  (`--stage-protocol cold`: nothing announced; the first scan's copy and binning are inside, hidden by nothing.)
+                ws, wd = seq_args(rewarm)
+                slam.sequence_announce_next(seq_scans[0], synth.pose_between(sc.gt_pose((rewarm - 1) % args.scans), guesses[0]))
+                assert slam.register_sequence(ws, g64[0], wd)[0] == 0, slam.last_error()
+                slam.sequence_announce_next(scans[steps % args.scans], synth.pose_between(sc.gt_pose((steps - 1) % args.scans), guesses[steps % args.scans]))
+            else:
+                for w in range(rewarm):  # (untimed registrations right before the clock: see below)
+                    i = w % args.scans
+                    slam.register(scans[i], guesses[i])
+            barrier()
+            t0 = time.perf_counter()
+            rc_ = call()
+            slam.synchronize()
+            t_local = time.perf_counter() - t0
+            slam.sequence_announce_next(None, None)  # (withdraws the copy staged for the call after the clock)
+            if dist is not None:
+                dist.barrier()
+            assert rc_ == 0 and seq_n.value == steps, (entry, rc_, seq_n.value, slam.last_error())
+            if not step_guess:  # (the headline's timed loop is the first one through here)
+                for k in range(steps):
+                    step_guess[k] = np.array(seq_g[k])
+            return max_over_ranks(t_local), list(seq_st), [np.array(seq_out[k]) for k in range(steps)]
         stats = [binding.Stats() for _ in range(steps)]
         pose = [np.zeros(7) for _ in range(steps)]
         if entry == "resident":
@@ -332,6 +375,10 @@ def main():
     st = binding.Stats()
 
     def warm():
+        if args.entry == "chained":  # (the sequence entry allocates its scan slots and work lists on first use)
+            ws, wd = seq_args(max(2, min(args.warmup, 8)))
+            assert slam.register_sequence(ws, g64[0], wd)[0] == 0, slam.last_error()
+            return
         for w in range(args.warmup):  # untimed: the entry point of the timed loop, every scan of the rotation at least once
             i = w % args.scans
             if args.entry == "resident":
@@ -383,7 +430,18 @@ def main():
             slam.reset_timing()
             t_max, step_stats, step_pose = timed_loop(args.entry, args.steps, rewarm=args.warmup)
     else:
-        t_max, step_stats, step_pose = timed_loop(args.entry, args.steps, rewarm=args.warmup)  # (the W warm-up steps run again, back to back with the clock)
+        entry_fallback = None
+        try:
+            t_max, step_stats, step_pose = timed_loop(args.entry, args.steps, rewarm=args.warmup)  # (the W warm-up steps run again, back to back with the clock)
+        except Exception as e:  # noqa: BLE001 -- the line must be printed: the sequence entry is this round's code, the staged loop is r05's
+            if args.entry != "chained":
+                raise
+            entry_fallback = repr(e)
+            print(f"bench: the chained entry failed in the timed region ({e}); timing the staged loop instead", file=sys.stderr)
+            step_guess.clear()
+            args.entry = "staged"
+            slam.synchronize(); warm(); slam.reset_timing()
+            t_max, step_stats, step_pose = timed_loop(args.entry, args.steps, rewarm=args.warmup)
     tm = slam.timing()
     iters_outer = iters_lm = accepted = 0
     poses, flags = [], 0
@@ -406,13 +464,17 @@ def main():
                 continue
             t_e, _, _ = timed_loop(entry, args.steps, rewarm=args.warmup)
             secondary[entry] = args.steps / t_e
-        if args.entry == "staged" and args.scans >= 2:
+        if args.entry == "chained":
+            other_protocol = "cold" if args.stage_protocol == "steady" else "steady"
+            t_e, _, _ = timed_loop("chained", args.steps, rewarm=args.warmup, protocol=other_protocol)
+            secondary["chained_%s_protocol" % other_protocol] = args.steps / t_e
+        if args.entry in ("staged", "chained") and args.scans >= 2:
             # the staged loop under the OTHER start-of-clock protocol: `value` of r01 - r04 was measured with nothing announced
             # when the clock starts ("cold"), r05 on with the stream crossing the clock start ("steady") -- both are in every line
             other_protocol = "cold" if args.stage_protocol == "steady" else "steady"
             t_e, _, _ = timed_loop("staged", args.steps, rewarm=args.warmup, protocol=other_protocol)
             secondary["staged_%s_protocol" % other_protocol] = args.steps / t_e
-        if world == 1 and args.scans >= 2:
+        if world == 1 and args.scans >= 2 and args.entry != "chained":
             # `steps` registrations as ONE so_icp_register_sequence call (round 6): the guesses chain on the device, guess_k = T_(k-1) o delta_k
             # with delta_k = gt(k-1)^-1 o guesses[k] (an odometry prediction that lands where the headline's guesses are, up to the
             # millimetres registration k - 1 ends from its ground truth), the launches of registration k + 1 are enqueued behind those of k
@@ -914,14 +976,19 @@ def main():
                             "every scan's H2D copy AND its spatial binning (scan_keys -> bin_offsets -> bin_place, enqueued behind the copy on the copy queue) "
                             "are inside the timed region, overlapped with the previous registration",
                   "host": "so_icp_register on HOST scan buffers, copy then register (nothing overlapped)",
-                  "resident": "so_icp_register_dev on scans uploaded BEFORE the timed region"}[args.entry]
+                  "resident": "so_icp_register_dev on scans uploaded BEFORE the timed region",
+                  "chained": "the K steps as ONE so_icp_register_sequence call on HOST scan buffers (the stream entry, round 6): guess_k = T_(k-1) o delta_k formed "
+                             "on the device (laserMapping.cpp:345-372), the launches of registration k + 1 enqueued behind those of k before k has reported, "
+                             "scan k + 1 copied (DMA from pinned caller memory) and binned beside registration k: every H2D copy AND every binning launch inside "
+                             "the timed region; each registration is bit for bit the one so_icp_register runs from the same guess (entry_points.staged = that "
+                             "loop of single calls, the r05 entry)"}[args.entry]
     out = {
         "metric": "icp_registrations_per_sec", "value": value, "unit": "registrations/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: OS1-128 synthetic scan ({Q} pts) vs {n_map}-pt local map, "
                                f"full ICP loop (kNN + plane fit + Jacobian + 6x6 reduce) in HIP; " + entry_text,
-                   "entry": args.entry, "queries": Q, "map_points": int(map_total), "map_points_this_rank": int(map_rank),
+                   "entry": args.entry, "entry_fallback": (entry_fallback if world == 1 else None), "queries": Q, "map_points": int(map_total), "map_points_this_rank": int(map_rank),
                    "max_iterations": max_outer, "lm_iterations": lm_iters, "plane_res": sc.plane_res, "k": 5,
                    "parallelism": ("single GPU" if world == 1 else
                                    (f"map replicated on {world} ranks, the scan's 64-point segments dealt round-robin, " +
@@ -963,10 +1030,13 @@ def main():
                  "fixed_overhead_ms_per_step": ms_per_step - tm.host_ms_total / max(tm.registrations, 1),
                  "stage_wait_ms_per_step": tm.stage_wait_ms_total / max(tm.registrations, 1),
                  "staged_by_dma_from_registered_memory": int(tm.staged_direct), "staged_through_copy_thread": int(tm.staged_copied),
-                 "stage_declined": int(tm.stage_declined), "stage_protocol": (args.stage_protocol if args.entry == "staged" else None),
+                 "stage_declined": int(tm.stage_declined), "stage_protocol": (args.stage_protocol if args.entry in ("staged", "chained") else None),
                  # timed registrations whose scan had been spatially binned behind its DMA, on the copy queue, while the registration before
                  # it ran (so_icp_stats::flags & SO_ICP_FLAG_BINNED_AHEAD; SOICP_PREBIN=0 disables): they start with their k-NN sweep
                  "binned_ahead_timed_steps": int(sum(1 for s_ in step_stats if s_.flags & binding.FLAG_BINNED_AHEAD)),
+                 # timed registrations whose launches were enqueued behind the registration before them, before that one had reported
+                 # (so_icp_register_sequence, SO_ICP_FLAG_CHAINED; SOICP_SEQ_CHAIN=0 disables), and how often a chain broke
+                 "chained_timed_steps": int(sum(1 for s_ in step_stats if s_.flags & binding.FLAG_CHAINED)), "chain_breaks": int(tm.seq_chain_breaks),
                  "scan_buffers": {"pinned": "pinned host memory (so_icp_host_alloc)", "registered": "registered host memory (so_icp_host_register)",
                                   "pageable": "pageable"}[args.scan_buffers],
                  "note": "c_abi = wall time inside the registration core (enqueue + wait + post-processing); stage_wait = host time the registrations "
@@ -1006,7 +1076,7 @@ def main():
         oposes = []
         stats_equal = True  # executed iteration counts, termination codes, 7 + 9 bin histograms of every outer iteration (SURVEY 8d "Parity check")
         for i in range(n_cpu):
-            orc, opose, ost, _ = om.register(scans[i % args.scans], guesses[i % args.scans], cfg_a)
+            orc, opose, ost, _ = om.register(scans[i % args.scans], step_guess.get(i, guesses[i % args.scans]), cfg_a)  # (chained entry: the guess the device formed)
             oposes.append(opose)
             if i < len(poses):
                 e = synth.pose_error(poses[i], opose)

@@ -256,6 +256,12 @@ int so_icp_register(so_icp_ctx *ctx, const float *scan_xyz, size_t n, size_t str
 int so_icp_register_sequence(so_icp_ctx *ctx, int count, const void *const *scans, const size_t *n_points, size_t stride_bytes,
                              int scans_on_device, const double pose0[7], const double *deltas, double *poses_out, double *guesses_out,
                              so_icp_stats *stats, int *n_done);
+/* A backlog worked off in several calls: name the scan that will START the next so_icp_register_sequence call (packed xyz in host memory,
+ * n points) and the motion prediction from the LAST scan of the coming call to it.  That call then copies and bins it beside its last
+ * registration, and the call after it -- whose scans[0] is this very buffer -- starts with its first sweep instead of a copy and a binning
+ * nothing hides (55 us for a 131 072-point scan).  The buffer must stay valid and unchanged until that second call returns; scan == NULL
+ * withdraws the announcement (and waits for a copy already under way).  Results never depend on it. */
+int so_icp_sequence_announce_next(so_icp_ctx *ctx, const float *scan_xyz, size_t n, const double delta[7]);
 /* Announce the NEXT scan: the host buffer travels to HBM on the context's copy stream while the caller goes on (typically:
  * while the previous so_icp_register is still running -- the node's feature callback, lmap.cpp:21-25, has the cloud long
  * before process() reaches it).  Packed xyz (stride 12) inside a buffer pinned with so_icp_host_register is read by DMA

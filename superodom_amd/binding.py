@@ -95,7 +95,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
             "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram",
             "so_icp_host_register", "so_icp_host_unregister", "so_icp_host_alloc", "so_icp_host_free", "so_icp_device_count", "so_icp_stage_cancel",
-            "so_icp_map_insert_stats", "so_icp_register_sequence", "so_icp_map_export_records"]
+            "so_icp_map_insert_stats", "so_icp_register_sequence", "so_icp_map_export_records", "so_icp_sequence_announce_next"]
 
 _lib = None
 
@@ -131,6 +131,7 @@ def load():
     L.so_icp_knn_surf.argtypes = [vp, f32p, C.c_size_t, C.c_int, f32p, f32p, i32p, u8p]
     L.so_icp_register.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, f64p, f64p, C.POINTER(Stats)]
     L.so_icp_register_dev.argtypes = [vp, vp, C.c_size_t, f64p, f64p, C.POINTER(Stats)]
+    L.so_icp_sequence_announce_next.argtypes = [vp, f32p, C.c_size_t, f64p]
     L.so_icp_register_sequence.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, f64p, f64p, f64p, f64p, C.POINTER(Stats), i32p]
     L.so_icp_upload_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.so_icp_free_scan.argtypes = [vp, vp]
@@ -398,6 +399,14 @@ class LidarSlamGpu:
                                                      deltas.ctypes.data_as(_F64P), out.ctypes.data_as(_F64P), guesses.ctypes.data_as(_F64P), st, C.byref(n_done))
         keep = (ptrs, ns, pose0, deltas, scans)
         return (lambda: fn(*args)), out, guesses, st, n_done, keep
+
+    def sequence_announce_next(self, scan, delta):
+        """so_icp_sequence_announce_next: the scan that will start the NEXT register_sequence call (None withdraws)"""
+        if scan is None:
+            self._check(self.L.so_icp_sequence_announce_next(self.h, None, 0, None)); return
+        assert isinstance(scan, np.ndarray) and scan.dtype == np.float32 and scan.flags.c_contiguous
+        d = np.ascontiguousarray(delta, dtype=np.float64)
+        self._check(self.L.so_icp_sequence_announce_next(self.h, _p(scan, C.c_float), len(scan), _p(d, C.c_double)))
 
     def register_sequence(self, scans, pose0, deltas, on_device=False):
         call, out, guesses, st, n_done, _keep = self.prepare_register_sequence(scans, pose0, deltas, on_device)

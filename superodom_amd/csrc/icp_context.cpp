@@ -303,8 +303,13 @@ struct so_icp_ctx {
   hipStream_t seq_stream = nullptr;
   StageSlot seq_slot[kStageSlots];
   DevBuf d_sbin_key, d_sbin_cnt, d_sbin_off; uint32_t sbin_log2 = 0;
-  DevBuf d_seq_flag; uint32_t seq_flag_value = 0;  // "scan in place" word of the sequence's copy / binning queue (MatchParams::begin_flag)
   int seq_depth = 2; uint32_t done_count_seen = 0;
+  // so_icp_sequence_announce_next: the scan that will START the next so_icp_register_sequence call -- copied and binned beside the LAST
+  // registration of the current call (under that registration's guess o delta), adopted by the next call when its scans[0] is this buffer
+  struct SeqNext { const void* next_scan = nullptr; size_t next_n = 0; double delta[7] = {0, 0, 0, 0, 0, 0, 1}; bool announced = false;  // for the coming call to stage
+                   const void* scan = nullptr; size_t n = 0;                                                                             // staged by the last call
+                   bool staged = false; int slot = 0; bool binned = false, needs_event = false; const float* d_scan = nullptr; } seq_next;
+  bool seq_copy_ahead = true;             // SOICP_SEQ_COPY_AHEAD=0: a scan's copy is enqueued with its binning, one registration ahead (experiment switch)
   bool seq_chain = true;                  // SOICP_SEQ_CHAIN=0: so_icp_register_sequence runs one registration after the other (same results)
   bool query_waves = true;                // SOICP_QUERY_WAVES=0: a small scan (<= 4 096 kept queries) is binned and swept in chunks like a large one
   bool knn_pack = true;                   // SOICP_KNN_PACK=0: one chunk per wavefront throughout (round-3 work list)
@@ -504,7 +509,6 @@ MatchParams match_params(float plane_res, int ablate) {
   mp.begin = 0; mp.begin_max_surface_features = -1; mp.begin_n = 0;
   mp.begin_args = RegBeginArgs{};
   mp.begin_ctr = nullptr; mp.begin_state = nullptr;
-  mp.begin_flag = nullptr; mp.begin_flag_want = 0;
   mp.chain_expect = 0;
   return mp;
 }
@@ -1353,7 +1357,7 @@ int register_batch_group(so_icp_ctx* c, const float* d_scan, size_t n, const dou
   hipStream_t s = c->stream;
   for (int h = 0; h < B; ++h) {
     std::memcpy(b.h_begin[h].pose, poses_in + 7 * (size_t)h, 7 * sizeof(double));
-    b.h_begin[h].max_outer = max_outer; b.h_begin[h].lm_max = lm_max;
+    b.h_begin[h].max_outer = max_outer; b.h_begin[h].lm_max = lm_max; b.h_begin[h].chain_expect = 0; b.h_begin[h].pad = 0;  // (a hypothesis starts from its own guess)
     b.h_active[h] = (uint32_t)h;
   }
   HIP_TRY(c, hipMemcpyAsync(b.begin.p, b.h_begin, (size_t)B * sizeof(RegBeginArgs), hipMemcpyHostToDevice, s));
@@ -1475,7 +1479,7 @@ so_icp_ctx::~so_icp_ctx() {
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   if (seq_stream) (void)hipStreamSynchronize(seq_stream);
   for (StageSlot& sl : seq_slot) { sl.dev.release(); for (DevBuf* b : {&sl.pb_keys, &sl.pb_vals, &sl.pb_chunks, &sl.pb_binned, &sl.pb_ctr}) b->release(); if (sl.ev) (void)hipEventDestroy(sl.ev); }
-  for (DevBuf* b : {&d_sbin_key, &d_sbin_cnt, &d_sbin_off, &d_seq_flag}) b->release();
+  for (DevBuf* b : {&d_sbin_key, &d_sbin_cnt, &d_sbin_off}) b->release();
   if (seq_stream) (void)hipStreamDestroy(seq_stream);
   for (StageSlot& sl : stage) { sl.dev.release(); for (DevBuf* b : {&sl.pb_keys, &sl.pb_vals, &sl.pb_chunks, &sl.pb_binned, &sl.pb_ctr}) b->release(); if (sl.pinned) (void)hipHostFree(sl.pinned); if (sl.ev) (void)hipEventDestroy(sl.ev); }
   for (const HostRange& r : host_ranges) { if (r.owned) (void)hipHostFree(const_cast<char*>(r.p)); else (void)hipHostUnregister(const_cast<char*>(r.p)); }
@@ -1611,6 +1615,7 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_QUERY_WAVES")) c->query_waves = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PREBIN")) c->prebin = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_SEQ_CHAIN")) c->seq_chain = std::atoi(ev) != 0;
+  if (const char* ev = std::getenv("SOICP_SEQ_COPY_AHEAD")) c->seq_copy_ahead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BATCH_CHAIN")) c->batch_chain = std::string(ev) != "0";
   if (const char* ev = std::getenv("SOICP_BATCH_MODE")) {  // "one_per_cu": one solve workgroup per compute unit (several processes on one device); "lanes"
     if (std::string(ev) == "one_per_cu") c->batch_degrade = 1;
@@ -1845,7 +1850,10 @@ struct SeqRun {
   const float* d_scan = nullptr; size_t n = 0;
   so_icp_ctx::StageSlot* slot = nullptr;   // host scan (its HBM copy) and / or the work list binned ahead; nullptr: resident scan swept by query waves
   bool query_waves = false, binned = false, enqueued = false, chained = false, needs_event = false;
-  uint32_t flag_value = 0;                  // what the sequence's queue stores into its flag word behind this scan's copy and binning
+  bool copied = false;                      // the H2D copy of this (host) scan is already in the sequence's queue (issued one registration early)
+  bool timed = false;                       // time_kernels 1: this registration's sweeps carry timing events
+  struct KnnEv { int it; hipEvent_t a, b; };
+  std::vector<KnnEv> knn_ev;
   uint32_t chain_expect = 0;
   double guess[7];                          // exact for an unchained start, the host's prediction for a chained one
   int pos[3] = {0, 0, 0}; int count_5x5 = 0;
@@ -1866,6 +1874,21 @@ inline bool cube_stable(const so_icp_ctx* c, const double t[3], double margin) {
 }
 }  // namespace
 
+int so_icp_sequence_announce_next(so_icp_ctx* c, const float* scan, size_t n, const double delta[7]) {
+  if (!c || (scan && !delta)) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  so_icp_ctx::SeqNext& nx = c->seq_next;
+  if (!scan || !n) {  // withdrawn: the announcement, and a copy the last call staged (which must have left its buffer before the caller reuses it)
+    if (nx.staged && c->seq_stream) { HIP_TRY(c, hipSetDevice(c->cfg.device_id)); HIP_TRY(c, hipStreamSynchronize(c->seq_stream)); }
+    nx = so_icp_ctx::SeqNext{};
+    return SO_ICP_OK;
+  }
+  // (what the LAST call staged for the coming call to adopt -- nx.staged and its slot -- stays: this names the scan BEHIND the coming call)
+  nx.next_scan = scan; nx.next_n = n; nx.announced = true;
+  std::memcpy(nx.delta, delta, sizeof(nx.delta));
+  return SO_ICP_OK;
+}
+
 int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans, const size_t* n_points, size_t stride_bytes, int scans_on_device,
                              const double pose0[7], const double* deltas, double* poses_out, double* guesses_out, so_icp_stats* stats, int* n_done) {
   if (n_done) *n_done = 0;
@@ -1877,7 +1900,7 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
   std::vector<so_icp_stats> local_stats;
   if (!stats) { local_stats.resize((size_t)count); stats = local_stats.data(); }
   const bool fast = c->seq_chain && c->dmap && c->cfg.world_size <= 1 && !c->batch_mode && !c->borrow.on && c->persistent_solve && c->direct_readback &&
-                    c->speculate && c->ablate == 0 && c->cfg.time_kernels == 0 && c->cfg.yaw_ratio == 0.0 && !c->comm && !c->group && !c->query_split &&
+                    c->speculate && c->ablate == 0 && c->cfg.time_kernels <= 1 && c->cfg.yaw_ratio == 0.0 && !c->comm && !c->group && !c->query_split &&
                     (scans_on_device || stride_bytes == 12) && count > 1;
   // the pose the chain continues from: the optimised pose of the registration, before MannualYawCorrection (fill_result)
   auto chain_from = [&](int k, double T[7]) {
@@ -1905,10 +1928,9 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
   // ---------------- chained path
   hipStream_t s = c->stream;
   if (!c->seq_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->seq_stream, hipStreamNonBlocking));
-  if (!c->d_seq_flag.p) { HIP_TRY(c, c->d_seq_flag.reserve(64)); HIP_TRY(c, hipMemset(c->d_seq_flag.p, 0, 64)); c->seq_flag_value = 0; }
   struct Drain {  // an early return must not leave copies reading the caller's buffers, nor launches of this call in the queue
     so_icp_ctx* c; bool ok = false;
-    ~Drain() { if (!ok) { (void)hipStreamSynchronize(c->seq_stream); (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); } }
+    ~Drain() { if (!ok) { (void)hipStreamSynchronize(c->seq_stream); (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); c->ev_used = 0; } }
   } drain{c};
   size_t n_max = 0;
   for (int k = 0; k < count; ++k) {
@@ -1923,13 +1945,18 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
   DevState* ds = c->d_state;
   CorrBuffers corr{c->d_nd.as<double4>(), c->d_coeff.as<double>(), c->d_status.as<uint8_t>()};
   std::vector<SeqRun> runs((size_t)count);
+  // scan 0 may already be in HBM with its work list: the call before this one staged it beside its last registration (so_icp_sequence_announce_next)
+  so_icp_ctx::SeqNext adopted = c->seq_next;
+  const bool adopt = adopted.staged && adopted.scan == scans[0] && adopted.n == n_points[0];
+  const int slot_base = adopt ? adopted.slot : 0;
+  c->seq_next.staged = false;
   for (int k = 0; k < count; ++k) {
     SeqRun& r = runs[(size_t)k];
     r.n = n_points[k];
     const size_t kept_upper = (max_sf >= 0 && r.n > (size_t)max_sf) ? (size_t)max_sf + 2 : r.n;
     r.query_waves = c->query_waves && r.n && kept_upper <= kQueryWaveMaxKept;
     r.ring = (k & 1) * 2;
-    if (!scans_on_device || !r.query_waves) r.slot = &c->seq_slot[k % so_icp_ctx::kStageSlots];
+    if (!scans_on_device || !r.query_waves) r.slot = &c->seq_slot[(slot_base + k) % so_icp_ctx::kStageSlots];
   }
   // the scan's way to HBM and its work list, on the sequence's own queue: copy (host scans), scan_keys -> bin_offsets -> bin_place under
   // `pose` (scans swept in chunks), one event.  Slot k % 3: its last user, scan k - 3, was collected before scan k - 1 was enqueued.
@@ -1941,8 +1968,11 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
     so_icp_ctx::StageSlot& sl = *r.slot;
     if (!sl.ev) HIP_TRY(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     if (!scans_on_device) {
-      HIP_TRY(c, sl.dev.reserve((r.n + 64) * 12));
-      HIP_TRY(c, hipMemcpyAsync(sl.dev.p, scans[k], r.n * 12, hipMemcpyHostToDevice, c->seq_stream));
+      if (!r.copied) {
+        HIP_TRY(c, sl.dev.reserve((r.n + 64) * 12));
+        HIP_TRY(c, hipMemcpyAsync(sl.dev.p, scans[k], r.n * 12, hipMemcpyHostToDevice, c->seq_stream));
+        r.copied = true;
+      }
       r.d_scan = sl.dev.as<float>();
       r.needs_event = true;
     }
@@ -1967,11 +1997,21 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
       r.binned = true; r.needs_event = true;
       r.d_binned = sl.pb_binned.as<float4>(); r.d_chunks = sl.pb_chunks.as<uint32_t>();
     }
-    if (r.needs_event) {
-      r.flag_value = ++c->seq_flag_value;
-      launch_stream_flag(c->d_seq_flag.as<uint32_t>(), r.flag_value, c->seq_stream);  // (a chained start waits for this on the device ...)
-      HIP_TRY(c, hipEventRecord(sl.ev, c->seq_stream));                                // (... an ordinary start through the queue)
-    }
+    if (r.needs_event) HIP_TRY(c, hipEventRecord(sl.ev, c->seq_stream));
+    return SO_ICP_OK;
+  };
+  // The copy of a host scan TWO registrations ahead (its slot's last user, scan k - 3, has been collected): the binning of scan k + 1 is then
+  // enqueued with its scan long in HBM and runs beside the FIRST SWEEP of registration k -- hundreds of short wavefronts next to a sweep that
+  // leaves 60 % of its issue slots empty -- instead of behind a 34 us copy, beside the first solve, whose one wavefront per SIMD it slowed
+  // by ~5 us (41 - 43 us against 36 - 37 for the second solve of the same registration: profiles/r06/sequence_timeline_flag_wait.txt).
+  auto copy_ahead = [&](int k) -> int {
+    if (k >= count || scans_on_device || !c->seq_copy_ahead) return SO_ICP_OK;
+    SeqRun& r = runs[(size_t)k];
+    if (!r.slot || !r.n || r.copied) return SO_ICP_OK;
+    so_icp_ctx::StageSlot& sl = *r.slot;
+    HIP_TRY(c, sl.dev.reserve((r.n + 64) * 12));
+    HIP_TRY(c, hipMemcpyAsync(sl.dev.p, scans[k], r.n * 12, hipMemcpyHostToDevice, c->seq_stream));
+    r.copied = true;
     return SO_ICP_OK;
   };
   // host side of a registration's start (register_core_once): window, map view, parameters.  false + rc == 0: cannot be started this way
@@ -1999,6 +2039,10 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
     r.ep.n_queries = (uint32_t)r.n; r.ep.q_stride = 3; r.ep.defer_publish = 0;
     r.mp.hring[0] = r.ep.hring[0]; r.mp.hring[1] = r.ep.hring[1]; r.mp.seq_base = r.seq_base; r.mp.publish_prev = 0;
     r.chained = chained;
+    // (every seventh registration -- a period coprime to the scan rotation of the benchmarks: an event pair on a dispatch was measured at
+    //  ~8 us of queue time here, where no idle moment between back-to-back chained launches hides it: 4 % of the rate at every third)
+    r.timed = c->cfg.time_kernels == 1 && (k % 7) == 0;
+    r.knn_ev.clear();
     r.chain_expect = chained ? c->done_count_seen + 1u : 0u;  // (exactly the registration in front of this one completes in between)
     r.mp.chain_expect = r.chain_expect; r.ep.chain_expect = r.chain_expect;
     return true;
@@ -2007,16 +2051,35 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
   // registration is enqueued behind it yet), the others leave their report to the sweep behind them (EvalParams::defer_publish)
   auto enqueue = [&](int k, int it0, int it1) -> int {
     SeqRun& r = runs[(size_t)k];
-    // scan and work list come from the other queue.  Ordinary start: the queue waits for that queue's event.  Chained start: no barrier
-    // packet between two registrations -- the first launch itself waits for the flag behind the scan's binning (MatchParams::begin_flag)
-    if (it0 == 0 && r.needs_event && !r.chain_expect) HIP_TRY(c, hipStreamWaitEvent(s, r.slot->ev, 0));
+    // Scan and work list come from the other queue.  The host WATCHES that queue's event for the scan (the copy went out a registration
+    // ago, the binning a moment ago: tens of microseconds, and the registration in front has only just begun) and enqueues this
+    // registration's launches once it has fired -- then nothing has to order the two queues on the device.  Measured alternatives: a
+    // barrier packet in front of the first launch (hipStreamWaitEvent) costs 5.6 us of command-processor time between two registrations;
+    // a first launch that polls a flag in device memory costs nothing -- and deadlocks when it is dispatched before the binning
+    // kernels it waits for (its 4 096 spinning wavefronts fill the chip: seen once, on a first call whose allocations had held the host up).
+    if (it0 == 0 && r.needs_event) {
+      const auto t_w = std::chrono::steady_clock::now();
+      bool fired = false;
+      for (unsigned spin = 0;; ++spin) {
+        const hipError_t q = hipEventQuery(r.slot->ev);
+        if (q == hipSuccess) { fired = true; break; }
+        if (q != hipErrorNotReady) break;
+        if ((spin & 15u) == 15u && std::chrono::steady_clock::now() - t_w > std::chrono::microseconds(400)) break;
+      }
+      (void)hipGetLastError();
+      if (!fired) HIP_TRY(c, hipStreamWaitEvent(s, r.slot->ev, 0));  // (the other queue is late: let the device order the two)
+    }
     for (int it = it0; it < it1; ++it) {
       MatchParams mp_it = r.mp;
       mp_it.publish_prev = (it > it0) ? 1 : 0;  // (the solve in front of this sweep deferred its report)
-      if (it == 0 && r.needs_event && r.chain_expect) { mp_it.begin_flag = c->d_seq_flag.as<uint32_t>(); mp_it.begin_flag_want = r.flag_value; }
+      hipEvent_t ka = nullptr, kb = nullptr;
+      if (r.timed) {  // (the events ride on the dispatch packet, no marker packets)
+        ka = next_event(c); kb = next_event(c);
+        if (ka && kb) r.knn_ev.push_back(SeqRun::KnnEv{it, ka, kb}); else ka = kb = nullptr;
+      }
       if (r.query_waves) {
         launch_knn_query_waves(r.d_scan, (uint32_t)r.n, ds, r.guess, max_outer, lm_max, it == 0, c->d_hist, c->view, mp_it, max_sf, c->d_status.as<uint8_t>(),
-                               c->d_nbr5.as<uint32_t>(), s, nullptr, nullptr, it == 0 ? r.chain_expect : 0u);
+                               c->d_nbr5.as<uint32_t>(), s, ka, kb, it == 0 ? r.chain_expect : 0u);
       } else {
         if (it == 0) {
           mp_it.begin = 1; mp_it.begin_args.max_outer = max_outer; mp_it.begin_args.lm_max = lm_max; mp_it.begin_max_surface_features = max_sf;
@@ -2024,7 +2087,7 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
           mp_it.begin_args.chain_expect = r.chain_expect; mp_it.begin_args.pad = 0;
           mp_it.begin_ctr = r.slot->pb_ctr.as<unsigned long long>(); mp_it.begin_state = ds;
         }
-        launch_knn_plane(r.d_binned, r.d_chunks, ds, c->view, mp_it, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s);
+        launch_knn_plane(r.d_binned, r.d_chunks, ds, c->view, mp_it, corr, c->d_nbr5.as<uint32_t>(), c->d_hist, s, ka, kb);
       }
       EvalParams ep_it = r.ep;
       ep_it.defer_publish = (it + 1 < it1) ? 1 : 0;
@@ -2062,7 +2125,12 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
   const int depth0 = std::max(1, std::min(c->seq_depth, max_outer));
   int rc = SO_ICP_OK;
   // scan 0: an ordinary start from pose0
-  if ((rc = stage_scan(0, pose0))) return rc;
+  if (adopt) {
+    SeqRun& r0 = runs[0];
+    r0.d_scan = adopted.d_scan; r0.binned = adopted.binned; r0.needs_event = adopted.needs_event;
+    if (r0.binned) { r0.d_binned = r0.slot->pb_binned.as<float4>(); r0.d_chunks = r0.slot->pb_chunks.as<uint32_t>(); }
+  } else if ((rc = stage_scan(0, pose0))) return rc;
+  if ((rc = copy_ahead(1))) return rc;
   bool started = prepare(0, pose0, false, &rc);
   if (rc) return rc;
   if (started && (rc = enqueue(0, 0, depth0))) return rc;
@@ -2086,10 +2154,52 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
         double pred[7];
         pose_compose(r.guess, deltas + 7 * (size_t)(k + 1), pred);  // (this registration will move r.guess by centimetres: good enough to bin under and to place the window)
         if ((rc = stage_scan(k + 1, pred))) return rc;
+        if ((rc = copy_ahead(k + 2))) return rc;
         int prc = 0;
         next_started = prepare(k + 1, pred, true, &prc);
         if (prc) return prc;
         if (next_started && (rc = enqueue(k + 1, 0, std::max(1, std::min(c->seq_depth, max_outer))))) return rc;
+      } else if (c->seq_next.announced && !scans_on_device) {
+        // the scan that will start the NEXT call: on its way to HBM and binned beside this call's last registration
+        so_icp_ctx::SeqNext& nx = c->seq_next;
+        nx.announced = false;
+        double pred[7];
+        pose_compose(r.guess, nx.delta, pred);
+        SeqRun rn;  // (a run record of its own, outside `runs`: the vector must not move under the references held here)
+        nx.scan = nx.next_scan; nx.n = nx.next_n;
+        rn.n = nx.n;
+        const size_t kept_upper = (max_sf >= 0 && rn.n > (size_t)max_sf) ? (size_t)max_sf + 2 : rn.n;
+        rn.query_waves = c->query_waves && rn.n && kept_upper <= kQueryWaveMaxKept;
+        nx.slot = (slot_base + count) % so_icp_ctx::kStageSlots;
+        rn.slot = &c->seq_slot[nx.slot];
+        const void* one[1] = {nx.scan};
+        {  // (stage_scan() of the lambda above, for a scan that is not in `scans`; a failure only means "not staged ahead")
+          SeqRun& rr = rn;
+          rr.d_scan = nullptr; rr.binned = false; rr.needs_event = false;
+          so_icp_ctx::StageSlot& sl = *rr.slot;
+          bool ok = rr.n > 0;
+          if (ok && !sl.ev) ok = hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) == hipSuccess;
+          if (ok) ok = sl.dev.reserve((rr.n + 64) * 12) == hipSuccess && hipMemcpyAsync(sl.dev.p, one[0], rr.n * 12, hipMemcpyHostToDevice, c->seq_stream) == hipSuccess;
+          if (ok) { rr.d_scan = sl.dev.as<float>(); rr.needs_event = true; }
+          if (ok && !rr.query_waves && c->prebin) {
+            const uint32_t lg = prebin_table_log2(rr.n);
+            const size_t m = rr.n + 256, T = (size_t)1 << lg;
+            ok = sl.pb_keys.reserve(m * 4) == hipSuccess && sl.pb_vals.reserve(m * 4) == hipSuccess && sl.pb_chunks.reserve(m * 4) == hipSuccess &&
+                 sl.pb_binned.reserve(m * 16) == hipSuccess && sl.pb_ctr.reserve(64) == hipSuccess && c->d_sbin_key.cap >= T * 4 && c->sbin_log2 == lg;
+            if (ok) {
+              const BinTable bt{c->d_sbin_key.as<uint32_t>(), c->d_sbin_cnt.as<uint32_t>(), c->d_sbin_off.as<uint32_t>(), lg};
+              sl.pb_chunk_cap = (uint32_t)(sl.pb_chunks.cap / 4);
+              launch_scan_keys(rr.d_scan, (uint32_t)rr.n, ds, pred, 0, 0, c->d_hist, c->view, max_sf, 0, 1, sl.pb_keys.as<uint32_t>(), sl.pb_vals.as<uint32_t>(), nullptr,
+                               bt, c->seq_stream, false, nullptr, 0, false, 0, sl.pb_ctr.as<unsigned long long>());
+              launch_bin_offsets(bt, sl.pb_chunks.as<uint32_t>(), sl.pb_chunk_cap, ds, c->seq_stream, nullptr, 0, sl.pb_ctr.as<unsigned long long>());
+              launch_bin_place(bt, rr.d_scan, (uint32_t)rr.n, sl.pb_keys.as<uint32_t>(), sl.pb_vals.as<uint32_t>(), sl.pb_binned.as<float4>(), c->seq_stream);
+              if (hipGetLastError() != hipSuccess) { c->sbin_log2 = 0; ok = false; } else rr.binned = true;
+            }
+          }
+          if (ok && rr.needs_event) ok = hipEventRecord(sl.ev, c->seq_stream) == hipSuccess;
+          (void)hipGetLastError();
+          nx.staged = ok; nx.binned = rr.binned; nx.needs_event = rr.needs_event; nx.d_scan = rr.d_scan;
+        }
       }
       // this registration's reports
       int last = 0;
@@ -2124,6 +2234,14 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
       if (!r.query_waves) c->knn_list_fits = ((H.bin_packed >> 21) & 0x1FFFFFull) + (H.bin_packed >> 42) <= (unsigned long long)kKnnBlocks * 4ull;
       c->done_count_seen = H.done_count;
       c->seq_depth = std::max(1, H.n_iterations);
+      for (const SeqRun::KnnEv& e : r.knn_ev) {  // sweeps that did real work (a launch behind the converged iteration was a no-op); they ended long ago
+        float ms = 0;
+        if (e.it < H.n_iterations && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+          c->timing.knn_ms_total += ms; c->timing.knn_launches++;
+          c->timing.knn_queries += r.query_waves ? (int64_t)r.n : (int64_t)(H.bin_packed & 0x1FFFFFull); c->timing.knn_map_points += c->view.n_points;
+        }
+      }
+      (void)hipGetLastError();
       fill_result(c, H, guess, st, pose_out, true);
       st->time_elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_icp).count();
       c->timing.registrations++;
@@ -2163,6 +2281,7 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
     }
   }
   c->scan_staged = false;
+  c->ev_used = 0;  // (the timing events of this call are free again)
   drain.ok = true;
   return SO_ICP_OK;
 }

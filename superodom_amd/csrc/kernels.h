@@ -59,11 +59,6 @@ struct MatchParams {
   RegBeginArgs begin_args;                 // guess + loop bounds
   const unsigned long long* begin_ctr;     // work-list counters left by the binning
   struct DevState* begin_state;
-  // chained BEGIN launch (so_icp_register_sequence): the scan's copy and binning ran on ANOTHER queue; instead of a barrier packet in front
-  // of this launch (5.6 us of command-processor time between two registrations, measured) that queue's last kernel stores a running
-  // number into *begin_flag and every wavefront of this launch waits until it reads >= begin_flag_want -- long true when it starts
-  const uint32_t* begin_flag;
-  uint32_t begin_flag_want;
 };
 
 struct EvalParams {
@@ -180,8 +175,6 @@ struct BatchView {
 };
 
 void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* d_hist, hipStream_t s);
-// one agent-scope store of `value` to *flag, behind everything enqueued on `s` so far (MatchParams::begin_flag)
-void launch_stream_flag(uint32_t* flag, uint32_t value, hipStream_t s);
 // Spatial binning of the scan without a sort: an open-addressing table keyed by the sort key (cube slot | half-cell Morton
 // code) counts the queries of every key, a block scan over the table turns the counts into bucket offsets + the chunk
 // list, and a scatter places the queries.  The order INSIDE a bucket depends on the order of the atomics -- harmless: it

@@ -112,18 +112,6 @@ __device__ __forceinline__ void reg_begin_state(DevState* st, const RegBeginArgs
     //  to it, and a clear ordered only by dispatch order could lose counts from run to run -- ADVICE r05.  It runs on; the host takes differences.)
   }
 }
-// MatchParams::begin_flag: the copy / binning queue's "this scan is in place" (one store behind that queue's kernels and copies), and the
-// wait of a chained BEGIN launch on the other queue (every wavefront; a launch that starts after the store -- the rule -- reads once)
-__global__ void stream_flag_kernel(uint32_t* flag, uint32_t value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool wait_begin_flag(const uint32_t* flag, uint32_t want) {
-  const unsigned long long t0 = wall_clock64();
-  // (running numbers: "reached" in wrap-around arithmetic)
-  while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-    if (wall_clock64() - t0 > 5000000ull) return false;  // 50 ms: give up (the launch becomes a no-op, the host reports the missing publication)
-    __builtin_amdgcn_s_sleep(8);
-  }
-  return true;
-}
 // stand-alone prologue (empty scan: scan_keys_kernel, which normally carries it, is not launched)
 __global__ __launch_bounds__(512) void reg_begin_kernel(DevState* st, RegBeginArgs a, int32_t* __restrict__ hist) {
   hist[threadIdx.x] = 0;  // kHistReplicas * kHistStride ints
@@ -857,7 +845,6 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   // (an instantiation of its own: selecting between the two sources at run time cost this kernel, which has no register to spare, 60 - 368
   //  bytes of scratch in every form that was tried)
   if (chained_begin && st->done_count != mp.begin_args.chain_expect) return;
-  if (chained_begin && mp.begin_flag && !wait_begin_flag(mp.begin_flag, mp.begin_flag_want)) return;
   // the report of the previous outer iteration, left to this launch by its solve (MatchParams::publish_prev)
   if (!BATCH && !begin && mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
     publish_state_to(mp.hring[(st->outer_iter - 1) & 1], st, mp.seq_base | (unsigned long long)st->outer_iter, (int)threadIdx.x, 256);
@@ -1687,7 +1674,6 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(const float* __rest
   if (mp.chain_expect && st->done_count != mp.chain_expect) return;  // chained registration whose predecessor was not over: no-op
   if (BEGIN) {
     if (a.chain_expect && st->done_count != a.chain_expect) return;  // (its guess: what the last solve of the registration in front left in T_chain)
-    if (a.chain_expect && mp.begin_flag && !wait_begin_flag(mp.begin_flag, mp.begin_flag_want)) return;  // (a host scan: its copy ran on another queue)
     if (blockIdx.x == 0) {
       hist[threadIdx.x] = 0; hist[256 + threadIdx.x] = 0;
       reg_begin_state(st_begin, a, (int)threadIdx.x);
@@ -3074,9 +3060,8 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n, int block) { return dim3((n + block - 1) / block); }
 
-void launch_stream_flag(uint32_t* flag, uint32_t value, hipStream_t s) { hipLaunchKernelGGL(stream_flag_kernel, dim3(1), dim3(1), 0, s, flag, value); }
 void launch_reg_begin(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist, hipStream_t s) {
-  RegBeginArgs a;
+  RegBeginArgs a{};  // (chain_expect = 0: the guess is the argument, not DevState::T_chain)
   for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
   a.max_outer = max_outer; a.lm_max = lm_max;
   hipLaunchKernelGGL(reg_begin_kernel, dim3(1), dim3(512), 0, s, st, a, hist);
@@ -3101,7 +3086,7 @@ void launch_scan_keys(const float* d_scan, uint32_t n, DevState* st, const doubl
 }
 void launch_reg_begin_prebinned(DevState* st, const double pose[7], int max_outer, int lm_max, int32_t* hist, const unsigned long long* ctr,
                                 uint8_t* status, uint32_t n, int max_sf, hipStream_t s) {
-  RegBeginArgs a;
+  RegBeginArgs a{};  // (chain_expect = 0: the guess is the argument, not DevState::T_chain)
   for (int i = 0; i < 7; ++i) a.pose[i] = pose[i];
   a.max_outer = max_outer; a.lm_max = lm_max;
   const bool sampling = max_sf >= 0 && n > (uint32_t)max_sf;

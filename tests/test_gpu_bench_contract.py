@@ -1,6 +1,6 @@
 """-m gpu: `python bench.py` prints ONE JSON line that carries what the driver's contract asks for (metric / value / unit / n_gpus / steps /
 warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the `roofline` and `cpu_baseline`
-objects, with the timed registrations checked against the oracle and -- staged entry -- binned ahead of their registration."""
+objects, with the timed registrations checked against the oracle, binned ahead of their registration and -- N = 1 -- chained on the device."""
 import json
 import os
 import subprocess
@@ -35,4 +35,6 @@ def test_bench_line_contract():
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert d["parity_iteration_counts_and_histograms_equal"] is True
     assert max(d["parity_vs_oracle_m_rad"]) < 1e-8
-    assert d["host"]["binned_ahead_timed_steps"] >= 4  # (steady staging protocol: the timed scans were binned behind their copies)
+    assert d["host"]["binned_ahead_timed_steps"] >= 4  # (the timed scans were binned behind their copies, beside the registration before them)
+    # N = 1: the timed steps are one so_icp_register_sequence call; all but the first start behind the registration in front of them
+    assert d["config"]["entry"] == "chained" and d["host"]["chained_timed_steps"] >= 4

@@ -73,8 +73,13 @@ def test_hip_path_on_planes_through_the_world_origin(oracle, gpu_slam_factory):
         assert np.array_equal(status, corrs["status"]), "MatchingResult of the last outer iteration, query by query"
         ok = corrs["status"] == 0
         assert ok.sum() > 0.5 * len(scan)
-        # the planes really pass (almost) through the origin: offsets of the accepted planes are millimetres, |x| = 1 / d in the hundreds
-        assert np.median(np.abs(corrs["d"][ok])) < 0.02, np.median(np.abs(corrs["d"][ok]))
+        # the surfaces really pass through the origin: the five neighbours of every accepted correspondence lie within centimetres of a
+        # coordinate plane.  (What A x = -1 makes of them is another matter -- no x with A x = -1 exists on the true plane, and the least-squares
+        # answer is a plane ACROSS the surface at the cluster's distance from the origin, |d| of metres: the reference's quirk, SURVEY App. C,
+        # kept bit for bit -- the statuses, histograms and costs above are Oracle-A's.)
+        nb = corrs["nbr"][ok].reshape(-1, 5, 3).astype(np.float64)
+        assert (np.abs(nb).max(axis=1).min(axis=1) < 0.06).mean() > 0.9  # (the rest: clusters astride an edge of the corner)
+        med_d = float(np.median(np.abs(corrs["d"][ok])))
         dt, dr = synth.pose_error(pose, opose)
-        print(f"origin_corner scan {i}: {int(ok.sum())} accepted planes, median |d| {np.median(np.abs(corrs['d'][ok])):.4f} m | pose vs oracle {dt:.2e} m {dr:.2e} rad")
+        print(f"origin_corner scan {i}: {int(ok.sum())} accepted planes, median |d| of the fitted planes {med_d:.3f} m | pose vs oracle {dt:.2e} m {dr:.2e} rad")
         assert dt <= 1e-8 and dr <= 1e-8, (i, dt, dr)

@@ -139,3 +139,35 @@ def test_sequence_edge_cases(soicp, gpu_slam_factory):
     z = slam.register_sequence([], sc.guess(0), np.zeros((0, 7)))
     assert z[0] == 0 and z[4] == 0
     slam.close(); plain.close()
+
+
+def test_a_run_worked_off_in_two_calls_with_the_next_scan_announced(soicp, gpu_slam_factory):
+    """so_icp_sequence_announce_next: the scan that starts the second call is copied and binned beside the last registration of the first;
+    the two calls give what one call over all eight scans gives, bit for bit (pose0 of the second call = the guess the chain arithmetic forms)."""
+    sc = synth.Scene("small")
+    mk = dict(plane_res=sc.plane_res, line_res=sc.plane_res / 2, max_surface_features=-1, max_iterations=5)
+    slam, plain = gpu_slam_factory(**mk), gpu_slam_factory(**mk)
+    for s in (slam, plain):
+        s.add_surf_point_cloud(sc.map_points)
+    ids = list(range(8))
+    scans = [slam.host_alloc_like(np.ascontiguousarray(sc.scan(i), dtype=np.float32)) for i in ids]
+    pose0 = sc.guess(0); deltas = _deltas(sc, ids)
+    whole = plain.register_sequence(scans, pose0, deltas)
+    assert whole[0] == 0
+    slam.sequence_announce_next(scans[4], deltas[4])
+    a = slam.register_sequence(scans[:4], pose0, deltas[:4])
+    assert a[0] == 0 and np.array_equal(a[1], whole[1][:4])
+    last = a[3][3].iterations[a[3][3].n_iterations - 1]
+    g4 = synth.pose_compose(np.array(last.pose_after), deltas[4])
+    d2 = deltas[4:].copy(); d2[0] = [0, 0, 0, 0, 0, 0, 1]
+    b = slam.register_sequence(scans[4:], g4, d2)
+    assert b[0] == 0 and np.array_equal(b[1], whole[1][4:]) and np.array_equal(b[2], whole[2][4:])
+    assert [_stats_tuple(x) for x in list(a[3]) + list(b[3])] == [_stats_tuple(x) for x in whole[3]]
+    assert b[3][0].flags & soicp.FLAG_BINNED_AHEAD and b[3][0].flags & soicp.FLAG_STAGED_SCAN
+    # an announcement that is not taken up (another scan starts the next call) and a withdrawn one change nothing
+    slam.sequence_announce_next(scans[1], deltas[1])
+    c1 = slam.register_sequence(scans[:3], pose0, deltas[:3])
+    c2 = slam.register_sequence(scans[5:], whole[2][5], np.vstack([[0, 0, 0, 0, 0, 0, 1], deltas[6:]]))
+    assert np.array_equal(c1[1], whole[1][:3]) and np.array_equal(c2[1], whole[1][5:])
+    slam.sequence_announce_next(None, None)
+    slam.close(); plain.close()
