@@ -59,6 +59,17 @@ struct MatchParams {
   RegBeginArgs begin_args;                 // guess + loop bounds
   const unsigned long long* begin_ctr;     // work-list counters left by the binning
   struct DevState* begin_state;
+  // Hand-over of HARD queries (round 6): the lanes of a work-list item that its near pass could not certify -- at most hand_max of them,
+  // else the item runs its full pass as before -- are not searched by their own wavefront (a second, dependent group pass: the 18 - 22 us
+  // wavefronts that end a 22 us sweep whose median wavefront lives 11 us) but appended to a ring {world query, scan index | generation}.
+  // Every wavefront of the launch looks at the ring once its own items are done and searches what it can claim, one query per trip, with
+  // the wave-cooperative exact scan of the 27 cells (query_wave_search: the same exact lists).  hand_ctr = {allocated, claimed}, running
+  // counts in the state block (never reset; equal when the launch ends: a wavefront that appends claims until nothing is left, so what
+  // nobody else took it searches itself).  nullptr: off (batched sweeps, sharded maps, sweeps that start with the full pass).
+  uint32_t* hand_ctr;
+  void* hand_ring;          // (1 << hand_log2) entries of 16 bytes, >= the kept queries of the scan
+  uint32_t hand_log2;
+  int32_t hand_max;
 };
 
 struct EvalParams {
@@ -122,7 +133,8 @@ struct DevState {
   // device-side control
   int32_t outer_iter, reg_done, lm_more, n_iterations;
   uint32_t packed_leftover;  // k-NN sweeps since the context was created (a running count: the host takes differences): queries of packed light chunks that the packed near pass could not finish (exact per-lane scan)
-  uint32_t pad2[3];
+  uint32_t pad2;
+  uint32_t hand_alloc, hand_taken;  // MatchParams::hand_ctr: queries handed over to the ring / claimed from it, running counts (an 8-byte aligned pair)
   // work-list counters of the hash binning in ONE word (kept queries | normal chunks << 21 | light chunks (<= 16 queries,
   // listed separately) << 42), so that a workgroup of bin_offsets_kernel reserves its three ranges with one atomic round trip
   unsigned long long bin_packed;
@@ -142,6 +154,7 @@ struct DevState {
   unsigned long long seq;      // host mirror only: publication word (see EvalParams::hring), written last
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState is copied in 8-byte words");
+static_assert(offsetof(DevState, hand_alloc) % 8 == 0 && offsetof(DevState, hand_taken) == offsetof(DevState, hand_alloc) + 4, "the two counts are read with one 8-byte load");
 
 constexpr int kHistReplicas = 16;    // histogram atomics are spread over replicas (contention), summed by eval_kernel
 constexpr int kHistStride = 32;      // ints per replica: reject[7] obs[9] stats[4]
