@@ -467,6 +467,10 @@ int so_icp_synchronize(so_icp_ctx *ctx);
 /* test aid: MatchingResult (LS.h:85-94) of every query of the last registration's LAST outer iteration, indexed like the scan
  * (254 = not sampled / not owned by this rank) */
 int so_icp_debug_match_status(so_icp_ctx *ctx, uint8_t *out, size_t n);
+/* test aid: the five neighbours (canonical map indices, nearest first) the LAST k-NN sweep of the last registration left for every query, indexed
+ * like the scan: out[5 * n].  Meaningful where that sweep found five neighbours inside the gate (every query the fit pass then judged: status
+ * 0, 3, 4, 5); elsewhere the entries are whatever an earlier sweep left */
+int so_icp_debug_neighbours(so_icp_ctx *ctx, uint32_t *out, size_t n);
 /* profiling aid: wall-clock stamps (100 MHz ticks) of the phases of the last fit / evaluation kernels (SOICP_ABLATE=128) */
 int so_icp_debug_stamps(so_icp_ctx *ctx, uint64_t out[16]);
 /* profiling aid: per-workgroup records (16 words each, 2 sweeps x workgroups) of the k-NN kernel's phases (SOICP_ABLATE=128);

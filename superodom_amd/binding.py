@@ -95,7 +95,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
             "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram",
             "so_icp_host_register", "so_icp_host_unregister", "so_icp_host_alloc", "so_icp_host_free", "so_icp_device_count", "so_icp_stage_cancel",
-            "so_icp_map_insert_stats", "so_icp_register_sequence", "so_icp_map_export_records", "so_icp_sequence_announce_next"]
+            "so_icp_map_insert_stats", "so_icp_register_sequence", "so_icp_map_export_records", "so_icp_sequence_announce_next", "so_icp_debug_neighbours"]
 
 _lib = None
 
@@ -167,6 +167,7 @@ def load():
     L.so_icp_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.so_icp_host_free.argtypes = [vp, vp]
     L.so_icp_debug_match_status.argtypes = [vp, u8p, C.c_size_t]
+    L.so_icp_debug_neighbours.argtypes = [vp, C.POINTER(C.c_uint32), C.c_size_t]
     L.so_icp_comm_init_inprocess.argtypes = [vp, C.c_uint64]
     L.so_icp_peer_export.argtypes = [vp, u8p]
     L.so_icp_peer_connect.argtypes = [vp, u8p, i32p]
@@ -352,6 +353,12 @@ class LidarSlamGpu:
         """MatchingResult of every query of the last registration's last outer iteration (so_icp_debug_match_status)."""
         out = np.zeros(n, np.uint8)
         self._check(self.L.so_icp_debug_match_status(self.h, _p(out, C.c_uint8), n))
+        return out
+
+    def neighbours(self, n):
+        """the five neighbours (canonical map indices) the last k-NN sweep left for every query (so_icp_debug_neighbours)"""
+        out = np.zeros((n, 5), np.uint32)
+        self._check(self.L.so_icp_debug_neighbours(self.h, _p(out, C.c_uint32), n))
         return out
 
     def upload_scan(self, scan):

@@ -314,6 +314,7 @@ struct so_icp_ctx {
   bool seq_chain = true;                  // SOICP_SEQ_CHAIN=0: so_icp_register_sequence runs one registration after the other (same results)
   bool query_waves = true;                // SOICP_QUERY_WAVES=0: a small scan (<= 4 096 kept queries) is binned and swept in chunks like a large one
   bool knn_pack = true;                   // SOICP_KNN_PACK=0: one chunk per wavefront throughout (round-3 work list)
+  uint32_t knn_hand_spin_ticks = 0;       // SOICP_KNN_HAND_SPIN_US: how long the helper wavefronts of the hand-over ring stay (MatchParams::hand_spin_ticks)
   int knn_hand_max = 2;                   // SOICP_KNN_HAND=n: a work-list item hands up to n uncertified queries to the ring (0: none; every item runs its own full pass)
   bool knn_list_fits = false;             // the last registration's work list (normal + light chunks) fitted the k-NN grid one chunk per wavefront:
                                           // packing four light chunks into a wavefront then only lengthens the longest wavefronts (a 13 k-point
@@ -497,13 +498,16 @@ int reserve_scan_buffers(so_icp_ctx* c, size_t n) {
   HIP_TRY(c, c->d_nd.reserve(m * 32)); HIP_TRY(c, c->d_coeff.reserve(m * 8)); HIP_TRY(c, c->d_status.reserve(m));
   HIP_TRY(c, c->d_nbr5.reserve(m * 20));
   // ring of handed-over queries (MatchParams::hand_ring): a power of two >= the scan's points; a new ring starts with generation 0 everywhere
-  if (c->knn_hand_max > 0) {
-    uint32_t lg = 10;
-    while (((size_t)1 << lg) < m) ++lg;
+  if (c->knn_hand_max != 0) {
+    // (kHandParts rings of 1 << hand_log2 entries behind kHandParts blocks of 4 KB with the parts' counts; a part never holds more than the
+    //  queries of its workgroups' items, every part of 1 / 16 of the scan's points is far beyond that)
+    uint32_t lg = 13;  // (>= 64 wavefronts x 2 items x 64 lanes: what a part's workgroups can hand over in one sweep at the most)
+    while (((size_t)kHandParts << lg) < m * 4) ++lg;
     if (lg > c->hand_log2 || !c->d_hand_ring.p) {
+      const size_t bytes = (size_t)kHandParts * kHandCtrStride * 4 + (((size_t)16 * kHandParts) << lg);
       c->d_hand_ring.release();
-      HIP_TRY(c, c->d_hand_ring.reserve(((size_t)16) << lg));
-      HIP_TRY(c, hipMemsetAsync(c->d_hand_ring.p, 0, ((size_t)16) << lg, c->stream));
+      HIP_TRY(c, c->d_hand_ring.reserve(bytes));
+      HIP_TRY(c, hipMemsetAsync(c->d_hand_ring.p, 0, bytes, c->stream));
       c->hand_log2 = lg;
     }
   }
@@ -511,11 +515,12 @@ int reserve_scan_buffers(so_icp_ctx* c, size_t n) {
 }
 // the hand-over of hard queries for a sweep of this context's single registrations (MatchParams::hand_ctr)
 void set_hand_over(so_icp_ctx* c, MatchParams& mp, size_t n) {
-  const bool on = c->knn_hand_max > 0 && c->d_hand_ring.p && ((size_t)1 << c->hand_log2) >= n && n < ((size_t)1 << 21) &&
+  const bool on = c->knn_hand_max != 0 && c->d_hand_ring.p && ((size_t)kHandParts << c->hand_log2) >= 4 * n && n < ((size_t)1 << 21) &&
                   c->cfg.world_size <= 1 && !c->batch_mode && !c->borrow.on;
-  mp.hand_ctr = on ? &c->d_state->hand_alloc : nullptr;
-  mp.hand_ring = on ? c->d_hand_ring.p : nullptr;
+  mp.hand_ctr = on ? c->d_hand_ring.as<uint32_t>() : nullptr;
+  mp.hand_ring = on ? static_cast<void*>(c->d_hand_ring.as<char>() + (size_t)kHandParts * kHandCtrStride * 4) : nullptr;
   mp.hand_log2 = c->hand_log2; mp.hand_max = c->knn_hand_max;
+  mp.hand_tally = &c->d_state->hand_alloc; mp.hand_spin_ticks = c->knn_hand_spin_ticks;
 }
 
 MatchParams match_params(float plane_res, int ablate) {
@@ -528,7 +533,7 @@ MatchParams match_params(float plane_res, int ablate) {
   mp.skip_near_pass = 0;
   mp.pack_light = 1;
   mp.packed_leftover = nullptr;
-  mp.hand_ctr = nullptr; mp.hand_ring = nullptr; mp.hand_log2 = 0; mp.hand_max = 0;
+  mp.hand_ctr = nullptr; mp.hand_ring = nullptr; mp.hand_log2 = 0; mp.hand_max = 0; mp.hand_tally = nullptr; mp.hand_spin_ticks = 0;
   mp.begin = 0; mp.begin_max_surface_features = -1; mp.begin_n = 0;
   mp.begin_args = RegBeginArgs{};
   mp.begin_ctr = nullptr; mp.begin_state = nullptr;
@@ -1638,7 +1643,8 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_KNN_PACK")) c->knn_pack = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_QUERY_WAVES")) c->query_waves = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("SOICP_KNN_HAND")) c->knn_hand_max = std::max(0, std::min(64, std::atoi(ev)));
+  if (const char* ev = std::getenv("SOICP_KNN_HAND_SPIN_US")) c->knn_hand_spin_ticks = (uint32_t)std::max(0.0, std::min(100.0, std::atof(ev)) * 100.0);
+  if (const char* ev = std::getenv("SOICP_KNN_HAND")) c->knn_hand_max = std::max(-64, std::min(64, std::atoi(ev)));
   if (const char* ev = std::getenv("SOICP_PREBIN")) c->prebin = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_SEQ_CHAIN")) c->seq_chain = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_SEQ_COPY_AHEAD")) c->seq_copy_ahead = std::atoi(ev) != 0;
@@ -3183,6 +3189,16 @@ int so_icp_debug_match_status(so_icp_ctx* c, uint8_t* out, size_t n) {
   HIP_TRY(c, hipSetDevice(c->cfg.device_id));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(out, c->d_status.p, n, hipMemcpyDeviceToHost));
+  return SO_ICP_OK;
+}
+int so_icp_debug_neighbours(so_icp_ctx* c, uint32_t* out, size_t n) {
+  if (!c || (!out && n)) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  if (!n) return SO_ICP_OK;
+  if (n * 20 > c->d_nbr5.cap) return fail(c, SO_ICP_E_INVALID, "so_icp_debug_neighbours: more entries than the last scan had");
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(out, c->d_nbr5.p, n * 20, hipMemcpyDeviceToHost));
   return SO_ICP_OK;
 }
 int so_icp_synchronize(so_icp_ctx* c) { if (!c) return SO_ICP_E_INVALID; NEED_DEVICE(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return SO_ICP_OK; }

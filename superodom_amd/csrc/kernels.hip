@@ -696,6 +696,13 @@ constexpr uint32_t kKeyIdxMask = (1u << kKeyIdxBits) - 1u;
 constexpr uint32_t kGroupMaxCand = 1u << kKeyIdxBits;
 constexpr uint32_t kTileCand = 384;                               // candidates staged in LDS at a time (7.8 KB per wavefront: 4 workgroups per CU = 132 KB)
 
+// The lane index, formed where it is used (two mbcnt instructions the optimiser cannot hoist or share): a value kept from the kernel's
+// prologue is live across every item of knn_plane_kernel, which has no register to spare -- it was spilled there by every wavefront.
+__device__ __forceinline__ int lane_id_here() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
+  return l;
+}
 // v_med3_i32 has no clang builtin; it is a pure VALU op (no memory, no wait states needed).
 __device__ __forceinline__ int32_t imed3(int32_t a, int32_t b, int32_t c) {
   int32_t r;
@@ -967,7 +974,6 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
     if (threadIdx.x < 24) lh[threadIdx.x] = 0;
     __syncthreads();
   }
-  const int lane_k = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform, and the compiler is told so: the LDS bases below live in SGPRs)
   float* tx = tiles[wv][0];
   float* ty = tiles[wv][1];
@@ -990,12 +996,16 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   // the candidates.  A lane whose exact 5th distance lies inside the scanned block's coverage is finished (on a map
   // voxelised at planeRes practically all of them); the others run the FULL pass with the reference's gate radius
   // sqrt(3*planeRes) (LidarSlam.cpp:526,741), where "not found inside the gate ball" is a certain TOO_FAR.
-  const float r_gate = sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f;
-  const float r_near = 0.5f * cell;
+  // (wave-uniform values formed by the vector unit -- the square root -- are moved to scalar registers: as vector registers live across
+  //  every item they were spilled in the kernel's prologue by every wavefront)
+  const float r_gate = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f)));
+  const float r_near = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(0.5f * cell)));
   const int first_pass = (r_near < 0.8f * r_gate && !(abl & 256) && !mp.skip_near_pass) ? 0 : 1;
   // hand-over of hard queries (MatchParams::hand_ctr): a single registration whose sweep starts with the near pass
   const bool hand = !BATCH && mp.hand_ctr != nullptr && first_pass == 0;
-  u4v* const hring = reinterpret_cast<u4v*>(mp.hand_ring);
+  const uint32_t hpart = blockIdx.x % kHandParts;  // this workgroup's part of the ring
+  uint32_t* const hctr = mp.hand_ctr + (size_t)hpart * kHandCtrStride;
+  u4v* const hring = reinterpret_cast<u4v*>(mp.hand_ring) + ((size_t)hpart << mp.hand_log2);
   const uint32_t hmask = (1u << mp.hand_log2) - 1u;
   // one wavefront per chunk of the work list (a second / further chunk when the list is longer than the grid)
   // (the body is instantiated twice -- packed light chunks / one chunk per wavefront -- so that neither path carries the other's
@@ -1006,8 +1016,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   // and row-table addresses) is formed per item.  Hoisted out of the item loop those values were SPILLED IN THE KERNEL'S PROLOGUE
   // BY EVERY WAVEFRONT, working or idle -- 7 MB of scratch writes per sweep in the PMC traffic (16.8 MB against 9.8 MB
   // algorithmic) for values a handful of integer operations rebuild.
-  int lane = lane_k;
-  asm volatile("" : "+v"(lane));
+  const int lane = lane_id_here();
   if (stamp) ts[0] = wall_clock64();
   uint32_t j = 0;
   bool valid_q = false;
@@ -1067,8 +1076,22 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   // the lanes of `hm` append their queries to the ring: one reservation for the wavefront, one 16-byte record per query
   // {world coordinates as the passes here use them, scan index | generation of the ring slot}, a single sc1 store each
   auto hand_over = [&](const unsigned long long hm) {
+    if (mp.hand_max < 0) {  // test hook (SOICP_KNN_HAND=-n): the wavefront searches the queries it would hand over itself, one after the other
+      unsigned long long m = hm;
+      while (m) {
+        const int L = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), L)), sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), L));
+        const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), L));
+        query_wave_search(sx, sy, sz, (uint32_t)__builtin_amdgcn_readlane((int)oi, L), map, mcell_start, mpts, mp.sq_max_dist_f, corr.status, nbr5, rowoff, rowbeg, lane);
+      }
+      return;
+    }
     uint32_t base = 0;
-    if (lane == 0) base = __hip_atomic_fetch_add(mp.hand_ctr, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+      base = __hip_atomic_fetch_add(hctr, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(mp.hand_tally, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (statistics; the result is not used)
+    }
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     if ((hm >> lane) & 1ull) {
       const uint32_t t = base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
@@ -1139,7 +1162,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
     if (ppass == 1 && hand) {  // a few lanes left: to the ring instead of a full pass (and exact scans) of this wavefront's own
       const unsigned long long hm = __ballot(valid_q && c.slot >= 0 && !resolved);
       const uint32_t nh = (uint32_t)__popcll(hm);
-      if (nh != 0u && nh <= (uint32_t)mp.hand_max) { hand_over(hm); handed = ((hm >> lane) & 1ull) != 0ull; break; }
+      if (nh != 0u && nh <= (uint32_t)(mp.hand_max < 0 ? -mp.hand_max : mp.hand_max)) { hand_over(hm); handed = ((hm >> lane) & 1ull) != 0ull; break; }
     }
     const bool pend = !resolved && !need_exact;
     if (ppass == 1 && __ballot(pend) == 0ull) break;
@@ -1406,7 +1429,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
     const unsigned long long hm = __ballot(valid_q && c.slot >= 0 && !resolved);
     const unsigned long long hp = hm & (split4 ? 0xFFFFull : (split ? 0xFFFFFFFFull : ~0ull));  // (a split chunk holds every query in two / four lanes)
     const uint32_t nh = (uint32_t)__popcll(hp);
-    if (nh != 0u && nh <= (uint32_t)mp.hand_max) { hand_over(hp); handed = ((hm >> lane) & 1ull) != 0ull; }
+    if (nh != 0u && nh <= (uint32_t)(mp.hand_max < 0 ? -mp.hand_max : mp.hand_max)) { hand_over(hp); handed = ((hm >> lane) & 1ull) != 0ull; }
   }
   bool pending = !resolved && !need_exact && !handed && !(pass == 0 && near_done);
   unsigned long long todo = __ballot(pending);
@@ -1732,39 +1755,65 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   // No wavefront waits for work: one that finds nothing to claim ends.  A wavefront that appended comes through here after its append, so
   // its own queries are claimed at the latest by itself: when the launch ends every record has been searched.
   if (hand) {
-    for (;;) {
-      uint32_t t = 0;
-      int have = 0;
-      if (lane_k == 0) {
-        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(mp.hand_ctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t a = (uint32_t)w;
-        uint32_t k = (uint32_t)(w >> 32);
-        while ((int32_t)(a - k) > 0) {
+    // one attempt: claim a record if one is there and search it; false: nothing to claim
+    // (Wavefront-uniform control flow throughout: every lane reads the two counts, lane 0 alone issues the compare-and-swap and its
+    //  result is broadcast before anything is decided.  The first version decided inside `if (lane == 0)` and left with a flag; the
+    //  optimiser threaded lane 0's "claimed" edge past the broadcast, and one claim in twelve searched its query with ONE active
+    //  lane -- 63 lanes of zeros in the five wavefront minima: a PENDING query with the neighbour list {0, 0, 0, 0, 0}.)
+    auto claim_one = [&]() -> bool {
+      const int lane_c = lane_id_here();
+      const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(hctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+      uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
+      bool have = false;
+      while ((int32_t)(a - k) > 0) {
+        uint32_t seen = k;
+        if (lane_c == 0) {
           uint32_t expect = k;
-          if (__hip_atomic_compare_exchange_strong(mp.hand_ctr + 1, &expect, k + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { t = k; have = 1; break; }
-          k = expect;
+          (void)__hip_atomic_compare_exchange_strong(hctr + 1, &expect, k + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          seen = expect;  // (the count before the exchange: k if this wavefront now owns record k)
         }
+        seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
+        if (seen == k) { have = true; break; }
+        k = seen;
       }
-      have = __builtin_amdgcn_readfirstlane(have);
-      if (!have) break;
-      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      if (!have) return false;
+      const uint32_t t = k;
       const uint32_t gen = ((t >> mp.hand_log2) % 2047u) + 1u;
       u4v e;
       const unsigned long long t0 = wall_clock64();
       for (;;) {
         e = load16_sc1(hring + (t & hmask));
-        if ((e.w >> 21) == gen) break;
+        const uint32_t ew = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w);
+        if ((ew >> 21) == gen) break;
         if (wall_clock64() - t0 > 10000000ull) __builtin_trap();  // 100 ms without the record of a reserved slot: fail loudly (the launch is lost, the context reports it)
         __builtin_amdgcn_s_sleep(2);
       }
       const float hx = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)e.x)), hy = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)e.y));
       const float hz = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)e.z));
       const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w) & 0x1FFFFFu;
-      query_wave_search(hx, hy, hz, hi, map, mcell_start, mpts, mp.sq_max_dist_f, corr.status, nbr5, rowoff, rowbeg, lane_k);
+      query_wave_search(hx, hy, hz, hi, map, mcell_start, mpts, mp.sq_max_dist_f, corr.status, nbr5, rowoff, rowbeg, lane_c);
       if (PROF) ++n_steal;
+      return true;
+    };
+    // HELPERS.  A wavefront that ends at the sweep's median (11 - 12 us) claims what the heavy items appended at 9 - 12 us and is done with it
+    // at 17 - 18: no earlier than the item's own second pass would have been.  The wavefronts WITHOUT an item (a 131 072-point sweep is
+    // ~3 200 items on 4 096 wavefronts) are free from the first microsecond: the first two of every part of the ring stay for
+    // hand_spin_ticks of the 100 MHz clock -- shorter than any sweep of a list this long lasts -- and look at their part's counts about
+    // once a microsecond.  They hold nothing anybody waits for; when the time is up they leave like everybody else, through the loop below.
+    if (mp.hand_spin_ticks != 0u && n_chunks >= 2048u) {
+      const uint32_t b0 = ((n_chunks + 3u) >> 2);                                   // first workgroup without an item
+      const uint32_t bh = b0 + ((hpart + kHandParts - (b0 % kHandParts)) % kHandParts);  // ... of this part of the ring
+      if (blockIdx.x == bh && wv < 2) {
+        const unsigned long long t_end = wall_clock64() + (unsigned long long)mp.hand_spin_ticks;
+        while (wall_clock64() < t_end) {
+          if (!claim_one()) __builtin_amdgcn_s_sleep(48);  // ~1.3 us at 2.4 GHz
+        }
+      }
     }
+    while (claim_one()) {}
   }
-  if (stamp && lane_k == 0) {  // one record per wavefront, no atomics (they would perturb the measurement)
+  if (stamp && (threadIdx.x & 63u) == 0u) {  // one record per wavefront, no atomics (they would perturb the measurement)
     unsigned long long* d = mp.kdbg + ((size_t)(begin ? 0 : (st->outer_iter & 1)) * gridDim.x * 4 + blockIdx.x * 4 + wv) * 16;
     d[0] = t_first; d[1] = wall_clock64();
     for (int i = 0; i < 5; ++i) d[2 + i] = acc[i];

@@ -61,10 +61,18 @@ def main():
                                                     "pose_plus", "store back"], np.round(lm_acc / a.reps, 2))))
     rec = slam.debug_knn_stamps()
     if rec is not None:
+        steals_all = (rec[..., 12].astype(np.uint64) >> np.uint64(32)).astype(np.int64)  # queries a wavefront claimed from the hand-over ring
+        rec = rec.copy(); rec[..., 12] = rec[..., 12].astype(np.uint64) & np.uint64(0xFFFFFFFF)
         rec = rec.astype(np.float64)
         for o in range(2):
             r = rec[o]
+            stl = steals_all[o][r[:, 0] > 0]
             r = r[r[:, 0] > 0]
+            if len(r) and stl.sum():
+                t0_ = r[:, 0].min()
+                w_ = stl > 0
+                print(f"knn sweep {o}: hand-over ring: {int(stl.sum())} queries claimed by {int(w_.sum())} wavefronts (max {int(stl.max())} by one); "
+                      f"those wavefronts end at p50 {np.percentile((r[w_, 1] - t0_) * 0.01, 50):.1f} max {((r[w_, 1] - t0_) * 0.01).max():.1f} us, the others at max {((r[~w_, 1] - t0_) * 0.01).max():.1f} us")
             if not len(r):
                 continue
             t0 = r[:, 0].min()
