@@ -130,8 +130,7 @@ typedef struct {
   so_icp_iter_stats iterations[SO_ICP_MAX_OUTER];
   uint32_t flags;                          /* SO_ICP_FLAG_*: degraded / non-default modes this registration ran in -- what the
                                               reference would print as a warning (LS.cpp:113-116 style), for the node's log */
-  uint32_t knn_handed_over;                /* queries of this registration's k-NN sweeps that the wavefront of their work-list item passed on to the ring of
-                                              hard queries instead of running a second pass of its own (SOICP_KNN_HAND; identical neighbour lists); was `reserved` */
+  uint32_t reserved;
 } so_icp_stats;
 
 /* so_icp_stats::flags */

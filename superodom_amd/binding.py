@@ -38,7 +38,7 @@ class Stats(C.Structure):
                 ("prediction_source", C.c_int32), ("total_translation", C.c_double), ("total_rotation", C.c_double),
                 ("translation_from_last", C.c_double), ("rotation_from_last", C.c_double), ("time_elapsed_ms", C.c_double),
                 ("uncertainty", C.c_double * 6), ("JtJ", C.c_double * 36), ("Jtr", C.c_double * 6),
-                ("iterations", IterStats * MAX_OUTER), ("flags", C.c_uint32), ("knn_handed_over", C.c_uint32)]
+                ("iterations", IterStats * MAX_OUTER), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # so_icp_stats.flags

@@ -179,7 +179,6 @@ struct so_icp_ctx {
   DevMapView view{};
   // scan / correspondence buffers
   DevBuf d_scan_own, d_keys0, d_vals0, d_chunks, d_binned, d_nd, d_coeff, d_status, d_nbr5;
-  DevBuf d_hand_ring; uint32_t hand_log2 = 0;  // ring of handed-over queries (MatchParams::hand_ring)
   DevBuf d_kdbg;   // profiling only
   DevBuf d_counts; // sharded device map: per-cube counters on their way through the all-reduce
   DevBuf d_small;  // hist[16] int32 | ticket | n_kept | fb_count | LmSums | partials
@@ -314,12 +313,9 @@ struct so_icp_ctx {
   bool seq_chain = true;                  // SOICP_SEQ_CHAIN=0: so_icp_register_sequence runs one registration after the other (same results)
   bool query_waves = true;                // SOICP_QUERY_WAVES=0: a small scan (<= 4 096 kept queries) is binned and swept in chunks like a large one
   bool knn_pack = true;                   // SOICP_KNN_PACK=0: one chunk per wavefront throughout (round-3 work list)
-  uint32_t knn_hand_spin_ticks = 0;       // SOICP_KNN_HAND_SPIN_US: how long the helper wavefronts of the hand-over ring stay (MatchParams::hand_spin_ticks)
-  int knn_hand_max = 2;                   // SOICP_KNN_HAND=n: a work-list item hands up to n uncertified queries to the ring (0: none; every item runs its own full pass)
   bool knn_list_fits = false;             // the last registration's work list (normal + light chunks) fitted the k-NN grid one chunk per wavefront:
                                           // packing four light chunks into a wavefront then only lengthens the longest wavefronts (a 13 k-point
                                           // voxel-filtered scan: sweeps 20.5 + 18.6 -> 17.2 + 16.9 us unpacked)
-  uint32_t hand_alloc_seen = 0;           // DevState::hand_alloc (a running count) as of the last report
   uint32_t packed_leftover_seen = 0;      // DevState::packed_leftover (a running count) as of the last report
   int knn_pack_hold = 0;                  // registrations left without packing after one in which the packed near pass left > 3 % of
                                           // the queries to the exact per-lane scan (sparse map, far-off guess): then it is not a saving
@@ -497,30 +493,7 @@ int reserve_scan_buffers(so_icp_ctx* c, size_t n) {
   HIP_TRY(c, c->d_binned.reserve(m * 16));
   HIP_TRY(c, c->d_nd.reserve(m * 32)); HIP_TRY(c, c->d_coeff.reserve(m * 8)); HIP_TRY(c, c->d_status.reserve(m));
   HIP_TRY(c, c->d_nbr5.reserve(m * 20));
-  // ring of handed-over queries (MatchParams::hand_ring): a power of two >= the scan's points; a new ring starts with generation 0 everywhere
-  if (c->knn_hand_max != 0) {
-    // (kHandParts rings of 1 << hand_log2 entries behind kHandParts blocks of 4 KB with the parts' counts; a part never holds more than the
-    //  queries of its workgroups' items, every part of 1 / 16 of the scan's points is far beyond that)
-    uint32_t lg = 13;  // (>= 64 wavefronts x 2 items x 64 lanes: what a part's workgroups can hand over in one sweep at the most)
-    while (((size_t)kHandParts << lg) < m * 4) ++lg;
-    if (lg > c->hand_log2 || !c->d_hand_ring.p) {
-      const size_t bytes = (size_t)kHandParts * kHandCtrStride * 4 + (((size_t)16 * kHandParts) << lg);
-      c->d_hand_ring.release();
-      HIP_TRY(c, c->d_hand_ring.reserve(bytes));
-      HIP_TRY(c, hipMemsetAsync(c->d_hand_ring.p, 0, bytes, c->stream));
-      c->hand_log2 = lg;
-    }
-  }
   return SO_ICP_OK;
-}
-// the hand-over of hard queries for a sweep of this context's single registrations (MatchParams::hand_ctr)
-void set_hand_over(so_icp_ctx* c, MatchParams& mp, size_t n) {
-  const bool on = c->knn_hand_max != 0 && c->d_hand_ring.p && ((size_t)kHandParts << c->hand_log2) >= 4 * n && n < ((size_t)1 << 21) &&
-                  c->cfg.world_size <= 1 && !c->batch_mode && !c->borrow.on;
-  mp.hand_ctr = on ? c->d_hand_ring.as<uint32_t>() : nullptr;
-  mp.hand_ring = on ? static_cast<void*>(c->d_hand_ring.as<char>() + (size_t)kHandParts * kHandCtrStride * 4) : nullptr;
-  mp.hand_log2 = c->hand_log2; mp.hand_max = c->knn_hand_max;
-  mp.hand_tally = &c->d_state->hand_alloc; mp.hand_spin_ticks = c->knn_hand_spin_ticks;
 }
 
 MatchParams match_params(float plane_res, int ablate) {
@@ -533,7 +506,6 @@ MatchParams match_params(float plane_res, int ablate) {
   mp.skip_near_pass = 0;
   mp.pack_light = 1;
   mp.packed_leftover = nullptr;
-  mp.hand_ctr = nullptr; mp.hand_ring = nullptr; mp.hand_log2 = 0; mp.hand_max = 0; mp.hand_tally = nullptr; mp.hand_spin_ticks = 0;
   mp.begin = 0; mp.begin_max_surface_features = -1; mp.begin_n = 0;
   mp.begin_args = RegBeginArgs{};
   mp.begin_ctr = nullptr; mp.begin_state = nullptr;
@@ -624,7 +596,6 @@ void fill_result(so_icp_ctx* c, const DevState& H, const double pose_in[7], so_i
   relative_motion(pose_in, T, st->total_translation, st->total_rotation);
   relative_motion(pose_in, T, st->translation_from_last, st->rotation_from_last);
   st->prediction_source = 0;
-  if (update_tracker) { st->knn_handed_over = H.hand_alloc - c->hand_alloc_seen; c->hand_alloc_seen = H.hand_alloc; }  // (running count: differences)
   std::memcpy(pose_out, T, sizeof(T));
 }
 
@@ -749,7 +720,6 @@ int register_core_once(so_icp_ctx* c, const float* d_scan, size_t n, const doubl
   mp.chunk_cap = chunk_cap;
   mp.pack_light = (c->knn_pack && c->knn_pack_hold == 0 && !c->knn_list_fits) ? 1 : 0;
   mp.packed_leftover = &c->d_state->packed_leftover;
-  set_hand_over(c, mp, n);
   if (c->knn_pack_hold > 0) --c->knn_pack_hold;
   if (mp.ablate & 128) {  // profiling: per-workgroup phase stamps of the k-NN sweeps
     HIP_TRY(c, c->d_kdbg.reserve((size_t)2 * kKnnBlocks * 4 * 16 * sizeof(unsigned long long)));
@@ -1520,7 +1490,7 @@ so_icp_ctx::~so_icp_ctx() {
   batch.release();
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_vals0, &d_chunks,
-                    &d_binned, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_hand_ring, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
+                    &d_binned, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
                     &d_found, &d_fblist, &d_kdbg, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
                     &pf_heads, &pf_temp, &pf_dec, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_pbin_key, &d_pbin_cnt, &d_pbin_off, &d_counts, &d_sub})
     b->release();
@@ -1643,8 +1613,6 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_PERSISTENT")) c->persistent_solve = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_KNN_PACK")) c->knn_pack = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_QUERY_WAVES")) c->query_waves = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("SOICP_KNN_HAND_SPIN_US")) c->knn_hand_spin_ticks = (uint32_t)std::max(0.0, std::min(100.0, std::atof(ev)) * 100.0);
-  if (const char* ev = std::getenv("SOICP_KNN_HAND")) c->knn_hand_max = std::max(-64, std::min(64, std::atoi(ev)));
   if (const char* ev = std::getenv("SOICP_PREBIN")) c->prebin = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_SEQ_CHAIN")) c->seq_chain = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_SEQ_COPY_AHEAD")) c->seq_copy_ahead = std::atoi(ev) != 0;
@@ -2064,7 +2032,6 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
     r.mp.chunk_cap = r.binned ? r.slot->pb_chunk_cap : 0;
     r.mp.pack_light = (c->knn_pack && c->knn_pack_hold == 0 && !c->knn_list_fits) ? 1 : 0;
     r.mp.packed_leftover = &ds->packed_leftover;
-    set_hand_over(c, r.mp, r.n);
     if (c->knn_pack_hold > 0) --c->knn_pack_hold;
     r.ep = eval_params(plane_res_now, c->cfg.tukey_variant, 0);
     r.seq_base = (++c->reg_counter) << 8;

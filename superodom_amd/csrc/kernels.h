@@ -59,25 +59,7 @@ struct MatchParams {
   RegBeginArgs begin_args;                 // guess + loop bounds
   const unsigned long long* begin_ctr;     // work-list counters left by the binning
   struct DevState* begin_state;
-  // Hand-over of HARD queries (round 6): the lanes of a work-list item that its near pass could not certify -- at most hand_max of them,
-  // else the item runs its full pass as before -- are not searched by their own wavefront (a second, dependent group pass: the 18 - 22 us
-  // wavefronts that end a 22 us sweep whose median wavefront lives 11 us) but appended to a ring {world query, scan index | generation}.
-  // Every wavefront of the launch looks at the ring once its own items are done and searches what it can claim, one query per trip, with
-  // the wave-cooperative exact scan of the 27 cells (query_wave_search: the same exact lists).  hand_ctr = {allocated, claimed}, running
-  // counts in the state block (never reset; equal when the launch ends: a wavefront that appends claims until nothing is left, so what
-  // nobody else took it searches itself).  nullptr: off (batched sweeps, sharded maps, sweeps that start with the full pass).
-  // The ring is kHandParts rings: workgroup b appends to and claims from part b % kHandParts, each with its counts on a 4 KB block of
-  // its own.  (One pair of counts for the launch was measured first: 4 096 wavefronts reading ONE word when they end -- agent-scope
-  // accesses to one address serialise at 50 - 70 ns each -- turned a 22 us sweep into 200 - 300 us, every access to that memory channel
-  // queueing behind them.)
-  uint32_t* hand_ctr;       // part p: {allocated, claimed} at hand_ctr[p * kHandCtrStride], an 8-byte aligned pair
-  void* hand_ring;          // kHandParts x (1 << hand_log2) entries of 16 bytes; the whole ring >= the kept queries of the scan
-  uint32_t hand_log2;
-  int32_t hand_max;
-  uint32_t hand_spin_ticks; // how long (100 MHz ticks) the helper wavefronts of a long work list stay to claim records (0: no helpers)
-  uint32_t* hand_tally;     // &DevState::hand_alloc: queries handed over, a running count for the host's statistics (no one waits on it)
 };
-constexpr uint32_t kHandParts = 64, kHandCtrStride = 1024;  // (uint32 words: 4 KB between the parts' counts)
 
 struct EvalParams {
   double a2;       // TukeyLoss a^2 with a = (double)sqrtf(3*planeRes)  (LidarSlam.cpp:271)
@@ -140,8 +122,7 @@ struct DevState {
   // device-side control
   int32_t outer_iter, reg_done, lm_more, n_iterations;
   uint32_t packed_leftover;  // k-NN sweeps since the context was created (a running count: the host takes differences): queries of packed light chunks that the packed near pass could not finish (exact per-lane scan)
-  uint32_t pad2;
-  uint32_t hand_alloc, pad2b;       // MatchParams::hand_tally: queries handed over to the ring of hard queries, a running count (the host takes differences)
+  uint32_t pad2[3];
   // work-list counters of the hash binning in ONE word (kept queries | normal chunks << 21 | light chunks (<= 16 queries,
   // listed separately) << 42), so that a workgroup of bin_offsets_kernel reserves its three ranges with one atomic round trip
   unsigned long long bin_packed;

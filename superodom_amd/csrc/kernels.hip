@@ -696,13 +696,6 @@ constexpr uint32_t kKeyIdxMask = (1u << kKeyIdxBits) - 1u;
 constexpr uint32_t kGroupMaxCand = 1u << kKeyIdxBits;
 constexpr uint32_t kTileCand = 384;                               // candidates staged in LDS at a time (7.8 KB per wavefront: 4 workgroups per CU = 132 KB)
 
-// The lane index, formed where it is used (two mbcnt instructions the optimiser cannot hoist or share): a value kept from the kernel's
-// prologue is live across every item of knn_plane_kernel, which has no register to spare -- it was spilled there by every wavefront.
-__device__ __forceinline__ int lane_id_here() {
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
-  return l;
-}
 // v_med3_i32 has no clang builtin; it is a pure VALU op (no memory, no wait states needed).
 __device__ __forceinline__ int32_t imed3(int32_t a, int32_t b, int32_t c) {
   int32_t r;
@@ -812,91 +805,6 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 #ifndef SO_KNN_PACK
 #define SO_KNN_PACK 1  // four light chunks (<= 16 queries each) per wavefront, one per row of 16 lanes (see knn_plane_kernel)
 #endif
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-// 16-byte agent-scope (sc1) store / load: one access, bypassing the non-coherent per-XCD L2 state [MI355X guide, G16]
-__device__ __forceinline__ void store16_sc1(u4v* p, u4v v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ u4v load16_sc1(const u4v* p) {
-  u4v v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-// One query, the WHOLE wavefront on it (knn_query_wave_kernel; the hand-over ring of knn_plane_kernel): the (clamped) 3 x 3 x 3 cells around
-// the query -- every map point inside the gate ball lies there, one cell >= the gate radius -- as <= 9 x-runs dealt to the 64 lanes with
-// the loads of a lane issued together, exact distances (octree.h:93-102), lane-local top 5, five wavefront minima, distance gate
-// (LidarSlam.cpp:741).  Leaves what a sweep leaves for query i: its status byte and, where PENDING, the five canonical indices.
-// rowoff[17] / rowbeg[16]: LDS of this wavefront.  Everything but `lane` is wavefront-uniform.
-__device__ __forceinline__ void query_wave_search(const float qx, const float qy, const float qz, const uint32_t i, const DevMapView& map,
-                                                  const uint32_t* __restrict__ mcell_start, const float4* __restrict__ mpts, const float sq_max_dist_f,
-                                                  uint8_t* __restrict__ status, uint32_t* __restrict__ nbr5, uint32_t* rowoff, uint32_t* rowbeg,
-                                                  const int lane) {
-  const int nc = map.nc;
-  const CellRef c = locate(map, qx, qy, qz);
-  if (c.slot < 0) {  // outside the window / no tree: LidarSlam.cpp:736-739
-    if (lane == 0) __builtin_nontemporal_store((uint8_t)SO_MATCH_NOT_ENOUGH, &status[i]);
-    return;
-  }
-  const int x0 = c.cx > 0 ? c.cx - 1 : 0, x1 = c.cx < nc - 1 ? c.cx + 1 : nc - 1;
-  uint32_t vb = 0, vl = 0;
-  if (lane < 9) {
-    const int y = c.cy + (lane % 3) - 1, z = c.cz + (lane / 3) - 1;
-    if (y >= 0 && y < nc && z >= 0 && z < nc) {
-      const uint32_t* row = mcell_start + (size_t)c.slot * map.ncell1 + ((size_t)z * nc + y) * nc;
-      vb = row[x0]; vl = row[x1 + 1] - vb;
-    }
-  }
-  uint32_t inc = vl;  // inclusive scan over lanes 0..15 (the nine runs sit in the first row of 16 lanes)
-  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);
-  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);
-  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);
-  inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 15);
-  __builtin_amdgcn_wave_barrier();  // (a second query of the wavefront: the table of the first has been read by every lane)
-  if (lane < 16) { rowoff[lane] = lane < 9 ? inc - vl : total; rowbeg[lane] = vb; }
-  if (lane == 0) rowoff[16] = total;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  Top5 loc;
-  loc.init();
-  for (uint32_t t0 = 0; t0 < total; t0 += 256u) {  // four loads of a lane in flight: a block of <= 256 points is one round trip
-    float ax_[4], ay_[4], az_[4];
-    uint32_t cn[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
-      cn[u] = 0xFFFFFFFFu; ax_[u] = ay_[u] = az_[u] = 0.f;
-      if (t < total) {
-        int r = 0;
-#pragma unroll
-        for (int step = 8; step >= 1; step >>= 1) r = (r + step < 16 && rowoff[r + step] <= t) ? r + step : r;
-        cn[u] = rowbeg[r] + (t - rowoff[r]);
-        const float4 p = mpts[cn[u]];
-        ax_[u] = p.x; ay_[u] = p.y; az_[u] = p.z;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (cn[u] != 0xFFFFFFFFu) loc.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, ax_[u], ay_[u], az_[u])) << 32) | cn[u]);
-  }
-  unsigned long long m5[5];
-#pragma unroll
-  for (int t = 0; t < 5; ++t) {
-    m5[t] = wave_min_u64(loc.b0);
-    if (loc.b0 == m5[t] && m5[t] != ~0ull) { loc.b0 = loc.b1; loc.b1 = loc.b2; loc.b2 = loc.b3; loc.b3 = loc.b4; loc.b4 = ~0ull; }  // (keys are unique)
-  }
-  if (lane == 0) {
-    const float d2_4 = __uint_as_float((uint32_t)(m5[4] >> 32));
-    int stq = SO_MATCH_PENDING;  // five neighbours inside the gate: the plane fit runs in slot 0 of the solve
-    if (m5[4] == ~0ull || (double)d2_4 > (double)sq_max_dist_f) stq = SO_MATCH_TOO_FAR;  // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
-    else {
-      uint32_t* o = nbr5 + (size_t)5 * i;
-      __builtin_nontemporal_store((uint32_t)m5[0], o); __builtin_nontemporal_store((uint32_t)m5[1], o + 1);
-      __builtin_nontemporal_store((uint32_t)m5[2], o + 2); __builtin_nontemporal_store((uint32_t)m5[3], o + 3);
-      __builtin_nontemporal_store((uint32_t)m5[4], o + 4);
-    }
-    __builtin_nontemporal_store((uint8_t)stq, &status[i]);
-  }
-}
 constexpr uint32_t kPartTile = kTileCand / 4;  // candidates a packed chunk may keep in its quarter of the wavefront's tile
 
 // PROF : the profiling / test-hook instantiation (per-wavefront stamps, SOICP_ABLATE switches, kernel statistics); the
@@ -974,6 +882,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
     if (threadIdx.x < 24) lh[threadIdx.x] = 0;
     __syncthreads();
   }
+  const int lane_k = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform, and the compiler is told so: the LDS bases below live in SGPRs)
   float* tx = tiles[wv][0];
   float* ty = tiles[wv][1];
@@ -986,7 +895,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   const bool stamp = PROF && (abl & 128) != 0 && mp.kdbg != nullptr;
   unsigned long long ts[4] = {0, 0, 0, 0}, acc[5] = {0, 0, 0, 0, 0}, t_first = 0, n_mine = 0, t_maxchunk = 0;
   unsigned long long n_cand_total = 0, n_q_total = 0, n_groups_total = 0, n_pass2 = 0, max_info = 0, n_fb_total = 0;
-  unsigned long long c_first = 0, n_steal = 0;
+  unsigned long long c_first = 0;
   if (stamp) { t_first = wall_clock64(); c_first = clock64(); }
   const int nc = map.nc;
   const float cell = (float)(1.0 / map.inv_cell);
@@ -996,17 +905,9 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   // the candidates.  A lane whose exact 5th distance lies inside the scanned block's coverage is finished (on a map
   // voxelised at planeRes practically all of them); the others run the FULL pass with the reference's gate radius
   // sqrt(3*planeRes) (LidarSlam.cpp:526,741), where "not found inside the gate ball" is a certain TOO_FAR.
-  // (wave-uniform values formed by the vector unit -- the square root -- are moved to scalar registers: as vector registers live across
-  //  every item they were spilled in the kernel's prologue by every wavefront)
-  const float r_gate = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f)));
-  const float r_near = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(0.5f * cell)));
+  const float r_gate = sqrtf(mp.sq_max_dist_f) * 1.0005f + 1e-4f;
+  const float r_near = 0.5f * cell;
   const int first_pass = (r_near < 0.8f * r_gate && !(abl & 256) && !mp.skip_near_pass) ? 0 : 1;
-  // hand-over of hard queries (MatchParams::hand_ctr): a single registration whose sweep starts with the near pass
-  const bool hand = !BATCH && mp.hand_ctr != nullptr && first_pass == 0;
-  const uint32_t hpart = blockIdx.x % kHandParts;  // this workgroup's part of the ring
-  uint32_t* const hctr = mp.hand_ctr + (size_t)hpart * kHandCtrStride;
-  u4v* const hring = reinterpret_cast<u4v*>(mp.hand_ring) + ((size_t)hpart << mp.hand_log2);
-  const uint32_t hmask = (1u << mp.hand_log2) - 1u;
   // one wavefront per chunk of the work list (a second / further chunk when the list is longer than the grid)
   // (the body is instantiated twice -- packed light chunks / one chunk per wavefront -- so that neither path carries the other's
   //  live values: the kernel sits at its 128-register budget)
@@ -1016,7 +917,8 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   // and row-table addresses) is formed per item.  Hoisted out of the item loop those values were SPILLED IN THE KERNEL'S PROLOGUE
   // BY EVERY WAVEFRONT, working or idle -- 7 MB of scratch writes per sweep in the PMC traffic (16.8 MB against 9.8 MB
   // algorithmic) for values a handful of integer operations rebuild.
-  const int lane = lane_id_here();
+  int lane = lane_k;
+  asm volatile("" : "+v"(lane));
   if (stamp) ts[0] = wall_clock64();
   uint32_t j = 0;
   bool valid_q = false;
@@ -1071,34 +973,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   top.init();
   bool resolved = (ckey == 0xFFFFFFFFu);  // no cube: nothing to search
   bool too_far_certain = false, need_exact = false;
-  bool handed = false;  // this lane's query went to the ring: whoever claims it writes its status byte and neighbour list
   int n_groups = 0;
-  // the lanes of `hm` append their queries to the ring: one reservation for the wavefront, one 16-byte record per query
-  // {world coordinates as the passes here use them, scan index | generation of the ring slot}, a single sc1 store each
-  auto hand_over = [&](const unsigned long long hm) {
-    if (mp.hand_max < 0) {  // test hook (SOICP_KNN_HAND=-n): the wavefront searches the queries it would hand over itself, one after the other
-      unsigned long long m = hm;
-      while (m) {
-        const int L = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        const float sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), L)), sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), L));
-        const float sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), L));
-        query_wave_search(sx, sy, sz, (uint32_t)__builtin_amdgcn_readlane((int)oi, L), map, mcell_start, mpts, mp.sq_max_dist_f, corr.status, nbr5, rowoff, rowbeg, lane);
-      }
-      return;
-    }
-    uint32_t base = 0;
-    if (lane == 0) {
-      base = __hip_atomic_fetch_add(hctr, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(mp.hand_tally, (uint32_t)__popcll(hm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (statistics; the result is not used)
-    }
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if ((hm >> lane) & 1ull) {
-      const uint32_t t = base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-      const u4v v = {__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz), oi | ((((t >> mp.hand_log2) % 2047u) + 1u) << 21)};
-      store16_sc1(hring + (t & hmask), v);
-    }
-  };
   uint32_t n_scanned = 0, n_left_stat = 0;
   if (stamp) { ts[1] = wall_clock64(); acc[0] += ts[1] - ts[0]; }
   // exact re-rank of a lane's survivors + certification (used by the packed near pass and by the group passes)
@@ -1108,11 +983,6 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
     // First the five best approximate keys only.  Every candidate that is NOT re-ranked has exact d2 >= R2:
     //   in-block outsiders: approximate d2 >= L (the first key left out, index bits cleared), exact >= L - kApproxAbsErr;
     //   points of the cube outside the block: farther than the block boundary (cov2).
-    // (the gate as a double is formed HERE, from a scalar the optimiser cannot see through: hoisted, the converted value was spilled in the
-    //  kernel's prologue by every wavefront -- 8 bytes per lane of scratch traffic, working or idle)
-    float gate_f = mp.sq_max_dist_f;
-    asm volatile("" : "+s"(gate_f));
-    const double gate = (double)gate_f;
     unsigned long long e[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
@@ -1129,7 +999,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
     bool have5 = top.b4 != ~0ull;
     double d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
     bool exact = have5 && d5 < R2;
-    bool far = !exact && R2 > gate;
+    bool far = !exact && R2 > (double)mp.sq_max_dist_f;
     // a 5th and a 6th candidate too close to call on approximate keys (a few lanes in a thousand): re-rank all eight
     if (__ballot(!exact && !far && gs[5] != 0xFFFFFFFFu)) {
       if (!exact && !far) {
@@ -1145,7 +1015,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
         have5 = top.b4 != ~0ull;
         d5 = (double)__uint_as_float((uint32_t)(top.b4 >> 32));
         exact = have5 && d5 < R2;
-        far = !exact && R2 > gate;
+        far = !exact && R2 > (double)mp.sq_max_dist_f;
       }
     }
     return exact ? 1 : (far ? 2 : (pass == 1 ? 3 : 0));  // (far: the true 5th neighbour is >= R2 > gate, LidarSlam.cpp:741)
@@ -1159,11 +1029,6 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   constexpr bool near_done = false;  // (group passes only: every lane takes part in its near pass)
   if constexpr (packed) if (first_pass == 0 && !(abl & 2))
   for (int ppass = 0; ppass < 2; ++ppass) {  // near pass, then -- for the rows that still have uncertified lanes -- the full pass (gate radius)
-    if (ppass == 1 && hand) {  // a few lanes left: to the ring instead of a full pass (and exact scans) of this wavefront's own
-      const unsigned long long hm = __ballot(valid_q && c.slot >= 0 && !resolved);
-      const uint32_t nh = (uint32_t)__popcll(hm);
-      if (nh != 0u && nh <= (uint32_t)(mp.hand_max < 0 ? -mp.hand_max : mp.hand_max)) { hand_over(hm); handed = ((hm >> lane) & 1ull) != 0ull; break; }
-    }
     const bool pend = !resolved && !need_exact;
     if (ppass == 1 && __ballot(pend) == 0ull) break;
     if (ppass == 1) __builtin_amdgcn_s_setprio(3);  // (a wavefront with a second pass ahead is one of the sweep's stragglers: issue priority from here on)
@@ -1413,7 +1278,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
     // candidates, a lane in another cube than its row -- goes to the exact per-lane scan of the 27 cells below (the group passes
     // are not instantiated here: registers and code size).  The host watches the count and turns the packing off for sweeps
     // where it is not rare.
-    unsigned long long left = __ballot(valid_q && c.slot >= 0 && !resolved && !handed);
+    unsigned long long left = __ballot(valid_q && c.slot >= 0 && !resolved);
     if (left) __builtin_amdgcn_s_setprio(3);
     if (left && lane == 0 && mp.packed_leftover) atomicAdd(leftover_ctr, (uint32_t)__popcll(left));
     if (PROF) n_left_stat = (uint32_t)__popcll(left);
@@ -1425,13 +1290,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   }
   if constexpr (!packed)
   for (int pass = first_pass; pass < 2; ++pass) {
-  if (hand && pass == 1) {  // a few lanes left: to the ring instead of a second group pass (and exact scans) of this wavefront's own
-    const unsigned long long hm = __ballot(valid_q && c.slot >= 0 && !resolved);
-    const unsigned long long hp = hm & (split4 ? 0xFFFFull : (split ? 0xFFFFFFFFull : ~0ull));  // (a split chunk holds every query in two / four lanes)
-    const uint32_t nh = (uint32_t)__popcll(hp);
-    if (nh != 0u && nh <= (uint32_t)(mp.hand_max < 0 ? -mp.hand_max : mp.hand_max)) { hand_over(hp); handed = ((hm >> lane) & 1ull) != 0ull; }
-  }
-  bool pending = !resolved && !need_exact && !handed && !(pass == 0 && near_done);
+  bool pending = !resolved && !need_exact && !(pass == 0 && near_done);
   unsigned long long todo = __ballot(pending);
   if (abl & 2) todo = 0;
   if (!todo) continue;  // (a packed wavefront may have nothing left for the near pass and still lanes for the full pass)
@@ -1712,7 +1571,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
     // What the group passes left (8 near-equidistant candidates, a block with more than 2048 candidates): the same exact answer
     // from the wave-cooperative scan -- round 5; the per-lane scan it replaces cost 60 us per lane and ended whole sweeps (open
     // scene, 0.5 m / 5 degree guesses: one chunk of 85 us in a 50 us sweep)
-    unsigned long long left = __ballot(valid_q && (!split || lane < (split4 ? 16 : 32)) && c.slot >= 0 && (need_exact || !resolved) && !handed);
+    unsigned long long left = __ballot(valid_q && (!split || lane < (split4 ? 16 : 32)) && c.slot >= 0 && (need_exact || !resolved));
     if (PROF && left && lane == 0) atomicAdd(&lh[17], (int)__popcll(left));
     while (left) {
       const int L = __ffsll((long long)left) - 1;
@@ -1720,7 +1579,7 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
       coop_exact_scan(L);
     }
   }
-  if (valid_q && (!split || lane < (split4 ? 16 : 32)) && !handed) {
+  if (valid_q && (!split || lane < (split4 ? 16 : 32))) {
     int status;
     if (c.slot < 0) {
       status = SO_MATCH_NOT_ENOUGH;  // LidarSlam.cpp:736-739
@@ -1750,75 +1609,12 @@ __global__ __launch_bounds__(256, 4) void knn_plane_kernel(const float4* __restr
   for (uint32_t chunk = blockIdx.x * 4 + wv; chunk < n_chunks; chunk += gridDim.x * 4) {
     if (SO_KNN_PACK && chunk < n_packed) do_item(std::true_type{}, chunk); else do_item(std::false_type{}, chunk);  // (n_packed = 0 unless `pack`)
   }
-  // The ring of handed-over queries: claim one (allocated > claimed: both counts in one 8-byte load, the claim a compare-and-swap by lane 0),
-  // wait for its record -- the appending wavefront stores it right behind its reservation --, search it with the whole wavefront, and again.
-  // No wavefront waits for work: one that finds nothing to claim ends.  A wavefront that appended comes through here after its append, so
-  // its own queries are claimed at the latest by itself: when the launch ends every record has been searched.
-  if (hand) {
-    // one attempt: claim a record if one is there and search it; false: nothing to claim
-    // (Wavefront-uniform control flow throughout: every lane reads the two counts, lane 0 alone issues the compare-and-swap and its
-    //  result is broadcast before anything is decided.  The first version decided inside `if (lane == 0)` and left with a flag; the
-    //  optimiser threaded lane 0's "claimed" edge past the broadcast, and one claim in twelve searched its query with ONE active
-    //  lane -- 63 lanes of zeros in the five wavefront minima: a PENDING query with the neighbour list {0, 0, 0, 0, 0}.)
-    auto claim_one = [&]() -> bool {
-      const int lane_c = lane_id_here();
-      const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(hctr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
-      uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32));
-      bool have = false;
-      while ((int32_t)(a - k) > 0) {
-        uint32_t seen = k;
-        if (lane_c == 0) {
-          uint32_t expect = k;
-          (void)__hip_atomic_compare_exchange_strong(hctr + 1, &expect, k + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          seen = expect;  // (the count before the exchange: k if this wavefront now owns record k)
-        }
-        seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
-        if (seen == k) { have = true; break; }
-        k = seen;
-      }
-      if (!have) return false;
-      const uint32_t t = k;
-      const uint32_t gen = ((t >> mp.hand_log2) % 2047u) + 1u;
-      u4v e;
-      const unsigned long long t0 = wall_clock64();
-      for (;;) {
-        e = load16_sc1(hring + (t & hmask));
-        const uint32_t ew = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w);
-        if ((ew >> 21) == gen) break;
-        if (wall_clock64() - t0 > 10000000ull) __builtin_trap();  // 100 ms without the record of a reserved slot: fail loudly (the launch is lost, the context reports it)
-        __builtin_amdgcn_s_sleep(2);
-      }
-      const float hx = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)e.x)), hy = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)e.y));
-      const float hz = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)e.z));
-      const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w) & 0x1FFFFFu;
-      query_wave_search(hx, hy, hz, hi, map, mcell_start, mpts, mp.sq_max_dist_f, corr.status, nbr5, rowoff, rowbeg, lane_c);
-      if (PROF) ++n_steal;
-      return true;
-    };
-    // HELPERS.  A wavefront that ends at the sweep's median (11 - 12 us) claims what the heavy items appended at 9 - 12 us and is done with it
-    // at 17 - 18: no earlier than the item's own second pass would have been.  The wavefronts WITHOUT an item (a 131 072-point sweep is
-    // ~3 200 items on 4 096 wavefronts) are free from the first microsecond: the first two of every part of the ring stay for
-    // hand_spin_ticks of the 100 MHz clock -- shorter than any sweep of a list this long lasts -- and look at their part's counts about
-    // once a microsecond.  They hold nothing anybody waits for; when the time is up they leave like everybody else, through the loop below.
-    if (mp.hand_spin_ticks != 0u && n_chunks >= 2048u) {
-      const uint32_t b0 = ((n_chunks + 3u) >> 2);                                   // first workgroup without an item
-      const uint32_t bh = b0 + ((hpart + kHandParts - (b0 % kHandParts)) % kHandParts);  // ... of this part of the ring
-      if (blockIdx.x == bh && wv < 2) {
-        const unsigned long long t_end = wall_clock64() + (unsigned long long)mp.hand_spin_ticks;
-        while (wall_clock64() < t_end) {
-          if (!claim_one()) __builtin_amdgcn_s_sleep(48);  // ~1.3 us at 2.4 GHz
-        }
-      }
-    }
-    while (claim_one()) {}
-  }
-  if (stamp && (threadIdx.x & 63u) == 0u) {  // one record per wavefront, no atomics (they would perturb the measurement)
+  if (stamp && lane_k == 0) {  // one record per wavefront, no atomics (they would perturb the measurement)
     unsigned long long* d = mp.kdbg + ((size_t)(begin ? 0 : (st->outer_iter & 1)) * gridDim.x * 4 + blockIdx.x * 4 + wv) * 16;
     d[0] = t_first; d[1] = wall_clock64();
     for (int i = 0; i < 5; ++i) d[2 + i] = acc[i];
     d[15] = clock64() - c_first;  // shader-clock ticks over the wavefront's life (d[1] - d[0] = the same span at 100 MHz)
-    d[7] = n_mine; d[8] = t_maxchunk; d[9] = n_cand_total; d[10] = n_q_total; d[11] = n_groups_total; d[12] = n_pass2 | (n_steal << 32); d[13] = max_info;
+    d[7] = n_mine; d[8] = t_maxchunk; d[9] = n_cand_total; d[10] = n_q_total; d[11] = n_groups_total; d[12] = n_pass2; d[13] = max_info;
     d[14] = n_fb_total | ((unsigned long long)(__builtin_amdgcn_s_getreg(63492) & 0xFFFFu) << 32) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xFu) << 48);  // + HW_ID[15:0] (wave, simd, cu, se), XCC_ID: where the wavefront ran
   }
   if (PROF) {
@@ -1892,6 +1688,7 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(const float* __rest
   const Pose pose = pose_from_array(T7);
   uint32_t* rowoff = rowtab[wv][0];
   uint32_t* rowbeg = rowtab[wv][1];
+  const int nc = map.nc;
   for (uint32_t base = i_lo; base < i_hi; base += 64u) {  // (one trip unless n / max_surface_features > 64)
     const uint32_t il = base + (uint32_t)lane;
     if (base != i_lo) { const uint32_t ic = il < n ? il : n - 1u; sx = scan[3 * ic]; sy = scan[3 * ic + 1]; sz = scan[3 * ic + 2]; }
@@ -1909,7 +1706,71 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(const float* __rest
       quat_rotate<double>(pose.q, (double)fx, (double)fy, (double)fz, pw[0], pw[1], pw[2]);  // LidarSlam.cpp:397-398
       pw[0] += pose.t[0]; pw[1] += pose.t[1]; pw[2] += pose.t[2];
       const float qx = (float)pw[0], qy = (float)pw[1], qz = (float)pw[2];                   // LidarSlam.cpp:728-731
-      query_wave_search(qx, qy, qz, i, map, mcell_start, mpts, mp.sq_max_dist_f, status, nbr5, rowoff, rowbeg, lane);
+      const CellRef c = locate(map, qx, qy, qz);
+      if (c.slot < 0) {  // outside the window / no tree: LidarSlam.cpp:736-739
+        if (lane == 0) __builtin_nontemporal_store((uint8_t)SO_MATCH_NOT_ENOUGH, &status[i]);
+        continue;
+      }
+      const int x0 = c.cx > 0 ? c.cx - 1 : 0, x1 = c.cx < nc - 1 ? c.cx + 1 : nc - 1;
+      uint32_t vb = 0, vl = 0;
+      if (lane < 9) {
+        const int y = c.cy + (lane % 3) - 1, z = c.cz + (lane / 3) - 1;
+        if (y >= 0 && y < nc && z >= 0 && z < nc) {
+          const uint32_t* row = mcell_start + (size_t)c.slot * map.ncell1 + ((size_t)z * nc + y) * nc;
+          vb = row[x0]; vl = row[x1 + 1] - vb;
+        }
+      }
+      uint32_t inc = vl;  // inclusive scan over lanes 0..15 (the nine runs sit in the first row of 16 lanes)
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, true);
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, true);
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, true);
+      inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, true);
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 15);
+      __builtin_amdgcn_wave_barrier();  // (a second point of the share: the table of the first has been read by every lane)
+      if (lane < 16) { rowoff[lane] = lane < 9 ? inc - vl : total; rowbeg[lane] = vb; }
+      if (lane == 0) rowoff[16] = total;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      Top5 loc;
+      loc.init();
+      for (uint32_t t0 = 0; t0 < total; t0 += 256u) {  // four loads of a lane in flight: a block of <= 256 points is one round trip
+        float ax_[4], ay_[4], az_[4];
+        uint32_t cn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
+          cn[u] = 0xFFFFFFFFu; ax_[u] = ay_[u] = az_[u] = 0.f;
+          if (t < total) {
+            int r = 0;
+#pragma unroll
+            for (int step = 8; step >= 1; step >>= 1) r = (r + step < 16 && rowoff[r + step] <= t) ? r + step : r;
+            cn[u] = rowbeg[r] + (t - rowoff[r]);
+            const float4 p = mpts[cn[u]];
+            ax_[u] = p.x; ay_[u] = p.y; az_[u] = p.z;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (cn[u] != 0xFFFFFFFFu) loc.insert(((unsigned long long)__float_as_uint(l2_d2(qx, qy, qz, ax_[u], ay_[u], az_[u])) << 32) | cn[u]);
+      }
+      unsigned long long m5[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        m5[t] = wave_min_u64(loc.b0);
+        if (loc.b0 == m5[t] && m5[t] != ~0ull) { loc.b0 = loc.b1; loc.b1 = loc.b2; loc.b2 = loc.b3; loc.b3 = loc.b4; loc.b4 = ~0ull; }  // (keys are unique)
+      }
+      if (lane == 0) {
+        const float d2_4 = __uint_as_float((uint32_t)(m5[4] >> 32));
+        int stq = SO_MATCH_PENDING;  // five neighbours inside the gate: the plane fit runs in slot 0 of the solve
+        if (m5[4] == ~0ull || (double)d2_4 > (double)mp.sq_max_dist_f) stq = SO_MATCH_TOO_FAR;  // LidarSlam.cpp:741-744 (d2[4] stays FLT_MAX with < 5 points)
+        else {
+          uint32_t* o = nbr5 + (size_t)5 * i;
+          __builtin_nontemporal_store((uint32_t)m5[0], o); __builtin_nontemporal_store((uint32_t)m5[1], o + 1);
+          __builtin_nontemporal_store((uint32_t)m5[2], o + 2); __builtin_nontemporal_store((uint32_t)m5[3], o + 3);
+          __builtin_nontemporal_store((uint32_t)m5[4], o + 4);
+        }
+        __builtin_nontemporal_store((uint8_t)stq, &status[i]);
+      }
     }
   }
 }
@@ -1990,6 +1851,15 @@ __device__ __forceinline__ int lm_control_regs(int slot, DevState* st, LmState& 
     for (int i = 0; i < 6; ++i) st->Jtr[i] = have ? S.g[i] : 0.0;
   }
   return 0;
+}
+
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+// 16-byte agent-scope (sc1) store / load: one access, bypassing the non-coherent per-XCD L2 state [MI355X guide, G16]
+__device__ __forceinline__ void store16_sc1(u4v* p, u4v v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u4v load16_sc1(const u4v* p) {
+  u4v v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
 }
 
 // system-scope 16-byte store / load (sc0 sc1): the peer-exchange inboxes are written over xGMI by other devices

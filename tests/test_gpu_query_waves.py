@@ -62,6 +62,8 @@ def test_query_wave_sweep_equals_the_chunked_sweep_and_the_oracle(oracle, soicp,
         assert not (sb.flags & soicp.FLAG_QUERY_WAVES), hex(sb.flags)
         assert np.array_equal(pa, pb), "the two sweeps must give the same bits"
         assert np.array_equal(ma, mb), "MatchingResult of every query"
+        judged = np.isin(ma, (0, 3, 4, 5))  # (five neighbours inside the gate: the fit pass judged the query)
+        assert judged.sum() > 100 and np.array_equal(a.neighbours(len(scan))[judged], b.neighbours(len(scan))[judged]), "neighbour lists of the last sweep"
         _same(sa, sb)
         orc, opose, ost, _ = om.register(scan, guess, oracle.default_config(max_iterations=5, max_surface_features=max_feat))
         assert orc == 0 and sa.n_iterations == ost.n_iterations
