@@ -2705,21 +2705,8 @@ __device__ __forceinline__ int eval_pass(int slot, int fuse_lm, const Pose& pose
       __syncthreads();
     }
     if (stamp) t_sums = wall_clock64();
-    if (BATCH) {  // (not latency-critical here: the controller works on the LDS copy of its state, no register staging)
-      if (tid == 0) {
-        int rd = 0;
-        const int more_ = lm_control_regs(slot, st, sh_S, sh_sums, sh_ctl, true, &rd);
-        sh.reg_done = rd;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const unsigned long long val = (k < 7) ? (unsigned long long)__double_as_longlong(sh_S.cand[k < 7 ? k : 0]) : (unsigned long long)more_;
-          const u4v v = {(unsigned int)val, (unsigned int)(val >> 32), (unsigned int)want, (unsigned int)(want >> 32)};
-          store16_sc1(hand + k, v);
-        }
-        for (int k = 0; k < 7; ++k) sh.pose[k] = sh_S.cand[k];
-        sh_more = more_;
-      }
-    } else
+    // (BATCH too, round 6: the one-thread controller on the LDS copy of its state was what spilled -- 316 bytes of scratch per lane in a launch
+    //  capped at 256 registers --, in the serial code every virtual workgroup's pass waits for)
     if (tid < 64) {  // the controller's wavefront (publishes the hand-off)
 #ifdef SO_LM_STAMPS
       const int more_ = lm_control_wave(slot, st, sh_S, sh_sums, sh_ctl, &sh.part_odd[0][0], hand, want, sh.pose, &sh.reg_done, tid, (slot == 1 && tid == 0) ? st->dbg : nullptr);
