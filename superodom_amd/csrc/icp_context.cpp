@@ -309,7 +309,6 @@ struct so_icp_ctx {
   struct SeqNext { const void* next_scan = nullptr; size_t next_n = 0; double delta[7] = {0, 0, 0, 0, 0, 0, 1}; bool announced = false;  // for the coming call to stage
                    const void* scan = nullptr; size_t n = 0;                                                                             // staged by the last call
                    bool staged = false; int slot = 0; bool binned = false, needs_event = false; const float* d_scan = nullptr; } seq_next;
-  bool seq_copy_ahead = true;             // SOICP_SEQ_COPY_AHEAD=0: a scan's copy is enqueued with its binning, one registration ahead (experiment switch)
   bool seq_chain = true;                  // SOICP_SEQ_CHAIN=0: so_icp_register_sequence runs one registration after the other (same results)
   bool query_waves = true;                // SOICP_QUERY_WAVES=0: a small scan (<= 4 096 kept queries) is binned and swept in chunks like a large one
   bool knn_pack = true;                   // SOICP_KNN_PACK=0: one chunk per wavefront throughout (round-3 work list)
@@ -1615,7 +1614,6 @@ so_icp_ctx* so_icp_create(const so_icp_config* cfg) {
   if (const char* ev = std::getenv("SOICP_QUERY_WAVES")) c->query_waves = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_PREBIN")) c->prebin = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_SEQ_CHAIN")) c->seq_chain = std::atoi(ev) != 0;
-  if (const char* ev = std::getenv("SOICP_SEQ_COPY_AHEAD")) c->seq_copy_ahead = std::atoi(ev) != 0;
   if (const char* ev = std::getenv("SOICP_BATCH_CHAIN")) c->batch_chain = std::string(ev) != "0";
   if (const char* ev = std::getenv("SOICP_BATCH_MODE")) {  // "one_per_cu": one solve workgroup per compute unit (several processes on one device); "lanes"
     if (std::string(ev) == "one_per_cu") c->batch_degrade = 1;
@@ -2005,7 +2003,7 @@ int so_icp_register_sequence(so_icp_ctx* c, int count, const void* const* scans,
   // leaves 60 % of its issue slots empty -- instead of behind a 34 us copy, beside the first solve, whose one wavefront per SIMD it slowed
   // by ~5 us (41 - 43 us against 36 - 37 for the second solve of the same registration: profiles/r06/sequence_timeline_flag_wait.txt).
   auto copy_ahead = [&](int k) -> int {
-    if (k >= count || scans_on_device || !c->seq_copy_ahead) return SO_ICP_OK;
+    if (k >= count || scans_on_device) return SO_ICP_OK;
     SeqRun& r = runs[(size_t)k];
     if (!r.slot || !r.n || r.copied) return SO_ICP_OK;
     so_icp_ctx::StageSlot& sl = *r.slot;

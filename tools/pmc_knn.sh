@@ -31,7 +31,7 @@ for (k, c), v in sorted(vals.items()):
     print(f"{k:42s} {c:22s} launches {len(v):4d} real {len(keep):4d} mean(real) {real[(k, c)]:14.1f}")
 if a == "0":
     kk = [k for (k, c) in real if "knn_plane" in k][0]
-    j = {"kernel": "soicp::knn_plane_kernel", "round": 5, "kernels_hip_sha256": sha,
+    j = {"kernel": "soicp::knn_plane_kernel", "round": 6, "kernels_hip_sha256": sha,
          "source": "tools/pmc_knn.sh: rocprofv3 --pmc SQ_INSTS_VALU ... --kernel-trace (own pass, no other trace domain), bench.py --steps 4 --warmup 1 --entry resident; no-op launches excluded",
          "valu_wave_insts_per_launch": real[(kk, "SQ_INSTS_VALU")], "salu_wave_insts_per_launch": real[(kk, "SQ_INSTS_SALU")],
          "lds_wave_insts_per_launch": real[(kk, "SQ_INSTS_LDS")], "waves_per_launch": real[(kk, "SQ_WAVES")],

@@ -37,7 +37,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     v = [x for k, vs in acc.items() if "solve_kernel" in k for x in vs]
     real = [x for x in v if x > 0.2 * max(v)] if v else []
     res["solve_" + ctr] = (sum(real) / len(real)) if real else None
-j = {"kernel": "soicp::knn_plane_kernel", "round": 5, "kernels_hip_sha256": sha,
+j = {"kernel": "soicp::knn_plane_kernel", "round": 6, "kernels_hip_sha256": sha,
      "source": "tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, bench.py --steps 4 --warmup 1); no-op launches excluded",
      "FETCH_SIZE_KB_per_launch": res["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": res["WRITE_SIZE"],
      "launches": [res["FETCH_SIZE_launches"], res["WRITE_SIZE_launches"]],
