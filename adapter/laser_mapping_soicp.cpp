@@ -152,8 +152,19 @@ bool laserMapping::loadPriorMap() {
 
 void laserMapping::laserFeatureInfoHandler(const so_wire::LaserFeature& msgIn) {  // :250-263
   std::lock_guard<std::mutex> lk(mBuf);
+  const bool next_in_line = surfLastBuf.empty();  // (process() takes the OLDEST queued frame and drops the rest, :689-699)
   cornerLastBuf.push(msgIn.cloud_corner);
   surfLastBuf.push(msgIn.cloud_surface);
+  if (next_in_line) {
+    // the raw surf cloud of the frame process() will take next: its copy to the device starts here, beside the frame in flight
+    // (adjustVoxelSize names the same payload -- the queue's element is MOVED into surfLast_ -- and starts with its first kernel)
+    const so_wire::PointCloud2& pc = surfLastBuf.front();
+    const size_t n = (size_t)pc.width * pc.height;
+    if (n) {
+      const XyzLayout L = xyz_layout(pc);
+      if (L.contiguous && !L.off_x) slam.AnnounceSurf(reinterpret_cast<const float*>(pc.data.data()), n, pc.point_step);
+    }
+  }
   realsenseBuf.push(msgIn.cloud_realsense);
   fullResBuf.push(msgIn.cloud_nodistortion);
   IMUPredictionBuf.push(Quaterniond(msgIn.initial_quaternion_w, msgIn.initial_quaternion_x, msgIn.initial_quaternion_y, msgIn.initial_quaternion_z));

@@ -117,6 +117,10 @@ void LidarSLAM::Localization(bool initialization, PredictionSource /*predictodom
   read_back(edge_point ? (int32_t)edge_point->points.size() : 0, T_out, timeLaserOdometry);
 }
 
+void LidarSLAM::AnnounceSurf(const float* xyz, size_t n, size_t stride_bytes) {
+  if (gpu_ && xyz && n) (void)so_icp_prefilter_announce(gpu_, xyz, n, stride_bytes);  // (a refused announcement only means "not staged ahead")
+}
+
 void LidarSLAM::PrefilterSurf(const float* xyz, size_t n, size_t stride_bytes, bool auto_voxel_size, float line_res, float plane_res,
                               so_icp_prefilter_info* info, const void** d_filtered, size_t* n_filtered) {
   ensure_context();

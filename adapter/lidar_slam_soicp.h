@@ -80,6 +80,9 @@ class LidarSLAM {
   // feeds LocalizationPrefiltered -- the filtered cloud never visits the host.  xyz may point into a PointCloud2 payload.
   void PrefilterSurf(const float* xyz, size_t n, size_t stride_bytes, bool auto_voxel_size, float line_res, float plane_res,
                      so_icp_prefilter_info* info, const void** d_filtered, size_t* n_filtered);
+  // optional, any thread: the raw surf cloud the NEXT PrefilterSurf call will name starts its H2D copy now (so_icp_prefilter_announce);
+  // the buffer must stay where it is, unchanged, until that call.  No-op before the context exists.
+  void AnnounceSurf(const float* xyz, size_t n, size_t stride_bytes);
   // utils::pointAssociateToMap over a cloud (the registered scan of laserMapping::publishTopic, laserMapping.cpp:464-493) on the
   // device: records with float x y z at 0 4 8 rewritten in place, keep[i] = the node publishes point i
   size_t TransformCloud(void* points, size_t n, size_t stride_bytes, const Transformd& T, std::vector<uint8_t>& keep);

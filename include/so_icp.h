@@ -365,10 +365,16 @@ typedef struct {
   int32_t statistic_in_input_order; /* 1: average_distance is the reference's own float accumulation in input order, bit for bit
                                        (taken whenever the value is close enough to 25 / 65 for its roundings to decide);
                                        0: mean|x| mean|y| mean|z| from exact sums -- within 3 n 2^-24 of it, same decision */
-  int32_t reserved;
+  int32_t reserved;                 /* 1: the cloud had been announced (so_icp_prefilter_announce): no copy on this call's path */
 } so_icp_prefilter_info;
 int so_icp_prefilter_scan(so_icp_ctx *ctx, const float *surf_xyz, size_t n, size_t stride_bytes, int auto_voxel_size,
                           float line_res, float plane_res, void **d_filtered_out, size_t *n_out, so_icp_prefilter_info *info);
+/* Announce the NEXT raw surf cloud (laserFeatureInfoHandler has it long before process() reaches it, lmap.cpp:250-263, 768-793): its H2D copy
+ * (34 us for a 131 072-point sweep over PCIe) goes into the pre-filter's queue now, beside the registration of the frame before, and the
+ * so_icp_prefilter_scan call that names the same buffer (pointer, n, stride) starts with its first kernel; so_icp_prefilter_info::reserved
+ * says 1 when that happened.  The buffer must stay valid and unchanged until that call returns; xyz == NULL withdraws the announcement
+ * (and waits for a copy under way).  One announcement at a time (a second one replaces the first); any thread.  Results never depend on it. */
+int so_icp_prefilter_announce(so_icp_ctx *ctx, const float *surf_xyz, size_t n, size_t stride_bytes);
 
 /* -------- two steps before Seam A: featureExtraction::removePointDistortion
  * (src/FeatureExtraction/featureExtraction.cpp:223-314) on the device.  Every finite point of the sweep is moved to the

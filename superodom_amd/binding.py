@@ -95,7 +95,7 @@ EXPORTED = ["so_icp_default_config", "so_icp_create", "so_icp_destroy", "so_icp_
             "so_icp_localization_dev", "so_icp_download_scan", "so_icp_prefilter_scan", "so_icp_stage_scan", "so_icp_debug_match_status", "so_icp_comm_init_inprocess", "so_icp_peer_export", "so_icp_peer_connect", "so_icp_peer_enable",
             "so_icp_deskew_scan", "so_icp_deskew_scan_dev", "so_icp_transform_cloud", "so_icp_shard_histogram",
             "so_icp_host_register", "so_icp_host_unregister", "so_icp_host_alloc", "so_icp_host_free", "so_icp_device_count", "so_icp_stage_cancel",
-            "so_icp_map_insert_stats", "so_icp_register_sequence", "so_icp_map_export_records", "so_icp_sequence_announce_next", "so_icp_debug_neighbours"]
+            "so_icp_map_insert_stats", "so_icp_register_sequence", "so_icp_map_export_records", "so_icp_sequence_announce_next", "so_icp_debug_neighbours", "so_icp_prefilter_announce"]
 
 _lib = None
 
@@ -156,6 +156,7 @@ def load():
         fn.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(C.c_double), C.c_size_t, C.c_int, C.POINTER(C.c_double),
                        C.POINTER(DeskewInfo)]
     L.so_icp_transform_cloud.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_size_t)]
+    L.so_icp_prefilter_announce.argtypes = [vp, f32p, C.c_size_t, C.c_size_t]
     L.so_icp_prefilter_scan.argtypes = [vp, f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_float, C.c_float, C.POINTER(vp),
                                         C.POINTER(C.c_size_t), C.POINTER(PrefilterInfo)]
     L.so_icp_debug_knn_stamps.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_size_t)]
@@ -454,6 +455,13 @@ class LidarSlamGpu:
         out = np.zeros((n, 3), np.float32)
         self._check(self.L.so_icp_download_scan(self.h, d_scan, n, _p(out, C.c_float)))
         return out
+
+    def prefilter_announce(self, surf_points):
+        """so_icp_prefilter_announce: the raw cloud of the NEXT prefilter_scan call starts its way to HBM now (None withdraws)"""
+        if surf_points is None:
+            self._check(self.L.so_icp_prefilter_announce(self.h, None, 0, 12)); return
+        assert isinstance(surf_points, np.ndarray) and surf_points.dtype == np.float32 and surf_points.flags.c_contiguous
+        self._check(self.L.so_icp_prefilter_announce(self.h, _p(surf_points, C.c_float), len(surf_points.reshape(-1, 3)), 12))
 
     def prefilter_scan(self, surf_points, auto_voxel_size, line_res, plane_res):
         """laserMapping::adjustVoxelSize on the device; returns (d_scan, n, PrefilterInfo)."""

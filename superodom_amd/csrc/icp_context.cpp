@@ -196,6 +196,9 @@ struct so_icp_ctx {
   DevBuf d_bin_key, d_bin_cnt, d_bin_off; uint32_t bin_log2 = 0; bool bin_dirty = true;
   int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
   std::vector<DevBuf> resident_scans;  // so_icp_upload_scan
+  // so_icp_prefilter_announce: the NEXT raw cloud, already on its way to HBM (pf_stage) when so_icp_prefilter_scan is called with the same buffer
+  DevBuf pf_stage; std::mutex pf_mu;
+  struct PfAnnounced { const void* ptr = nullptr; size_t n = 0, stride = 0; bool on = false; } pf_announced;
   DevBuf pf_in, pf_out, pf_small, pf_w, pf_s, pf_k0, pf_k1, pf_v0, pf_v1, pf_flags, pf_pos, pf_heads, pf_temp;  // so_icp_prefilter_scan
   DevBuf pf_dec;                      // {counters[16], VgDecision, partial statistics}: the pre-filter decided on the device
   VgDecision* h_pf = nullptr;         // pinned read-back of the decision
@@ -1490,7 +1493,7 @@ so_icp_ctx::~so_icp_ctx() {
   if (comm && rccl.CommDestroy) rccl.CommDestroy(comm);
   for (DevBuf* b : {&d_world, &d_mpts, &d_cell_start, &d_cube_slot, &d_scan_own, &d_keys0, &d_vals0, &d_chunks,
                     &d_binned, &d_nd, &d_coeff, &d_status, &d_nbr5, &d_small, &d_q, &d_nbr, &d_d2, &d_idx,
-                    &d_found, &d_fblist, &d_kdbg, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
+                    &d_found, &d_fblist, &d_kdbg, &pf_stage, &pf_in, &pf_out, &pf_small, &pf_w, &pf_s, &pf_k0, &pf_k1, &pf_v0, &pf_v1, &pf_flags, &pf_pos,
                     &pf_heads, &pf_temp, &pf_dec, &d_bin_key, &d_bin_cnt, &d_bin_off, &d_pbin_key, &d_pbin_cnt, &d_pbin_off, &d_counts, &d_sub})
     b->release();
   for (DevBuf& b : resident_scans) b.release();
@@ -2845,6 +2848,26 @@ static int prefilter_fast(so_icp_ctx* c, hipStream_t s, size_t n, uint32_t sf, i
   return SO_ICP_OK;
 }
 
+int so_icp_prefilter_announce(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes) {
+  if (!c) return SO_ICP_E_INVALID;
+  NEED_DEVICE(c);
+  HIP_TRY(c, hipSetDevice(c->cfg.device_id));
+  if (stride_bytes == 0) stride_bytes = 12;
+  if (stride_bytes % 4) return fail(c, SO_ICP_E_INVALID, "stride_bytes must be a multiple of 4");
+  hipStream_t s = aux_stream(c);
+  std::lock_guard<std::mutex> lk(c->pf_mu);
+  if (!xyz || !n) {  // withdrawn: a copy under way must have left the caller's buffer before the caller reuses it
+    if (c->pf_announced.on) HIP_TRY(c, hipStreamSynchronize(s));
+    c->pf_announced = so_icp_ctx::PfAnnounced{};
+    return SO_ICP_OK;
+  }
+  // (the pre-filter's queue: whatever still reads pf_stage -- nothing does, a taken buffer became pf_in -- or writes it is in front of this copy)
+  HIP_TRY(c, c->pf_stage.reserve(n * stride_bytes + 64));
+  HIP_TRY(c, hipMemcpyAsync(c->pf_stage.p, xyz, n * stride_bytes, hipMemcpyHostToDevice, s));
+  c->pf_announced.ptr = xyz; c->pf_announced.n = n; c->pf_announced.stride = stride_bytes; c->pf_announced.on = true;
+  return SO_ICP_OK;
+}
+
 int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stride_bytes, int auto_voxel_size, float line_res,
                           float plane_res, void** d_out, size_t* n_out, so_icp_prefilter_info* info) {
   if (!c || (!xyz && n) || !d_out || !n_out) return SO_ICP_E_INVALID;
@@ -2863,12 +2886,23 @@ int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stri
   li.line_res = line_res; li.plane_res = plane_res;
   *d_out = nullptr; *n_out = 0;
   if (!n) { if (info) *info = li; return so_icp_set_resolution(c, line_res, plane_res); }
-  // raw cloud -> device (with its stride)
-  HIP_TRY(c, c->pf_in.reserve(n * stride_bytes + 64));
-  HIP_TRY(c, hipMemcpyAsync(c->pf_in.p, xyz, n * stride_bytes, hipMemcpyHostToDevice, s));
+  // raw cloud -> device (with its stride) -- unless it was announced (so_icp_prefilter_announce): then its copy went into the queue long
+  // ago (34 us for a 131 072-point sweep, beside the registration of the frame before) and the two buffers change places
+  bool announced = false;
+  {
+    std::lock_guard<std::mutex> lk(c->pf_mu);
+    announced = c->pf_announced.on && c->pf_announced.ptr == (const void*)xyz && c->pf_announced.n == n && c->pf_announced.stride == stride_bytes &&
+                c->pf_stage.p != nullptr;
+    c->pf_announced.on = false;  // (taken, or not meant for this call: a copy still in this queue ends before this call's read-back does)
+    if (announced) std::swap(c->pf_in, c->pf_stage);
+  }
+  if (!announced) {
+    HIP_TRY(c, c->pf_in.reserve(n * stride_bytes + 64));
+    HIP_TRY(c, hipMemcpyAsync(c->pf_in.p, xyz, n * stride_bytes, hipMemcpyHostToDevice, s));
+  }
   if (c->pf_fast) {
     const int frc = prefilter_fast(c, s, n, sf, auto_voxel_size, line_res, plane_res, li, d_out, n_out);
-    if (frc != kPrefilterHostPath) { if (frc == SO_ICP_OK && info) *info = li; return frc; }
+    if (frc != kPrefilterHostPath) { li.reserved = announced ? 1 : 0; if (frc == SO_ICP_OK && info) *info = li; return frc; }
     std::memset(&li, 0, sizeof(li)); li.line_res = line_res; li.plane_res = plane_res;
   }
   // statistics + bounding box (fp64 tree sums; the reference accumulates |x|,|y|,|z| in float in input order --
@@ -2923,6 +2957,7 @@ int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stri
     else HIP_TRY(c, hipMemcpy2DAsync(c->pf_out.p, 12, c->pf_in.p, stride_bytes, 12, n, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     *d_out = c->pf_out.p; *n_out = n;
+    li.reserved = announced ? 1 : 0;
     if (info) *info = li;
     return SO_ICP_OK;
   }
@@ -2948,6 +2983,7 @@ int so_icp_prefilter_scan(so_icp_ctx* c, const float* xyz, size_t n, size_t stri
   HIP_TRY(c, hipMemcpyAsync(&n_leaves, c->pf_small.p, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(c, hipStreamSynchronize(s));
   *d_out = c->pf_out.p; *n_out = n_leaves;
+  li.reserved = announced ? 1 : 0;
   if (info) *info = li;
   return SO_ICP_OK;
 }

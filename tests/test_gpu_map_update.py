@@ -468,3 +468,40 @@ def test_map_export_as_records_equals_the_packed_export(gpu_slam_factory):
     rec5 = slam.export_map_records(32, only_5x5=True, pos=pos)
     assert len(sub) > 0 and np.array_equal(np.ascontiguousarray(rec5).view(np.float32).reshape(-1, 8)[:, :3], sub)
     slam.close()
+
+
+def test_an_announced_raw_cloud_is_filtered_from_its_staged_copy(oracle, gpu_slam_factory):
+    """so_icp_prefilter_announce: the raw cloud of the next so_icp_prefilter_scan call starts its H2D copy ahead; the call that names the same
+    buffer takes the staged copy (info.reserved == 1), a call with another buffer ignores it, a withdrawn announcement is forgotten --
+    filtered clouds and decisions identical in every case (lmap.cpp:600-651)."""
+    sc = synth.Scene("small")
+    slam = gpu_slam_factory(plane_res=0.4, line_res=0.2, max_surface_features=-1, max_iterations=3)
+    slam.add_surf_point_cloud(sc.map_points)
+    clouds = [slam.host_alloc_like(np.ascontiguousarray(sc.scan(i), dtype=np.float32)) for i in range(3)] + \
+             [np.ascontiguousarray(sc.scan(3), dtype=np.float32)]  # (pinned pool memory and a pageable numpy array)
+    plain = []
+    for cl in clouds:
+        d, n, info = slam.prefilter_scan(cl, True, 0.2, 0.4)
+        assert info.reserved == 0
+        plain.append((slam.download_scan(d, n).copy(), info.average_distance, info.plane_res, info.count_far_points))
+    for k, cl in enumerate(clouds):
+        slam.prefilter_announce(cl)
+        d, n, info = slam.prefilter_scan(cl, True, 0.2, 0.4)
+        assert info.reserved == 1, "the announced copy was not taken"
+        got = slam.download_scan(d, n)
+        assert np.array_equal(got, plain[k][0]) and (info.average_distance, info.plane_res, info.count_far_points) == plain[k][1:]
+    # an announcement for another buffer; two announcements in a row (the second replaces the first); a withdrawn one
+    slam.prefilter_announce(clouds[0])
+    d, n, info = slam.prefilter_scan(clouds[1], True, 0.2, 0.4)
+    assert info.reserved == 0 and np.array_equal(slam.download_scan(d, n), plain[1][0])
+    slam.prefilter_announce(clouds[0]); slam.prefilter_announce(clouds[2])
+    d, n, info = slam.prefilter_scan(clouds[2], True, 0.2, 0.4)
+    assert info.reserved == 1 and np.array_equal(slam.download_scan(d, n), plain[2][0])
+    slam.prefilter_announce(clouds[1]); slam.prefilter_announce(None)
+    d, n, info = slam.prefilter_scan(clouds[1], True, 0.2, 0.4)
+    assert info.reserved == 0 and np.array_equal(slam.download_scan(d, n), plain[1][0])
+    # the staged copy is the cloud AS ANNOUNCED: the frame after it comes out of the other buffer again
+    slam.prefilter_announce(clouds[0])
+    d, n, info = slam.prefilter_scan(clouds[0], False, 0.2, 0.4)
+    d2, n2, info2 = slam.prefilter_scan(clouds[0], False, 0.2, 0.4)
+    assert info.reserved == 1 and info2.reserved == 0 and np.array_equal(slam.download_scan(d2, n2), oracle.voxel_grid(np.asarray(clouds[0]), 0.4))

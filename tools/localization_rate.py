@@ -47,6 +47,8 @@ for mode in a.modes.split(","):
             slam.stage_scan(bufs[(k + 1) % 4])
         if mode.startswith("node"):
             d_scan, n_f, info = slam.prefilter_scan(bufs[i], False, sc.plane_res / 2, sc.plane_res)
+            if mode == "node":  # (the feature callback has the next raw cloud long before process() reaches it: its copy overlaps this frame's registration)
+                slam.prefilter_announce(bufs[(k + 1) % 4])
             t_pre = time.perf_counter() - t
             rc, pose, st = slam.localization_dev(True, guesses[i], d_scan, n_f, 0.1 * k)
             pre.append(t_pre); nf = n_f
