@@ -39,11 +39,24 @@ def cloud():
 
 slam = binding.LidarSlamGpu(plane_res=0.4, line_res=0.2)
 t_end, n_clouds, n_pts, n_bad = time.time() + a.seconds, 0, 0, 0
+n_announced = 0
 while time.time() < t_end:
     raw = cloud()
     auto = bool(rng.random() < 0.5)
     line, plane = [(0.1, 0.2), (0.2, 0.4), (0.05, 0.1), (0.4, 0.8)][int(rng.integers(0, 4))]
+    # so_icp_prefilter_announce at random: for this cloud (the staged copy must be taken), for another buffer (ignored), announced and
+    # withdrawn, or not at all -- the filtered cloud must not depend on it
+    how = int(rng.integers(0, 4))
+    if how == 0:
+        slam.prefilter_announce(raw)
+    elif how == 1:
+        other = cloud(); slam.prefilter_announce(other)
+    elif how == 2:
+        slam.prefilter_announce(raw); slam.prefilter_announce(None)
     d, n, info = slam.prefilter_scan(raw, auto, line, plane)
+    n_announced += int(info.reserved == 1)
+    if (how == 0) != (info.reserved == 1):
+        n_bad += 1; print("announcement taken / not taken against expectation:", how, info.reserved)
     got = slam.download_scan(d, n) if n else np.zeros((0, 3), np.float32)
     ab = np.abs(raw).astype(np.float32)
     avg = [np.add.accumulate(ab[:, k], dtype=np.float32)[-1] / np.float32(len(raw)) for k in range(3)]
@@ -62,5 +75,5 @@ while time.time() < t_end:
     if not ok:
         n_bad += 1
         print(f"MISMATCH cloud {n_clouds} n {len(raw)} auto {auto} res {line}/{plane} -> {info.plane_res} far {info.count_far_points}/{far} avg {info.average_distance}/{avg_dist} out {got.shape}/{ref.shape}", flush=True)
-print(f"soak: {n_clouds} clouds, {n_pts} points, {n_bad} mismatches (seed {a.seed})")
+print(f"soak: {n_clouds} clouds, {n_pts} points, {n_announced} filtered from an announced copy, {n_bad} mismatches (seed {a.seed})")
 sys.exit(1 if n_bad else 0)

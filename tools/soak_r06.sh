@@ -11,4 +11,6 @@ timeout 200 python tools/soak_knn.py --seconds 25 --seed 306 2>&1 | tail -1 > $O
 timeout 200 python tools/soak_localization.py --seconds 40 --seed 306 2>&1 | tail -1 > $O/soak_localization.txt
 timeout 200 python tools/soak_map_insert.py --seconds 25 --seed 312 --oracle 2>&1 | tail -1 > $O/soak_map_insert.txt
 timeout 200 python tools/soak_shards.py --seconds 30 --seed 306 2>&1 | tail -1 > $O/soak_shards.txt
+timeout 200 python tools/soak_prefilter.py --seconds 40 --seed 306 2>&1 | tail -1 > $O/soak_prefilter.txt
+timeout 200 python tools/soak_deskew.py --seconds 15 --seed 306 2>&1 | tail -1 > $O/soak_deskew.txt
 for f in $O/soak_*.txt; do echo "== $(basename $f)"; cat $f; done | tee $O/all.txt
