@@ -197,7 +197,7 @@ struct so_icp_ctx {
   int32_t* h_hist = nullptr;  // pinned: per-outer-iteration copy of the histogram replicas (profiling mode)
   std::vector<DevBuf> resident_scans;  // so_icp_upload_scan
   // so_icp_prefilter_announce: the NEXT raw cloud, already on its way to HBM (pf_stage) when so_icp_prefilter_scan is called with the same buffer
-  DevBuf pf_stage; std::mutex pf_mu;
+  DevBuf pf_stage; std::mutex pf_mu, aux_mu;
   struct PfAnnounced { const void* ptr = nullptr; size_t n = 0, stride = 0; bool on = false; } pf_announced;
   DevBuf pf_in, pf_out, pf_small, pf_w, pf_s, pf_k0, pf_k1, pf_v0, pf_v1, pf_flags, pf_pos, pf_heads, pf_temp;  // so_icp_prefilter_scan
   DevBuf pf_dec;                      // {counters[16], VgDecision, partial statistics}: the pre-filter decided on the device
@@ -970,6 +970,7 @@ int register_core(so_icp_ctx* c, const float* d_scan, size_t n, const double pos
 // The queue of the host-in / host-out steps around Localization() (pre-filter, de-skew, registered scan): they touch nothing the
 // map insert of the previous frame uses, so they need not wait behind it in the context's queue.
 static hipStream_t aux_stream(so_icp_ctx* c) {
+  std::lock_guard<std::mutex> lk(c->aux_mu);  // (created on first use, and so_icp_prefilter_announce may be that use, on the callback's thread)
   if (!c->pf_stream && hipStreamCreateWithFlags(&c->pf_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return c->stream; }
   return c->pf_stream;
 }
