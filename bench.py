@@ -789,6 +789,24 @@ def main():
                     assert rc_ == 0, (name, k, rc_)
                 cx.synchronize()
                 t_reg = (time.perf_counter() - t0) / K
+                # the same K registrations as ONE so_icp_register_sequence call on the resident clouds (a backlog in localization mode: guesses
+                # chained on the device, delta_k = gt(k-1)^-1 o guess_k)
+                t_seq = None
+                try:
+                    dk = np.zeros((K, 7)); dk[:, 6] = 1.0
+                    for k in range(1, K):
+                        dk[k] = synth.pose_between(scene.gt_pose((k - 1) % ns), gs[k % ns])
+                    seq_list = [d_filt[k % ns] for k in range(K)]
+                    for rep_ in range(2):  # (the first call allocates the sequence's buffers)
+                        call_s, _o, _g, st_s, n_s, _keep_s = cx.prepare_register_sequence(seq_list, gk[0], dk, on_device=True)
+                        cx.synchronize()
+                        t0 = time.perf_counter()
+                        rc_s = call_s()
+                        cx.synchronize()
+                        t_seq = (time.perf_counter() - t0) / K
+                        assert rc_s == 0 and n_s.value == K, (rc_s, n_s.value)
+                except Exception as e_seq:  # noqa: BLE001
+                    t_seq = None
                 # node order per frame: pre-filter + Localization() (registration + map insert), host buffers in pinned memory
                 bufs = [cx.host_alloc_like(x) for x in host_scans]
                 frames = 32
@@ -807,9 +825,11 @@ def main():
                 stock[name] = {"config": cite, "plane_res": plane_res, "max_surface_features": max_feat, "max_iterations": 5,
                                "raw_points": int(len(host_scans[0])), "filtered_points": int(len(filt[0])), "sampled_queries": sampled,
                                "registration_ms": 1e3 * t_reg, "registrations_per_s": 1.0 / t_reg, "node_frame_ms": 1e3 * t_frame,
+                               "registration_ms_in_a_sequence": (1e3 * t_seq if t_seq else None),
                                "outer_iterations": sum(s_.n_iterations for s_ in st_k) / K,
                                "lm_iterations": sum(s_.iterations[i].lm_iterations for s_ in st_k for i in range(s_.n_iterations)) / K,
-                               "note": "registration_ms = so_icp_register_dev on the pre-filtered resident cloud (sampling rule inside); node_frame_ms = "
+                               "note": "registration_ms = so_icp_register_dev on the pre-filtered resident cloud (sampling rule inside); registration_ms_in_a_sequence = "
+                                       "the same registrations as one so_icp_register_sequence call (guesses chained on the device); node_frame_ms = "
                                        "so_icp_prefilter_scan + so_icp_localization_dev incl. the map insert, back-to-back frames"}
                 stock_cpu_jobs.append((name, map_before, filt, gs, plane_res, max_feat, st_k[:ns], po_k[:ns]))
             finally:
