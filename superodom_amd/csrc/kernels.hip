@@ -1680,8 +1680,10 @@ __global__ __launch_bounds__(256) void knn_query_wave_kernel(const float* __rest
     }
   } else {
     if (st->reg_done) return;  // the registration already converged: this launch is a no-op
-    // the report of the previous outer iteration, left to this launch by its solve (MatchParams::publish_prev)
-    if (mp.publish_prev && blockIdx.x == 0 && st->outer_iter > 0)
+    // the report of the previous outer iteration, left to this launch by its solve (MatchParams::publish_prev): by a workgroup of its own
+    // behind the searching ones (the launch has one more) -- the write-back + system fence + PCIe stores take 2.7 us, which in front of
+    // workgroup 0's searches made a 9 us sweep a 12 us one
+    if (mp.publish_prev && blockIdx.x + 1u == gridDim.x && st->outer_iter > 0)
       publish_state_to(mp.hring[(st->outer_iter - 1) & 1], st, mp.seq_base | (unsigned long long)st->outer_iter, (int)threadIdx.x, 256);
   }
   if (i_lo >= i_hi) return;
@@ -3129,7 +3131,7 @@ void launch_knn_query_waves(const float* d_scan, uint32_t n, DevState* st, const
   const double per_wave = sampled ? (double)n / (double)max_sf : 1.0;
   const uint32_t n_waves = sampled ? (uint32_t)max_sf + 1u : n;  // first(max_sf) = ceil(max_sf * (n / max_sf)) >= n - 1: the last share is short or empty
   auto* k = begin ? knn_query_wave_kernel<true> : knn_query_wave_kernel<false>;
-  const dim3 grid((n_waves + 3u) / 4u);
+  const dim3 grid((n_waves + 3u) / 4u + ((!begin && mp.publish_prev) ? 1u : 0u));  // (+ the workgroup that publishes the deferred report)
   if (ev_start && ev_stop)
     hipExtLaunchKernelGGL(k, grid, dim3(256), 0, s, ev_start, ev_stop, 0, d_scan, n, n_waves, per_wave, st, st, a, hist, map.pts, map.cell_start, map, mp, max_sf, status, nbr5);
   else
