@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 from superodom_amd import binding, synth  # noqa: E402
 
 ap = argparse.ArgumentParser(); ap.add_argument("--count", type=int, default=48); ap.add_argument("--stock", action="store_true")
-ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--reps", type=int, default=3); ap.add_argument("--no-single", action="store_true", help="skip the loop of single calls (kernel timelines of the sequence alone)")
 a = ap.parse_args()
 sc = synth.Scene("os1_128_2m")
 S = 4
@@ -46,7 +46,7 @@ for rep in range(a.reps):
         " stock" if a.stock else "", K, 1e3 * t, 1 / t, sum(1 for s_ in st if s_.flags & binding.FLAG_CHAINED), sum(s_.n_iterations for s_ in st) / K, tm.seq_chain_breaks))
 # the loop of single calls on the same scans (resident / staged entry of the bench)
 stk = [binding.Stats() for _ in range(K)]; pk = [np.zeros(7) for _ in range(K)]
-if a.stock:
+if a.stock and not a.no_single:
     calls = [cx.prepare_register_dev(seq[k][0], seq[k][1], guesses[k % S], stk[k], pk[k]) for k in range(K)]
     for rep in range(a.reps):
         cx.synchronize(); t0 = time.perf_counter()

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/sql
-rocprofv3 --kernel-trace --output-format csv -d /tmp/sql -- python $R/tools/seq_rate.py --count 16 --reps 1 $1 > /tmp/sql.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/sql -- python $R/tools/seq_rate.py --count 16 --reps 2 --no-single $1 > /tmp/sql.log 2>&1
 grep "sequence" /tmp/sql.log | tail -1
 python - <<'PY'
 import csv, glob
